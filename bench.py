@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py -- training rays/s of the LONER mapping iteration on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one mapping iteration (optimizer.py:276-385 of the reference) over the default window:
+8 keyframes x 512 rays x 512 samples, default network (16-level hash grid -> 64 -> 1), joint
+optimisation of the density field and of 7 of the 8 poses (the first is anchored), occupancy-grid
+step every 10th iteration, synthetic 64x1024 scans of an analytic scene (loner_amd/utils/synthetic.py).
+With N > 1 the SAME 8-keyframe window is sharded over the ranks (keyframe i -> rank i mod N) with an
+RCCL all-reduce of the density gradient per step ("strong" scaling).
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--keyframes", type=int, default=8)
+    ap.add_argument("--rays", type=int, default=512)
+    ap.add_argument("--samples", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-iters", type=int, default=3)
+    return ap.parse_args()
+
+
+def build_window(n_kf, device=None):
+    from loner_amd.common.frame import Frame
+    from loner_amd.common.pose import Pose
+    from loner_amd.common.sensors import LidarScan
+    from loner_amd.mapping.keyframe import KeyFrame
+    from loner_amd.utils import synthetic as SY
+    from loner_amd.common.pose_utils import tensor_to_transform
+    dirs, ts = SY.lidar_pattern()
+    base = SY.trajectory_pose6(n_kf)
+    gen = torch.Generator().manual_seed(1)
+    kfs = []
+    for i in range(n_kf):
+        dist = SY.scene_ranges(dirs, tensor_to_transform(base[i]))
+        p6 = base[i].clone()
+        if i > 0:                                   # initial pose error N(0, 2 cm / 0.2 deg)
+            p6[:3] += torch.randn(3, generator=gen) * 0.02
+            p6[3:] += torch.randn(3, generator=gen) * 0.2 * 3.14159265 / 180
+        fr = Frame(None, LidarScan(dirs.clone(), dist, ts + 3.0 * i, sky_rays=torch.Tensor()), Pose())
+        fr._lidar_pose = Pose(pose_tensor=p6, fixed=False)
+        fr._gt_lidar_pose = Pose(pose_tensor=base[i].clone(), fixed=True)
+        kfs.append(KeyFrame(fr, device))
+    kfs[0].is_anchored = True
+    return kfs
+
+
+def cpu_baseline(args):
+    """The oracle (CPU restatement of the reference's mapping iteration, oracle/mapping_step.py) timed on the
+    host cores on a bounded sample of the same workload: 2 keyframes x 512 rays x 512 samples."""
+    from oracle import mapping_step as MS
+    from oracle import network as NW
+    from loner_amd.common.settings import default_nerf_config
+    from loner_amd.utils import synthetic as SY
+    from oracle import poses as OP
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    nc = default_nerf_config()
+    spec = NW.NetworkSpec.from_config(nc["pos_encoding_sigma"], nc["sigma_network"])
+    scale, shift = SY.world_cube()
+    cfg = MS.MapperConfig(n_rays=args.rays, n_samples=args.samples)
+    m = MS.OracleMapper(spec, NW.init_params(spec, 0), scale, shift, cfg, grid_size=100)
+    dirs, _ = SY.lidar_pattern()
+    base = SY.trajectory_pose6(2)
+    kfs = [MS.OracleKeyframe(dirs, SY.scene_ranges(dirs, OP.transform_from_pose6(base[i])), base[i].clone(), anchored=(i == 0))
+           for i in range(2)]
+    torch.manual_seed(0)
+    m.iterate(kfs, 1)                                # warm-up
+    t0 = time.time()
+    n_valid = m.iterate(kfs, args.cpu_baseline_iters)
+    dt = time.time() - t0
+    return {"value": n_valid / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"{args.cpu_baseline_iters} mapping iterations of 2 keyframes x {args.rays} rays x {args.samples} samples, "
+                      f"default network, torch CPU fp32, {dt:.1f} s",
+            "ms_per_iter": 1e3 * dt / args.cpu_baseline_iters}
+
+
+class KernelTimer:
+    """HIP-event timing of selected C-ABI calls on the stream they are launched on (torch's current stream)."""
+
+    def __init__(self, ops, names):
+        self.ops, self.names = ops, names
+        self.events = {n: [] for n in names}
+        self.enabled = False
+        self._orig = {}
+        for n in names:
+            self._orig[n] = getattr(ops, n)
+            setattr(ops, n, self._wrap(n))
+
+    def _wrap(self, name):
+        orig = self._orig[name]
+
+        def inner(*a, **k):
+            if not self.enabled:
+                return orig(*a, **k)
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(*a, **k)
+            e1.record()
+            self.events[name].append((e0, e1))
+            return r
+        return inner
+
+    def summary(self):
+        out = {}
+        for n, evs in self.events.items():
+            if evs:
+                ms = [a.elapsed_time(b) for a, b in evs]
+                out[n] = {"calls": len(ms), "avg_ms": sum(ms) / len(ms), "total_ms": sum(ms)}
+        return out
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+
+    from loner_amd import ops
+    from loner_amd.common.pose_utils import WorldCube
+    from loner_amd.common.settings import default_optimizer_settings
+    from loner_amd.mapping.optimizer import OptimizationSettings, Optimizer
+    from loner_amd.mapping.sharding import DistContext
+    from loner_amd.utils import synthetic as SY
+
+    settings = default_optimizer_settings(log_directory=f"/tmp/loner_amd_bench_{rank}")
+    settings["num_samples"]["lidar"] = args.rays
+    settings["num_samples"]["sky"] = 0
+    settings["model_config"]["model"]["render"]["N_samples_train"] = args.samples
+    scale, shift = SY.world_cube()
+    torch.manual_seed(0)                                   # identical initial parameters on every rank
+    opt = Optimizer(settings, None, WorldCube(torch.tensor(scale), torch.from_numpy(shift)), local, False, True, False)
+    window = build_window(args.keyframes)
+    if world > 1:
+        ctx = DistContext()
+        opt.set_distributed(ctx)
+        my_window = ctx.owned(window)
+        torch.manual_seed(1000 + rank)                     # different ray draws per rank
+    else:
+        my_window = window
+    phase = lambda n: OptimizationSettings(n, False, False, False, True)
+
+    timer = KernelTimer(ops, ["density_backward", "density_forward", "los_loss_fused", "sample_rays_occ", "adam_step",
+                              "occ_grid_step", "compact_rays", "lidar_rays_backward", "points_grad_to_rays"])
+    # ---- warm-up (untimed) ----
+    if args.warmup > 0:
+        opt._do_iterate_optimizer(my_window, [None], optimizer_settings=phase(args.warmup))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    opt._do_iterate_optimizer(my_window, [None], optimizer_settings=phase(args.steps))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+
+    n_valid = torch.tensor([float(opt.last_stats["n_valid_rays"]), elapsed], device="cuda", dtype=torch.float64)
+    if world > 1:
+        rays_total = n_valid[0:1].clone(); dist.all_reduce(rays_total)
+        t_max = n_valid[1:2].clone(); dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        total_rays, elapsed = float(rays_total), float(t_max)
+    else:
+        total_rays = float(n_valid[0])
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ksum = timer.summary()
+    spec = opt._model.nerf_model._model_sigma.spec
+    n_local = opt.last_stats["n_valid_rays"] / max(args.steps, 1)          # rays per launch on this rank
+    pts = n_local * args.samples
+    # algorithmic work of the dominant kernel: fp32 MFMA flops of the density backward
+    h, ind, nh = spec.n_neurons, spec.in_dim, spec.n_hidden
+    mac = h * ind + (nh - 1) * h * h
+    flops_bwd = pts * 2.0 * (3 * mac + h)         # recompute fwd + input grad + weight grad (+ output layer)
+    bytes_bwd = pts * 20.0 + n_local * 52.0 + float(spec.n_params) * 4.0 * 3.0
+    roofline = None
+    if "density_backward" in ksum:
+        t = ksum["density_backward"]["avg_ms"] * 1e-3
+        ach = flops_bwd / t / 1e12
+        roofline = {"kernel": "density_backward_kernel<4,true>", "bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s",
+                    "frac": ach / 157.3, "traffic": None, "avg_launch_ms": ksum["density_backward"]["avg_ms"],
+                    "algorithmic_flops_per_launch": flops_bwd, "algorithmic_bytes_per_launch": bytes_bwd,
+                    "hbm_achieved_GBps": bytes_bwd / t / 1e9, "hbm_peak_GBps": 8000.0,
+                    "note": "peak = dense fp32 MFMA (v_mfma_f32_16x16x4_f32) rate from MI355X_MICROARCH.md; the kernel is "
+                            "L2-gather/atomic + fp32-MFMA bound, its HBM traffic is far below the 8 TB/s roof"}
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                roofline["traffic"] = json.load(open(tf)).get("density_backward_bytes_per_launch")
+            except Exception:
+                pass
+    line = {
+        "metric": "training rays/sec", "value": total_rays / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"mapping iteration, {args.keyframes}-keyframe window x {args.rays} rays x {args.samples} samples, "
+                               "default cfg (HashGrid 16x2 T=2^18 -> 64 -> 1, L1_JS loss, OGM sampler), joint map+pose optimisation, "
+                               "synthetic 64x1024 scans (stand-in for Fusion Portable canteen, BASELINE configs[1])",
+                   "keyframes": args.keyframes, "rays_per_keyframe": args.rays, "samples_per_ray": args.samples,
+                   "parallelism": f"keyframe-sharded x{world}" if world > 1 else "single GPU"},
+        "roofline": roofline, "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in ksum.items()},
+        "final_loss": float(opt.last_stats["loss_terms"][-1, 0]),
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args)
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

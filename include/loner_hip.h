@@ -1,0 +1,243 @@
+/*
+ * loner_hip.h -- C ABI of libloner_hip.so, the MI355X (gfx950) implementation of the
+ * LONER mapping-thread hot path.
+ *
+ * The reference (umautobots/LONER) is pure Python: its "native" layer on this path is
+ * torch ops plus the tinycudann CUDA extension, reached through Python classes.  It has
+ * no FFI of its own, so every entry point below cites the reference *function* it
+ * replaces (paths relative to the reference root).  The Python classes that mirror the
+ * reference's interface (loner_amd/models/..., loner_amd/mapping/...) bind these symbols
+ * with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the comment says "host";
+ *   - tensors are dense, row-major, float32 unless stated; the caller owns all buffers;
+ *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*);
+ *   - return value 0 = success, negative = LnrStatus error (nothing was enqueued);
+ *   - the library keeps no global state and is re-entrant per stream;
+ *   - `n_rays_dev` (nullable): if non-null the kernels read the live ray count from
+ *     device memory (<= the `n_rays` capacity given by value) so that a window whose
+ *     ray count depends on data (rays dropped by the cube test) needs no host sync.
+ *
+ * Ray record (13 floats): [origin(3) dir(3) viewdir(3) 0 0 near far]  (ray_utils.py:307-310)
+ */
+#ifndef LONER_HIP_H
+#define LONER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LNR_RAY_STRIDE 13
+#define LNR_MAX_LEVELS 32
+
+typedef enum LnrStatus {
+    LNR_OK = 0,
+    LNR_ERR_INVALID_ARG = -1,
+    LNR_ERR_UNSUPPORTED = -2,   /* legal config the kernels do not cover (message via lnr_last_error) */
+    LNR_ERR_LAUNCH = -3,        /* hipGetLastError() != hipSuccess after a launch */
+    LNR_ERR_WORKSPACE = -4      /* workspace too small */
+} LnrStatus;
+
+typedef enum LnrEncoding { LNR_ENC_HASHGRID = 0, LNR_ENC_FREQUENCY = 1 } LnrEncoding;
+
+typedef enum LnrActivation {
+    LNR_ACT_NONE = 0, LNR_ACT_RELU = 1, LNR_ACT_SINE = 2, LNR_ACT_LEAKY_RELU = 3,
+    LNR_ACT_EXPONENTIAL = 4, LNR_ACT_SIGMOID = 5, LNR_ACT_SQUAREPLUS = 6,
+    LNR_ACT_SOFTPLUS = 7, LNR_ACT_TANH = 8
+} LnrActivation;
+
+/* Density network = input encoding + bias-free MLP; the config schema is tinycudann's as
+ * used by src/models/nerf_tcnn.py:29-38 (cfg/nerf_config/default_nerf_hash.yaml keys
+ * pos_encoding_sigma / sigma_network).  Fill the first block, call lnr_net_spec_finalize. */
+typedef struct LnrNetSpec {
+    /* -- configuration -- */
+    int32_t encoding;          /* LnrEncoding */
+    int32_t n_levels;          /* HashGrid */
+    int32_t n_features;        /* HashGrid: features per level, 1 | 2 | 4 | 8 */
+    int32_t log2_table;        /* HashGrid: log2_hashmap_size */
+    int32_t base_res;          /* HashGrid: base_resolution */
+    float   per_level_scale;   /* HashGrid */
+    int32_t n_frequencies;     /* Frequency */
+    int32_t activation;        /* LnrActivation of the hidden layers */
+    int32_t n_neurons;         /* hidden width, multiple of 16, <= 256 */
+    int32_t n_hidden;          /* hidden layers, >= 1 */
+    /* -- derived by lnr_net_spec_finalize -- */
+    int32_t enc_dim;           /* encoding outputs */
+    int32_t in_dim;            /* enc_dim rounded up to 16 (padding inputs are the constant 1) */
+    int32_t n_mlp_params;      /* H*in_dim + (n_hidden-1)*H*H + 16*H */
+    int64_t n_params;          /* MLP matrices first ([out][in] row-major), then encoding tables */
+    float    level_scale[LNR_MAX_LEVELS];
+    uint32_t level_res[LNR_MAX_LEVELS];
+    uint32_t level_size[LNR_MAX_LEVELS];    /* entries */
+    uint32_t level_offset[LNR_MAX_LEVELS];  /* entries, from the start of the encoding block */
+    uint32_t level_hashed[LNR_MAX_LEVELS];
+} LnrNetSpec;
+
+/* Loss configuration = model_config.loss (cfg/model_config/default_model_config.yaml:42-63). */
+typedef struct LnrLossConfig {
+    int32_t selection;     /* 0 L1_JS, 1 L2_JS, 2 L1_LOS, 3 L2_LOS  (optimizer.py:493-534,568-574) */
+    float min_js, max_js, js_alpha;
+    float los_lambda;      /* already decayed by the caller if decay_los_lambda (optimizer.py:448-452) */
+    float depth_lambda;
+    float min_eps;         /* min_depth_eps */
+    float fixed_eps;       /* LOS variants: the (decayed) depth_eps for this iteration */
+} LnrLossConfig;
+
+const char* lnr_last_error(void);          /* host; thread-local text for the last negative status */
+int  lnr_version(void);
+
+/* ---- density network ------------------------------------------------------------------------- */
+int lnr_net_spec_finalize(LnrNetSpec* spec /*host, in/out*/);
+
+/* sigma = MLP(enc((xyz+1)/2))[0]           replaces tinycudann forward at nerf_tcnn.py:63-72
+ * Points are given either explicitly (pts != NULL, [n_points,3] in the world cube [-1,1]) or
+ * implicitly as rays [n_rays,13] + z [n_rays,n_samples] (xyz = o + d*z, rendering_tcnn.py:241). */
+int lnr_density_forward(const LnrNetSpec* spec /*host*/, const float* params,
+                        const float* pts, int64_t n_points,
+                        const float* rays, const float* z, int32_t n_rays, int32_t n_samples,
+                        const int32_t* n_rays_dev,
+                        float* sigma /*[n_points] or [n_rays*n_samples]*/, void* stream);
+
+/* Backward of the above                     replaces tinycudann backward (loss.backward(), optimizer.py:366)
+ * grad_params [n_params] is ACCUMULATED into (caller zeroes it; lnr_adam_step can re-zero it).
+ * d_pts (nullable) [*,3] receives dL/dxyz per point (needed only when poses are optimised).
+ * workspace: lnr_density_backward_workspace() bytes. */
+size_t lnr_density_backward_workspace(const LnrNetSpec* spec /*host*/);
+int lnr_density_backward(const LnrNetSpec* spec /*host*/, const float* params,
+                         const float* pts, int64_t n_points,
+                         const float* rays, const float* z, int32_t n_rays, int32_t n_samples,
+                         const int32_t* n_rays_dev,
+                         const float* d_sigma, float* grad_params, float* d_pts,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- rays ------------------------------------------------------------------------------------- */
+/* LidarRayDirections.build_lidar_rays (ray_utils.py:269-322) + get_far_val (:31-60) for one
+ * keyframe: gather, rotate, normalise, clip to the cube.  Writes ALL n_index candidates plus a
+ * keep flag (the `far > near + 1/scale` test, :318-322).  transform: 12 floats = rows of [R|t]. */
+int lnr_build_lidar_rays(const float* directions /*[3,n_points]*/, const float* distances /*[n_points]*/,
+                         int64_t n_points, const int64_t* index /*[n_index]*/, int32_t n_index,
+                         const float* transform /*[12]*/, float range_min, float range_max,
+                         float scale, const float* shift /*host [3]*/,
+                         float* rays /*[n_index,13]*/, float* depths /*[n_index]*/,
+                         uint8_t* keep /*[n_index]*/, void* stream);
+
+/* Order-preserving compaction of candidate rays by `keep` (the boolean indexing at
+ * ray_utils.py:322 and the vstack at optimizer.py:333-338 for a whole window).
+ * seg_start [n_seg+1] (host) delimits the keyframes inside the candidate arrays;
+ * out_seg_start [n_seg+1] (device) receives the compacted segment starts; n_out_dev the total. */
+int lnr_compact_rays(const float* rays_in, const float* depths_in, const uint8_t* keep, const int64_t* src_index,
+                     int32_t n_in, const int32_t* seg_start /*host*/, int32_t n_seg,
+                     float* rays_out, float* depths_out, int64_t* src_index_out,
+                     int32_t* out_seg_start, int32_t* n_out_dev, void* stream);
+
+/* Backward of lnr_build_lidar_rays for a window: dL/drays -> dL/d[R|t] per keyframe
+ * (the autograd tail ray_utils.py:281-305 <- keyframe.py:80-88).  d_transform [n_seg,12]. */
+int lnr_lidar_rays_backward(const float* d_rays /*[n,13]*/, const float* rays /*[n,13]*/,
+                            const int64_t* src_index /*[n]*/, const int32_t* seg_start /*device [n_seg+1]*/,
+                            int32_t n_seg, const float* const* directions /*host array of n_seg device ptrs*/,
+                            const int64_t* n_points /*host [n_seg]*/, const float* transforms /*[n_seg,12]*/,
+                            float scale, float* d_transform /*[n_seg,12]*/, void* stream);
+
+/* ---- samplers ---------------------------------------------------------------------------------- */
+/* OccupancyGridModel.interpolate (model_tcnn.py:122-131): trilinear lookup, zero padding. */
+int lnr_occ_interpolate(const float* grid /*[V,V,V] z,y,x*/, int32_t V, const float* pts /*[n,3]*/,
+                        int64_t n, float* out /*[n]*/, void* stream);
+
+/* OccGridRaySampler.get_samples (ray_sampling.py:53-92) incl. sample_pdf (rendering_tcnn.py:18-67).
+ * steps: torch.linspace(0,1,n_samples/2) as a device table.  u_jitter/u_pdf [n_rays,n_samples/2]:
+ * the two torch.rand draws; either may be NULL, then a counter-based generator keyed by
+ * (seed, ray, sample) is used.  dbg_inds/dbg_probs/dbg_cdf (nullable) expose the searchsorted
+ * indices, point_probs and cdf for stage-wise parity tests. */
+int lnr_sample_rays_occ(const float* rays, int32_t n_rays, const int32_t* n_rays_dev,
+                        const float* grid, int32_t V, int32_t n_samples, float perturb,
+                        const float* steps, const float* u_jitter, const float* u_pdf, uint64_t seed,
+                        float* z_out /*[n_rays,n_samples] sorted*/,
+                        int64_t* dbg_inds, float* dbg_probs, float* dbg_cdf, void* stream);
+
+/* UniformRaySampler.get_samples (ray_sampling.py:22-43). steps: linspace(0,1,n_samples). */
+int lnr_sample_rays_uniform(const float* rays, int32_t n_rays, const int32_t* n_rays_dev,
+                            int32_t n_samples, float perturb, const float* steps,
+                            const float* u_jitter, uint64_t seed, float* z_out, void* stream);
+
+/* ---- volume rendering ---------------------------------------------------------------------------- */
+/* raw2outputs(sigma_only=True, far, ret_var=True) (rendering_tcnn.py:71-147).
+ * noise [n_rays,n_samples] = randn*raw_noise_std (rendering_tcnn.py:104) or NULL with
+ * noise_std>0 for the in-kernel generator (noise_std==0: no noise).  Outputs nullable. */
+int lnr_render_forward(const float* sigma, const float* z, const float* rays, int32_t n_rays,
+                       const int32_t* n_rays_dev, int32_t n_samples,
+                       const float* noise, float noise_std, uint64_t seed,
+                       float* depth, float* weights, float* opacity, float* variance, void* stream);
+
+/* Backward of lnr_render_forward for arbitrary upstream gradients (nullable each):
+ * g_depth[n], g_weights[n,S], g_opacity[n], g_variance[n]  ->  d_sigma [n,S] and the direct
+ * ray-record contribution d_rays [n,13] (cols 3:6 through |dir|, col 12 = far); d_rays is
+ * OVERWRITTEN.  Points' contribution to cols 0:6 is added by lnr_points_grad_to_rays. */
+int lnr_render_backward(const float* sigma, const float* z, const float* rays, int32_t n_rays,
+                        const int32_t* n_rays_dev, int32_t n_samples,
+                        const float* noise, float noise_std, uint64_t seed,
+                        const float* g_depth, const float* g_weights, const float* g_opacity,
+                        const float* g_variance, float* d_sigma, float* d_rays, void* stream);
+
+/* xyz = o + d*z  =>  d_rays[:,0:3] += sum_s d_pts ; d_rays[:,3:6] += sum_s z*d_pts
+ * (rendering_tcnn.py:241 backward). */
+int lnr_points_grad_to_rays(const float* d_pts /*[n,S,3]*/, const float* z, int32_t n_rays,
+                            const int32_t* n_rays_dev, int32_t n_samples, float* d_rays, void* stream);
+
+/* ---- loss ------------------------------------------------------------------------------------------ */
+/* get_weights_gt (losses.py:29-51); eps_ray [n] per-ray or NULL -> eps_scalar. */
+int lnr_weights_gt(const float* s /*[n,S] metres*/, const float* g /*[n] metres*/, const float* eps_ray,
+                   float eps_scalar, int32_t normalise, int32_t n_rays, int32_t n_samples,
+                   float* out /*[n,S]*/, void* stream);
+
+/* get_logits_grad (losses.py:54-62), defaults eps=2, l_free=0.25, l_occ=2.5. */
+int lnr_logits_grad(const float* s /*[n,S]*/, const float* g /*[n]*/, int32_t n_rays, int32_t n_samples,
+                    float margin, float l_free, float l_occ, float* out, void* stream);
+
+/* Fused Optimizer.compute_loss (optimizer.py:437-595, lidar branch) forward + backward:
+ * render (as lnr_render_forward), weighted mean/var, JS divergence (:476-482,:614-626), dynamic
+ * margin (:495-503), target weights (:504-506), depth MSE + LOS L1/L2 + opacity terms, then the
+ * analytic backward to d_sigma [n,S] and the direct part of d_rays [n,13] (overwritten).
+ * Reproduces the reference's `depth > far[0]` broadcast quirk (:460-461).
+ * counts_dev [2] int32: {number of rays, number of opaque rays} over the WHOLE batch the loss is
+ * normalised by (all GPUs) -- from lnr_count_opaque, all-reduced by the caller when sharded.
+ * loss_out [4] float (accumulated with atomics; caller zeroes): {total, depth, los, opacity};
+ * ray_stats (nullable) [n,8]: {depth, opacity, variance, mean_m, std_m, js, eps, opaque}.
+ * weights_out (nullable) [n,S]. */
+int lnr_count_opaque(const float* rays, const float* depth_gt, int32_t n_rays, const int32_t* n_rays_dev,
+                     int32_t* counts_dev /*[2], overwritten*/, void* stream);
+int lnr_los_loss_fused(const float* sigma, const float* z, const float* rays, const float* depth_gt,
+                       int32_t n_rays, const int32_t* n_rays_dev, int32_t n_samples,
+                       const float* noise, float noise_std, uint64_t seed,
+                       float scale, const LnrLossConfig* cfg /*host*/, const int32_t* counts_dev,
+                       float* loss_out, float* d_sigma, float* d_rays, float* ray_stats,
+                       float* weights_out, void* stream);
+
+/* ---- optimisers -------------------------------------------------------------------------------------- */
+/* torch.optim.Adam step (optimizer.py:257-269,376-380): betas (b1,b2), eps, no weight decay,
+ * `step` = 1-based step count.  If zero_grad != 0 the gradient is cleared after use
+ * (zero_grad(set_to_none=True), :380).  grad_scale multiplies the gradient first (1.0 normally). */
+int lnr_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t count,
+                  float lr, float beta1, float beta2, float eps, int32_t step, float grad_scale,
+                  int32_t zero_grad, void* stream);
+
+/* Optimizer._step_occupancy_grid (optimizer.py:598-609): pseudo-gradient per sample
+ * (losses.py:54-62) scattered trilinearly into the logit grid, SGD step grid -= lr*grad.
+ * grad_buf (nullable [V^3]): if given, the gradient is accumulated there (caller zeroes) and
+ * applied by lnr_occ_grid_apply; if NULL the update is applied in place atomically. */
+int lnr_occ_grid_step(float* grid, int32_t V, const float* rays, const float* z, const float* depth_gt,
+                      int32_t n_rays, const int32_t* n_rays_dev, int32_t n_samples, float scale,
+                      float lr, float margin, float l_free, float l_occ, float* grad_buf, void* stream);
+int lnr_occ_grid_apply(float* grid, float* grad_buf, int64_t count, float lr, int32_t zero_grad, void* stream);
+
+/* ---- self test ------------------------------------------------------------------------------------------ */
+/* Checks the MFMA fragment layout the density kernels rely on; out[0]=max abs error. */
+int lnr_selftest_mfma(float* out /*[1]*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LONER_HIP_H */

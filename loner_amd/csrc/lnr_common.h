@@ -1,0 +1,119 @@
+// Shared device/host helpers for libloner_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/loner_hip.h"
+
+#define LNR_WAVE 64
+
+void lnr_set_error(const char* fmt, ...);
+
+#define LNR_REQUIRE(cond, ...)                        \
+    do {                                              \
+        if (!(cond)) {                                \
+            lnr_set_error(__VA_ARGS__);               \
+            return LNR_ERR_INVALID_ARG;               \
+        }                                             \
+    } while (0)
+
+#define LNR_CHECK_LAUNCH(name)                                                        \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) {                                                       \
+            lnr_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));      \
+            return LNR_ERR_LAUNCH;                                                    \
+        }                                                                             \
+    } while (0)
+
+static inline int lnr_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------------
+// wave-level primitives (64 lanes)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// exclusive prefix product / inclusive helpers over 64 lanes
+__device__ __forceinline__ float wave_excl_prod(float v, int lane) {
+    float inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc *= t;
+    }
+    float ex = __shfl_up(inc, 1, 64);
+    return lane == 0 ? 1.0f : ex;
+}
+__device__ __forceinline__ float wave_excl_sum(float v, int lane) {
+    float inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    float ex = __shfl_up(inc, 1, 64);
+    return lane == 0 ? 0.0f : ex;
+}
+
+// ---------------------------------------------------------------------------------------------
+// counter-based RNG (Philox4x32-10), used when the caller passes no random tensors
+// ---------------------------------------------------------------------------------------------
+struct Philox4 { uint32_t x, y, z, w; };
+
+__host__ __device__ __forceinline__ uint32_t lnr_mulhi32(uint32_t a, uint32_t b) {
+    return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);
+}
+
+__host__ __device__ inline Philox4 philox4x32_10(uint64_t counter_lo, uint64_t counter_hi, uint64_t key) {
+    uint32_t c0 = (uint32_t)counter_lo, c1 = (uint32_t)(counter_lo >> 32);
+    uint32_t c2 = (uint32_t)counter_hi, c3 = (uint32_t)(counter_hi >> 32);
+    uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+        uint32_t hi0 = lnr_mulhi32(M0, c0), lo0 = M0 * c0;
+        uint32_t hi1 = lnr_mulhi32(M1, c2), lo1 = M1 * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    Philox4 o; o.x = c0; o.y = c1; o.z = c2; o.w = c3;
+    return o;
+}
+// uniform in [0,1) with 24 random bits (same mapping torch uses for float32)
+__host__ __device__ __forceinline__ float lnr_u01(uint32_t bits) {
+    return (float)(bits & 0x00FFFFFFu) * (1.0f / 16777216.0f);
+}
+// stream ids keep the three per-iteration draws independent
+#define LNR_STREAM_JITTER 0x11ull
+#define LNR_STREAM_PDF 0x22ull
+#define LNR_STREAM_NOISE 0x33ull
+
+__device__ __forceinline__ float lnr_rand_uniform(uint64_t seed, uint64_t stream_id, uint64_t ray, uint32_t idx) {
+    Philox4 p = philox4x32_10(((uint64_t)idx >> 2) | (ray << 20), stream_id, seed);
+    uint32_t v = (idx & 3) == 0 ? p.x : (idx & 3) == 1 ? p.y : (idx & 3) == 2 ? p.z : p.w;
+    return lnr_u01(v);
+}
+__device__ __forceinline__ float lnr_rand_normal(uint64_t seed, uint64_t ray, uint32_t idx) {
+    Philox4 p = philox4x32_10(((uint64_t)idx >> 1) | (ray << 20), LNR_STREAM_NOISE, seed);
+    uint32_t a = (idx & 1) ? p.z : p.x, b = (idx & 1) ? p.w : p.y;
+    float u1 = 1.0f - lnr_u01(a);   // (0,1]
+    float u2 = lnr_u01(b);
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+
+__device__ __forceinline__ int lnr_live_rays(int n_rays, const int32_t* n_rays_dev) {
+    if (n_rays_dev == nullptr) return n_rays;
+    int v = *n_rays_dev;
+    return v < n_rays ? v : n_rays;
+}

@@ -1,0 +1,65 @@
+// Host-side helpers: error text, network spec derivation.
+#include <math.h>
+#include <stdarg.h>
+
+#include "lnr_common.h"
+
+static thread_local char g_err[512] = "";
+
+void lnr_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* lnr_last_error(void) { return g_err; }
+extern "C" int lnr_version(void) { return 100; }
+
+// Level geometry of the multiresolution grid, as published for tiny-cuda-nn's GridEncoding:
+//   scale = 2^(level*log2(per_level_scale)) * base - 1 ; res = ceil(scale) + 1
+//   size  = min(roundup8(res^3), 2^log2_table) ; hashed iff res^3 > size
+extern "C" int lnr_net_spec_finalize(LnrNetSpec* s) {
+    LNR_REQUIRE(s != nullptr, "lnr_net_spec_finalize: null spec");
+    LNR_REQUIRE(s->n_neurons == 16 || s->n_neurons == 32 || s->n_neurons == 64 || s->n_neurons == 128 || s->n_neurons == 256,
+                "n_neurons must be 16, 32, 64, 128 or 256, got %d", s->n_neurons);
+    LNR_REQUIRE(s->n_hidden >= 1 && s->n_hidden <= 8, "n_hidden_layers must be in [1,8], got %d", s->n_hidden);
+    LNR_REQUIRE(s->activation >= LNR_ACT_NONE && s->activation <= LNR_ACT_TANH, "unknown activation %d", s->activation);
+    if (s->encoding == LNR_ENC_HASHGRID) {
+        LNR_REQUIRE(s->n_levels >= 1 && s->n_levels <= LNR_MAX_LEVELS, "n_levels must be in [1,%d]", LNR_MAX_LEVELS);
+        LNR_REQUIRE(s->n_features == 1 || s->n_features == 2 || s->n_features == 4 || s->n_features == 8,
+                    "n_features_per_level must be 1, 2, 4 or 8, got %d", s->n_features);
+        LNR_REQUIRE(s->log2_table >= 4 && s->log2_table <= 28, "log2_hashmap_size out of range: %d", s->log2_table);
+        LNR_REQUIRE(s->base_res >= 1, "base_resolution must be >= 1");
+        const uint64_t cap = 1ull << s->log2_table;
+        uint64_t off = 0;
+        const float l2 = log2f(s->per_level_scale);
+        for (int l = 0; l < s->n_levels; ++l) {
+            float scale = exp2f((float)l * l2) * (float)s->base_res - 1.0f;
+            uint32_t res = (uint32_t)ceilf(scale) + 1u;
+            uint64_t dense = (uint64_t)res * res * res;
+            uint64_t size = ((dense + 7ull) / 8ull) * 8ull;
+            if (size > cap) size = cap;
+            s->level_scale[l] = scale;
+            s->level_res[l] = res;
+            s->level_size[l] = (uint32_t)size;
+            s->level_offset[l] = (uint32_t)off;
+            s->level_hashed[l] = dense > size ? 1u : 0u;
+            off += size;
+        }
+        LNR_REQUIRE(off * (uint64_t)s->n_features < (1ull << 32), "encoding table too large");
+        s->enc_dim = s->n_levels * s->n_features;
+        s->n_params = (int64_t)off * s->n_features;
+    } else if (s->encoding == LNR_ENC_FREQUENCY) {
+        LNR_REQUIRE(s->n_frequencies >= 1 && s->n_frequencies <= 32, "n_frequencies must be in [1,32]");
+        s->enc_dim = 3 * 2 * s->n_frequencies;
+        s->n_params = 0;
+    } else {
+        lnr_set_error("unknown encoding %d", s->encoding);
+        return LNR_ERR_INVALID_ARG;
+    }
+    s->in_dim = ((s->enc_dim + 15) / 16) * 16;
+    s->n_mlp_params = s->n_neurons * s->in_dim + (s->n_hidden - 1) * s->n_neurons * s->n_neurons + 16 * s->n_neurons;
+    s->n_params += s->n_mlp_params;
+    return LNR_OK;
+}

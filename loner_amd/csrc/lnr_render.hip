@@ -1,0 +1,496 @@
+// Volume rendering, line-of-sight loss and their analytic backward (gfx950).
+//
+// Replaces  raw2outputs                 src/models/rendering_tcnn.py:71-147
+//           Optimizer.compute_loss      src/mapping/optimizer.py:437-595 (lidar branch)
+//           get_weights_gt              src/models/losses.py:29-51
+//           get_logits_grad             src/models/losses.py:54-62
+//           calculate_JS/KL_divergence  src/mapping/optimizer.py:614-626
+// and the autograd backward of all of them (loss.backward(), optimizer.py:366).
+//
+// One wavefront (64 lanes) per ray; lane L owns the C consecutive samples [L*C, L*C+C).  The
+// transmittance product and the reverse "sum of G*w behind me" are wave-level scans (shuffles),
+// per-ray reductions (opacity, depth, weighted mean / variance, target normaliser) are wave
+// reductions.  All per-sample state stays in registers; HBM traffic is sigma, z (+noise) in and
+// d_sigma (+optional weights) out.
+#include "lnr_common.h"
+
+#define RENDER_BLOCK 256
+#define RAYS_PER_BLOCK (RENDER_BLOCK / 64)
+
+__device__ __forceinline__ float wave_excl_suffix_sum(float v, int lane) {
+    float inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_down(inc, o, 64);
+        if (lane + o < 64) inc += t;
+    }
+    float ex = __shfl_down(inc, 1, 64);
+    return lane == 63 ? 0.0f : ex;
+}
+
+template <int C>
+struct RayState {
+    float z[C], e[C], T[C], w[C], r[C], dl[C];   // depth, exp(-delta*relu), transmittance, weight, relu(dens), delta*|d|
+    bool pos[C];                                  // dens > 0
+    float opacity, depth, variance, dnorm;
+};
+
+// forward volume rendering of one ray held by one wave
+template <int C>
+__device__ __forceinline__ void render_ray(RayState<C>& st, const float* __restrict__ sigma, const float* __restrict__ z,
+                                           const float* __restrict__ noise, float noise_std, uint64_t seed, int ray,
+                                           int S, int lane, const float* __restrict__ rayrec) {
+    const int base = lane * C;
+    const size_t row = (size_t)ray * S;
+    float dens[C];
+#pragma unroll
+    for (int t = 0; t < C; ++t) {
+        const int i = base + t;
+        if (i < S) {
+            st.z[t] = z[row + i];
+            float n = 0.0f;
+            if (noise) n = noise[row + i];
+            else if (noise_std > 0.0f) n = lnr_rand_normal(seed, (uint64_t)ray, (uint32_t)i) * noise_std;
+            dens[t] = sigma[row + i] + n;
+        } else {
+            st.z[t] = 0.0f;
+            dens[t] = 0.0f;
+        }
+    }
+    const float dx = rayrec[3], dy = rayrec[4], dz = rayrec[5];
+    st.dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+    // z of the sample after my last one comes from the next lane
+    const float z_next_lane = __shfl_down(st.z[0], 1, 64);
+    float tprod = 1.0f;
+#pragma unroll
+    for (int t = 0; t < C; ++t) {
+        const int i = base + t;
+        float delta;
+        if (i < S - 1) delta = ((t + 1 < C) ? st.z[(t + 1 < C) ? t + 1 : t] : z_next_lane) - st.z[t];
+        else delta = 1e10f;
+        delta *= st.dnorm;
+        st.dl[t] = delta;
+        st.pos[t] = dens[t] > 0.0f;
+        st.r[t] = st.pos[t] ? dens[t] : 0.0f;
+        st.e[t] = (i < S) ? expf(-delta * st.r[t]) : 1.0f;
+        const float alpha = 1.0f - st.e[t];
+        st.T[t] = tprod;                           // local exclusive product, fixed up below
+        tprod *= (i < S) ? (1.0f - alpha + 1e-10f) : 1.0f;
+    }
+    const float lane_prefix = wave_excl_prod(tprod, lane);
+    float o_part = 0.0f, d_part = 0.0f;
+#pragma unroll
+    for (int t = 0; t < C; ++t) {
+        st.T[t] *= lane_prefix;
+        st.w[t] = (base + t < S) ? (1.0f - st.e[t]) * st.T[t] : 0.0f;
+        o_part += st.w[t];
+        d_part += st.w[t] * st.z[t];
+    }
+    st.opacity = wave_sum(o_part);
+    st.depth = wave_sum(d_part) + (1.0f - st.opacity) * rayrec[12];
+    float v_part = 0.0f;
+#pragma unroll
+    for (int t = 0; t < C; ++t) {
+        const float q = st.depth - st.z[t];
+        v_part += st.w[t] * q * q;
+    }
+    st.variance = wave_sum(v_part);
+}
+
+// backward of render_ray given G[t] = dL/dw (already including the depth/opacity/variance paths)
+// and g_far = dL/dfar.  Writes d_sigma and the direct ray-record gradient.
+template <int C>
+__device__ __forceinline__ void render_ray_backward(const RayState<C>& st, const float G[C], float g_far, int ray, int S, int lane,
+                                                    const float* __restrict__ rayrec, float* __restrict__ d_sigma,
+                                                    float* __restrict__ d_rays) {
+    const int base = lane * C;
+    float gw[C];
+    float local = 0.0f;
+#pragma unroll
+    for (int t = 0; t < C; ++t) { gw[t] = G[t] * st.w[t]; local += gw[t]; }
+    const float behind_lanes = wave_excl_suffix_sum(local, lane);   // sum over lanes after mine
+    float suffix = behind_lanes;                                     // running sum over k > i
+    float dnorm_part = 0.0f;
+#pragma unroll
+    for (int t = C - 1; t >= 0; --t) {
+        const int i = base + t;
+        if (i < S) {
+            const float alpha = 1.0f - st.e[t];
+            const float tt = 1.0f - alpha + 1e-10f;     // the factor the forward pass multiplied by
+            const float d_alpha = G[t] * st.T[t] - suffix / tt;
+            const float d_x = d_alpha * st.e[t];        // x = delta' * relu(dens)
+            d_sigma[(size_t)ray * S + i] = st.pos[t] ? d_x * st.dl[t] : 0.0f;
+            // delta' = delta * |d| -> gradient to |d| (delta itself carries no gradient: z is detached)
+            if (st.dnorm > 0.0f) dnorm_part += d_x * st.r[t] * (st.dl[t] / st.dnorm);
+        }
+        suffix += gw[t];
+    }
+    const float d_norm = wave_sum(dnorm_part);
+    if (lane < LNR_RAY_STRIDE) {
+        float v = 0.0f;
+        if (lane >= 3 && lane < 6 && st.dnorm > 0.0f) v = d_norm * rayrec[lane] / st.dnorm;
+        if (lane == 12) v = g_far;
+        d_rays[(size_t)ray * LNR_RAY_STRIDE + lane] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// plain rendering forward / backward (API-parity path: Model.forward + autograd)
+// ------------------------------------------------------------------------------------------------
+template <int C>
+__global__ void __launch_bounds__(RENDER_BLOCK)
+render_forward_kernel(const float* __restrict__ sigma, const float* __restrict__ z, const float* __restrict__ rays, int n_rays,
+                      const int32_t* __restrict__ n_rays_dev, int S, const float* __restrict__ noise, float noise_std,
+                      uint64_t seed, float* __restrict__ depth, float* __restrict__ weights, float* __restrict__ opacity,
+                      float* __restrict__ variance) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    if (ray >= lnr_live_rays(n_rays, n_rays_dev)) return;
+    const float* rr = rays + (size_t)ray * LNR_RAY_STRIDE;
+    RayState<C> st;
+    render_ray<C>(st, sigma, z, noise, noise_std, seed, ray, S, lane, rr);
+    if (weights) {
+#pragma unroll
+        for (int t = 0; t < C; ++t) if (lane * C + t < S) weights[(size_t)ray * S + lane * C + t] = st.w[t];
+    }
+    if (lane == 0) {
+        if (depth) depth[ray] = st.depth;
+        if (opacity) opacity[ray] = st.opacity;
+        if (variance) variance[ray] = st.variance;
+    }
+}
+
+template <int C>
+__global__ void __launch_bounds__(RENDER_BLOCK)
+render_backward_kernel(const float* __restrict__ sigma, const float* __restrict__ z, const float* __restrict__ rays, int n_rays,
+                       const int32_t* __restrict__ n_rays_dev, int S, const float* __restrict__ noise, float noise_std,
+                       uint64_t seed, const float* __restrict__ g_depth, const float* __restrict__ g_weights,
+                       const float* __restrict__ g_opacity, const float* __restrict__ g_variance,
+                       float* __restrict__ d_sigma, float* __restrict__ d_rays) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    if (ray >= lnr_live_rays(n_rays, n_rays_dev)) return;
+    const float* rr = rays + (size_t)ray * LNR_RAY_STRIDE;
+    RayState<C> st;
+    render_ray<C>(st, sigma, z, noise, noise_std, seed, ray, S, lane, rr);
+    const float gD = g_depth ? g_depth[ray] : 0.0f;
+    const float gO = g_opacity ? g_opacity[ray] : 0.0f;
+    const float gV = g_variance ? g_variance[ray] : 0.0f;
+    // variance depends on depth: dV/dD = 2 * sum_i w_i (D - z_i)
+    float q_part = 0.0f;
+#pragma unroll
+    for (int t = 0; t < C; ++t) q_part += st.w[t] * (st.depth - st.z[t]);
+    const float gD_tot = gD + gV * 2.0f * wave_sum(q_part);
+    const float far = rr[12];
+    float G[C];
+#pragma unroll
+    for (int t = 0; t < C; ++t) {
+        const int i = lane * C + t;
+        const float q = st.depth - st.z[t];
+        float g = gO + gD_tot * (st.z[t] - far) + gV * q * q;
+        if (g_weights && i < S) g += g_weights[(size_t)ray * S + i];
+        G[t] = (i < S) ? g : 0.0f;
+    }
+    render_ray_backward<C>(st, G, gD_tot * (1.0f - st.opacity), ray, S, lane, rr, d_sigma, d_rays);
+}
+
+// ------------------------------------------------------------------------------------------------
+// target weights (losses.py:29-51) for one ray, shared by the fused loss and lnr_weights_gt
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float std_normal_cdf(float x) { return 0.5f * (1.0f + erff(x / 1.41421356237309515f)); }
+
+// un-normalised truncated-Gaussian density at sample depth s (metres)
+__device__ __forceinline__ float target_raw(float s, float g, float eps, float sd, float clip_norm) {
+    const bool inside = (s - (g - eps) > 0.0f) && ((g + eps) - s > 0.0f);    // heaviside(., 0)
+    if (!inside) return 0.0f;
+    const float t = (s - g) / sd;
+    return 0.39894228040143270f * expf(-0.5f * (t * t)) / sd / clip_norm;
+}
+
+__device__ __forceinline__ void target_params(float g, float eps, float* sd, float* clip_norm) {
+    *sd = eps / 3.0f;
+    const float lo = (g - eps - g) / *sd;
+    const float hi = (g + eps - g) / *sd;
+    *clip_norm = std_normal_cdf(hi) - std_normal_cdf(lo);
+}
+
+__device__ __forceinline__ float gaussian_kl(float m1, float s1, float m2, float s2) {
+    const float d = m1 - m2;
+    return logf(s2 / s1) + (s1 * s1 + d * d) / (2.0f * (s2 * s2)) - 0.5f;
+}
+__device__ __forceinline__ float gaussian_js(float m1, float s1, float m2, float s2) {
+    const float mm = 0.5f * (m1 + m2);
+    const float sm = 0.5f * sqrtf(s1 * s1 + s2 * s2);
+    return 0.5f * gaussian_kl(m1, s1, mm, sm) + 0.5f * gaussian_kl(m2, s2, mm, sm);
+}
+
+template <int C>
+__global__ void __launch_bounds__(RENDER_BLOCK)
+los_loss_fused_kernel(const float* __restrict__ sigma, const float* __restrict__ z, const float* __restrict__ rays,
+                      const float* __restrict__ depth_gt, int n_rays, const int32_t* __restrict__ n_rays_dev, int S,
+                      const float* __restrict__ noise, float noise_std, uint64_t seed, float scale, const LnrLossConfig cfg,
+                      const int32_t* __restrict__ counts, float* __restrict__ loss_out, float* __restrict__ d_sigma,
+                      float* __restrict__ d_rays, float* __restrict__ ray_stats, float* __restrict__ weights_out) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    if (ray >= lnr_live_rays(n_rays, n_rays_dev)) return;
+    const float* rr = rays + (size_t)ray * LNR_RAY_STRIDE;
+    RayState<C> st;
+    render_ray<C>(st, sigma, z, noise, noise_std, seed, ray, S, lane, rr);
+
+    // masks, incl. the reference's broadcast quirk: every depth is compared with far of ray 0
+    const float dgt = depth_gt[ray];
+    const float far0 = rays[12];
+    const bool opaque = (dgt > 0.0f) && !(dgt > far0);
+    const float g = dgt * scale;                       // metres
+    const float n_all = (float)counts[0] * (float)S;
+    const float n_op = (float)counts[1];
+
+    // weighted mean / variance of the sample depths (metres) under the rendered weights
+    float m_part = 0.0f;
+#pragma unroll
+    for (int t = 0; t < C; ++t) m_part += (st.z[t] * scale) * st.w[t];
+    const float wden = st.opacity + 1e-10f;
+    const float mean = wave_sum(m_part) / wden;
+    float v_part = 0.0f;
+#pragma unroll
+    for (int t = 0; t < C; ++t) { const float q = st.z[t] * scale - mean; v_part += q * q * st.w[t]; }
+    const float var = wave_sum(v_part) / wden + 1e-10f;
+    const float sd_pred = sqrtf(var);
+    const float js = gaussian_js(g, cfg.min_eps / 3.0f, mean, sd_pred);
+
+    float eps;
+    if (cfg.selection <= 1) {           // L1_JS / L2_JS: dynamic margin
+        float score = js;
+        if (score < cfg.min_js) score = 0.0f;
+        if (score > cfg.max_js) score = cfg.max_js;
+        eps = cfg.min_eps * (1.0f + cfg.js_alpha * score);
+    } else {
+        eps = cfg.fixed_eps;
+    }
+    float sd_t, clip_norm;
+    target_params(g, eps, &sd_t, &clip_norm);
+    float raw[C];
+    float r_part = 0.0f;
+#pragma unroll
+    for (int t = 0; t < C; ++t) {
+        raw[t] = (lane * C + t < S) ? target_raw(st.z[t] * scale, g, eps, sd_t, clip_norm) : 0.0f;
+        r_part += raw[t];
+    }
+    const float rden = wave_sum(r_part) + 1e-6f;
+
+    const bool l1 = (cfg.selection == 0 || cfg.selection == 2);
+    const float depth_m = st.depth * scale;
+    const float gO = opaque ? ((st.opacity - 1.0f > 0.0f) ? 1.0f : (st.opacity - 1.0f < 0.0f ? -1.0f : 0.0f)) / n_op : 0.0f;
+    const float gD = opaque ? cfg.depth_lambda * 2.0f * (depth_m - g) * scale / n_op : 0.0f;
+    const float far = rr[12];
+    float G[C];
+    float los_part = 0.0f;
+#pragma unroll
+    for (int t = 0; t < C; ++t) {
+        const int i = lane * C + t;
+        const float target = opaque ? raw[t] / rden : 0.0f;
+        const float diff = st.w[t] - target;
+        float gw;
+        if (l1) { los_part += fabsf(diff); gw = (diff > 0.0f ? 1.0f : (diff < 0.0f ? -1.0f : 0.0f)); }
+        else { los_part += diff * diff; gw = 2.0f * diff; }
+        G[t] = (i < S) ? cfg.los_lambda * gw / n_all + gO + gD * (st.z[t] - far) : 0.0f;
+        if (weights_out && i < S) weights_out[(size_t)ray * S + i] = st.w[t];
+    }
+    const float los_sum = wave_sum(los_part);
+    render_ray_backward<C>(st, G, gD * (1.0f - st.opacity), ray, S, lane, rr, d_sigma, d_rays);
+
+    if (lane == 0) {
+        const float l_depth = opaque ? cfg.depth_lambda * (depth_m - g) * (depth_m - g) / n_op : 0.0f;
+        const float l_los = cfg.los_lambda * los_sum / n_all;
+        const float l_op = opaque ? fabsf(st.opacity - 1.0f) / n_op : 0.0f;
+        atomicAdd(loss_out + 0, l_depth + l_los + l_op);
+        atomicAdd(loss_out + 1, l_depth);
+        atomicAdd(loss_out + 2, l_los);
+        atomicAdd(loss_out + 3, l_op);
+        if (ray_stats) {
+            float* o = ray_stats + (size_t)ray * 8;
+            o[0] = st.depth; o[1] = st.opacity; o[2] = st.variance; o[3] = mean; o[4] = sd_pred; o[5] = js; o[6] = eps;
+            o[7] = opaque ? 1.0f : 0.0f;
+        }
+    }
+}
+
+__global__ void count_opaque_kernel(const float* __restrict__ rays, const float* __restrict__ depth_gt, int n_rays,
+                                    const int32_t* __restrict__ n_rays_dev, int32_t* __restrict__ counts) {
+    __shared__ int partial[16];
+    const int n = lnr_live_rays(n_rays, n_rays_dev);
+    const float far0 = n > 0 ? rays[12] : 0.0f;
+    int c = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float d = depth_gt[i];
+        c += ((d > 0.0f) && !(d > far0)) ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += partial[w];
+        counts[0] = n;
+        counts[1] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// standalone elementwise pieces of the reference API
+// ------------------------------------------------------------------------------------------------
+__global__ void weights_gt_kernel(const float* __restrict__ s, const float* __restrict__ g, const float* __restrict__ eps_ray,
+                                  float eps_scalar, int normalise, int n_rays, int S, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const float gg = g[ray];
+    const float eps = eps_ray ? eps_ray[ray] : eps_scalar;
+    float sd, cn;
+    target_params(gg, eps, &sd, &cn);
+    float part = 0.0f;
+    for (int i = lane; i < S; i += 64) part += target_raw(s[(size_t)ray * S + i], gg, eps, sd, cn);
+    const float den = wave_sum(part) + 1e-6f;
+    for (int i = lane; i < S; i += 64) {
+        const float v = target_raw(s[(size_t)ray * S + i], gg, eps, sd, cn);
+        out[(size_t)ray * S + i] = normalise ? v / den : v;
+    }
+}
+
+__global__ void logits_grad_kernel(const float* __restrict__ s, const float* __restrict__ g, int64_t total, int S, float margin,
+                                   float l_free, float l_occ, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float x = s[i] - g[i / S];
+    const float free_side = (-x - margin > 0.0f) ? 1.0f : 0.0f;
+    const float near_surface = ((x + margin > 0.0f) && (margin - x > 0.0f)) ? 1.0f : 0.0f;
+    out[i] = l_free * free_side - l_occ * near_surface;
+}
+
+__global__ void points_grad_to_rays_kernel(const float* __restrict__ d_pts, const float* __restrict__ z, int n_rays,
+                                           const int32_t* __restrict__ n_rays_dev, int S, float* __restrict__ d_rays) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    if (ray >= lnr_live_rays(n_rays, n_rays_dev)) return;
+    float a[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = lane; i < S; i += 64) {
+        const size_t m = (size_t)ray * S + i;
+        const float zv = z[m];
+        const float gx = d_pts[3 * m], gy = d_pts[3 * m + 1], gz = d_pts[3 * m + 2];
+        a[0] += gx; a[1] += gy; a[2] += gz;
+        a[3] += zv * gx; a[4] += zv * gy; a[5] += zv * gz;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a[k] = wave_sum(a[k]);
+    if (lane < 6) {
+        float v = lane == 0 ? a[0] : lane == 1 ? a[1] : lane == 2 ? a[2] : lane == 3 ? a[3] : lane == 4 ? a[4] : a[5];
+        d_rays[(size_t)ray * LNR_RAY_STRIDE + lane] += v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static int chunk_for(int S) {
+    int c = (S + 63) / 64;
+    int p = 1;
+    while (p < c) p <<= 1;
+    return p;
+}
+
+#define DISPATCH_C(S, CALL)                                    \
+    switch (chunk_for(S)) {                                    \
+        case 1: { constexpr int C = 1; CALL; } break;          \
+        case 2: { constexpr int C = 2; CALL; } break;          \
+        case 4: { constexpr int C = 4; CALL; } break;          \
+        case 8: { constexpr int C = 8; CALL; } break;          \
+        case 16: { constexpr int C = 16; CALL; } break;        \
+        case 32: { constexpr int C = 32; CALL; } break;        \
+        default:                                               \
+            lnr_set_error("n_samples=%d not supported (max 2048)", S); \
+            return LNR_ERR_UNSUPPORTED;                        \
+    }
+
+extern "C" int lnr_render_forward(const float* sigma, const float* z, const float* rays, int32_t n_rays, const int32_t* n_rays_dev,
+                                  int32_t n_samples, const float* noise, float noise_std, uint64_t seed, float* depth,
+                                  float* weights, float* opacity, float* variance, void* stream) {
+    LNR_REQUIRE(sigma && z && rays && n_rays >= 0 && n_samples >= 2, "lnr_render_forward: bad argument");
+    if (n_rays == 0) return LNR_OK;
+    const dim3 grid(lnr_div_up(n_rays, RAYS_PER_BLOCK)), block(RENDER_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_C(n_samples, hipLaunchKernelGGL(render_forward_kernel<C>, grid, block, 0, st, sigma, z, rays, n_rays, n_rays_dev, n_samples,
+                                             noise, noise_std, seed, depth, weights, opacity, variance));
+    LNR_CHECK_LAUNCH("lnr_render_forward");
+    return LNR_OK;
+}
+
+extern "C" int lnr_render_backward(const float* sigma, const float* z, const float* rays, int32_t n_rays, const int32_t* n_rays_dev,
+                                   int32_t n_samples, const float* noise, float noise_std, uint64_t seed, const float* g_depth,
+                                   const float* g_weights, const float* g_opacity, const float* g_variance, float* d_sigma,
+                                   float* d_rays, void* stream) {
+    LNR_REQUIRE(sigma && z && rays && d_sigma && d_rays && n_rays >= 0 && n_samples >= 2, "lnr_render_backward: bad argument");
+    if (n_rays == 0) return LNR_OK;
+    const dim3 grid(lnr_div_up(n_rays, RAYS_PER_BLOCK)), block(RENDER_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_C(n_samples, hipLaunchKernelGGL(render_backward_kernel<C>, grid, block, 0, st, sigma, z, rays, n_rays, n_rays_dev, n_samples,
+                                             noise, noise_std, seed, g_depth, g_weights, g_opacity, g_variance, d_sigma, d_rays));
+    LNR_CHECK_LAUNCH("lnr_render_backward");
+    return LNR_OK;
+}
+
+extern "C" int lnr_count_opaque(const float* rays, const float* depth_gt, int32_t n_rays, const int32_t* n_rays_dev,
+                                int32_t* counts_dev, void* stream) {
+    LNR_REQUIRE(rays && depth_gt && counts_dev && n_rays >= 0, "lnr_count_opaque: bad argument");
+    hipLaunchKernelGGL(count_opaque_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, rays, depth_gt, n_rays, n_rays_dev, counts_dev);
+    LNR_CHECK_LAUNCH("lnr_count_opaque");
+    return LNR_OK;
+}
+
+extern "C" int lnr_los_loss_fused(const float* sigma, const float* z, const float* rays, const float* depth_gt, int32_t n_rays,
+                                  const int32_t* n_rays_dev, int32_t n_samples, const float* noise, float noise_std, uint64_t seed,
+                                  float scale, const LnrLossConfig* cfg, const int32_t* counts_dev, float* loss_out, float* d_sigma,
+                                  float* d_rays, float* ray_stats, float* weights_out, void* stream) {
+    LNR_REQUIRE(sigma && z && rays && depth_gt && cfg && counts_dev && loss_out && d_sigma && d_rays, "lnr_los_loss_fused: null argument");
+    LNR_REQUIRE(cfg->selection >= 0 && cfg->selection <= 3, "lnr_los_loss_fused: unknown loss selection %d", cfg->selection);
+    LNR_REQUIRE(n_rays >= 0 && n_samples >= 2, "lnr_los_loss_fused: bad sizes");
+    if (n_rays == 0) return LNR_OK;
+    const dim3 grid(lnr_div_up(n_rays, RAYS_PER_BLOCK)), block(RENDER_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_C(n_samples, hipLaunchKernelGGL(los_loss_fused_kernel<C>, grid, block, 0, st, sigma, z, rays, depth_gt, n_rays, n_rays_dev,
+                                             n_samples, noise, noise_std, seed, scale, *cfg, counts_dev, loss_out, d_sigma, d_rays,
+                                             ray_stats, weights_out));
+    LNR_CHECK_LAUNCH("lnr_los_loss_fused");
+    return LNR_OK;
+}
+
+extern "C" int lnr_weights_gt(const float* s, const float* g, const float* eps_ray, float eps_scalar, int32_t normalise,
+                              int32_t n_rays, int32_t n_samples, float* out, void* stream) {
+    LNR_REQUIRE(s && g && out && n_rays >= 0 && n_samples > 0, "lnr_weights_gt: bad argument");
+    if (n_rays == 0) return LNR_OK;
+    hipLaunchKernelGGL(weights_gt_kernel, dim3(lnr_div_up(n_rays, RAYS_PER_BLOCK)), dim3(RENDER_BLOCK), 0, (hipStream_t)stream, s, g,
+                       eps_ray, eps_scalar, normalise, n_rays, n_samples, out);
+    LNR_CHECK_LAUNCH("lnr_weights_gt");
+    return LNR_OK;
+}
+
+extern "C" int lnr_logits_grad(const float* s, const float* g, int32_t n_rays, int32_t n_samples, float margin, float l_free,
+                               float l_occ, float* out, void* stream) {
+    LNR_REQUIRE(s && g && out && n_rays >= 0 && n_samples > 0, "lnr_logits_grad: bad argument");
+    const int64_t total = (int64_t)n_rays * n_samples;
+    if (total == 0) return LNR_OK;
+    hipLaunchKernelGGL(logits_grad_kernel, dim3(lnr_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, s, g, total, n_samples,
+                       margin, l_free, l_occ, out);
+    LNR_CHECK_LAUNCH("lnr_logits_grad");
+    return LNR_OK;
+}
+
+extern "C" int lnr_points_grad_to_rays(const float* d_pts, const float* z, int32_t n_rays, const int32_t* n_rays_dev,
+                                       int32_t n_samples, float* d_rays, void* stream) {
+    LNR_REQUIRE(d_pts && z && d_rays && n_rays >= 0 && n_samples > 0, "lnr_points_grad_to_rays: bad argument");
+    if (n_rays == 0) return LNR_OK;
+    hipLaunchKernelGGL(points_grad_to_rays_kernel, dim3(lnr_div_up(n_rays, RAYS_PER_BLOCK)), dim3(RENDER_BLOCK), 0, (hipStream_t)stream,
+                       d_pts, z, n_rays, n_rays_dev, n_samples, d_rays);
+    LNR_CHECK_LAUNCH("lnr_points_grad_to_rays");
+    return LNR_OK;
+}

@@ -1,0 +1,485 @@
+"""Optimizer: the per-keyframe optimisation loop of the mapping thread, on the MI355X.
+
+Same class surface as the reference's src/mapping/optimizer.py (constructor :74-76,
+iterate_optimizer :144, _do_iterate_optimizer :194, compute_loss :437, should_enable_lidar :427,
+_step_occupancy_grid :598, and the privates the Mapper reads: _keyframe_count, _global_step, _model,
+_optimizer, _occupancy_grid_model, _occupancy_grid_optimizer - mapper.py:104-130,161-175), so
+it drops into the reference's Mapper unchanged.  What differs is where the work happens:
+
+  reference (per iteration)                      here
+  --------------------------------------------   ------------------------------------------------
+  CPU randint + CPU ray build + H2D copy          index draw, gather/rotate/clip and compaction on
+  (optimizer.py:285-340)                          the GPU from HBM-resident keyframe buffers
+  ~20 torch ops materialising [N,S] tensors       sampler / density fwd / fused render+loss+backward
+  (ray_sampling.py, rendering_tcnn.py,            / density bwd kernels chained on one HIP stream
+   optimizer.py:437-595) + autograd
+  loss.item() and eps.cpu() syncs (:354,:503)     no host sync inside the loop; the NaN / finite
+                                                  checks (:368-374,:590) run once per call
+  torch.optim.Adam over 7.4 M params              one fused Adam kernel (lnr_adam_step)
+
+Random numbers: by default the kernels' counter-based generator is used (seeded per iteration from
+torch's CPU generator).  For parity tests a `draws` object with the reference's draw order
+(per-keyframe randint, then rand, rand, randn) can be injected via `set_draws`.
+"""
+import os
+import time
+from dataclasses import dataclass
+from typing import List, Tuple
+
+import torch
+
+from .. import hip, ops
+from ..common.pose_utils import WorldCube, tensor_to_transform
+from ..common.ray_utils import device_scan
+from ..models.model_tcnn import Model, OccupancyGridModel
+from ..models.ray_sampling import OccGridRaySampler, UniformRaySampler
+
+
+@dataclass
+class OptimizationSettings:
+    """Parameters of one optimisation phase (optimizer.py:41-60)."""
+    num_iterations: int = 1
+    freeze_poses: bool = False
+    latest_kf_only: bool = False
+    freeze_sigma_mlp: bool = False
+    freeze_rgb_mlp: bool = False
+
+    def from_dict(dict):
+        get = lambda k, d: dict[k] if k in dict else d
+        return OptimizationSettings(get("num_iterations", 1), get("freeze_poses", False), get("latest_kf_only", False),
+                                    get("freeze_sigma_mlp", False), get("freeze_rgb_mlp", False))
+
+
+class HipAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (betas 0.9/0.999, eps 1e-8, no weight decay) with the update done by
+    lnr_adam_step.  State keys match torch's Adam so that state_dict() round-trips (mapper.py:161-175)."""
+
+    def __init__(self, param_groups):
+        super().__init__(param_groups, dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8))
+
+    @torch.no_grad()
+    def step(self, zero_grad=True):
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                st["step"] += 1
+                ops.adam_step(p.data.view(-1), p.grad.view(-1), st["exp_avg"].view(-1), st["exp_avg_sq"].view(-1),
+                              group["lr"], st["step"], betas=group["betas"], eps=group["eps"], zero_grad=zero_grad)
+
+
+class _LidarLossFn(torch.autograd.Function):
+    """loss = compute_loss(rays, params): the HIP path computes the loss AND its gradients in the forward
+    call; backward hands them to autograd (scaled by the incoming gradient)."""
+
+    @staticmethod
+    def forward(ctx, rays, params, opt, depths, iteration_idx):
+        out = opt._loss_and_grads(rays.detach().float().contiguous(), depths, params, iteration_idx,
+                                  want_ray_grads=rays.requires_grad, want_param_grads=params.requires_grad)
+        ctx.save_for_backward(out["d_rays"] if out["d_rays"] is not None else torch.empty(0),
+                              out["grad_params"] if out["grad_params"] is not None else torch.empty(0))
+        ctx.has = (out["d_rays"] is not None, out["grad_params"] is not None)
+        ctx.rays_device = rays.device
+        return out["loss"][0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        d_rays, grad_params = ctx.saved_tensors
+        return ((g * d_rays).to(ctx.rays_device) if ctx.has[0] else None), (g * grad_params if ctx.has[1] else None), None, None, None
+
+
+class Optimizer:
+    def __init__(self, settings, calibration, world_cube: WorldCube, device, use_gt_poses: bool = False,
+                 lidar_only: bool = True, enable_sky_segmentation: bool = True):
+        if not torch.cuda.is_available():
+            raise RuntimeError("loner_amd.mapping.Optimizer needs an MI355X/HIP device; there is no CPU path")
+        hip.load()                                           # fail early and loudly if the library is missing
+        self._settings = settings
+        self._calibration = calibration
+        self._device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        self._use_gt_poses = use_gt_poses
+        self._optimization_settings = OptimizationSettings()
+        self._lidar_only = lidar_only
+        self._model_config = settings.model_config
+        self._scale_factor = world_cube.scale_factor
+        self._data_prep_device = 'cpu' if settings.data_prep_on_cpu else self._device
+        self._world_cube = world_cube.to(self._data_prep_device)
+        self._ray_range = torch.Tensor(list(self._model_config.model.ray_range)).to(self._data_prep_device)
+        self._scale_f = float(world_cube.scale_factor)
+        self._shift_f = [float(v) for v in torch.as_tensor(world_cube.shift).reshape(-1).cpu()]
+
+        self._model = Model(self._model_config.model).to(self._device)
+
+        if self._settings.samples_selection.strategy == 'OGM':
+            self._occupancy_grid_model = OccupancyGridModel(self._model_config.model.occ_model).to(self._device)
+            self._occupancy_grid = self._occupancy_grid_model()
+            occ_params = [p for p in self._occupancy_grid_model.parameters() if p.requires_grad]
+            self._occupancy_grid_optimizer = torch.optim.SGD(occ_params, lr=self._model_config.model.occ_model.lr)
+            self._ray_sampler = OccGridRaySampler()
+            self._ray_sampler.update_occ_grid(self._occupancy_grid.detach())
+        elif self._settings.samples_selection.strategy == 'UNIFORM':
+            self._ray_sampler = UniformRaySampler()
+        else:
+            raise RuntimeError(f"Can't find samples_selection strategy: {self._settings.samples_selection.strategy}")
+        if not self._lidar_only:
+            raise NotImplementedError("camera rays are not enabled in the reference either (optimizer.py:433-434)")
+
+        self._keyframe_count = 0
+        self._global_step = 0
+        self._keyframe_schedule = self._settings["keyframe_schedule"]
+        self._optimizer = None
+        self._num_lidar_samples = self._settings.num_samples.lidar
+        self._enable_sky_segmentation = enable_sky_segmentation
+        self._progress_bar = None
+
+        self._draws = None           # None: in-kernel generator; else an object with the reference's draw order
+        self._dist = None            # sharded-window context (mapping/sharding.py), None on one GPU
+        self._results_lidar = None
+        self._depth_eps = None
+        self._grad_buf = None
+        self.last_stats = {}
+
+    # -------------------------------------------------------------------------------------------
+    def set_draws(self, draws):
+        """Inject host random draws (objects with ray_index/sky_index/jitter/pdf/noise, see oracle.mapping_step)."""
+        self._draws = draws
+
+    def set_distributed(self, dist_ctx):
+        self._dist = dist_ctx
+
+    # -------------------------------------------------------------------------------------------
+    def iterate_optimizer(self, keyframe_window: List, optimizer_settings: OptimizationSettings = None) -> float:
+        """Run the iteration schedule selected by the keyframe count (optimizer.py:144-192)."""
+        cumulative_kf_idx = 0
+        for item in self._keyframe_schedule:
+            kf_count = item["num_keyframes"]
+            iteration_schedule = item["iteration_schedule"]
+            cumulative_kf_idx += kf_count
+            if cumulative_kf_idx >= self._keyframe_count + 1 or kf_count == -1:
+                break
+        num_its = sum(i["num_iterations"] for i in iteration_schedule)
+        start_time = time.time()
+        result = self._do_iterate_optimizer(keyframe_window, iteration_schedule, optimizer_settings=optimizer_settings)
+        torch.cuda.synchronize(self._device)
+        elapsed_time = time.time() - start_time
+        os.makedirs(self._settings.log_directory, exist_ok=True)
+        with open(f"{self._settings.log_directory}/timing.csv", 'a+') as f:
+            f.write(f"{num_its},{elapsed_time}\n")
+        if self._progress_bar is None:
+            print(f"Elapsed Time: {elapsed_time}. Per Iteration: {elapsed_time / num_its}, Its/Sec: {num_its / elapsed_time}")
+        self._keyframe_count += 1
+        return result
+
+    def should_enable_lidar(self) -> bool:
+        return not self._optimization_settings.freeze_sigma_mlp or not self._optimization_settings.freeze_poses
+
+    def should_enable_camera(self) -> bool:
+        return False
+
+    # -------------------------------------------------------------------------------------------
+    def _do_iterate_optimizer(self, keyframe_window: List, iteration_schedule, profiler=None,
+                              optimizer_settings: OptimizationSettings = None) -> float:
+        if len(keyframe_window) == 1 and self._dist is None:     # sharded: anchoring is decided on the whole window
+            keyframe_window[0].is_anchored = True
+        if len(iteration_schedule) > 1 and self._settings.skip_pose_refinement:
+            iteration_schedule = iteration_schedule[1:]
+        losses_log, depth_eps_log = [], []
+        if optimizer_settings is not None:
+            iteration_schedule = [None]
+
+        for iteration_config in iteration_schedule:
+            if optimizer_settings is None:
+                os_ = self._optimization_settings
+                os_.freeze_poses = iteration_config["freeze_poses"] or self._settings.freeze_poses or self._use_gt_poses
+                os_.latest_kf_only = iteration_config["latest_kf_only"] if "latest_kf_only" in iteration_config else False
+                os_.freeze_rgb_mlp = iteration_config["freeze_rgb_mlp"]
+                os_.freeze_sigma_mlp = iteration_config["freeze_sigma_mlp"]
+                os_.num_iterations = iteration_config["num_iterations"]
+            else:
+                self._optimization_settings = optimizer_settings
+            os_ = self._optimization_settings
+            os_.freeze_poses = os_.freeze_poses or self._settings.freeze_poses or self._use_gt_poses
+
+            if self._settings.samples_selection.strategy == 'OGM':
+                self._ray_sampler.update_occ_grid(self._occupancy_grid.detach())
+            self._model.freeze_sigma_head(os_.freeze_sigma_mlp)
+            self._model.freeze_rgb_head(True)
+            optimize_poses = not os_.freeze_poses
+
+            if os_.latest_kf_only:
+                active = [max(keyframe_window, key=lambda kf: float(kf.get_time()))]
+            else:
+                active = keyframe_window
+            for kf in active:
+                if not kf.is_anchored:
+                    kf.get_lidar_pose().set_fixed(not optimize_poses)
+            tracking = (not os_.freeze_poses) and os_.freeze_rgb_mlp and os_.freeze_sigma_mlp
+
+            sigma_params = self._model.get_sigma_parameters()
+            groups = []
+            if not tracking and sigma_params:
+                groups.append({'params': sigma_params, 'lr': self._model_config.train.lrate_sigma_mlp})
+            # poses are optimised on the device as one [K,6] tensor (rows of fixed/anchored keyframes get zero gradient)
+            pose_cpu = [kf.get_lidar_pose().get_pose_tensor() for kf in active]
+            pose_dev = torch.stack([p.detach().to(self._device, torch.float32) for p in pose_cpu]).contiguous()
+            free_rows = torch.tensor([(optimize_poses and not kf.is_anchored) for kf in active], device=self._device)
+            any_free = bool(optimize_poses and any(not kf.is_anchored for kf in active))
+            pose_dev.requires_grad_(any_free)
+            if any_free:
+                groups.append({'params': [pose_dev], 'lr': self._model_config.train.lrate_pose})
+            self._optimizer = HipAdam(groups) if groups else None
+            gamma = float(self._model_config.train.lrate_gamma)
+            base_lrs = [g['lr'] for g in groups]
+
+            n_it = os_.num_iterations
+            loss_log = torch.zeros(max(n_it, 1), 4, device=self._device)
+            eps_log = torch.zeros(max(n_it, 1), device=self._device)
+            valid_log = torch.zeros(max(n_it, 1), device=self._device, dtype=torch.int32)
+
+            for it_idx in range(n_it):
+                if not self.should_enable_lidar():
+                    break
+                batch = self._build_window_rays(active, pose_dev if any_free else pose_dev.detach())
+                valid_log[it_idx:it_idx + 1] = batch["n_dev"]
+                out = self._loss_and_grads(batch["rays"], batch["depths"], sigma_params[0] if sigma_params else
+                                           self._model.nerf_model._model_sigma.params, it_idx, want_ray_grads=any_free,
+                                           want_param_grads=not os_.freeze_sigma_mlp, n_rays_dev=batch["n_dev"],
+                                           loss_out=loss_log[it_idx], accumulate_into_param_grad=True)
+                eps_log[it_idx:it_idx + 1] = out["mean_eps"]
+                if any_free:
+                    self._pose_backward(batch, out["d_rays"], pose_dev, free_rows)
+                if self._optimizer is not None:
+                    for g, lr0 in zip(self._optimizer.param_groups, base_lrs):
+                        g['lr'] = lr0 * (gamma ** it_idx)
+                    self._optimizer.step(zero_grad=True)
+                if self.should_enable_lidar() and self._settings.samples_selection.strategy == 'OGM' and \
+                        self._global_step % self._model_config.model.occ_model.N_iters_acc == 0:
+                    self._step_occupancy_grid()
+                self._global_step += 1
+                if profiler is not None:
+                    profiler.step()
+                if self._progress_bar is not None:
+                    self._progress_bar.update()
+
+            # ---- one host sync per phase: checks the reference does every iteration (:368-374,:590) ----
+            loss_host = loss_log[:, 0].cpu()
+            if n_it and torch.isnan(loss_host).any():
+                raise AssertionError("NaN Loss Encountered")
+            if any_free and not torch.isfinite(pose_dev.detach()).all():
+                raise RuntimeError("Fatal: Encountered invalid pose tensor.")
+            with torch.no_grad():
+                for k, p in enumerate(pose_cpu):
+                    p.data.copy_(pose_dev[k].detach().to(p.device))
+            sigma = self._model.nerf_model._model_sigma.params
+            if sigma.grad is not None and os_.freeze_sigma_mlp:
+                sigma.grad = None
+            losses_log.append(loss_host.tolist())
+            depth_eps_log.append(eps_log.cpu().tolist())
+            self._depth_eps = depth_eps_log[-1][-1] if n_it else None
+            self.last_stats = {"n_valid_rays": int(valid_log.sum().item()), "iterations": n_it,
+                               "loss_terms": loss_log.detach().cpu()}
+
+        if self._settings.debug.log_losses:
+            for name, logs in (("losses", losses_log), ("depth_eps", depth_eps_log)):
+                d = f"{self._settings.log_directory}/{name}/keyframe_{self._keyframe_count}"
+                os.makedirs(d, exist_ok=True)
+                for i, log in enumerate(logs):
+                    with open(f"{d}/phase_{i}.csv", 'w+') as f:
+                        f.write("\n".join(str(v) for v in log))
+        return None
+
+    # -------------------------------------------------------------------------------------------
+    def _draw_indices(self, kf, count):
+        n = len(kf.get_lidar_scan())
+        strat = self._settings.rays_selection.strategy
+        if strat == 'RANDOM':
+            if self._draws is not None:
+                return self._draws.ray_index(n, count).to(self._device)
+            return (torch.rand(count, device=self._device) * n).long().clamp_(max=n - 1)
+        if strat == 'MASK':
+            mask_index_map = kf.get_lidar_scan().mask.nonzero(as_tuple=True)[0].to(self._device)
+            pick = torch.randint(len(mask_index_map), (count,)).to(self._device)
+            return mask_index_map[pick]
+        if strat == 'FIXED':
+            return torch.arange(count, device=self._device)
+        raise RuntimeError(f"Can't find rays_selection strategy: {strat}")
+
+    def _build_window_rays(self, active, pose_dev):
+        """optimizer.py:285-340 on the device: per keyframe index draw, ray build; then one compaction."""
+        dev = self._device
+        T = tensor_to_transform(pose_dev)                        # [K,4,4], differentiable w.r.t. pose_dev
+        T12 = T[:, :3, :4].reshape(len(active), 12)
+        T12_c = T12.detach().contiguous()
+        n_lidar = self._num_lidar_samples
+        n_sky = self._settings.num_samples.sky if self._enable_sky_segmentation else 0
+        segs, seg_dirs, seg_is_sky, seg_kf = [], [], [], []
+        rays_l, depth_l, keep_l, idx_l = [], [], [], []
+        rr = [float(self._ray_range[0]), float(self._ray_range[1])]
+        for k, kf in enumerate(active):
+            scan = kf.get_lidar_scan()
+            dirs, dist = device_scan(scan, dev)
+            idx = self._draw_indices(kf, n_lidar)
+            sky_dirs = scan.sky_rays
+            sky_idx = None
+            if n_sky > 0 and sky_dirs is not None and sky_dirs.nelement() > 0:
+                if self._draws is not None:
+                    sky_idx = self._draws.sky_index(sky_dirs.shape[1], n_sky).to(dev)
+                else:
+                    sky_idx = (torch.rand(n_sky, device=dev) * sky_dirs.shape[1]).long().clamp_(max=sky_dirs.shape[1] - 1)
+            r, d, kp = ops.build_lidar_rays(dirs, dist, idx, T12_c[k], rr, self._scale_f, self._shift_f)
+            rays_l.append(r); depth_l.append(d); keep_l.append(kp); idx_l.append(idx)
+            segs.append(idx.shape[0]); seg_dirs.append(dirs); seg_is_sky.append(False); seg_kf.append(k)
+            if sky_idx is not None:
+                sdirs = sky_dirs.detach().to(dev, torch.float32).contiguous()
+                sdist = torch.full((sdirs.shape[1],), rr[1] + 1.0, device=dev)
+                r, d, kp = ops.build_lidar_rays(sdirs, sdist, sky_idx, T12_c[k], rr, self._scale_f, self._shift_f)
+                rays_l.append(r); depth_l.append(d); keep_l.append(kp); idx_l.append(sky_idx)
+                segs.append(sky_idx.shape[0]); seg_dirs.append(sdirs); seg_is_sky.append(True); seg_kf.append(k)
+        seg_start = [0]
+        for s in segs:
+            seg_start.append(seg_start[-1] + s)
+        rays, depths, src, out_seg, n_dev = ops.compact_rays(torch.cat(rays_l), torch.cat(depth_l), torch.cat(keep_l),
+                                                             torch.cat(idx_l), seg_start)
+        return dict(rays=rays, depths=depths, src=src, seg_start=out_seg, n_dev=n_dev, T12=T12, T12_c=T12_c,
+                    seg_dirs=seg_dirs, seg_is_sky=seg_is_sky, seg_kf=seg_kf)
+
+    def _pose_backward(self, batch, d_rays, pose_dev, free_rows):
+        """dL/drays -> dL/d[R|t] per keyframe (HIP) -> dL/dpose6 (torch autograd through tensor_to_transform)."""
+        K = pose_dev.shape[0]
+        seg_T = batch["T12_c"][torch.tensor(batch["seg_kf"], device=self._device)]
+        dT_seg = ops.lidar_rays_backward(d_rays, batch["rays"], batch["src"], batch["seg_start"], batch["seg_dirs"], seg_T,
+                                         self._scale_f)
+        dT = torch.zeros(K, 12, device=self._device)
+        for s, (k, sky) in enumerate(zip(batch["seg_kf"], batch["seg_is_sky"])):
+            if not sky:                      # sky rays are built from a detached pose (keyframe.py:93)
+                dT[k] += dT_seg[s]
+        (g,) = torch.autograd.grad(batch["T12"], pose_dev, dT)
+        g = g * free_rows[:, None].to(g.dtype)
+        pose_dev.grad = g if pose_dev.grad is None else pose_dev.grad + g
+
+    # -------------------------------------------------------------------------------------------
+    def _loss_config(self, iteration_idx) -> hip.LossConfig:
+        lc = self._model_config.loss
+        cfg = hip.LossConfig()
+        if lc.loss_selection not in hip.LOSS_SELECTIONS:
+            raise ValueError(f"Can't use unknown Loss {lc.loss_selection}")
+        cfg.selection = hip.LOSS_SELECTIONS[lc.loss_selection]
+        cfg.min_js, cfg.max_js, cfg.js_alpha = lc.JS_loss.min_js_score, lc.JS_loss.max_js_score, lc.JS_loss.alpha
+        if lc.decay_los_lambda:
+            cfg.los_lambda = max(lc.los_lambda * (lc.los_lambda_decay_rate ** ((self._global_step + 1) / lc.los_lambda_decay_steps)),
+                                 lc.min_los_lambda)
+        else:
+            cfg.los_lambda = lc.los_lambda
+        cfg.depth_lambda = lc.depthloss_lambda
+        cfg.min_eps = lc.min_depth_eps
+        if lc.decay_depth_eps:
+            cfg.fixed_eps = max(lc.depth_eps * (lc.depth_eps_decay_rate ** (iteration_idx / lc.depth_eps_decay_steps)), lc.min_depth_eps)
+        else:
+            cfg.fixed_eps = lc.depth_eps
+        return cfg
+
+    def _loss_and_grads(self, rays, depths, params, iteration_idx, want_ray_grads, want_param_grads, n_rays_dev=None,
+                        loss_out=None, accumulate_into_param_grad=False, draws=None):
+        """sample -> density -> fused render+loss(+backward) -> density backward.  rays [N,13], depths [N] on device."""
+        draws = draws if draws is not None else self._draws
+        render = self._model_config.model.render
+        S, perturb, noise_std = render.N_samples_train, render.perturb, float(render.raw_noise_std)
+        spec = self._model.nerf_model._model_sigma.spec
+        dev = self._device
+        n = rays.shape[0]
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if draws is None else 0
+        u1 = u2 = noise = None
+        ogm = self._settings.samples_selection.strategy == 'OGM'
+        if draws is not None:
+            if perturb > 0:
+                u1 = draws.jitter(n, S // 2 if ogm else S).to(dev)
+            if ogm:
+                u2 = draws.pdf(n, S // 2).to(dev)
+        if ogm:
+            z = ops.sample_rays_occ(rays, self._occupancy_grid.detach(), S, perturb, u_jitter=u1, u_pdf=u2, seed=seed,
+                                    n_rays_dev=n_rays_dev)
+        else:
+            z = ops.sample_rays_uniform(rays, S, perturb, u_jitter=u1, seed=seed, n_rays_dev=n_rays_dev)
+        if draws is not None and noise_std > 0:
+            noise = (draws.noise(n, S) * noise_std).to(dev)
+        counts = ops.count_opaque(rays, depths, n_rays_dev=n_rays_dev)
+        if self._dist is not None:
+            self._dist.all_reduce_counts(counts)
+        p = params.detach()
+        sigma = ops.density_forward(spec, p, rays=rays, z=z, n_rays_dev=n_rays_dev)
+        loss, d_sigma, d_rays, stats, _ = ops.los_loss_fused(sigma, z, rays, depths, self._scale_f, self._loss_config(iteration_idx),
+                                                            counts, noise=noise, noise_std=noise_std, seed=seed + 1,
+                                                            n_rays_dev=n_rays_dev, want_stats=True, loss_out=loss_out)
+        grad_params = None
+        if want_param_grads or want_ray_grads:
+            if accumulate_into_param_grad and want_param_grads:
+                if params.grad is None:
+                    params.grad = torch.zeros_like(params)
+                grad_params = params.grad
+            else:
+                grad_params = torch.zeros_like(p)
+            d_pts = ops.density_backward(spec, p, d_sigma, grad_params, rays=rays, z=z, n_rays_dev=n_rays_dev,
+                                         want_d_pts=want_ray_grads)
+            if want_ray_grads:
+                ops.points_grad_to_rays(d_pts, z, d_rays, n_rays_dev=n_rays_dev)
+            if self._dist is not None and want_param_grads:
+                self._dist.all_reduce_grads(grad_params)
+        self._results_lidar = {"rays": rays, "depths": depths, "samples_fine": z, "n_rays_dev": n_rays_dev, "stats": stats}
+        mean_eps = stats[:, 6].sum() / counts[0].clamp(min=1).float()
+        return dict(loss=loss, d_rays=d_rays if want_ray_grads else None,
+                    grad_params=grad_params if want_param_grads else None, stats=stats, z=z, mean_eps=mean_eps.reshape(1))
+
+    def compute_loss(self, camera_samples: Tuple[torch.Tensor, torch.Tensor], lidar_samples: Tuple[torch.Tensor, torch.Tensor],
+                     iteration_idx: int, override_enables: bool = False, tracking=False) -> torch.Tensor:
+        """Differentiable lidar loss for (rays [N,13], depths [N]) - optimizer.py:437-595.  The returned scalar
+        back-propagates into the density parameters and into `rays` (hence into keyframe poses)."""
+        if not ((override_enables or self.should_enable_lidar()) and lidar_samples is not None):
+            print("Warning: zero loss")
+            return torch.zeros((), device=self._device)
+        rays, depths = lidar_samples
+        rays = rays.reshape(-1, rays.shape[-1])
+        depths = depths.reshape(-1).to(self._device).float().contiguous()
+        params = self._model.nerf_model._model_sigma.params
+        rays_dev = rays if rays.device == self._device else rays.to(self._device)
+        loss = _LidarLossFn.apply(rays_dev, params, self, depths, iteration_idx)
+        stats = self._results_lidar["stats"]
+        self._results_lidar.update(depth_fine=stats[:, 0], opacity_fine=stats[:, 1], variance=stats[:, 2])
+        self._depth_eps = float(stats[:, 6].mean().item())
+        assert not torch.isnan(loss), "NaN Loss Encountered"
+        return loss
+
+    # -------------------------------------------------------------------------------------------
+    def _step_occupancy_grid(self):
+        """optimizer.py:598-609; must follow a loss evaluation (uses its rays / samples / depths)."""
+        res = self._results_lidar
+        if res is None:
+            raise RuntimeError("_step_occupancy_grid called before compute_loss")
+        occ = self._model_config.model.occ_model
+        grid = self._occupancy_grid_model.occupancy_grid
+        if self._dist is not None:
+            if self._grad_buf is None:
+                self._grad_buf = torch.zeros_like(grid.data)
+            ops.occ_grid_step(grid.data, res["rays"], res["samples_fine"], res["depths"], self._scale_f, occ.lr,
+                              grad_buf=self._grad_buf, n_rays_dev=res["n_rays_dev"])
+            self._dist.all_reduce_grads(self._grad_buf)
+            ops.occ_grid_apply(grid.data, self._grad_buf, occ.lr, zero_grad=True)
+        else:
+            ops.occ_grid_step(grid.data, res["rays"], res["samples_fine"], res["depths"], self._scale_f, occ.lr,
+                              n_rays_dev=res["n_rays_dev"])
+        self._occupancy_grid = self._occupancy_grid_model()
+        self._ray_sampler.update_occ_grid(self._occupancy_grid.detach())
+
+    def calculate_KL_divergence(self, mean1, std1, mean2, std2):
+        var1, var2 = std1 * std1, std2 * std2
+        return torch.log(std2 / std1) + (var1 + (mean1 - mean2) ** 2) / (2 * var2) - 0.5
+
+    def calculate_JS_divergence(self, mean1, std1, mean2, std2):
+        mean_m = 0.5 * (mean1 + mean2)
+        std_m = 0.5 * torch.sqrt(std1 ** 2 + std2 ** 2)
+        return 0.5 * self.calculate_KL_divergence(mean1, std1, mean_m, std_m) + \
+            0.5 * self.calculate_KL_divergence(mean2, std2, mean_m, std_m)

@@ -1,0 +1,303 @@
+"""Tensor-level wrappers around the C ABI (one Python function per entry point).
+
+Every function takes/returns torch tensors that live on the HIP device, allocates outputs with
+torch, and enqueues the kernel on torch's current stream.  No function here computes anything
+itself - the arithmetic is in libloner_hip.so.
+"""
+import ctypes as C
+
+import torch
+
+from . import hip
+from .hip import _ptr, _stream, check, load, require_device
+
+_steps_cache = {}
+
+
+def linspace_table(count: int, device) -> torch.Tensor:
+    """torch.linspace(0,1,count) on `device` (ray_sampling.py:27,59); cached."""
+    key = (count, str(device))
+    t = _steps_cache.get(key)
+    if t is None:
+        t = torch.linspace(0, 1, count).to(device)
+        _steps_cache[key] = t
+    return t
+
+
+def _f32c(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+# ---------------------------------------------------------------- density network
+def density_forward(spec, params, pts=None, rays=None, z=None, n_rays_dev=None):
+    require_device(params, pts, rays, z)
+    params = _f32c(params)
+    if pts is not None:
+        pts = _f32c(pts).reshape(-1, 3)
+        n = pts.shape[0]
+        sigma = torch.empty(n, device=params.device, dtype=torch.float32)
+        check(load().lnr_density_forward(C.byref(spec), _ptr(params), _ptr(pts), n, None, None, 0, 0, None,
+                                         _ptr(sigma), _stream()), "lnr_density_forward")
+        return sigma
+    rays, z = _f32c(rays), _f32c(z)
+    n, s = z.shape
+    sigma = torch.zeros(n, s, device=params.device, dtype=torch.float32) if n_rays_dev is not None \
+        else torch.empty(n, s, device=params.device, dtype=torch.float32)
+    check(load().lnr_density_forward(C.byref(spec), _ptr(params), None, 0, _ptr(rays), _ptr(z), n, s,
+                                     _ptr(n_rays_dev), _ptr(sigma), _stream()), "lnr_density_forward")
+    return sigma
+
+
+_workspaces = {}
+
+
+def _workspace(spec, device):
+    need = load().lnr_density_backward_workspace(C.byref(spec))
+    key = str(device)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty((need + 3) // 4, device=device, dtype=torch.float32)
+        _workspaces[key] = ws
+    return ws, need
+
+
+def density_backward(spec, params, d_sigma, grad_params, pts=None, rays=None, z=None, n_rays_dev=None,
+                     want_d_pts=False):
+    """Accumulates into grad_params [n_params]; returns d_pts ([...,3]) or None."""
+    require_device(params, d_sigma, grad_params, pts, rays, z)
+    params, d_sigma = _f32c(params), _f32c(d_sigma)
+    assert grad_params.dtype == torch.float32 and grad_params.is_contiguous()
+    ws, need = _workspace(spec, params.device)
+    if pts is not None:
+        pts = _f32c(pts).reshape(-1, 3)
+        n = pts.shape[0]
+        d_pts = torch.empty(n, 3, device=params.device, dtype=torch.float32) if want_d_pts else None
+        check(load().lnr_density_backward(C.byref(spec), _ptr(params), _ptr(pts), n, None, None, 0, 0, None,
+                                          _ptr(d_sigma), _ptr(grad_params), _ptr(d_pts), _ptr(ws), need, _stream()),
+              "lnr_density_backward")
+        return d_pts
+    rays, z = _f32c(rays), _f32c(z)
+    n, s = z.shape
+    d_pts = torch.zeros(n, s, 3, device=params.device, dtype=torch.float32) if want_d_pts else None
+    check(load().lnr_density_backward(C.byref(spec), _ptr(params), None, 0, _ptr(rays), _ptr(z), n, s,
+                                      _ptr(n_rays_dev), _ptr(d_sigma), _ptr(grad_params), _ptr(d_pts), _ptr(ws), need,
+                                      _stream()), "lnr_density_backward")
+    return d_pts
+
+
+# ---------------------------------------------------------------- rays
+def build_lidar_rays(directions, distances, index, transform12, ray_range, scale, shift):
+    """-> (rays [m,13], depths [m], keep [m] uint8) for ALL candidates."""
+    require_device(directions, distances, index, transform12)
+    directions, distances, transform12 = _f32c(directions), _f32c(distances), _f32c(transform12)
+    index = index.to(torch.int64).contiguous()
+    m = index.shape[0]
+    dev = directions.device
+    rays = torch.empty(m, hip.RAY_STRIDE, device=dev, dtype=torch.float32)
+    depths = torch.empty(m, device=dev, dtype=torch.float32)
+    keep = torch.empty(m, device=dev, dtype=torch.uint8)
+    sh = (C.c_float * 3)(float(shift[0]), float(shift[1]), float(shift[2]))
+    check(load().lnr_build_lidar_rays(_ptr(directions), _ptr(distances), directions.shape[1], _ptr(index), m,
+                                      _ptr(transform12), float(ray_range[0]), float(ray_range[1]), float(scale), sh,
+                                      _ptr(rays), _ptr(depths), _ptr(keep), _stream()), "lnr_build_lidar_rays")
+    return rays, depths, keep
+
+
+def compact_rays(rays, depths, keep, src_index, seg_start):
+    """seg_start: python list [n_seg+1].  -> (rays_out [cap,13], depths_out, src_out, out_seg_start dev int32
+    [n_seg+1], n_out dev int32 [1]); only the first n_out rows are meaningful."""
+    require_device(rays, depths, keep, src_index)
+    n_in = rays.shape[0]
+    dev = rays.device
+    n_seg = len(seg_start) - 1
+    rays_out = torch.zeros_like(rays)
+    depths_out = torch.zeros_like(depths)
+    src_out = torch.zeros_like(src_index) if src_index is not None else None
+    out_seg = torch.zeros(n_seg + 1, device=dev, dtype=torch.int32)
+    n_out = torch.zeros(1, device=dev, dtype=torch.int32)
+    seg = (C.c_int32 * (n_seg + 1))(*[int(v) for v in seg_start])
+    check(load().lnr_compact_rays(_ptr(rays), _ptr(depths), _ptr(keep), _ptr(src_index), n_in, seg, n_seg,
+                                  _ptr(rays_out), _ptr(depths_out), _ptr(src_out), _ptr(out_seg), _ptr(n_out), _stream()),
+          "lnr_compact_rays")
+    return rays_out, depths_out, src_out, out_seg, n_out
+
+
+def lidar_rays_backward(d_rays, rays, src_index, seg_start_dev, directions_list, transforms, scale):
+    """-> d_transform [n_seg, 12]"""
+    require_device(d_rays, rays, src_index, seg_start_dev, transforms)
+    n_seg = len(directions_list)
+    dev = rays.device
+    out = torch.zeros(n_seg, 12, device=dev, dtype=torch.float32)
+    ptrs = (C.c_void_p * n_seg)(*[d.data_ptr() for d in directions_list])
+    npts = (C.c_int64 * n_seg)(*[int(d.shape[1]) for d in directions_list])
+    check(load().lnr_lidar_rays_backward(_ptr(_f32c(d_rays)), _ptr(rays), _ptr(src_index), _ptr(seg_start_dev), n_seg, ptrs,
+                                         npts, _ptr(_f32c(transforms)), float(scale), _ptr(out), _stream()),
+          "lnr_lidar_rays_backward")
+    return out
+
+
+# ---------------------------------------------------------------- samplers
+def occ_interpolate(grid, pts):
+    require_device(grid, pts)
+    v = grid.shape[-1]
+    g = _f32c(grid).reshape(v, v, v)
+    p = _f32c(pts)
+    out = torch.empty(p.shape[:-1], device=p.device, dtype=torch.float32)
+    check(load().lnr_occ_interpolate(_ptr(g), v, _ptr(p), out.numel(), _ptr(out), _stream()), "lnr_occ_interpolate")
+    return out
+
+
+def sample_rays_occ(rays, grid, n_samples, perturb, u_jitter=None, u_pdf=None, seed=0, n_rays_dev=None, debug=False):
+    require_device(rays, grid, u_jitter, u_pdf)
+    rays = _f32c(rays)
+    v = grid.shape[-1]
+    g = _f32c(grid).reshape(v, v, v)
+    n = rays.shape[0]
+    h = n_samples // 2
+    steps = linspace_table(h, rays.device)
+    z = torch.zeros(n, n_samples, device=rays.device, dtype=torch.float32)
+    inds = probs = cdf = None
+    if debug:
+        inds = torch.zeros(n, h, device=rays.device, dtype=torch.int64)
+        probs = torch.zeros(n, h, device=rays.device, dtype=torch.float32)
+        cdf = torch.zeros(n, h - 1, device=rays.device, dtype=torch.float32)
+    check(load().lnr_sample_rays_occ(_ptr(rays), n, _ptr(n_rays_dev), _ptr(g), v, n_samples, float(perturb), _ptr(steps),
+                                     _ptr(_f32c(u_jitter)), _ptr(_f32c(u_pdf)), int(seed) & (2 ** 64 - 1), _ptr(z),
+                                     _ptr(inds), _ptr(probs), _ptr(cdf), _stream()), "lnr_sample_rays_occ")
+    if debug:
+        return z, dict(inds=inds, probs=probs, cdf=cdf)
+    return z
+
+
+def sample_rays_uniform(rays, n_samples, perturb, u_jitter=None, seed=0, n_rays_dev=None):
+    require_device(rays, u_jitter)
+    rays = _f32c(rays)
+    n = rays.shape[0]
+    steps = linspace_table(n_samples, rays.device)
+    z = torch.zeros(n, n_samples, device=rays.device, dtype=torch.float32)
+    check(load().lnr_sample_rays_uniform(_ptr(rays), n, _ptr(n_rays_dev), n_samples, float(perturb), _ptr(steps),
+                                         _ptr(_f32c(u_jitter)), int(seed) & (2 ** 64 - 1), _ptr(z), _stream()),
+          "lnr_sample_rays_uniform")
+    return z
+
+
+# ---------------------------------------------------------------- rendering
+def render_forward(sigma, z, rays, noise=None, noise_std=0.0, seed=0, n_rays_dev=None):
+    require_device(sigma, z, rays, noise)
+    sigma, z, rays = _f32c(sigma), _f32c(z), _f32c(rays)
+    n, s = z.shape
+    dev = z.device
+    depth = torch.zeros(n, device=dev); opacity = torch.zeros(n, device=dev); variance = torch.zeros(n, device=dev)
+    weights = torch.zeros(n, s, device=dev)
+    check(load().lnr_render_forward(_ptr(sigma), _ptr(z), _ptr(rays), n, _ptr(n_rays_dev), s, _ptr(_f32c(noise)),
+                                    float(noise_std), int(seed), _ptr(depth), _ptr(weights), _ptr(opacity), _ptr(variance),
+                                    _stream()), "lnr_render_forward")
+    return depth, weights, opacity, variance
+
+
+def render_backward(sigma, z, rays, g_depth, g_weights, g_opacity, g_variance, noise=None, noise_std=0.0, seed=0,
+                    n_rays_dev=None):
+    require_device(sigma, z, rays)
+    sigma, z, rays = _f32c(sigma), _f32c(z), _f32c(rays)
+    n, s = z.shape
+    d_sigma = torch.zeros(n, s, device=z.device)
+    d_rays = torch.zeros(n, hip.RAY_STRIDE, device=z.device)
+    check(load().lnr_render_backward(_ptr(sigma), _ptr(z), _ptr(rays), n, _ptr(n_rays_dev), s, _ptr(_f32c(noise)),
+                                     float(noise_std), int(seed), _ptr(_f32c(g_depth)), _ptr(_f32c(g_weights)),
+                                     _ptr(_f32c(g_opacity)), _ptr(_f32c(g_variance)), _ptr(d_sigma), _ptr(d_rays), _stream()),
+          "lnr_render_backward")
+    return d_sigma, d_rays
+
+
+def points_grad_to_rays(d_pts, z, d_rays, n_rays_dev=None):
+    require_device(d_pts, z, d_rays)
+    n, s = z.shape
+    check(load().lnr_points_grad_to_rays(_ptr(_f32c(d_pts)), _ptr(_f32c(z)), n, _ptr(n_rays_dev), s, _ptr(d_rays), _stream()),
+          "lnr_points_grad_to_rays")
+    return d_rays
+
+
+# ---------------------------------------------------------------- loss pieces
+def weights_gt(s, g, eps, normalise=True):
+    require_device(s, g)
+    s = _f32c(s)
+    n, k = s.shape
+    g = _f32c(g).reshape(-1)
+    out = torch.empty_like(s)
+    if isinstance(eps, torch.Tensor):
+        require_device(eps)
+        e = _f32c(eps).reshape(-1)
+        check(load().lnr_weights_gt(_ptr(s), _ptr(g), _ptr(e), 0.0, int(normalise), n, k, _ptr(out), _stream()), "lnr_weights_gt")
+    else:
+        check(load().lnr_weights_gt(_ptr(s), _ptr(g), None, float(eps), int(normalise), n, k, _ptr(out), _stream()), "lnr_weights_gt")
+    return out
+
+
+def logits_grad(s, g, margin=2.0, l_free=0.25, l_occ=2.5):
+    require_device(s, g)
+    s = _f32c(s)
+    n, k = s.shape
+    out = torch.empty_like(s)
+    check(load().lnr_logits_grad(_ptr(s), _ptr(_f32c(g).reshape(-1)), n, k, float(margin), float(l_free), float(l_occ),
+                                 _ptr(out), _stream()), "lnr_logits_grad")
+    return out
+
+
+def count_opaque(rays, depth_gt, n_rays_dev=None):
+    require_device(rays, depth_gt)
+    counts = torch.zeros(2, device=rays.device, dtype=torch.int32)
+    check(load().lnr_count_opaque(_ptr(_f32c(rays)), _ptr(_f32c(depth_gt)), rays.shape[0], _ptr(n_rays_dev), _ptr(counts),
+                                  _stream()), "lnr_count_opaque")
+    return counts
+
+
+def los_loss_fused(sigma, z, rays, depth_gt, scale, cfg: hip.LossConfig, counts, noise=None, noise_std=0.0, seed=0,
+                   n_rays_dev=None, want_stats=False, want_weights=False, loss_out=None):
+    require_device(sigma, z, rays, depth_gt, counts, noise)
+    sigma, z, rays, depth_gt = _f32c(sigma), _f32c(z), _f32c(rays), _f32c(depth_gt)
+    n, s = z.shape
+    dev = z.device
+    if loss_out is None:
+        loss_out = torch.zeros(4, device=dev)
+    d_sigma = torch.zeros(n, s, device=dev)
+    d_rays = torch.zeros(n, hip.RAY_STRIDE, device=dev)
+    stats = torch.zeros(n, 8, device=dev) if want_stats else None
+    w = torch.zeros(n, s, device=dev) if want_weights else None
+    check(load().lnr_los_loss_fused(_ptr(sigma), _ptr(z), _ptr(rays), _ptr(depth_gt), n, _ptr(n_rays_dev), s,
+                                    _ptr(_f32c(noise)), float(noise_std), int(seed), float(scale), C.byref(cfg), _ptr(counts),
+                                    _ptr(loss_out), _ptr(d_sigma), _ptr(d_rays), _ptr(stats), _ptr(w), _stream()),
+          "lnr_los_loss_fused")
+    return loss_out, d_sigma, d_rays, stats, w
+
+
+# ---------------------------------------------------------------- optimisers
+def adam_step(params, grads, exp_avg, exp_avg_sq, lr, step, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, zero_grad=True):
+    require_device(params, grads, exp_avg, exp_avg_sq)
+    check(load().lnr_adam_step(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), params.numel(), float(lr),
+                               float(betas[0]), float(betas[1]), float(eps), int(step), float(grad_scale), int(zero_grad),
+                               _stream()), "lnr_adam_step")
+
+
+def occ_grid_step(grid, rays, z, depth_gt, scale, lr, margin=2.0, l_free=0.25, l_occ=2.5, grad_buf=None, n_rays_dev=None):
+    require_device(grid, rays, z, depth_gt, grad_buf)
+    v = grid.shape[-1]
+    n, s = z.shape
+    check(load().lnr_occ_grid_step(_ptr(grid), v, _ptr(_f32c(rays)), _ptr(_f32c(z)), _ptr(_f32c(depth_gt)), n, _ptr(n_rays_dev),
+                                   s, float(scale), float(lr), float(margin), float(l_free), float(l_occ), _ptr(grad_buf),
+                                   _stream()), "lnr_occ_grid_step")
+
+
+def occ_grid_apply(grid, grad_buf, lr, zero_grad=True):
+    require_device(grid, grad_buf)
+    check(load().lnr_occ_grid_apply(_ptr(grid), _ptr(grad_buf), grid.numel(), float(lr), int(zero_grad), _stream()),
+          "lnr_occ_grid_apply")
+
+
+def selftest_mfma(device="cuda"):
+    out = torch.full((1,), -1.0, device=device)
+    check(load().lnr_selftest_mfma(_ptr(out), _stream()), "lnr_selftest_mfma")
+    return float(out.item())

@@ -81,7 +81,8 @@ def lidar_loss(rendered: dict, z: torch.Tensor, rays: torch.Tensor, depth_gt: to
     js = gaussian_js(g, cfg.min_eps / 3.0, mean[:, None], std[:, None]).reshape(-1)
 
     depth_m = rendered["depth"][:, None] * scale
-    loss = cfg.depth_lambda * torch.nn.functional.mse_loss(depth_m[opaque, 0], g[opaque, 0])
+    term_depth = cfg.depth_lambda * torch.nn.functional.mse_loss(depth_m[opaque, 0], g[opaque, 0])
+    loss = term_depth
 
     if cfg.selection in ("L1_JS", "L2_JS"):
         score = js.detach().clone()
@@ -103,9 +104,11 @@ def lidar_loss(rendered: dict, z: torch.Tensor, rays: torch.Tensor, depth_gt: to
         los = torch.nn.functional.l1_loss(w, target)
     else:
         los = torch.nn.functional.mse_loss(w, target)
-    loss = loss + cfg.los_lambda * los
-    loss = loss + torch.abs(rendered["opacity"][opaque] - 1).mean()
-    aux = dict(opaque=opaque, mean=mean.detach(), std=std.detach(), js=js.detach(),
+    term_los = cfg.los_lambda * los
+    term_opacity = torch.abs(rendered["opacity"][opaque] - 1).mean()
+    loss = loss + term_los
+    loss = loss + term_opacity
+    aux = dict(terms=(term_depth, term_los, term_opacity), opaque=opaque, mean=mean.detach(), std=std.detach(), js=js.detach(),
                eps=eps if isinstance(eps, float) else eps.detach(), target=target.detach(),
                depth_eps=depth_eps)
     return loss, aux

@@ -1,0 +1,397 @@
+"""HIP kernels vs the CPU oracle and the golden fixtures - needs an MI355X (pytest -m gpu).
+
+Every test calls the product through the C ABI (loner_amd.ops -> ctypes -> libloner_hip.so) and uses
+oracle/ only as the checker.  Integer / rounding-defined stages are asserted bit-exact; floating point
+stages to the tolerance written next to each assert (north_star: 1e-4 relative on depth outputs).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import loss as OL
+from oracle import mapping_step as MS
+from oracle import network as NW
+from oracle import occupancy as OC
+from oracle import poses as OP
+from oracle import rays as OR
+from oracle import render as ORD
+from oracle import sampling as SP
+
+DEV = "cuda"
+
+
+def dv(x, dtype=torch.float32):
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(x)
+    return x.to(DEV, dtype).contiguous()
+
+
+def rel(a, b):
+    a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, np.float64)
+    b = b.detach().cpu().double().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from loner_amd import ops as _ops
+    from loner_amd import hip
+    hip.load()
+    return _ops
+
+
+# ------------------------------------------------------------------------------------------- basics
+def test_mfma_fragment_layout(ops):
+    assert ops.selftest_mfma(DEV) == 0.0
+
+
+def test_library_refuses_cpu_tensors(ops):
+    from loner_amd import hip
+    spec = hip.make_net_spec(dict(otype="Frequency", n_frequencies=4), dict(n_neurons=16, n_hidden_layers=1))
+    with pytest.raises(RuntimeError):
+        ops.density_forward(spec, torch.zeros(int(spec.n_params)), pts=torch.zeros(4, 3))
+
+
+# ------------------------------------------------------------------------------------------- rays
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_build_lidar_rays_matches_golden_and_oracle(ops, golden, i):
+    g = golden("g1_rays")
+    dirs, dist = dv(g[f"dirs_g{i}"]), dv(g[f"dist_g{i}"])
+    n = dirs.shape[1]
+    T = torch.from_numpy(g[f"T{i}"])
+    idx = torch.arange(n, device=DEV)
+    rays, depths, keep = ops.build_lidar_rays(dirs, dist, idx, dv(T[:3, :4].reshape(12)), g["ray_range"], float(g["scale"]), g["shift"])
+    # all candidates vs the reference's ignore_world_cube=True output, kept subset vs its default output
+    assert rel(rays, g[f"rays_all{i}"]) < 1e-6
+    k = keep.bool().cpu()
+    assert int(k.sum()) == g[f"rays{i}"].shape[0]                 # same rays dropped
+    assert rel(rays.cpu()[k], g[f"rays{i}"]) < 1e-6
+    assert np.array_equal(depths.cpu()[k].numpy(), g[f"depths{i}"])  # bit-exact (a single IEEE division)
+    # backward: dL/d[R|t] against torch autograd through the oracle
+    Tt = T.clone().requires_grad_(True)
+    r_o, _, keep_o = OR.lidar_ray_records(torch.from_numpy(g[f"dirs_g{i}"]), torch.from_numpy(g[f"dist_g{i}"]), torch.arange(n), Tt,
+                                          torch.from_numpy(g["ray_range"]), torch.tensor(float(g["scale"])), torch.from_numpy(g["shift"]),
+                                          keep_all=True)
+    cot = torch.randn(n, 13, generator=torch.Generator().manual_seed(i))
+    (r_o * cot).sum().backward()
+    seg = torch.tensor([0, n], device=DEV, dtype=torch.int32)
+    dT = ops.lidar_rays_backward(dv(cot), rays, idx, seg, [dirs], dv(T[:3, :4].reshape(1, 12)), float(g["scale"]))
+    assert rel(dT.reshape(3, 4), Tt.grad[:3, :4]) < 2e-4
+
+
+def test_compact_rays_preserves_order_and_segments(ops):
+    gen = torch.Generator().manual_seed(3)
+    n = 3000
+    rays = torch.randn(n, 13, generator=gen)
+    depths = torch.rand(n, generator=gen)
+    keep = (torch.rand(n, generator=gen) > 0.3).to(torch.uint8)
+    src = torch.randint(0, 65536, (n,), generator=gen)
+    seg = [0, 700, 700, 1900, 3000]                      # includes an empty segment
+    r, d, s, out_seg, n_out = ops.compact_rays(dv(rays), dv(depths), keep.to(DEV), src.to(DEV), seg)
+    k = keep.bool()
+    m = int(k.sum())
+    assert int(n_out.item()) == m
+    assert torch.equal(r.cpu()[:m], rays[k]) and torch.equal(d.cpu()[:m], depths[k]) and torch.equal(s.cpu()[:m], src[k])
+    expect = [int(k[:b].sum()) for b in seg]
+    assert out_seg.cpu().tolist() == expect
+
+
+# ------------------------------------------------------------------------------------------- occupancy / samplers
+def test_occ_interpolate_bit_exact(ops, golden):
+    g = golden("g2_occ_lookup")
+    out = ops.occ_interpolate(dv(g["grid"]), dv(g["pts"]))
+    assert np.array_equal(out.cpu().numpy(), g["out"])
+
+
+@pytest.mark.parametrize("S", [128, 512])
+def test_occ_sampler_zero_grid_bit_identical_to_reference(ops, golden, S):
+    g = golden("g4_samplers")
+    z = ops.sample_rays_occ(dv(g["rays"]), dv(g["zero_grid"]), S, 1.0, u_jitter=dv(g[f"zero_u1_{S}"]), u_pdf=dv(g[f"zero_u2_{S}"]))
+    assert np.array_equal(z.cpu().numpy(), g[f"zero_z{S}"])
+
+
+@pytest.mark.parametrize("S", [128, 512])
+def test_occ_sampler_trained_grid_bit_identical_to_oracle(ops, golden, S):
+    g = golden("g4_samplers")
+    z, dbg = ops.sample_rays_occ(dv(g["rays"]), dv(g["trained_grid"]), S, 1.0, u_jitter=dv(g[f"trained_u1_{S}"]),
+                                 u_pdf=dv(g[f"trained_u2_{S}"]), debug=True)
+    zo, st = SP.sample_occupancy(g["rays"], g["trained_grid"], S, 1.0, g[f"trained_u1_{S}"], g[f"trained_u2_{S}"], return_stages=True)
+    assert np.array_equal(dbg["probs"].cpu().numpy(), st["probs"])            # correctly rounded sigmoid on both sides
+    assert np.array_equal(dbg["cdf"].cpu().numpy(), st["cdf"])                # cascade sum + float64 running cdf
+    assert np.array_equal(dbg["inds"].cpu().numpy(), st["inds"])              # bit-identical sample indices
+    assert np.array_equal(z.cpu().numpy(), zo)
+    # and against the reference itself: identical wherever its float32 exp happened to round correctly
+    ref_same = (st["probs"] == g[f"trained_probs{S}"]).all(axis=1)
+    assert ref_same.mean() > 0.5
+    assert np.array_equal(z.cpu().numpy()[ref_same], g[f"trained_z{S}"][ref_same])
+
+
+def test_occ_sampler_large_and_ragged_sample_counts(ops, golden):
+    g = golden("g4_samplers")
+    rays = g["rays"][:9]
+    gen = torch.Generator().manual_seed(5)
+    for S in (20, 100, 2048):                      # K<64 rows, non-power-of-two, test-time S
+        u1, u2 = torch.rand(9, S // 2, generator=gen).numpy(), torch.rand(9, S // 2, generator=gen).numpy()
+        z = ops.sample_rays_occ(dv(rays), dv(g["trained_grid"]), S, 1.0, u_jitter=dv(u1), u_pdf=dv(u2))
+        zo = SP.sample_occupancy(rays, g["trained_grid"], S, 1.0, u1, u2)
+        assert np.array_equal(z.cpu().numpy(), zo), S
+
+
+def test_uniform_sampler_bit_exact(ops, golden):
+    g = golden("g4_samplers")
+    z = ops.sample_rays_uniform(dv(g["rays"]), 128, 1.0, u_jitter=dv(g["uniform_u128"]))
+    assert np.array_equal(z.cpu().numpy(), g["uniform_z128"])
+    z = ops.sample_rays_uniform(dv(g["rays"]), 128, 0.0)
+    assert np.array_equal(z.cpu().numpy(), g["uniform_z128_det"])
+
+
+def test_samplers_internal_rng_properties(ops, golden):
+    g = golden("g4_samplers")
+    rays = dv(g["rays"])
+    z1 = ops.sample_rays_occ(rays, dv(g["trained_grid"]), 512, 1.0, seed=11)
+    z2 = ops.sample_rays_occ(rays, dv(g["trained_grid"]), 512, 1.0, seed=11)
+    z3 = ops.sample_rays_occ(rays, dv(g["trained_grid"]), 512, 1.0, seed=12)
+    assert torch.equal(z1, z2) and not torch.equal(z1, z3)
+    assert bool((z1[:, 1:] >= z1[:, :-1]).all())
+    assert bool((z1 >= rays[:, 11:12] - 1e-7).all()) and bool((z1 <= rays[:, 12:13] + 1e-7).all())
+
+
+# ------------------------------------------------------------------------------------------- density network
+NETS = {
+    "default": (dict(otype="HashGrid", n_levels=16, n_features_per_level=2, log2_hashmap_size=18, base_resolution=16),
+                dict(activation="ReLU", n_neurons=64, n_hidden_layers=1)),
+    "small_hash": (dict(otype="HashGrid", n_levels=4, n_features_per_level=2, log2_hashmap_size=12, base_resolution=8),
+                   dict(activation="ReLU", n_neurons=32, n_hidden_layers=1)),
+    "hash_f4_2hidden": (dict(otype="HashGrid", n_levels=6, n_features_per_level=4, log2_hashmap_size=14, base_resolution=4, per_level_scale=1.5),
+                        dict(activation="ReLU", n_neurons=64, n_hidden_layers=2)),
+    "hash_f1": (dict(otype="HashGrid", n_levels=10, n_features_per_level=1, log2_hashmap_size=13, base_resolution=8),
+                dict(activation="LeakyReLU", n_neurons=16, n_hidden_layers=1)),
+    "hash_f8": (dict(otype="HashGrid", n_levels=3, n_features_per_level=8, log2_hashmap_size=12, base_resolution=8),
+                dict(activation="Tanh", n_neurons=32, n_hidden_layers=1)),
+    "freq_siren": (dict(otype="Frequency", n_frequencies=8), dict(activation="Sine", n_neurons=64, n_hidden_layers=3)),
+    "freq_relu128": (dict(otype="Frequency", n_frequencies=12), dict(activation="ReLU", n_neurons=128, n_hidden_layers=2)),
+    "freq_wide256": (dict(otype="Frequency", n_frequencies=6), dict(activation="ReLU", n_neurons=256, n_hidden_layers=1)),
+}
+
+
+def _net(name, seed=0, table_gain=1.0):
+    from loner_amd import hip
+    enc, net = NETS[name]
+    spec_o = NW.NetworkSpec.from_config(enc, net)
+    spec_h = hip.make_net_spec(enc, net)
+    assert spec_o.n_params == int(spec_h.n_params) and spec_o.n_mlp_params == spec_h.n_mlp_params
+    for l, lv in enumerate(spec_o.levels):
+        assert (lv.res, lv.size, lv.offset, int(lv.hashed)) == (spec_h.level_res[l], spec_h.level_size[l], spec_h.level_offset[l], spec_h.level_hashed[l])
+        assert abs(lv.scale - spec_h.level_scale[l]) <= 2e-7 * lv.scale
+    params = NW.init_params(spec_o, seed)
+    if spec_o.n_enc_params:
+        params[spec_o.n_mlp_params:] *= table_gain
+    return spec_o, spec_h, params
+
+
+@pytest.mark.parametrize("name", list(NETS))
+def test_density_forward_matches_oracle(ops, name):
+    spec_o, spec_h, params = _net(name, table_gain=3000.0)
+    gen = torch.Generator().manual_seed(1)
+    pts = torch.rand(1000, 3, generator=gen) * 1.98 - 0.99          # 1000: not a multiple of the 16-sample tile
+    sig = ops.density_forward(spec_h, dv(params), pts=dv(pts))
+    ref64 = NW.density(spec_o, params.double(), pts.double())
+    ref32 = NW.density(spec_o, params, pts)
+    scale = float(ref64.abs().max())
+    err = float((sig.cpu().double() - ref64).abs().max()) / scale
+    err32 = float((ref32.double() - ref64).abs().max()) / scale
+    print(f"{name}: |sigma|max={scale:.3g}  hip-vs-fp64 {err:.2e}  torch-fp32-vs-fp64 {err32:.2e}")
+    assert err < 1e-5 + 4 * err32
+
+
+@pytest.mark.parametrize("name", list(NETS))
+def test_density_backward_matches_oracle_autograd(ops, name):
+    spec_o, spec_h, params = _net(name, seed=2, table_gain=3000.0)
+    gen = torch.Generator().manual_seed(4)
+    n = 777
+    pts = (torch.rand(n, 3, generator=gen) * 1.9 - 0.95)
+    d_sigma = torch.randn(n, generator=gen)
+    d_sigma[torch.rand(n, generator=gen) < 0.3] = 0.0                 # exact zeros exercise the skip paths
+    grad = torch.zeros(int(spec_h.n_params), device=DEV)
+    d_pts = ops.density_backward(spec_h, dv(params), dv(d_sigma), grad, pts=dv(pts), want_d_pts=True)
+    p64 = params.double().requires_grad_(True)
+    x64 = pts.double().requires_grad_(True)
+    (NW.density(spec_o, p64, x64) * d_sigma.double()).sum().backward()
+    e_p = rel(grad, p64.grad)
+    e_x = rel(d_pts, x64.grad)
+    print(f"{name}: dparams rel {e_p:.2e}  dpts rel {e_x:.2e}")
+    assert e_p < 2e-5
+    assert e_x < 2e-4
+    # without input gradients the parameter gradient must be the same
+    grad2 = torch.zeros_like(grad)
+    assert ops.density_backward(spec_h, dv(params), dv(d_sigma), grad2, pts=dv(pts), want_d_pts=False) is None
+    assert rel(grad2, grad) < 1e-6
+
+
+def test_density_rays_form_equals_points_form(ops, golden):
+    g = golden("g4_samplers")
+    spec_o, spec_h, params = _net("small_hash", table_gain=3000.0)
+    rays, z = dv(g["rays"]), dv(g["zero_z128"])
+    s1 = ops.density_forward(spec_h, dv(params), rays=rays, z=z)
+    pts = rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]
+    s2 = ops.density_forward(spec_h, dv(params), pts=pts.reshape(-1, 3)).reshape(z.shape)
+    assert torch.equal(s1, s2)
+
+
+# ------------------------------------------------------------------------------------------- rendering
+def test_render_forward_backward_matches_golden(ops, golden):
+    g = golden("g5_render")
+    n, S = g["z"].shape
+    rays = torch.zeros(n, 13)
+    rays[:, 3:6] = torch.from_numpy(g["dirs"]); rays[:, 12] = torch.from_numpy(g["far"])[:, 0]
+    sigma, z, noise = dv(g["sigma"]), dv(g["z"]), dv(g["noise"])
+    depth, weights, opacity, variance = ops.render_forward(sigma, z, dv(rays), noise=noise, noise_std=1.0)
+    assert rel(depth, g["depth"]) < 1e-5 and rel(weights, g["weights"]) < 1e-5
+    assert rel(opacity, g["opacity"]) < 1e-5 and rel(variance, g["variance"]) < 1e-4
+    d_sigma, d_rays = ops.render_backward(sigma, z, dv(rays), dv(g["cot_depth"]), dv(g["cot_weights"]), dv(g["cot_opacity"]),
+                                          dv(g["cot_variance"]), noise=noise, noise_std=1.0)
+    assert rel(d_sigma, g["dsigma"]) < 1e-4
+    assert rel(d_rays[:, 3:6], g["ddirs"]) < 1e-4
+    assert rel(d_rays[:, 12], g["dfar"][:, 0]) < 1e-4
+
+
+def test_render_ragged_and_long_rays_match_oracle(ops):
+    gen = torch.Generator().manual_seed(9)
+    for S in (2, 7, 100, 2048):
+        n = 10
+        z = torch.sort(torch.rand(n, S, generator=gen) * 0.5 + 0.01, dim=1).values
+        sigma = torch.randn(n, S, generator=gen) * 20
+        rays = torch.zeros(n, 13)
+        rays[:, 3:6] = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=1) * 1.1
+        rays[:, 12] = 0.6
+        out = ORD.composite(sigma.double(), z.double(), rays[:, 3:6].double(), rays[:, 12:13].double())
+        depth, weights, opacity, variance = ops.render_forward(dv(sigma), dv(z), dv(rays))
+        assert rel(depth, out["depth"]) < 1e-5 and rel(weights, out["weights"]) < 1e-5, S
+        assert rel(opacity, out["opacity"]) < 1e-5 and rel(variance, out["variance"]) < 1e-4, S
+
+
+def test_target_weights_and_logit_grad_match_golden(ops, golden):
+    g = golden("g6_targets")
+    s, gt, eps = dv(g["s"]), dv(g["g"]), dv(g["eps"])
+    assert rel(ops.weights_gt(s, gt, 1.37), g["w_float"]) < 1e-5
+    assert rel(ops.weights_gt(s, gt, eps), g["w_tensor"]) < 1e-5
+    assert rel(ops.weights_gt(s, gt, eps, normalise=False), g["w_unnorm"]) < 1e-5
+    assert np.array_equal(ops.logits_grad(s, gt).cpu().numpy(), g["logits_grad"])
+
+
+# ------------------------------------------------------------------------------------------- fused loss
+def _g8_setup(golden):
+    from loner_amd import hip
+    g = golden("g8_compute_loss")
+    enc = dict(otype="HashGrid", n_levels=4, n_features_per_level=2, log2_hashmap_size=12, base_resolution=8)
+    net = dict(activation="ReLU", n_neurons=32, n_hidden_layers=1)
+    return g, NW.NetworkSpec.from_config(enc, net), hip.make_net_spec(enc, net)
+
+
+def test_fused_loss_matches_reference_compute_loss(ops, golden):
+    """loss value, per-ray stats and every gradient of Optimizer.compute_loss (reference, G8), on the
+    reference's own sample depths (sampler parity is asserted separately)."""
+    from loner_amd import hip
+    g, spec_o, spec_h = _g8_setup(golden)
+    rays, z, depths, params = dv(g["rays"]), dv(g["z"]), dv(g["depths"]), dv(g["params"])
+    noise = dv(g["noise"])
+    counts = ops.count_opaque(rays, depths)
+    cfg = hip.LossConfig(selection=0, min_js=1.0, max_js=10.0, js_alpha=1.0, los_lambda=1000.0, depth_lambda=0.005, min_eps=0.5, fixed_eps=3.0)
+    sigma = ops.density_forward(spec_h, params, rays=rays, z=z)
+    loss, d_sigma, d_rays, stats, w = ops.los_loss_fused(sigma, z, rays, depths, float(g["scale"]), cfg, counts, noise=noise,
+                                                        noise_std=1.0, want_stats=True, want_weights=True)
+    n = rays.shape[0]
+    far0 = g["rays"][0, 12]
+    opaque = (g["depths"] > 0) & ~(g["depths"] > far0)
+    assert counts.cpu().tolist() == [n, int(opaque.sum())] and 0 < int(opaque.sum()) < n
+    assert rel(w, g["weights"]) < 1e-4
+    assert rel(stats[:, 0], g["depth"]) < 1e-4                     # north_star: depth within 1e-4 relative
+    assert rel(stats[:, 1], g["opacity"]) < 1e-4 and rel(stats[:, 2], g["variance"]) < 1e-3
+    assert abs(float(loss[0]) - float(g["loss"])) / float(g["loss"]) < 1e-4
+    assert abs(float(stats[:, 6].mean()) - float(g["depth_eps"])) < 1e-4
+    grad = torch.zeros(int(spec_h.n_params), device=DEV)
+    d_pts = ops.density_backward(spec_h, params, d_sigma, grad, rays=rays, z=z, want_d_pts=True)
+    ops.points_grad_to_rays(d_pts, z, d_rays)
+    assert rel(grad, g["dparams"]) < 2e-4
+    assert rel(d_rays, g["drays"]) < 2e-4
+    # pose tail: rays -> [R|t] (HIP) -> 6-vector (torch autograd), against the reference's pose gradients
+    from loner_amd.common.pose_utils import tensor_to_transform
+    seg, lo = [0], 0
+    dirs, srcs, poses = [], [], []
+    for k in range(2):
+        n_k = g[f"dirs{k}"].shape[1]
+        dirs.append(dv(g[f"dirs{k}"])); srcs.append(torch.arange(n_k, device=DEV))
+        poses.append(torch.from_numpy(g[f"pose{k}"]).clone().requires_grad_(True))
+        seg.append(seg[-1] + n_k)
+    assert seg[-1] == n                                                 # no ray was dropped in this fixture
+    T = torch.stack([tensor_to_transform(p)[:3, :4].reshape(12) for p in poses])
+    dT = ops.lidar_rays_backward(d_rays, rays, torch.cat(srcs), torch.tensor(seg, device=DEV, dtype=torch.int32), dirs, dv(T.detach()), float(g["scale"]))
+    T.backward(dT.cpu())
+    assert rel(poses[0].grad, g["dpose0"]) < 5e-4 and rel(poses[1].grad, g["dpose1"]) < 5e-4
+
+
+@pytest.mark.parametrize("selection", ["L2_JS", "L1_LOS", "L2_LOS"])
+def test_fused_loss_other_selections_match_oracle(ops, golden, selection):
+    from loner_amd import hip
+    g, spec_o, spec_h = _g8_setup(golden)
+    rays, z, depths, params = dv(g["rays"]), dv(g["z"]), dv(g["depths"]), dv(g["params"])
+    cfg_o = OL.LossConfig(selection=selection)
+    it = 3
+    eps_fixed = max(cfg_o.eps0 * cfg_o.eps_decay_rate ** (it / cfg_o.eps_decay_steps), cfg_o.min_eps)
+    cfg = hip.LossConfig(selection=hip.LOSS_SELECTIONS[selection], min_js=1.0, max_js=10.0, js_alpha=1.0, los_lambda=1000.0,
+                         depth_lambda=0.005, min_eps=0.5, fixed_eps=eps_fixed)
+    sigma = ops.density_forward(spec_h, params, rays=rays, z=z)
+    counts = ops.count_opaque(rays, depths)
+    loss, d_sigma, d_rays, _, _ = ops.los_loss_fused(sigma, z, rays, depths, float(g["scale"]), cfg, counts, noise=dv(g["noise"]), noise_std=1.0)
+    sig_o = sigma.cpu().clone().requires_grad_(True)
+    rays_o = torch.from_numpy(g["rays"]).clone().requires_grad_(True)
+    zo = torch.from_numpy(g["z"])
+    out = ORD.composite(sig_o, zo, rays_o[:, 3:6], rays_o[:, 12:13], torch.from_numpy(g["noise"]))
+    lo, _ = OL.lidar_loss(out, zo, rays_o, torch.from_numpy(g["depths"]), torch.tensor(float(g["scale"])), cfg_o, it)
+    lo.backward()
+    assert abs(float(loss[0]) - float(lo)) / float(lo) < 1e-4
+    assert rel(d_sigma, sig_o.grad) < 2e-4
+    assert rel(d_rays[:, [3, 4, 5, 12]], rays_o.grad[:, [3, 4, 5, 12]]) < 2e-4
+
+
+# ------------------------------------------------------------------------------------------- optimisers
+def test_adam_step_matches_oracle(ops):
+    gen = torch.Generator().manual_seed(0)
+    n = 10007
+    p0 = torch.randn(n, generator=gen)
+    p_o = p0.clone()
+    adam = MS.AdamState([p_o], [0.01])
+    p, m, v = dv(p0), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 6):
+        gr = torch.randn(n, generator=gen) * (10.0 ** (step - 3))
+        gr[::7] = 0.0
+        gd = dv(gr)
+        ops.adam_step(p, gd, m, v, 0.01, step, zero_grad=True)
+        adam.step([gr])
+        assert float(gd.abs().max()) == 0.0
+    assert rel(p, p_o) < 1e-6
+
+
+def test_occ_grid_step_matches_oracle(ops, golden):
+    g = golden("g4_samplers")
+    rays, z = g["rays"], g["trained_z128"]
+    gen = torch.Generator().manual_seed(2)
+    V = 24
+    grid0 = torch.randn(1, 1, V, V, V, generator=gen)
+    depths = torch.from_numpy(g["depths"])
+    scale = 85.76
+    pts = ORD.sample_points(torch.from_numpy(rays), torch.from_numpy(z))
+    expect = OC.grid_step(grid0, pts, torch.from_numpy(z) * scale, depths[:, None] * scale, 1e-2)
+    grid = dv(grid0.clone())
+    ops.occ_grid_step(grid, dv(rays), dv(z), dv(depths), scale, 1e-2)
+    assert float((expect - grid0).abs().max()) > 0
+    assert rel(grid.cpu() - grid0, expect - grid0) < 1e-4
+    # two-stage form used when the window is sharded
+    grid2, buf = dv(grid0.clone()), torch.zeros(V ** 3, device=DEV)
+    ops.occ_grid_step(grid2, dv(rays), dv(z), dv(depths), scale, 1e-2, grad_buf=buf)
+    ops.occ_grid_apply(grid2, buf, 1e-2)
+    assert rel(grid2.cpu() - grid0, expect - grid0) < 1e-4 and float(buf.abs().max()) == 0.0

@@ -1,0 +1,236 @@
+"""Boundary classes (Model, samplers, KeyFrame, Optimizer) on the MI355X vs oracle / golden fixtures."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mapping_step as MS
+from oracle import network as NW
+from oracle import poses as OP
+from oracle import render as ORD
+
+DEV = "cuda"
+
+
+def rel(a, b):
+    a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, np.float64)
+    b = b.detach().cpu().double().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+SMALL_ENC = dict(otype="HashGrid", n_levels=4, n_features_per_level=2, log2_hashmap_size=12, base_resolution=8)
+SMALL_NET = dict(activation="ReLU", n_neurons=32, n_hidden_layers=1, otype="FullyFusedMLP", output_activation="None")
+
+
+def small_settings(n_rays, n_samples, voxel=32):
+    from loner_amd.common.settings import default_optimizer_settings
+    s = default_optimizer_settings()
+    mc = s["model_config"]
+    mc["model"]["nerf_config"]["pos_encoding_sigma"] = dict(SMALL_ENC)
+    mc["model"]["nerf_config"]["sigma_network"] = dict(SMALL_NET)
+    mc["model"]["nerf_config"]["pos_encoding_intensity"]["log2_hashmap_size"] = 10
+    mc["model"]["render"]["N_samples_train"] = n_samples
+    mc["model"]["occ_model"]["voxel_size"] = voxel
+    s["num_samples"]["lidar"] = n_rays
+    s["num_samples"]["sky"] = 0
+    return s
+
+
+def make_keyframes(pose6_list, device=None):
+    from loner_amd.common.frame import Frame
+    from loner_amd.common.pose import Pose
+    from loner_amd.common.sensors import LidarScan
+    from loner_amd.mapping.keyframe import KeyFrame
+    from loner_amd.utils import synthetic as SY
+    dirs, ts = SY.lidar_pattern()
+    base = SY.trajectory_pose6(8)
+    kfs = []
+    for i, p6 in enumerate(pose6_list):
+        dist = SY.scene_ranges(dirs, OP.transform_from_pose6(base[i]))
+        fr = Frame(None, LidarScan(dirs.clone(), dist, ts + float(i), sky_rays=torch.Tensor()), Pose())
+        fr._lidar_pose = Pose(pose_tensor=p6.clone(), fixed=False)
+        fr._gt_lidar_pose = Pose(pose_tensor=base[i].clone(), fixed=True)
+        kfs.append(KeyFrame(fr, device))
+    return kfs
+
+
+def world_cube():
+    from loner_amd.common.pose_utils import WorldCube
+    from loner_amd.utils import synthetic as SY
+    scale, shift = SY.world_cube()
+    return WorldCube(torch.tensor(scale), torch.from_numpy(shift))
+
+
+def test_keyframe_build_lidar_rays_api_and_pose_gradient(golden):
+    g = golden("g1_rays")
+    from loner_amd.common.pose_utils import WorldCube, tensor_to_transform
+    from loner_amd.common.ray_utils import LidarRayDirections
+    from loner_amd.common.sensors import LidarScan
+    wc = WorldCube(torch.tensor(float(g["scale"])), torch.from_numpy(g["shift"]))
+    for i in range(3):
+        scan = LidarScan(torch.from_numpy(g[f"dirs_g{i}"]), torch.from_numpy(g[f"dist_g{i}"]), torch.zeros(g[f"dist_g{i}"].shape[0]))
+        p6 = torch.from_numpy(g[f"pose{i}"]).clone().requires_grad_(True)       # pose on the CPU, like the reference
+        rays, depths = LidarRayDirections(scan).build_lidar_rays(torch.arange(len(scan)), torch.from_numpy(g["ray_range"]), wc,
+                                                                tensor_to_transform(p6))
+        assert rays.is_cuda and rays.shape == g[f"rays{i}"].shape
+        assert rel(rays, g[f"rays{i}"]) < 1e-6
+        (rays * torch.from_numpy(g[f"cot{i}"]).to(DEV)).sum().backward()
+        assert rel(p6.grad, g[f"dpose{i}"]) < 5e-4
+
+
+def test_model_forward_api_and_autograd_match_oracle(golden):
+    from loner_amd.common.settings import Settings, default_model_config
+    from loner_amd.models.model_tcnn import Model, OccupancyGridModel
+    from loner_amd.models.ray_sampling import OccGridRaySampler
+    g = golden("g4_samplers")
+    mc = default_model_config()
+    mc["model"]["nerf_config"]["pos_encoding_sigma"] = dict(SMALL_ENC)
+    mc["model"]["nerf_config"]["sigma_network"] = dict(SMALL_NET)
+    mc["model"]["nerf_config"]["pos_encoding_intensity"]["log2_hashmap_size"] = 10
+    mc["model"]["render"].update(N_samples_train=128, raw_noise_std=0.0, perturb=1.0, chunk=48)   # 64 rays -> 2 chunks
+    cfg = Settings(mc).model
+    model = Model(cfg).to(DEV)
+    spec_o = NW.NetworkSpec.from_config(SMALL_ENC, SMALL_NET)
+    params = NW.init_params(spec_o, 5)
+    params[spec_o.n_mlp_params:] *= 3000
+    with torch.no_grad():
+        model.nerf_model._model_sigma.params.copy_(params)
+    assert set(model.state_dict()) >= {"nerf_model._model_sigma.params", "nerf_model._pos_encoding.params",
+                                       "nerf_model._model_intensity.params"}
+    occ = OccupancyGridModel(Settings(dict(voxel_size=24))).to(DEV)
+    with torch.no_grad():
+        occ.occupancy_grid.copy_(torch.from_numpy(g["trained_grid"])[None, None])
+    sampler = OccGridRaySampler()
+    sampler.update_occ_grid(occ().detach())
+    rays = torch.from_numpy(g["rays"]).to(DEV).requires_grad_(True)
+    torch.manual_seed(0)
+    res = model(rays, sampler, torch.tensor(85.76), camera=False, return_variance=True)
+    assert set(res) >= {"rgb_fine", "depth_fine", "weights_fine", "opacity_fine", "variance", "samples_fine", "points_fine"}
+    z = res["samples_fine"]
+    assert z.shape == (64, 128) and bool((z[:, 1:] >= z[:, :-1]).all())
+    # oracle on the same sample depths
+    p_o = params.clone().requires_grad_(True)
+    rays_o = torch.from_numpy(g["rays"]).clone().requires_grad_(True)
+    zc = z.detach().cpu()
+    sig = NW.density(spec_o, p_o, ORD.sample_points(rays_o, zc).reshape(-1, 3)).reshape(64, 128)
+    out = ORD.composite(sig, zc, rays_o[:, 3:6], rays_o[:, 12:13])
+    assert rel(res["depth_fine"], out["depth"]) < 1e-4                      # north_star tolerance
+    assert rel(res["weights_fine"], out["weights"]) < 1e-4
+    assert rel(res["opacity_fine"], out["opacity"]) < 1e-4 and rel(res["variance"], out["variance"]) < 1e-3
+    assert rel(res["points_fine"], ORD.sample_points(rays_o, zc)) < 1e-6
+    gen = torch.Generator().manual_seed(1)
+    cd, cw, co = torch.randn(64, generator=gen), torch.randn(64, 128, generator=gen), torch.randn(64, generator=gen)
+    (res["depth_fine"] * cd.to(DEV)).sum().add((res["weights_fine"] * cw.to(DEV)).sum()).add((res["opacity_fine"] * co.to(DEV)).sum()).backward()
+    ((out["depth"] * cd).sum() + (out["weights"] * cw).sum() + (out["opacity"] * co).sum()).backward()
+    assert rel(model.nerf_model._model_sigma.params.grad, p_o.grad) < 2e-4
+    assert rel(rays.grad, rays_o.grad) < 2e-4
+    # inference entry used by the analysis scripts (testing=True -> N_samples_test, no jitter)
+    with torch.no_grad():
+        res_t = model(rays.detach(), sampler, torch.tensor(85.76), testing=True, camera=False, return_variance=True)
+    assert res_t["samples_fine"].shape == (64, 2048) and torch.isfinite(res_t["depth_fine"]).all()
+    pts = torch.rand(3, 5, 3, device=DEV) * 1.8 - 0.9
+    sig_pts = model.inference_points(pts, None, sigma_only=True)
+    assert rel(sig_pts[:, 0], NW.density(spec_o, params, pts.cpu().reshape(-1, 3))) < 1e-5
+
+
+class _Replay:
+    def __init__(self, g):
+        keys = sorted(k for k in g if k.startswith("draw"))
+        self.draws = [torch.from_numpy(g[k]) for k in keys]
+        self.kinds = [k.split("_")[1] for k in keys]
+        self.i = 0
+
+    def _next(self, kind):
+        assert self.kinds[self.i] == kind, (self.i, self.kinds[self.i], kind)
+        v = self.draws[self.i]
+        self.i += 1
+        return v
+
+    def ray_index(self, n, c): return self._next("randint")
+    def sky_index(self, n, c): return self._next("randint")
+    def jitter(self, n, h): return self._next("rand")
+    def pdf(self, n, h): return self._next("rand")
+    def noise(self, n, s): return self._next("randn")
+
+
+def test_optimizer_loop_reproduces_reference_trajectory(golden):
+    """_do_iterate_optimizer for 12 iterations / 2 keyframes with the reference's recorded random draws:
+    final pose, occupancy grid (2 grid steps) and parameters against the reference's (G9)."""
+    from loner_amd.mapping.optimizer import OptimizationSettings, Optimizer
+    g = golden("g9_loop")
+    opt = Optimizer(small_settings(48, 64), None, world_cube(), 0, False, True, False)
+    with torch.no_grad():
+        opt._model.nerf_model._model_sigma.params.copy_(torch.from_numpy(g["params0"]))
+    kfs = make_keyframes([torch.from_numpy(g["pose_init0"]), torch.from_numpy(g["pose_init1"])])
+    kfs[0].is_anchored = True
+    rp = _Replay(g)
+    opt.set_draws(rp)
+    opt._do_iterate_optimizer(kfs, [None], optimizer_settings=OptimizationSettings(12, False, False, False, True))
+    assert rp.i == int(g["n_draws"])                                   # same number and order of draws (A.9)
+    assert opt._global_step == int(g["global_step"])
+    assert np.abs(kfs[0].get_lidar_pose().get_pose_tensor().detach().numpy() - g["pose_final0"]).max() == 0
+    pose1 = kfs[1].get_lidar_pose().get_pose_tensor().detach().cpu().numpy()
+    print("pose error vs reference", np.abs(pose1 - g["pose_final1"]).max(), "pose travel", np.abs(g["pose_final1"] - g["pose_init1"]).max())
+    assert np.abs(pose1 - g["pose_final1"]).max() < 5e-4
+    assert rel(opt._occupancy_grid_model.occupancy_grid[0, 0], g["grid1"]) < 2e-3
+    assert rel(opt._model.nerf_model._model_sigma.params, g["params1"]) < 5e-2
+    sd = opt._optimizer.state_dict()
+    assert sd["state"][0]["step"] == 12 and set(sd["state"][0]) >= {"exp_avg", "exp_avg_sq"}
+
+
+def test_optimizer_schedule_default_config_properties():
+    """Default network (16-level hash grid, 64-wide MLP), 2 keyframes, in-kernel RNG: the schedule runs, the
+    anchored keyframe does not move, the free one does, the loss goes down, nothing is NaN."""
+    from loner_amd.common.settings import default_optimizer_settings
+    from loner_amd.mapping.optimizer import Optimizer
+    from loner_amd.utils import synthetic as SY
+    s = default_optimizer_settings()
+    s["num_samples"]["sky"] = 0
+    s["keyframe_schedule"][0]["iteration_schedule"][0]["num_iterations"] = 60
+    s["keyframe_schedule"][1]["iteration_schedule"][1]["num_iterations"] = 20
+    torch.manual_seed(0)
+    opt = Optimizer(s, None, world_cube(), 0, False, True, False)
+    base = SY.trajectory_pose6(8)
+    noisy = base[1].clone(); noisy[:3] += 0.02
+    kfs = make_keyframes([base[0], noisy])
+    opt.iterate_optimizer(kfs[:1])
+    assert opt._keyframe_count == 1 and opt._global_step == 60 and kfs[0].is_anchored
+    l0 = opt.last_stats["loss_terms"][:, 0]
+    assert torch.isfinite(l0).all() and float(l0[-10:].mean()) < float(l0[:10].mean())
+    assert opt.last_stats["n_valid_rays"] == 60 * 512
+    p_before = kfs[1].get_lidar_pose().get_pose_tensor().detach().clone()
+    opt.iterate_optimizer(kfs)
+    assert opt._global_step == 80
+    assert torch.equal(kfs[0].get_lidar_pose().get_pose_tensor().detach(), base[0])
+    assert not torch.equal(kfs[1].get_lidar_pose().get_pose_tensor().detach(), p_before)
+    assert float(opt._occupancy_grid_model.occupancy_grid.abs().max()) > 0
+    with open(f"{s['log_directory']}/timing.csv") as f:
+        assert len(f.read().strip().splitlines()) >= 2
+
+
+def test_compute_loss_is_differentiable_like_the_reference(golden):
+    """Optimizer.compute_loss returns a scalar whose .backward() reaches the density parameters and CPU poses."""
+    from loner_amd.mapping.optimizer import OptimizationSettings, Optimizer
+    opt = Optimizer(small_settings(64, 64), None, world_cube(), 0, False, True, False)
+    from loner_amd.utils import synthetic as SY
+    base = SY.trajectory_pose6(8)
+    kfs = make_keyframes([base[0], base[1]])
+    for kf in kfs:
+        kf.get_lidar_pose().set_fixed(False)
+    opt._optimization_settings = OptimizationSettings(1, False, False, False, True)
+    rays, depths = [], []
+    for kf in kfs:
+        r, d = kf.build_lidar_rays(torch.randint(65536, (64,)), opt._ray_range, opt._world_cube)
+        rays.append(r); depths.append(d)
+    loss = opt.compute_loss(None, (torch.vstack(rays), torch.cat(depths)), 0)
+    assert loss.dim() == 0 and torch.isfinite(loss)
+    loss.backward()
+    assert opt._model.nerf_model._model_sigma.params.grad.abs().sum() > 0
+    for kf in kfs:
+        gp = kf.get_lidar_pose().get_pose_tensor().grad
+        assert gp is not None and torch.isfinite(gp).all() and gp.abs().sum() > 0
+    opt._step_occupancy_grid()
+    assert float(opt._occupancy_grid_model.occupancy_grid.abs().max()) > 0

@@ -1,0 +1,146 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol, host logic (network spec
+derivation, settings, pose maths, schedules) and the no-fallback rule."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    import __graft_entry__ as ge
+    ge.build()
+    from loner_amd import hip
+    return hip.LIB_PATH
+
+
+def test_library_exports_every_symbol_in_the_header(lib_path):
+    header = open(os.path.join(ROOT, "include", "loner_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(lnr_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(lib_path)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/loner_hip.h but not exported"
+    from loner_amd import hip
+    assert sorted(hip.declared_symbols()) == declared            # the ctypes table binds exactly the header
+    assert hip.load().lnr_version() >= 100
+
+
+def test_net_spec_matches_oracle_level_geometry(lib_path):
+    from loner_amd import hip
+    from oracle import network as NW
+    cases = [
+        (dict(otype="HashGrid", n_levels=16, n_features_per_level=2, log2_hashmap_size=18, base_resolution=16), dict(n_neurons=64, n_hidden_layers=1)),
+        (dict(otype="HashGrid", n_levels=16, n_features_per_level=2, log2_hashmap_size=19, base_resolution=16), dict(n_neurons=64, n_hidden_layers=4)),
+        (dict(otype="HashGrid", n_levels=7, n_features_per_level=4, log2_hashmap_size=15, base_resolution=5, per_level_scale=1.38), dict(n_neurons=128, n_hidden_layers=2)),
+        (dict(otype="Frequency", n_frequencies=12), dict(n_neurons=256, n_hidden_layers=1, activation="Sine")),
+    ]
+    for enc, net in cases:
+        h = hip.make_net_spec(enc, net)
+        o = NW.NetworkSpec.from_config(enc, net)
+        assert (h.enc_dim, h.in_dim, h.n_mlp_params, int(h.n_params)) == (o.enc_dim, o.in_dim, o.n_mlp_params, o.n_params)
+        for l, lv in enumerate(o.levels):
+            assert (h.level_res[l], h.level_size[l], h.level_offset[l], h.level_hashed[l]) == (lv.res, lv.size, lv.offset, int(lv.hashed))
+            assert abs(h.level_scale[l] - lv.scale) <= 2e-7 * lv.scale      # exp2f/log2f: libm vs numpy, <= 1 ulp
+    # the default density network of the reference: 3072 MLP weights + 3 706 880 x 2 table entries
+    h = hip.make_net_spec(*cases[0])
+    assert h.n_mlp_params == 3072 and int(h.n_params) == 7416832
+    assert list(h.level_size[:3]) == [4096, 32768, 262144] and list(h.level_hashed[:4]) == [0, 0, 0, 1]
+
+
+def test_bad_configs_fail_loudly(lib_path):
+    from loner_amd import hip
+    with pytest.raises(RuntimeError):
+        hip.make_net_spec(dict(otype="HashGrid"), dict(n_neurons=48))
+    with pytest.raises(RuntimeError):
+        hip.make_net_spec(dict(otype="SphericalHarmonics"), dict(n_neurons=64))
+    with pytest.raises(RuntimeError):
+        hip.make_net_spec(dict(otype="HashGrid", n_features_per_level=3), dict(n_neurons=64))
+    with pytest.raises(RuntimeError):
+        hip.make_net_spec(dict(otype="HashGrid"), dict(n_neurons=64, output_activation="Sigmoid"))
+
+
+def test_no_cpu_fallback_and_product_never_imports_the_oracle(lib_path):
+    from loner_amd import hip, ops
+    spec = hip.make_net_spec(dict(otype="Frequency", n_frequencies=4), dict(n_neurons=16, n_hidden_layers=1))
+    with pytest.raises(RuntimeError):
+        ops.density_forward(spec, torch.zeros(int(spec.n_params)), pts=torch.zeros(4, 3))
+    if not torch.cuda.is_available():
+        from loner_amd.common.pose_utils import WorldCube
+        from loner_amd.common.settings import default_optimizer_settings
+        from loner_amd.mapping.optimizer import Optimizer
+        with pytest.raises(RuntimeError):
+            Optimizer(default_optimizer_settings(), None, WorldCube(torch.tensor(85.0), torch.zeros(3)), 0)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "loner_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
+                assert "/root/reference" not in src
+
+
+def test_missing_library_is_an_error(lib_path, tmp_path):
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from loner_amd import hip\n"
+            "hip.LIB_PATH = %r\n"
+            "try:\n    hip.load()\nexcept RuntimeError as e:\n    print('RAISED')\n") % (ROOT, str(tmp_path / "nope.so"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert "RAISED" in out.stdout
+
+
+def test_pose_maths_matches_oracle_and_scipy():
+    from scipy.spatial.transform import Rotation
+    from loner_amd.common.pose_utils import axis_angle_to_matrix, matrix_to_axis_angle, tensor_to_transform
+    from oracle import poses as OP
+    gen = torch.Generator().manual_seed(0)
+    aa = torch.randn(50, 3, generator=gen) * 1.2
+    aa[:3] *= 1e-9
+    R = axis_angle_to_matrix(aa)
+    assert torch.equal(R, OP.rotation_from_axis_angle(aa))
+    assert np.abs(R.numpy() - Rotation.from_rotvec(aa.double().numpy()).as_matrix()).max() < 1e-6
+    for i in range(50):
+        back = matrix_to_axis_angle(R[i])
+        assert np.abs(axis_angle_to_matrix(back).numpy() - R[i].numpy()).max() < 1e-5
+    p = torch.randn(6, generator=gen).requires_grad_(True)
+    q = p.detach().clone().requires_grad_(True)
+    cot = torch.randn(4, 4, generator=gen)
+    (tensor_to_transform(p) * cot).sum().backward()
+    (OP.transform_from_pose6(q) * cot).sum().backward()
+    assert torch.allclose(p.grad, q.grad, atol=1e-6)
+    assert tensor_to_transform(torch.zeros(3, 6)).shape == (3, 4, 4)
+    z = torch.zeros(6, requires_grad=True)                       # identity pose: gradient must be finite
+    tensor_to_transform(z).sum().backward()
+    assert torch.isfinite(z.grad).all()
+
+
+def test_settings_schema_and_schedule_selection():
+    from loner_amd.common.settings import Settings, default_optimizer_settings
+    from loner_amd.mapping.optimizer import OptimizationSettings
+    s = default_optimizer_settings()
+    assert s.model_config.model.render.N_samples_train == 512 and s.model_config.model.occ_model.voxel_size == 100
+    assert s.num_samples.lidar == 512 and s.samples_selection.strategy == "OGM"
+    assert isinstance(s.model_config.model.ray_range, tuple)          # lists become tuples on attribute access
+    assert s["keyframe_schedule"][0]["iteration_schedule"][0]["num_iterations"] == 1000
+    assert s.model_config.loss.JS_loss.max_js_score == 10.0
+    o = OptimizationSettings.from_dict({"num_iterations": 7, "freeze_poses": True})
+    assert (o.num_iterations, o.freeze_poses, o.latest_kf_only, o.freeze_sigma_mlp) == (7, True, False, False)
+    import pickle
+    assert pickle.loads(pickle.dumps(s)).num_samples.lidar == 512
+
+
+def test_synthetic_scene_is_exact_and_has_transparent_rays():
+    from loner_amd.utils import synthetic as SY
+    from loner_amd.common.pose_utils import tensor_to_transform
+    dirs, ts = SY.lidar_pattern()
+    assert dirs.shape == (3, 65536) and abs(float(dirs.norm(dim=0).mean()) - 1) < 1e-6
+    r = SY.scene_ranges(dirs, tensor_to_transform(SY.trajectory_pose6(3)[2]))
+    assert float(r.min()) > 1.0 and int((r > 50).sum()) > 100          # window rays exceed the 50 m range
+    scale, shift = SY.world_cube()
+    assert abs(scale - 85.7614) < 1e-3 and np.allclose(shift, [7.5, 5.0, 0.0])

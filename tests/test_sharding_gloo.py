@@ -1,0 +1,118 @@
+"""Keyframe-window sharding (loner_amd/mapping/sharding.py) on CPU: 2 processes, gloo backend.
+
+The HIP kernels normalise the loss with GLOBAL counts (#rays, #opaque) and the density gradient is
+summed over ranks.  Here the oracle plays the kernels' role: each rank evaluates its own keyframes,
+the counts and gradients go through DistContext, and the result must equal the single-process
+evaluation of the whole window.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _window(n_kf=4, n_rays=24, n_samples=32, seed=0):
+    from oracle import poses as OP
+    from oracle import rays as OR
+    from loner_amd.utils import synthetic as SY
+    dirs, _ = SY.lidar_pattern()
+    base = SY.trajectory_pose6(n_kf)
+    gen = torch.Generator().manual_seed(seed)
+    scale, shift = SY.world_cube()
+    out = []
+    for k in range(n_kf):
+        T = OP.transform_from_pose6(base[k])
+        dist_k = SY.scene_ranges(dirs, T)
+        idx = torch.randint(dirs.shape[1], (n_rays,), generator=gen)
+        if k == 0:
+            idx[3] = int((dist_k > 50).nonzero()[0])          # make sure transparent rays exist
+        rays, depths, _ = OR.lidar_ray_records(dirs, dist_k, idx, T, torch.tensor([1.0, 50.0]), torch.tensor(scale), torch.from_numpy(shift))
+        z = torch.sort(torch.rand(rays.shape[0], n_samples, generator=gen) * (rays[:, 12:13] - rays[:, 11:12]) + rays[:, 11:12], dim=1).values
+        noise = torch.randn(rays.shape[0], n_samples, generator=gen)
+        out.append((rays.float(), depths.float(), z.float(), noise))
+    return out, scale
+
+
+def _rank_loss(spec, params, items, scale, counts_global):
+    """sum over this rank's keyframes of the loss terms re-normalised by the global counts."""
+    from oracle import loss as OL
+    from oracle import network as NW
+    from oracle import render as ORD
+    rays = torch.cat([i[0] for i in items]); depths = torch.cat([i[1] for i in items])
+    z = torch.cat([i[2] for i in items]); noise = torch.cat([i[3] for i in items])
+    sigma = NW.density(spec, params, ORD.sample_points(rays, z).reshape(-1, 3)).reshape(z.shape)
+    out = ORD.composite(sigma, z, rays[:, 3:6], rays[:, 12:13], noise)
+    loss, aux = OL.lidar_loss(out, z, rays, depths, torch.tensor(scale), OL.LossConfig())
+    n_local, op_local = rays.shape[0], int(aux["opaque"].sum())
+    td, tl, to = aux["terms"]
+    n_glob, op_glob = counts_global
+    return td * (op_local / op_glob) + tl * (n_local / n_glob) + to * (op_local / op_glob), (n_local, op_local)
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import loss as OL
+    from oracle import network as NW
+    from loner_amd.mapping.sharding import DistContext, shard_window
+    ctx = DistContext()
+    window, scale = _window()
+    spec = NW.NetworkSpec.from_config(dict(otype="HashGrid", n_levels=4, n_features_per_level=2, log2_hashmap_size=10, base_resolution=4),
+                                      dict(n_neurons=16, n_hidden_layers=1))
+    params = NW.init_params(spec, 3)
+    params[spec.n_mlp_params:] *= 3000
+    mine = ctx.owned(window)
+    assert [i for i, w in enumerate(window) if any(w is m for m in mine)] == shard_window(len(window), world, rank)
+    # local counts -> global counts (the kernels' lnr_count_opaque + all_reduce_counts)
+    rays = torch.cat([i[0] for i in mine]); depths = torch.cat([i[1] for i in mine])
+    far0 = window[0][0][0, 12]                                     # every rank's first ray has the same far here
+    assert float(rays[0, 12]) == float(far0)
+    local = torch.tensor([rays.shape[0], int(((depths > 0) & ~(depths > far0)).sum())], dtype=torch.int32)
+    counts = ctx.all_reduce_counts(local.clone())
+    p = params.clone().requires_grad_(True)
+    loss_r, _ = _rank_loss(spec, p, mine, scale, (int(counts[0]), int(counts[1])))
+    loss_r.backward()
+    grad = p.grad.clone()
+    ctx.all_reduce_grads(grad)
+    total = loss_r.detach().clone().reshape(1)
+    dist.all_reduce(total)
+    if rank == 0:
+        ret["counts"] = counts.tolist(); ret["grad"] = grad.numpy(); ret["loss"] = float(total)
+    # replicas stay identical: every rank applies the same reduced gradient
+    gathered = [torch.zeros_like(grad) for _ in range(world)]
+    dist.all_gather(gathered, grad)
+    assert all(torch.equal(gathered[0], gr) for gr in gathered)
+    dist.destroy_process_group()
+
+
+def test_sharded_window_equals_single_process():
+    from oracle import network as NW
+    port = 29500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    window, scale = _window()
+    spec = NW.NetworkSpec.from_config(dict(otype="HashGrid", n_levels=4, n_features_per_level=2, log2_hashmap_size=10, base_resolution=4),
+                                      dict(n_neurons=16, n_hidden_layers=1))
+    params = NW.init_params(spec, 3)
+    params[spec.n_mlp_params:] *= 3000
+    n = sum(i[0].shape[0] for i in window)
+    p = params.clone().requires_grad_(True)
+    # single process = one "rank" owning everything, interleaved in the same keyframe order as the reference
+    loss, (n_all, op_all) = _rank_loss(spec, p, window, scale, (n, 1))     # provisional opaque count
+    loss_single, _ = _rank_loss(spec, p, window, scale, (n_all, op_all))
+    loss_single.backward()
+    assert ret["counts"] == [n_all, op_all] and 0 < op_all < n_all
+    assert abs(ret["loss"] - float(loss_single)) / abs(float(loss_single)) < 1e-5
+    assert np.abs(ret["grad"] - p.grad.numpy()).max() / np.abs(p.grad.numpy()).max() < 1e-4
+
+
+def test_shard_window_round_robin():
+    from loner_amd.mapping.sharding import shard_window
+    assert shard_window(8, 8, 3) == [3]
+    assert shard_window(8, 2, 1) == [1, 3, 5, 7]
+    assert shard_window(3, 4, 3) == []
+    assert sorted(sum((shard_window(8, 4, r) for r in range(4)), [])) == list(range(8))
