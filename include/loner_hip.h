@@ -105,8 +105,9 @@ int lnr_density_forward(const LnrNetSpec* spec /*host*/, const float* params,
 /* Backward of the above                     replaces tinycudann backward (loss.backward(), optimizer.py:366)
  * grad_params [n_params] is ACCUMULATED into (caller zeroes it; lnr_adam_step can re-zero it).
  * d_pts (nullable) [*,3] receives dL/dxyz per point (needed only when poses are optimised).
- * workspace: lnr_density_backward_workspace() bytes. */
-size_t lnr_density_backward_workspace(const LnrNetSpec* spec /*host*/);
+ * workspace: lnr_density_backward_workspace(spec, n_points) bytes for up to n_points points per call
+ * (per-workgroup weight-gradient slabs + the record regions of the table-gradient partition). */
+size_t lnr_density_backward_workspace(const LnrNetSpec* spec /*host*/, int64_t n_points);
 int lnr_density_backward(const LnrNetSpec* spec /*host*/, const float* params,
                          const float* pts, int64_t n_points,
                          const float* rays, const float* z, int32_t n_rays, int32_t n_samples,

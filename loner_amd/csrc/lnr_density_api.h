@@ -17,6 +17,21 @@ struct PointSrc {
     const int32_t* n_rays_dev;
 };
 
+// record sink of the backward kernel (see GradSink in lnr_density_impl.h)
+struct BwdSinkArgs {
+    void* regions;         // [grid][nown][cap] records (8 bytes when n_features == 1, else 16)
+    int* counts;           // [grid][nown]
+    int nown, nown_padded; // owners; padded to a multiple of 4 words for LDS alignment
+    int cap, shift;
+    float combine_scale_max;
+    int debug;             // getenv("LNR_DEBUG") bits, profiling experiments only
+};
+
+#define LNR_BWD_MAX_BLOCKS 512
+#define LNR_SLICE_SHIFT 13            // 8192 floats (32 KB of LDS) per owner
+#define LNR_REGION_BUDGET (24ull << 30)
+#define LNR_COMBINE_SCALE_MAX 3000.0f
+
 // launch plan chosen by the dispatcher
 struct DensityPlan {
     int grid;        // workgroups
@@ -29,7 +44,8 @@ struct DensityPlan {
     int lnr_density_fwd_ht##HT(const LnrNetSpec* spec, const float* params, const PointSrc* src, float* sigma,      \
                                const DensityPlan* plan, hipStream_t st);                                            \
     int lnr_density_bwd_ht##HT(const LnrNetSpec* spec, const float* params, const PointSrc* src, const float* d_sigma, \
-                               float* grad_table, float* d_pts, float* slabs, const DensityPlan* plan, hipStream_t st);
+                               float* grad_table, float* d_pts, float* slabs, const BwdSinkArgs* sink,         \
+                               const DensityPlan* plan, hipStream_t st);
 LNR_DECLARE_HT(1)
 LNR_DECLARE_HT(2)
 LNR_DECLARE_HT(4)

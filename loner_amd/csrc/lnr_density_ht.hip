@@ -33,22 +33,30 @@ int LNR_CAT(lnr_density_fwd_ht, LNR_HT)(const LnrNetSpec* spec, const float* par
     return LNR_OK;
 }
 
-#define LNR_LAUNCH_BWD(DX, WL)                                                                                       \
+#define LNR_LAUNCH_BWD(DX, WL, DWK)                                                                                  \
     do {                                                                                                             \
-        rc = set_lds(density_backward_kernel<LNR_HT, DX, WL>, plan->lds, "lnr_density_backward");                    \
+        rc = set_lds(density_backward_kernel<LNR_HT, DX, WL, DWK>, plan->lds, "lnr_density_backward");               \
         if (rc) return rc;                                                                                           \
-        hipLaunchKernelGGL((density_backward_kernel<LNR_HT, DX, WL>), grid, block, plan->lds, st, *spec, params, *src, \
-                           d_sigma, grad_table, d_pts, slabs);                                                       \
+        hipLaunchKernelGGL((density_backward_kernel<LNR_HT, DX, WL, DWK>), grid, block, plan->lds, st, *spec, params, *src, \
+                           d_sigma, grad_table, d_pts, slabs, *sink);                                                \
     } while (0)
 
 int LNR_CAT(lnr_density_bwd_ht, LNR_HT)(const LnrNetSpec* spec, const float* params, const PointSrc* src, const float* d_sigma,
-                                         float* grad_table, float* d_pts, float* slabs, const DensityPlan* plan, hipStream_t st) {
+                                         float* grad_table, float* d_pts, float* slabs, const BwdSinkArgs* sink,
+                                         const DensityPlan* plan, hipStream_t st) {
     int rc;
     const dim3 grid(plan->grid), block(64 * plan->waves);
+#if LNR_HT <= 4
+    // the reference's default shape class (one hidden layer, 32 encoded features): register-resident dW1
+    if (plan->w_lds && spec->n_hidden == 1 && spec->in_dim == 32) {
+        if (d_pts) LNR_LAUNCH_BWD(true, true, 2); else LNR_LAUNCH_BWD(false, true, 2);
+        return LNR_OK;
+    }
+#endif
     if (d_pts) {
-        if (plan->w_lds) LNR_LAUNCH_BWD(true, true); else LNR_LAUNCH_BWD(true, false);
+        if (plan->w_lds) LNR_LAUNCH_BWD(true, true, 0); else LNR_LAUNCH_BWD(true, false, 0);
     } else {
-        if (plan->w_lds) LNR_LAUNCH_BWD(false, true); else LNR_LAUNCH_BWD(false, false);
+        if (plan->w_lds) LNR_LAUNCH_BWD(false, true, 0); else LNR_LAUNCH_BWD(false, false, 0);
     }
     return LNR_OK;
 }

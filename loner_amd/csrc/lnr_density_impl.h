@@ -179,41 +179,113 @@ __device__ __forceinline__ void hash_features4(const LnrNetSpec& spec, const flo
     }
 }
 
-// Backward of hash_features4: scatter d_out into the table gradient, optionally accumulate d/dx.
+// ------------------------------------------------------------------------------------------------
+// Table-gradient sink.  Float atomics to global memory top out at ~21 G atomics/s on MI355X whatever
+// the scope, locality or table size (profiles/r01_atomic_throughput.txt) - 25 ms for the 537 M updates
+// of one default iteration.  Instead every workgroup appends {float index, value} records to
+// per-(workgroup, owner) regions in HBM (slot allocation = LDS atomic on a per-owner cursor) and a second
+// kernel gives each slice of the table to one workgroup that sums its records in LDS
+// (table_grad_reduce_kernel).  A record that does not fit its region falls back to a global atomic.
+// ------------------------------------------------------------------------------------------------
+struct GradSink {
+    float* grad_table;     // fallback target
+    void* regions;         // [n_workgroups][nown][cap] records: uint2 {idx, v} (pair=0) or uint4 {idx, v0, v1, -} (pair=1)
+    int* cursors;          // LDS, [nown]
+    int nown, cap, shift;
+    float combine_scale_max;   // levels coarser than this are run-length combined over the 16 samples of a tile
+    int debug;                 // LNR_DEBUG bits (profiling experiments only): 1 skip record store, 2 skip cursor atomic
+};
+
+// one float
+__device__ __forceinline__ void sink_emit1(const GradSink& s, uint32_t fidx, float v) {
+    if (v == 0.0f) return;
+    const int owner = (int)(fidx >> s.shift);
+    const int slot = atomicAdd(&s.cursors[owner], 1);
+    if (slot < s.cap) reinterpret_cast<uint2*>(s.regions)[((size_t)blockIdx.x * s.nown + owner) * s.cap + slot] = make_uint2(fidx, __float_as_uint(v));
+    else atomicAdd(s.grad_table + fidx, v);
+}
+// two consecutive floats (fidx even: both belong to the same owner slice); one 16-byte store = one line transaction
+__device__ __forceinline__ void sink_emit2(const GradSink& s, uint32_t fidx, float v0, float v1) {
+    if (v0 == 0.0f && v1 == 0.0f) return;
+    const int owner = (int)(fidx >> s.shift);
+    if (s.debug & 2) { if (v0 == 1e30f) s.cursors[owner] = 1; return; }
+    const int slot = atomicAdd(&s.cursors[owner], 1);
+    if (s.debug & 1) return;
+    if (slot < s.cap)
+        reinterpret_cast<uint4*>(s.regions)[((size_t)blockIdx.x * s.nown + owner) * s.cap + slot] =
+            make_uint4(fidx, __float_as_uint(v0), __float_as_uint(v1), 0u);
+    else { atomicAdd(s.grad_table + fidx, v0); atomicAdd(s.grad_table + fidx + 1, v1); }
+}
+template <int FPL>
+__device__ __forceinline__ void sink_emit(const GradSink& s, uint32_t fidx, const float v[FPL]) {
+    if constexpr (FPL == 1) sink_emit1(s, fidx, v[0]);
+    else if constexpr (FPL == 2) sink_emit2(s, fidx, v[0], v[1]);
+    else { sink_emit2(s, fidx, v[0], v[1]); sink_emit2(s, fidx + 2, v[2], v[3]); }
+}
+
+// Backward of hash_features4 for the 16 lanes of one lane group (= 16 consecutive samples, normally of one
+// ray): emit table-gradient records, optionally accumulate d/dx.  Must be called by whole lane groups
+// (row-uniform control flow): coarse levels are combined across the row with segmented shuffles because
+// neighbouring samples of a ray fall into the same cell there.
 template <int F, bool WANT_DX>
 __device__ __forceinline__ void hash_features4_bwd(const LnrNetSpec& spec, const float* lvt, const float* __restrict__ table,
-                                                   float* __restrict__ grad_table, const float x[3], int k0,
+                                                   const GradSink& sink, const float x[3], int k0, int lane,
                                                    const float d_out[4], float dx[3]) {
     constexpr int NLV = F >= 4 ? 1 : 4 / F;
     constexpr int FPL = F >= 4 ? 4 : F;
+    const int c16 = lane & 15, row = lane >> 4;
 #pragma unroll
     for (int li = 0; li < NLV; ++li) {
-        const int lv = k0 / F + li;
+        const int lv = k0 / F + li;                       // row-uniform
         const int f0 = (F == 8) ? (k0 & 7) : 0;
         if (lv >= spec.n_levels) continue;
-        LevelCell c = level_cell(lvt, lv, x);
         float g[FPL];
         bool any = false;
 #pragma unroll
         for (int f = 0; f < FPL; ++f) { g[f] = d_out[li * FPL + f]; any |= (g[f] != 0.0f); }
-        if (!any) continue;
+        const unsigned row_any = (unsigned)((__ballot(any) >> (16 * row)) & 0xFFFFull);
+        if (row_any == 0u) continue;                      // row-uniform
+        LevelCell c = level_cell(lvt, lv, x);
+        const bool combine = c.scale < sink.combine_scale_max;     // row-uniform (depends on the level only)
         float dfrac[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int corner = 0; corner < 8; ++corner) {
             const float w = corner_weight(c, corner);
-            const size_t e = (size_t)cell_entry(c, corner) * F + f0;
+            const uint32_t entry = cell_entry(c, corner);
+            const uint32_t e = entry * F + f0;
+            float v[FPL];
 #pragma unroll
-            for (int f = 0; f < FPL; ++f) atomicAdd(grad_table + e + f, w * g[f]);
+            for (int f = 0; f < FPL; ++f) v[f] = w * g[f];
+            if (combine) {
+                // segmented sum over runs of equal entry along the row
+                const uint32_t prev = __shfl_up(entry, 1, 16);
+                const bool head = (c16 == 0) || (prev != entry);
+                int seg = head ? 1 : 0;
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { const int t = __shfl_up(seg, o, 16); if (c16 >= o) seg += t; }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    const int s2 = __shfl_down(seg, o, 16);
+                    const bool take = (c16 + o < 16) && (s2 == seg);
+#pragma unroll
+                    for (int f = 0; f < FPL; ++f) { const float t = __shfl_down(v[f], o, 16); if (take) v[f] += t; }
+                }
+                if (head) sink_emit<FPL>(sink, e, v);
+            } else {
+                sink_emit<FPL>(sink, e, v);
+            }
             if constexpr (WANT_DX) {
-                float dot = 0.0f;
+                if (any) {
+                    float dot = 0.0f;
 #pragma unroll
-                for (int f = 0; f < FPL; ++f) dot += g[f] * table[e + f];
-                const float wx = (corner & 1) ? c.frac[0] : 1.0f - c.frac[0];
-                const float wy = (corner & 2) ? c.frac[1] : 1.0f - c.frac[1];
-                const float wz = (corner & 4) ? c.frac[2] : 1.0f - c.frac[2];
-                dfrac[0] += ((corner & 1) ? dot : -dot) * wy * wz;
-                dfrac[1] += ((corner & 2) ? dot : -dot) * wx * wz;
-                dfrac[2] += ((corner & 4) ? dot : -dot) * wx * wy;
+                    for (int f = 0; f < FPL; ++f) dot += g[f] * table[(size_t)e + f];
+                    const float wx = (corner & 1) ? c.frac[0] : 1.0f - c.frac[0];
+                    const float wy = (corner & 2) ? c.frac[1] : 1.0f - c.frac[1];
+                    const float wz = (corner & 4) ? c.frac[2] : 1.0f - c.frac[2];
+                    dfrac[0] += ((corner & 1) ? dot : -dot) * wy * wz;
+                    dfrac[1] += ((corner & 2) ? dot : -dot) * wx * wz;
+                    dfrac[2] += ((corner & 4) ? dot : -dot) * wx * wy;
+                }
             }
         }
         if constexpr (WANT_DX) {
@@ -228,7 +300,7 @@ __device__ __forceinline__ float freq_phase(const LnrNetSpec& spec, const float 
     const int per_dim = 2 * spec.n_frequencies;
     const int dim = k / per_dim;
     const int rem = k - dim * per_dim;
-    const float mult = exp2f((float)(rem >> 1));
+    const float mult = (float)(1u << (rem >> 1));     // exact power of two (exp2f is not exact on the GPU)
     float xv = dim == 0 ? x[0] : (dim == 1 ? x[1] : x[2]);
     float ph = __fmul_rn(__fmul_rn(xv, mult), LNR_PI_F);
     if (rem & 1) ph = __fadd_rn(ph, LNR_PI_2_F);
@@ -277,17 +349,17 @@ __device__ __forceinline__ void features4(const LnrNetSpec& spec, const float* l
 
 template <bool WANT_DX>
 __device__ __forceinline__ void features4_bwd(const LnrNetSpec& spec, const float* lvt, const float* __restrict__ table,
-                                              float* __restrict__ grad_table, const float x[3], int k0,
+                                              const GradSink& sink, const float x[3], int k0, int lane,
                                               const float d_out[4], float dx[3]) {
     if (spec.encoding == LNR_ENC_FREQUENCY) {
         if constexpr (WANT_DX) freq_features4_bwd(spec, x, k0, d_out, dx);
         return;
     }
     switch (spec.n_features) {
-        case 1: hash_features4_bwd<1, WANT_DX>(spec, lvt, table, grad_table, x, k0, d_out, dx); break;
-        case 2: hash_features4_bwd<2, WANT_DX>(spec, lvt, table, grad_table, x, k0, d_out, dx); break;
-        case 4: hash_features4_bwd<4, WANT_DX>(spec, lvt, table, grad_table, x, k0, d_out, dx); break;
-        default: hash_features4_bwd<8, WANT_DX>(spec, lvt, table, grad_table, x, k0, d_out, dx); break;
+        case 1: hash_features4_bwd<1, WANT_DX>(spec, lvt, table, sink, x, k0, lane, d_out, dx); break;
+        case 2: hash_features4_bwd<2, WANT_DX>(spec, lvt, table, sink, x, k0, lane, d_out, dx); break;
+        case 4: hash_features4_bwd<4, WANT_DX>(spec, lvt, table, sink, x, k0, lane, d_out, dx); break;
+        default: hash_features4_bwd<8, WANT_DX>(spec, lvt, table, sink, x, k0, lane, d_out, dx); break;
     }
 }
 
@@ -394,11 +466,17 @@ density_forward_kernel(const LnrNetSpec spec, const float* __restrict__ params, 
 // ------------------------------------------------------------------------------------------------
 // LDS map (floats): [level tables][W : n_mlp if W_LDS][dW : n_mlp][per-wave scratch x nw]
 //   scratch = T_dz [H*16] | T_x [in_dim*16] | if n_hidden>1: T_a [H*16] | zsave [n_hidden*H*16]
-template <int HT, bool WANT_DX, bool W_LDS>
-__global__ void __launch_bounds__(LNR_DENSITY_BLOCK)
+// DWK > 0: single-hidden-layer networks with in_dim == 16*DWK keep the layer-1 weight gradient in MFMA
+// accumulators for the whole kernel (no per-tile LDS float atomics, which run at < 1 lane/clk/CU on CDNA4);
+// DWK == 0: general path, per-tile accumulation into the workgroup's LDS copy.
+#ifndef LNR_BWD_WAVES_PER_SIMD
+#define LNR_BWD_WAVES_PER_SIMD (LNR_HT <= 4 ? 2 : 1)
+#endif
+template <int HT, bool WANT_DX, bool W_LDS, int DWK>
+__global__ void __launch_bounds__(LNR_DENSITY_BLOCK, LNR_BWD_WAVES_PER_SIMD)
 density_backward_kernel(const LnrNetSpec spec, const float* __restrict__ params, const PointSrc src,
                         const float* __restrict__ d_sigma, float* __restrict__ grad_table,
-                        float* __restrict__ d_pts, float* __restrict__ slabs) {
+                        float* __restrict__ d_pts, float* __restrict__ slabs, const BwdSinkArgs sa) {
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     const float* lvt = smem_all;
     float* smem = smem_all + LNR_LV_WORDS;
@@ -408,9 +486,15 @@ density_backward_kernel(const LnrNetSpec spec, const float* __restrict__ params,
     const int in_dim = spec.in_dim;
     const int n_mlp = spec.n_mlp_params;
     const int nw = blockDim.x >> 6;
+    int* cursors = reinterpret_cast<int*>(smem);               // [sa.nown] record cursors
+    smem += sa.nown_padded;
     float* dW = smem + (W_LDS ? n_mlp : 0);
+    for (int i = threadIdx.x; i < sa.nown; i += blockDim.x) cursors[i] = 0;
     for (int i = threadIdx.x; i < n_mlp; i += blockDim.x) { if (W_LDS) smem[i] = params[i]; dW[i] = 0.0f; }
     __syncthreads();
+    GradSink sink;
+    sink.grad_table = grad_table; sink.regions = sa.regions; sink.cursors = cursors;
+    sink.nown = sa.nown; sink.cap = sa.cap; sink.shift = sa.shift; sink.combine_scale_max = sa.combine_scale_max; sink.debug = sa.debug;
     const float* W = W_LDS ? smem : params;
     const float* W1 = W;
     const float* Wh = W + H * in_dim;
@@ -432,6 +516,12 @@ density_backward_kernel(const LnrNetSpec spec, const float* __restrict__ params,
     f32x4 dWo_acc[HT];
 #pragma unroll
     for (int jt = 0; jt < HT; ++jt) dWo_acc[jt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    constexpr int DWK_N = DWK > 0 ? DWK : 1;
+    f32x4 dW1_acc[HT][DWK_N];
+#pragma unroll
+    for (int jt = 0; jt < HT; ++jt)
+#pragma unroll
+        for (int kt = 0; kt < DWK_N; ++kt) dW1_acc[jt][kt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     const int64_t M = live_points(src);
     const int64_t n_tiles = M > 0 ? (M + 15) / 16 : 0;
@@ -505,6 +595,17 @@ density_backward_kernel(const LnrNetSpec spec, const float* __restrict__ params,
             // weight gradient  dW_l[j][k] += sum_c dZ[j][c] * P[k][c]
             const int K = (l == 0) ? in_dim : H;
             float* dWl = (l == 0) ? dW1 : dWh + (l - 1) * H * H;
+            if constexpr (DWK > 0) {           // n_hidden == 1, in_dim == 16*DWK: accumulate in registers
+#pragma unroll
+                for (int kt = 0; kt < DWK; ++kt) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(T_p + (16 * kt + c) * 16 + 4 * g);
+#pragma unroll
+                    for (int jt = 0; jt < HT; ++jt) {
+                        const float4 a4 = *reinterpret_cast<const float4*>(T_dz + (16 * jt + c) * 16 + 4 * g);
+                        MFMA4(dW1_acc[jt][kt], a4, b4.x, b4.y, b4.z, b4.w);
+                    }
+                }
+            } else
             for (int kt = 0; kt < K / 16; ++kt) {
                 const float4 b4 = *reinterpret_cast<const float4*>(T_p + (16 * kt + c) * 16 + 4 * g);
 #pragma unroll
@@ -541,9 +642,9 @@ density_backward_kernel(const LnrNetSpec spec, const float* __restrict__ params,
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
                                 D = __builtin_amdgcn_mfma_f32_16x16x4f32(W1[(16 * jt + 4 * g + r) * in_dim + 16 * kt + c], dZ[jt][r], D, 0, 0, 0);
-                        if (ds != 0.0f) {
+                        {   // all 16 lanes of the row take part (segmented shuffles); dead samples carry zeros
                             const float dfeat[4] = {D.x, D.y, D.z, D.w};
-                            features4_bwd<WANT_DX>(spec, lvt, table, grad_table, x, 16 * kt + 4 * g, dfeat, dx);
+                            features4_bwd<WANT_DX>(spec, lvt, table, sink, x, 16 * kt + 4 * g, lane, dfeat, dx);
                         }
                     }
                 }
@@ -565,6 +666,14 @@ density_backward_kernel(const LnrNetSpec spec, const float* __restrict__ params,
         }
     }
 
+    if constexpr (DWK > 0) {       // flush the register-resident layer-1 weight gradient once per wave
+#pragma unroll
+        for (int jt = 0; jt < HT; ++jt)
+#pragma unroll
+            for (int kt = 0; kt < DWK; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicAdd(dW1 + (16 * jt + 4 * g + r) * in_dim + 16 * kt + c, dW1_acc[jt][kt][r]);
+    }
     // output-layer weight gradient: reduce the per-lane partial sums over the 16 sample lanes
 #pragma unroll
     for (int jt = 0; jt < HT; ++jt) {
@@ -578,5 +687,7 @@ density_backward_kernel(const LnrNetSpec spec, const float* __restrict__ params,
     __syncthreads();
     float* slab = slabs + (size_t)blockIdx.x * n_mlp;
     for (int i = threadIdx.x; i < n_mlp; i += blockDim.x) slab[i] = dW[i];
+    for (int i = threadIdx.x; i < sa.nown; i += blockDim.x)
+        sa.counts[(size_t)blockIdx.x * sa.nown + i] = cursors[i] < sa.cap ? cursors[i] : sa.cap;
 }
 

@@ -55,8 +55,8 @@ def density_forward(spec, params, pts=None, rays=None, z=None, n_rays_dev=None):
 _workspaces = {}
 
 
-def _workspace(spec, device):
-    need = load().lnr_density_backward_workspace(C.byref(spec))
+def _workspace(spec, device, n_points):
+    need = load().lnr_density_backward_workspace(C.byref(spec), int(n_points))
     key = str(device)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() * 4 < need:
@@ -71,7 +71,8 @@ def density_backward(spec, params, d_sigma, grad_params, pts=None, rays=None, z=
     require_device(params, d_sigma, grad_params, pts, rays, z)
     params, d_sigma = _f32c(params), _f32c(d_sigma)
     assert grad_params.dtype == torch.float32 and grad_params.is_contiguous()
-    ws, need = _workspace(spec, params.device)
+    n_points = (pts.numel() // 3) if pts is not None else z.numel()
+    ws, need = _workspace(spec, params.device, n_points)
     if pts is not None:
         pts = _f32c(pts).reshape(-1, 3)
         n = pts.shape[0]

@@ -22,7 +22,7 @@ if [[ "$MODE" == "all" || "$MODE" == "bench" ]]; then
 fi
 if [[ "$MODE" == "prof" || "$MODE" == "all+prof" ]]; then
   rm -rf gpurun_out/prof
-  timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o r01 -- python bench.py --steps ${STEPS:-30} --warmup ${WARMUP:-10} --no-cpu-baseline > gpurun_out/prof_bench.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r01 -- python bench.py --steps ${STEPS:-30} --warmup ${WARMUP:-10} --no-cpu-baseline > gpurun_out/prof_bench.log 2>&1
   echo "prof exit $?" >> gpurun_out/prof_bench.log
   find gpurun_out/prof -name "*kernel_stats*" | head; tail -3 gpurun_out/prof_bench.log
 fi
