@@ -30,6 +30,12 @@ void lnr_set_error(const char* fmt, ...);
 
 static inline int lnr_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Separately rounded float multiply / add.  __fmul_rn/__fadd_rn inline to plain fmul/fadd, which the backend may
+// still contract into an fma under -ffp-contract=fast; the empty asm pins the intermediate in a VGPR so that the
+// product is rounded on its own, as the reference's torch ops do.
+__device__ __forceinline__ float lnr_mul_rn(float a, float b) { float r = a * b; asm volatile("" : "+v"(r)); return r; }
+__device__ __forceinline__ float lnr_add_rn(float a, float b) { float r = a + b; asm volatile("" : "+v"(r)); return r; }
+
 // ---------------------------------------------------------------------------------------------
 // wave-level primitives (64 lanes)
 // ---------------------------------------------------------------------------------------------

@@ -50,10 +50,10 @@ __device__ __forceinline__ void load_unit_point(const PointSrc& s, int64_t m, fl
         float zv = s.z[m];
         const float* r = s.rays + ray * LNR_RAY_STRIDE;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) p[d] = __fadd_rn(r[d], __fmul_rn(r[3 + d], zv));   // o + d*z, as the reference rounds it
+        for (int d = 0; d < 3; ++d) p[d] = lnr_add_rn(r[d], lnr_mul_rn(r[3 + d], zv));   // o + d*z, as the reference rounds it
     }
 #pragma unroll
-    for (int d = 0; d < 3; ++d) x[d] = (p[d] + 1.0f) * 0.5f;
+    for (int d = 0; d < 3; ++d) x[d] = lnr_mul_rn(lnr_add_rn(p[d], 1.0f), 0.5f);   // (xyz+1)/2 rounded like the reference (no fma)
 }
 
 __device__ __forceinline__ float act_fwd(float v, int kind) {
@@ -119,7 +119,7 @@ __device__ __forceinline__ LevelCell level_cell(const float* lvt, int lv, const 
     c.hashed = u[4 * LNR_MAX_LEVELS + lv];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        float pos = __fadd_rn(__fmul_rn(x[d], c.scale), 0.5f);
+        float pos = lnr_add_rn(lnr_mul_rn(x[d], c.scale), 0.5f);
         float fl = floorf(pos);
         c.frac[d] = pos - fl;
         c.base[d] = (uint32_t)(int32_t)fl;
@@ -302,8 +302,8 @@ __device__ __forceinline__ float freq_phase(const LnrNetSpec& spec, const float 
     const int rem = k - dim * per_dim;
     const float mult = (float)(1u << (rem >> 1));     // exact power of two (exp2f is not exact on the GPU)
     float xv = dim == 0 ? x[0] : (dim == 1 ? x[1] : x[2]);
-    float ph = __fmul_rn(__fmul_rn(xv, mult), LNR_PI_F);
-    if (rem & 1) ph = __fadd_rn(ph, LNR_PI_2_F);
+    float ph = lnr_mul_rn(lnr_mul_rn(xv, mult), LNR_PI_F);
+    if (rem & 1) ph = lnr_add_rn(ph, LNR_PI_2_F);
     *dphase_dx = mult * LNR_PI_F;
     *dim_out = dim;
     return ph;

@@ -82,7 +82,7 @@ occ_grid_step_kernel(float* __restrict__ grid, int V, const float* __restrict__ 
         else if (x + margin > 0.0f && margin - x > 0.0f) gval = -l_occ;
         if (gval == 0.0f) continue;
         const float* r = rays + (size_t)ray * LNR_RAY_STRIDE;
-        const float px = __fadd_rn(r[0], __fmul_rn(r[3], zv)), py = __fadd_rn(r[1], __fmul_rn(r[4], zv)), pz = __fadd_rn(r[2], __fmul_rn(r[5], zv));
+        const float px = lnr_add_rn(r[0], lnr_mul_rn(r[3], zv)), py = lnr_add_rn(r[1], lnr_mul_rn(r[4], zv)), pz = lnr_add_rn(r[2], lnr_mul_rn(r[5], zv));
         const float ix = ((px + 1.0f) * fV - 1.0f) * 0.5f, iy = ((py + 1.0f) * fV - 1.0f) * 0.5f, iz = ((pz + 1.0f) * fV - 1.0f) * 0.5f;
         const float x0 = floorf(ix), y0 = floorf(iy), z0 = floorf(iz);
         const float fx = ix - x0, fy = iy - y0, fz = iz - z0;
