@@ -126,6 +126,24 @@ int lnr_build_lidar_rays(const float* directions /*[3,n_points]*/, const float* 
                          float* rays /*[n_index,13]*/, float* depths /*[n_index]*/,
                          uint8_t* keep /*[n_index]*/, void* stream);
 
+/* The same for a whole keyframe window in one launch (optimizer.py:285-340): segment s covers candidates
+ * [seg_start[s], seg_start[s+1]) of keyframe pose row seg_pose[s]; distances[s] == NULL means the constant
+ * const_distance[s] (sky rays, sensors.py:162-167).  index (device, concatenated) may be NULL: the indices are
+ * then drawn in-kernel (the torch.randint of optimizer.py:288,301) and returned in index_out.  All per-segment
+ * arrays are HOST arrays of length n_seg (seg_start: n_seg+1); transforms [n_poses,12] is on the device. */
+int lnr_build_window_rays(const float* const* directions, const float* const* distances, const float* const_distance,
+                          const int64_t* n_points, const int32_t* seg_start, const int32_t* seg_pose, int32_t n_seg,
+                          const int64_t* index, int64_t* index_out, uint64_t seed, const float* transforms,
+                          float range_min, float range_max, float scale, const float* shift /*host [3]*/,
+                          float* rays, float* depths, uint8_t* keep, void* stream);
+
+/* tensor_to_transform (pose_utils.py:288-302) for n poses: pose6 [n,6] = [t, axis-angle] -> transforms [n,12]
+ * (rows of [R|t]); and its backward d_transforms [n,12] -> d_pose6 [n,6] (mask nullable: 0 = fixed pose;
+ * accumulate != 0 adds to d_pose6). */
+int lnr_pose_forward(const float* pose6, int32_t n, float* transforms, void* stream);
+int lnr_pose_backward(const float* pose6, const float* d_transforms, const uint8_t* mask, int32_t n, float* d_pose6,
+                      int32_t accumulate, void* stream);
+
 /* Order-preserving compaction of candidate rays by `keep` (the boolean indexing at
  * ray_utils.py:322 and the vstack at optimizer.py:333-338 for a whole window).
  * seg_start [n_seg+1] (host) delimits the keyframes inside the candidate arrays;
@@ -205,7 +223,7 @@ int lnr_logits_grad(const float* s /*[n,S]*/, const float* g /*[n]*/, int32_t n_
  * Reproduces the reference's `depth > far[0]` broadcast quirk (:460-461).
  * counts_dev [2] int32: {number of rays, number of opaque rays} over the WHOLE batch the loss is
  * normalised by (all GPUs) -- from lnr_count_opaque, all-reduced by the caller when sharded.
- * loss_out [4] float (accumulated with atomics; caller zeroes): {total, depth, los, opacity};
+ * loss_out [8] float (accumulated with atomics; caller zeroes): {total, depth, los, opacity, sum of eps, -,-,-};
  * ray_stats (nullable) [n,8]: {depth, opacity, variance, mean_m, std_m, js, eps, opaque}.
  * weights_out (nullable) [n,S]. */
 int lnr_count_opaque(const float* rays, const float* depth_gt, int32_t n_rays, const int32_t* n_rays_dev,

@@ -63,37 +63,63 @@ extern "C" int lnr_adam_step(float* params, float* grads, float* exp_avg, float*
 }
 
 // ------------------------------------------------------------------------------------------------
-// occupancy grid step: one thread per sample; the pseudo-gradient is 0 for samples more than
-// `margin` behind the surface, so most of the scatter is skipped.
+// occupancy grid step.  A wave walks 64 consecutive samples of a ray; at V=100 about 20 consecutive
+// samples fall into the same voxel, and a float atomic costs one L2 transaction per touched 64-byte line
+// per instruction (profiles/r01_scatter_transactions.txt), so each of the 8 corner contributions is first
+// summed over runs of equal voxel index with segmented shuffles and only run heads issue atomics.
+// The pseudo-gradient is 0 more than `margin` behind the surface, so most runs are skipped altogether.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 occ_grid_step_kernel(float* __restrict__ grid, int V, const float* __restrict__ rays, const float* __restrict__ z,
                      const float* __restrict__ depth_gt, int n_rays, const int32_t* __restrict__ n_rays_dev, int S, float scale,
                      float lr, float margin, float l_free, float l_occ, float* __restrict__ grad_buf) {
+    const int lane = threadIdx.x & 63;
     const int64_t total = (int64_t)lnr_live_rays(n_rays, n_rays_dev) * S;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n_chunks = (total + 63) / 64;
+    const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const float fV = (float)V;
-    for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < total; m += stride) {
-        const int ray = (int)(m / S);
-        const float zv = z[m];
+    for (int64_t chunk = wave_id; chunk < n_chunks; chunk += n_waves) {
+        const int64_t m = chunk * 64 + lane;
+        const bool live = m < total;
+        const int64_t mm = live ? m : total - 1;
+        const int ray = (int)(mm / S);
+        const float zv = z[mm];
         const float x = zv * scale - depth_gt[ray] * scale;
         float gval = 0.0f;
         if (-x - margin > 0.0f) gval = l_free;
         else if (x + margin > 0.0f && margin - x > 0.0f) gval = -l_occ;
-        if (gval == 0.0f) continue;
+        if (!live) gval = 0.0f;
+        if (__ballot(gval != 0.0f) == 0ull) continue;
         const float* r = rays + (size_t)ray * LNR_RAY_STRIDE;
         const float px = lnr_add_rn(r[0], lnr_mul_rn(r[3], zv)), py = lnr_add_rn(r[1], lnr_mul_rn(r[4], zv)), pz = lnr_add_rn(r[2], lnr_mul_rn(r[5], zv));
         const float ix = ((px + 1.0f) * fV - 1.0f) * 0.5f, iy = ((py + 1.0f) * fV - 1.0f) * 0.5f, iz = ((pz + 1.0f) * fV - 1.0f) * 0.5f;
         const float x0 = floorf(ix), y0 = floorf(iy), z0 = floorf(iz);
         const float fx = ix - x0, fy = iy - y0, fz = iz - z0;
+        // run structure: consecutive lanes with the same base voxel AND the same ray
+        const int cell = ((int)z0 * 1024 + (int)y0) * 1024 + (int)x0;
+        const int prev_cell = __shfl_up(cell, 1, 64), prev_ray = __shfl_up(ray, 1, 64);
+        const bool head = (lane == 0) || (prev_cell != cell) || (prev_ray != ray);
+        int seg = head ? 1 : 0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(seg, o, 64); if (lane >= o) seg += t; }
 #pragma unroll
         for (int corner = 0; corner < 8; ++corner) {
             const float xc = x0 + (float)(corner & 1), yc = y0 + (float)((corner >> 1) & 1), zc = z0 + (float)((corner >> 2) & 1);
-            if (xc < 0.0f || xc >= fV || yc < 0.0f || yc >= fV || zc < 0.0f || zc >= fV) continue;
+            const bool inside = !(xc < 0.0f || xc >= fV || yc < 0.0f || yc >= fV || zc < 0.0f || zc >= fV);
             const float w = ((corner & 1) ? fx : 1.0f - fx) * ((corner & 2) ? fy : 1.0f - fy) * ((corner & 4) ? fz : 1.0f - fz);
-            const size_t idx = ((size_t)(int)zc * V + (int)yc) * V + (int)xc;
-            if (grad_buf) atomicAdd(grad_buf + idx, gval * w);
-            else atomicAdd(grid + idx, -lr * (gval * w));
+            float v = inside ? gval * w : 0.0f;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int s2 = __shfl_down(seg, o, 64);
+                const float t = __shfl_down(v, o, 64);
+                if (lane + o < 64 && s2 == seg) v += t;
+            }
+            if (head && inside && v != 0.0f) {
+                const size_t idx = ((size_t)(int)zc * V + (int)yc) * V + (int)xc;
+                if (grad_buf) atomicAdd(grad_buf + idx, v);
+                else atomicAdd(grid + idx, -lr * v);
+            }
         }
     }
 }

@@ -88,6 +88,84 @@ extern "C" int lnr_build_lidar_rays(const float* directions, const float* distan
     return LNR_OK;
 }
 
+// Whole-window variant: every candidate ray of every keyframe (lidar and sky segments) in ONE launch.
+// index == NULL: the source index of each candidate is drawn here (counter-based generator keyed by
+// (seed, segment, i)) - the torch.randint of optimizer.py:288/301 - and written to index_out.
+struct WindowTable {
+    int32_t n_seg;
+    int32_t start[LNR_MAX_SEG + 1];     // candidate range of each segment
+    int32_t pose[LNR_MAX_SEG];          // row of `transforms` used by the segment
+    const float* dirs[LNR_MAX_SEG];
+    const float* dist[LNR_MAX_SEG];     // NULL -> const_dist (sky rays: ray_range[1] + 1)
+    float const_dist[LNR_MAX_SEG];
+    int64_t n_points[LNR_MAX_SEG];
+};
+
+__global__ void build_window_rays_kernel(const WindowTable tab, const int64_t* __restrict__ index, int64_t* __restrict__ index_out,
+                                         uint64_t seed, const float* __restrict__ transforms, float range_min, float range_max,
+                                         float scale, float sx, float sy, float sz, float* __restrict__ rays,
+                                         float* __restrict__ depths, uint8_t* __restrict__ keep) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = tab.start[tab.n_seg];
+    if (i >= total) return;
+    int seg = 0;
+    while (seg + 1 < tab.n_seg && i >= tab.start[seg + 1]) ++seg;
+    const int64_t n_points = tab.n_points[seg];
+    int64_t src;
+    if (index) src = index[i];
+    else {
+        const float u = lnr_rand_uniform(seed, 0x44ull + (uint64_t)seg, (uint64_t)(i - tab.start[seg]) >> 2, (uint32_t)(i - tab.start[seg]) & 3u);
+        src = (int64_t)(u * (float)n_points);
+        if (src >= n_points) src = n_points - 1;
+    }
+    if (index_out) index_out[i] = src;
+    const float* D = tab.dirs[seg];
+    const float l0 = D[src], l1 = D[n_points + src], l2 = D[2 * n_points + src];
+    const float dist = tab.dist[seg] ? tab.dist[seg][src] : tab.const_dist[seg];
+    const float* T = transforms + 12 * tab.pose[seg];
+    float o[3], d[3], v[3];
+    o[0] = (T[3] + sx) / scale; o[1] = (T[7] + sy) / scale; o[2] = (T[11] + sz) / scale;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) v[r] = T[4 * r] * l0 + T[4 * r + 1] * l1 + T[4 * r + 2] * l2;
+    const float nrm = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) d[r] = v[r] / nrm;
+    const float near = range_min / scale;
+    const float far = fminf(range_max / scale, cube_exit(o, d, nullptr, nullptr, nullptr));
+    float* rec = rays + (size_t)i * LNR_RAY_STRIDE;
+    rec[0] = o[0]; rec[1] = o[1]; rec[2] = o[2];
+    rec[3] = d[0]; rec[4] = d[1]; rec[5] = d[2];
+    rec[6] = -d[0]; rec[7] = -d[1]; rec[8] = -d[2];
+    rec[9] = 0.0f; rec[10] = 0.0f; rec[11] = near; rec[12] = far;
+    depths[i] = dist / scale;
+    keep[i] = (far > near + 1.0f / scale) ? 1 : 0;
+}
+
+extern "C" int lnr_build_window_rays(const float* const* directions, const float* const* distances, const float* const_distance,
+                                     const int64_t* n_points, const int32_t* seg_start, const int32_t* seg_pose, int32_t n_seg,
+                                     const int64_t* index, int64_t* index_out, uint64_t seed, const float* transforms,
+                                     float range_min, float range_max, float scale, const float* shift, float* rays, float* depths,
+                                     uint8_t* keep, void* stream) {
+    LNR_REQUIRE(directions && distances && const_distance && n_points && seg_start && seg_pose && transforms && shift && rays && depths && keep,
+                "lnr_build_window_rays: null argument");
+    LNR_REQUIRE(n_seg >= 1 && n_seg <= LNR_MAX_SEG, "lnr_build_window_rays: n_seg must be in [1,%d]", LNR_MAX_SEG);
+    LNR_REQUIRE(index != nullptr || index_out != nullptr, "lnr_build_window_rays: need index or index_out");
+    WindowTable tab;
+    tab.n_seg = n_seg;
+    for (int s = 0; s < n_seg; ++s) {
+        tab.start[s] = seg_start[s]; tab.pose[s] = seg_pose[s]; tab.dirs[s] = directions[s]; tab.dist[s] = distances[s];
+        tab.const_dist[s] = const_distance[s]; tab.n_points[s] = n_points[s];
+        LNR_REQUIRE(directions[s] != nullptr && n_points[s] > 0, "lnr_build_window_rays: segment %d has no points", s);
+    }
+    tab.start[n_seg] = seg_start[n_seg];
+    const int total = seg_start[n_seg];
+    if (total <= 0) return LNR_OK;
+    hipLaunchKernelGGL(build_window_rays_kernel, dim3(lnr_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, tab, index, index_out, seed,
+                       transforms, range_min, range_max, scale, shift[0], shift[1], shift[2], rays, depths, keep);
+    LNR_CHECK_LAUNCH("lnr_build_window_rays");
+    return LNR_OK;
+}
+
 // single-workgroup, order-preserving stream compaction (a window is at most a few thousand rays)
 __global__ void __launch_bounds__(1024)
 compact_rays_kernel(const float* __restrict__ rays_in, const float* __restrict__ depths_in, const uint8_t* __restrict__ keep,

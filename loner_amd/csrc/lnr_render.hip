@@ -308,6 +308,7 @@ los_loss_fused_kernel(const float* __restrict__ sigma, const float* __restrict__
         atomicAdd(loss_out + 1, l_depth);
         atomicAdd(loss_out + 2, l_los);
         atomicAdd(loss_out + 3, l_op);
+        atomicAdd(loss_out + 4, eps);                 // sum of the per-ray margins (-> _depth_eps = mean)
         if (ray_stats) {
             float* o = ray_stats + (size_t)ray * 8;
             o[0] = st.depth; o[1] = st.opacity; o[2] = st.variance; o[3] = mean; o[4] = sd_pred; o[5] = js; o[6] = eps;

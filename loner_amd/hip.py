@@ -53,6 +53,11 @@ _SIGNATURES = {
                                        P, C.c_size_t, P]),
     "lnr_build_lidar_rays": (C.c_int, [P, P, C.c_int64, P, C.c_int32, P, C.c_float, C.c_float, C.c_float,
                                        C.POINTER(C.c_float), P, P, P, P]),
+    "lnr_build_window_rays": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_float), C.POINTER(C.c_int64),
+                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, P, P, C.c_uint64, P, C.c_float, C.c_float,
+                                        C.c_float, C.POINTER(C.c_float), P, P, P, P]),
+    "lnr_pose_forward": (C.c_int, [P, C.c_int32, P, P]),
+    "lnr_pose_backward": (C.c_int, [P, P, P, C.c_int32, P, C.c_int32, P]),
     "lnr_compact_rays": (C.c_int, [P, P, P, P, C.c_int32, C.POINTER(C.c_int32), C.c_int32, P, P, P, P, P, P]),
     "lnr_lidar_rays_backward": (C.c_int, [P, P, P, P, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), P,
                                           C.c_float, P, P]),

@@ -227,7 +227,8 @@ class Optimizer:
             # poses are optimised on the device as one [K,6] tensor (rows of fixed/anchored keyframes get zero gradient)
             pose_cpu = [kf.get_lidar_pose().get_pose_tensor() for kf in active]
             pose_dev = torch.stack([p.detach().to(self._device, torch.float32) for p in pose_cpu]).contiguous()
-            free_rows = torch.tensor([(optimize_poses and not kf.is_anchored) for kf in active], device=self._device)
+            free_rows = torch.tensor([(optimize_poses and not kf.is_anchored) for kf in active], device=self._device).to(torch.uint8)
+            tab = self._window_tables(active)
             any_free = bool(optimize_poses and any(not kf.is_anchored for kf in active))
             pose_dev.requires_grad_(any_free)
             if any_free:
@@ -237,20 +238,18 @@ class Optimizer:
             base_lrs = [g['lr'] for g in groups]
 
             n_it = os_.num_iterations
-            loss_log = torch.zeros(max(n_it, 1), 4, device=self._device)
-            eps_log = torch.zeros(max(n_it, 1), device=self._device)
+            loss_log = torch.zeros(max(n_it, 1), 8, device=self._device)
             valid_log = torch.zeros(max(n_it, 1), device=self._device, dtype=torch.int32)
 
             for it_idx in range(n_it):
                 if not self.should_enable_lidar():
                     break
-                batch = self._build_window_rays(active, pose_dev if any_free else pose_dev.detach())
+                batch = self._build_window_rays(active, pose_dev, tab)
                 valid_log[it_idx:it_idx + 1] = batch["n_dev"]
                 out = self._loss_and_grads(batch["rays"], batch["depths"], sigma_params[0] if sigma_params else
                                            self._model.nerf_model._model_sigma.params, it_idx, want_ray_grads=any_free,
                                            want_param_grads=not os_.freeze_sigma_mlp, n_rays_dev=batch["n_dev"],
-                                           loss_out=loss_log[it_idx], accumulate_into_param_grad=True)
-                eps_log[it_idx:it_idx + 1] = out["mean_eps"]
+                                           loss_out=loss_log[it_idx], accumulate_into_param_grad=True, want_stats=False)
                 if any_free:
                     self._pose_backward(batch, out["d_rays"], pose_dev, free_rows)
                 if self._optimizer is not None:
@@ -279,7 +278,7 @@ class Optimizer:
             if sigma.grad is not None and os_.freeze_sigma_mlp:
                 sigma.grad = None
             losses_log.append(loss_host.tolist())
-            depth_eps_log.append(eps_log.cpu().tolist())
+            depth_eps_log.append((loss_log[:, 4] / valid_log.clamp(min=1).float()).cpu().tolist())
             self._depth_eps = depth_eps_log[-1][-1] if n_it else None
             self.last_stats = {"n_valid_rays": int(valid_log.sum().item()), "iterations": n_it,
                                "loss_terms": loss_log.detach().cpu()}
@@ -294,73 +293,79 @@ class Optimizer:
         return None
 
     # -------------------------------------------------------------------------------------------
-    def _draw_indices(self, kf, count):
-        n = len(kf.get_lidar_scan())
-        strat = self._settings.rays_selection.strategy
-        if strat == 'RANDOM':
-            if self._draws is not None:
-                return self._draws.ray_index(n, count).to(self._device)
-            return (torch.rand(count, device=self._device) * n).long().clamp_(max=n - 1)
-        if strat == 'MASK':
-            mask_index_map = kf.get_lidar_scan().mask.nonzero(as_tuple=True)[0].to(self._device)
-            pick = torch.randint(len(mask_index_map), (count,)).to(self._device)
-            return mask_index_map[pick]
-        if strat == 'FIXED':
-            return torch.arange(count, device=self._device)
-        raise RuntimeError(f"Can't find rays_selection strategy: {strat}")
-
-    def _build_window_rays(self, active, pose_dev):
-        """optimizer.py:285-340 on the device: per keyframe index draw, ray build; then one compaction."""
+    def _window_tables(self, active):
+        """Static per-window segment tables (built once per optimisation phase): per keyframe one lidar segment and,
+        when sky segmentation is on, one sky segment (keyframe.py:91-100)."""
         dev = self._device
-        T = tensor_to_transform(pose_dev)                        # [K,4,4], differentiable w.r.t. pose_dev
-        T12 = T[:, :3, :4].reshape(len(active), 12)
-        T12_c = T12.detach().contiguous()
         n_lidar = self._num_lidar_samples
         n_sky = self._settings.num_samples.sky if self._enable_sky_segmentation else 0
-        segs, seg_dirs, seg_is_sky, seg_kf = [], [], [], []
-        rays_l, depth_l, keep_l, idx_l = [], [], [], []
         rr = [float(self._ray_range[0]), float(self._ray_range[1])]
+        dirs_l, dist_l, const_l, counts, poses, is_sky, lens = [], [], [], [], [], [], []
         for k, kf in enumerate(active):
             scan = kf.get_lidar_scan()
             dirs, dist = device_scan(scan, dev)
-            idx = self._draw_indices(kf, n_lidar)
-            sky_dirs = scan.sky_rays
-            sky_idx = None
-            if n_sky > 0 and sky_dirs is not None and sky_dirs.nelement() > 0:
-                if self._draws is not None:
-                    sky_idx = self._draws.sky_index(sky_dirs.shape[1], n_sky).to(dev)
-                else:
-                    sky_idx = (torch.rand(n_sky, device=dev) * sky_dirs.shape[1]).long().clamp_(max=sky_dirs.shape[1] - 1)
-            r, d, kp = ops.build_lidar_rays(dirs, dist, idx, T12_c[k], rr, self._scale_f, self._shift_f)
-            rays_l.append(r); depth_l.append(d); keep_l.append(kp); idx_l.append(idx)
-            segs.append(idx.shape[0]); seg_dirs.append(dirs); seg_is_sky.append(False); seg_kf.append(k)
-            if sky_idx is not None:
-                sdirs = sky_dirs.detach().to(dev, torch.float32).contiguous()
-                sdist = torch.full((sdirs.shape[1],), rr[1] + 1.0, device=dev)
-                r, d, kp = ops.build_lidar_rays(sdirs, sdist, sky_idx, T12_c[k], rr, self._scale_f, self._shift_f)
-                rays_l.append(r); depth_l.append(d); keep_l.append(kp); idx_l.append(sky_idx)
-                segs.append(sky_idx.shape[0]); seg_dirs.append(sdirs); seg_is_sky.append(True); seg_kf.append(k)
-        seg_start = [0]
-        for s in segs:
-            seg_start.append(seg_start[-1] + s)
-        rays, depths, src, out_seg, n_dev = ops.compact_rays(torch.cat(rays_l), torch.cat(depth_l), torch.cat(keep_l),
-                                                             torch.cat(idx_l), seg_start)
-        return dict(rays=rays, depths=depths, src=src, seg_start=out_seg, n_dev=n_dev, T12=T12, T12_c=T12_c,
-                    seg_dirs=seg_dirs, seg_is_sky=seg_is_sky, seg_kf=seg_kf)
+            dirs_l.append(dirs); dist_l.append(dist); const_l.append(0.0); counts.append(n_lidar); poses.append(k)
+            is_sky.append(False); lens.append(dirs.shape[1])
+            sky = scan.sky_rays
+            if n_sky > 0 and sky is not None and sky.nelement() > 0:
+                sdirs = sky.detach().to(dev, torch.float32).contiguous()
+                dirs_l.append(sdirs); dist_l.append(None); const_l.append(rr[1] + 1.0); counts.append(n_sky); poses.append(k)
+                is_sky.append(True); lens.append(sdirs.shape[1])
+        tab = ops.WindowTables(dirs_l, dist_l, const_l, counts, poses)
+        tab.is_sky, tab.seg_kf, tab.lens, tab.dirs_list = is_sky, poses, lens, dirs_l
+        tab.seg_kf_dev = torch.tensor(poses, device=dev)
+        tab.lidar_seg_mask = torch.tensor([0.0 if s else 1.0 for s in is_sky], device=dev)[:, None]
+        tab.has_sky = any(is_sky)
+        return tab
 
-    def _pose_backward(self, batch, d_rays, pose_dev, free_rows):
-        """dL/drays -> dL/d[R|t] per keyframe (HIP) -> dL/dpose6 (torch autograd through tensor_to_transform)."""
-        K = pose_dev.shape[0]
-        seg_T = batch["T12_c"][torch.tensor(batch["seg_kf"], device=self._device)]
-        dT_seg = ops.lidar_rays_backward(d_rays, batch["rays"], batch["src"], batch["seg_start"], batch["seg_dirs"], seg_T,
-                                         self._scale_f)
-        dT = torch.zeros(K, 12, device=self._device)
-        for s, (k, sky) in enumerate(zip(batch["seg_kf"], batch["seg_is_sky"])):
-            if not sky:                      # sky rays are built from a detached pose (keyframe.py:93)
-                dT[k] += dT_seg[s]
-        (g,) = torch.autograd.grad(batch["T12"], pose_dev, dT)
-        g = g * free_rows[:, None].to(g.dtype)
-        pose_dev.grad = g if pose_dev.grad is None else pose_dev.grad + g
+    def _draw_window_indices(self, active, tab):
+        """Host-injected draws (parity tests) or non-RANDOM strategies; None -> drawn inside the build kernel."""
+        strat = self._settings.rays_selection.strategy
+        if strat == 'RANDOM' and self._draws is None:
+            return None
+        out = []
+        for s in range(tab.n_seg):
+            kf = active[tab.seg_kf[s]]
+            count = tab.seg_start_list[s + 1] - tab.seg_start_list[s]
+            if tab.is_sky[s]:
+                idx = self._draws.sky_index(tab.lens[s], count) if self._draws is not None else \
+                    torch.randint(0, tab.lens[s], (count,))
+            elif strat == 'RANDOM':
+                idx = self._draws.ray_index(tab.lens[s], count)
+            elif strat == 'MASK':
+                m = kf.get_lidar_scan().mask.nonzero(as_tuple=True)[0]
+                idx = m[torch.randint(len(m), (count,))]
+            elif strat == 'FIXED':
+                idx = torch.arange(count)
+            else:
+                raise RuntimeError(f"Can't find rays_selection strategy: {strat}")
+            out.append(idx.to(self._device))
+        return torch.cat(out)
+
+    def _build_window_rays(self, active, pose_dev, tab):
+        """optimizer.py:285-340 on the device: pose -> [R|t], index draw + ray build for the whole window in one
+        launch, one order-preserving compaction."""
+        T12 = ops.pose_forward(pose_dev)
+        rr = [float(self._ray_range[0]), float(self._ray_range[1])]
+        index = self._draw_window_indices(active, tab)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if index is None else 0
+        rays_c, depths_c, keep, src_c = ops.build_window_rays(tab, T12, rr, self._scale_f, self._shift_f, index=index, seed=seed)
+        rays, depths, src, out_seg, n_dev = ops.compact_rays(rays_c, depths_c, keep, src_c, tab.seg_start_list)
+        return dict(rays=rays, depths=depths, src=src, seg_start=out_seg, n_dev=n_dev, T12=T12, tab=tab)
+
+    def _pose_backward(self, batch, d_rays, pose_dev, free_mask_u8):
+        """dL/drays -> dL/d[R|t] per segment (HIP) -> dL/dpose6 (HIP, analytic axis-angle Jacobian)."""
+        tab = batch["tab"]
+        seg_T = batch["T12"] if not tab.has_sky else batch["T12"][tab.seg_kf_dev]
+        dT_seg = ops.lidar_rays_backward(d_rays, batch["rays"], batch["src"], batch["seg_start"], tab.dirs_list, seg_T, self._scale_f)
+        if tab.has_sky:          # sky rays are built from a detached pose (keyframe.py:93): drop their contribution
+            dT = torch.zeros(pose_dev.shape[0], 12, device=self._device).index_add_(0, tab.seg_kf_dev, dT_seg * tab.lidar_seg_mask)
+        else:
+            dT = dT_seg
+        if pose_dev.grad is None:
+            pose_dev.grad = ops.pose_backward(pose_dev, dT, mask=free_mask_u8)
+        else:
+            ops.pose_backward(pose_dev, dT, mask=free_mask_u8, out=pose_dev.grad, accumulate=True)
 
     # -------------------------------------------------------------------------------------------
     def _loss_config(self, iteration_idx) -> hip.LossConfig:
@@ -384,7 +389,7 @@ class Optimizer:
         return cfg
 
     def _loss_and_grads(self, rays, depths, params, iteration_idx, want_ray_grads, want_param_grads, n_rays_dev=None,
-                        loss_out=None, accumulate_into_param_grad=False, draws=None):
+                        loss_out=None, accumulate_into_param_grad=False, draws=None, want_stats=True):
         """sample -> density -> fused render+loss(+backward) -> density backward.  rays [N,13], depths [N] on device."""
         draws = draws if draws is not None else self._draws
         render = self._model_config.model.render
@@ -414,7 +419,7 @@ class Optimizer:
         sigma = ops.density_forward(spec, p, rays=rays, z=z, n_rays_dev=n_rays_dev)
         loss, d_sigma, d_rays, stats, _ = ops.los_loss_fused(sigma, z, rays, depths, self._scale_f, self._loss_config(iteration_idx),
                                                             counts, noise=noise, noise_std=noise_std, seed=seed + 1,
-                                                            n_rays_dev=n_rays_dev, want_stats=True, loss_out=loss_out)
+                                                            n_rays_dev=n_rays_dev, want_stats=want_stats, loss_out=loss_out)
         grad_params = None
         if want_param_grads or want_ray_grads:
             if accumulate_into_param_grad and want_param_grads:
@@ -430,9 +435,8 @@ class Optimizer:
             if self._dist is not None and want_param_grads:
                 self._dist.all_reduce_grads(grad_params)
         self._results_lidar = {"rays": rays, "depths": depths, "samples_fine": z, "n_rays_dev": n_rays_dev, "stats": stats}
-        mean_eps = stats[:, 6].sum() / counts[0].clamp(min=1).float()
         return dict(loss=loss, d_rays=d_rays if want_ray_grads else None,
-                    grad_params=grad_params if want_param_grads else None, stats=stats, z=z, mean_eps=mean_eps.reshape(1))
+                    grad_params=grad_params if want_param_grads else None, stats=stats, z=z)
 
     def compute_loss(self, camera_samples: Tuple[torch.Tensor, torch.Tensor], lidar_samples: Tuple[torch.Tensor, torch.Tensor],
                      iteration_idx: int, override_enables: bool = False, tracking=False) -> torch.Tensor:

@@ -45,8 +45,7 @@ def density_forward(spec, params, pts=None, rays=None, z=None, n_rays_dev=None):
         return sigma
     rays, z = _f32c(rays), _f32c(z)
     n, s = z.shape
-    sigma = torch.zeros(n, s, device=params.device, dtype=torch.float32) if n_rays_dev is not None \
-        else torch.empty(n, s, device=params.device, dtype=torch.float32)
+    sigma = torch.empty(n, s, device=params.device, dtype=torch.float32)      # rows >= *n_rays_dev are never read
     check(load().lnr_density_forward(C.byref(spec), _ptr(params), None, 0, _ptr(rays), _ptr(z), n, s,
                                      _ptr(n_rays_dev), _ptr(sigma), _stream()), "lnr_density_forward")
     return sigma
@@ -83,7 +82,7 @@ def density_backward(spec, params, d_sigma, grad_params, pts=None, rays=None, z=
         return d_pts
     rays, z = _f32c(rays), _f32c(z)
     n, s = z.shape
-    d_pts = torch.zeros(n, s, 3, device=params.device, dtype=torch.float32) if want_d_pts else None
+    d_pts = torch.empty(n, s, 3, device=params.device, dtype=torch.float32) if want_d_pts else None
     check(load().lnr_density_backward(C.byref(spec), _ptr(params), None, 0, _ptr(rays), _ptr(z), n, s,
                                       _ptr(n_rays_dev), _ptr(d_sigma), _ptr(grad_params), _ptr(d_pts), _ptr(ws), need,
                                       _stream()), "lnr_density_backward")
@@ -108,6 +107,65 @@ def build_lidar_rays(directions, distances, index, transform12, ray_range, scale
     return rays, depths, keep
 
 
+class WindowTables:
+    """Host-side per-segment tables of a keyframe window for lnr_build_window_rays (built once per window)."""
+
+    def __init__(self, dirs_list, dist_list, const_dist, seg_counts, seg_pose):
+        n = len(dirs_list)
+        self.n_seg = n
+        self.keepalive = (list(dirs_list), list(dist_list))
+        self.dirs = (C.c_void_p * n)(*[d.data_ptr() for d in dirs_list])
+        self.dist = (C.c_void_p * n)(*[(d.data_ptr() if d is not None else None) for d in dist_list])
+        self.const_dist = (C.c_float * n)(*[float(c) for c in const_dist])
+        self.n_points = (C.c_int64 * n)(*[int(d.shape[1]) for d in dirs_list])
+        starts = [0]
+        for c in seg_counts:
+            starts.append(starts[-1] + int(c))
+        self.seg_start_list = starts
+        self.seg_start = (C.c_int32 * (n + 1))(*starts)
+        self.seg_pose = (C.c_int32 * n)(*[int(p) for p in seg_pose])
+        self.total = starts[-1]
+
+
+def build_window_rays(tab: WindowTables, transforms, ray_range, scale, shift, index=None, seed=0):
+    """-> (rays [total,13], depths, keep, src_index) for every candidate of the window, one launch."""
+    require_device(transforms, index)
+    dev = transforms.device
+    rays = torch.empty(tab.total, hip.RAY_STRIDE, device=dev, dtype=torch.float32)
+    depths = torch.empty(tab.total, device=dev, dtype=torch.float32)
+    keep = torch.empty(tab.total, device=dev, dtype=torch.uint8)
+    idx_out = None
+    if index is None:
+        idx_out = torch.empty(tab.total, device=dev, dtype=torch.int64)
+    else:
+        index = index.to(torch.int64).contiguous()
+    sh = (C.c_float * 3)(float(shift[0]), float(shift[1]), float(shift[2]))
+    check(load().lnr_build_window_rays(tab.dirs, tab.dist, tab.const_dist, tab.n_points, tab.seg_start, tab.seg_pose, tab.n_seg,
+                                       _ptr(index), _ptr(idx_out), int(seed) & (2 ** 64 - 1), _ptr(_f32c(transforms)),
+                                       float(ray_range[0]), float(ray_range[1]), float(scale), sh, _ptr(rays), _ptr(depths),
+                                       _ptr(keep), _stream()), "lnr_build_window_rays")
+    return rays, depths, keep, (index if index is not None else idx_out)
+
+
+def pose_forward(pose6):
+    require_device(pose6)
+    p = _f32c(pose6.detach()).reshape(-1, 6)
+    T = torch.empty(p.shape[0], 12, device=p.device, dtype=torch.float32)
+    check(load().lnr_pose_forward(_ptr(p), p.shape[0], _ptr(T), _stream()), "lnr_pose_forward")
+    return T
+
+
+def pose_backward(pose6, d_transforms, mask=None, out=None, accumulate=False):
+    require_device(pose6, d_transforms, mask, out)
+    p = _f32c(pose6.detach()).reshape(-1, 6)
+    if out is None:
+        out = torch.empty_like(p)
+        accumulate = False
+    check(load().lnr_pose_backward(_ptr(p), _ptr(_f32c(d_transforms)), _ptr(mask), p.shape[0], _ptr(out), int(accumulate), _stream()),
+          "lnr_pose_backward")
+    return out
+
+
 def compact_rays(rays, depths, keep, src_index, seg_start):
     """seg_start: python list [n_seg+1].  -> (rays_out [cap,13], depths_out, src_out, out_seg_start dev int32
     [n_seg+1], n_out dev int32 [1]); only the first n_out rows are meaningful."""
@@ -115,9 +173,9 @@ def compact_rays(rays, depths, keep, src_index, seg_start):
     n_in = rays.shape[0]
     dev = rays.device
     n_seg = len(seg_start) - 1
-    rays_out = torch.zeros_like(rays)
-    depths_out = torch.zeros_like(depths)
-    src_out = torch.zeros_like(src_index) if src_index is not None else None
+    rays_out = torch.empty_like(rays)
+    depths_out = torch.empty_like(depths)
+    src_out = torch.empty_like(src_index) if src_index is not None else None
     out_seg = torch.zeros(n_seg + 1, device=dev, dtype=torch.int32)
     n_out = torch.zeros(1, device=dev, dtype=torch.int32)
     seg = (C.c_int32 * (n_seg + 1))(*[int(v) for v in seg_start])
@@ -160,7 +218,7 @@ def sample_rays_occ(rays, grid, n_samples, perturb, u_jitter=None, u_pdf=None, s
     n = rays.shape[0]
     h = n_samples // 2
     steps = linspace_table(h, rays.device)
-    z = torch.zeros(n, n_samples, device=rays.device, dtype=torch.float32)
+    z = torch.empty(n, n_samples, device=rays.device, dtype=torch.float32)
     inds = probs = cdf = None
     if debug:
         inds = torch.zeros(n, h, device=rays.device, dtype=torch.int64)
@@ -263,8 +321,8 @@ def los_loss_fused(sigma, z, rays, depth_gt, scale, cfg: hip.LossConfig, counts,
     n, s = z.shape
     dev = z.device
     if loss_out is None:
-        loss_out = torch.zeros(4, device=dev)
-    d_sigma = torch.zeros(n, s, device=dev)
+        loss_out = torch.zeros(8, device=dev)
+    d_sigma = torch.empty(n, s, device=dev)
     d_rays = torch.zeros(n, hip.RAY_STRIDE, device=dev)
     stats = torch.zeros(n, 8, device=dev) if want_stats else None
     w = torch.zeros(n, s, device=dev) if want_weights else None

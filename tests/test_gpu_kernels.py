@@ -401,3 +401,51 @@ def test_occ_grid_step_matches_oracle(ops, golden):
     ops.occ_grid_step(grid2, dv(rays), dv(z), dv(depths), scale, 1e-2, grad_buf=buf)
     ops.occ_grid_apply(grid2, buf, 1e-2)
     assert rel(grid2.cpu() - grid0, expect - grid0) < 1e-4 and float(buf.abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------- pose kernels / window build
+def test_pose_forward_backward_match_oracle_autograd(ops):
+    gen = torch.Generator().manual_seed(6)
+    p = torch.randn(9, 6, generator=gen)
+    p[0, 3:] = 0.0                      # identity rotation: exercises the small-angle branch and |aa| = 0
+    p[1, 3:] *= 1e-8
+    T = ops.pose_forward(dv(p))
+    po = p.clone().requires_grad_(True)
+    To = torch.stack([OP.transform_from_pose6(po[i])[:3, :4].reshape(12) for i in range(9)])
+    assert rel(T, To) < 1e-6
+    cot = torch.randn(9, 12, generator=gen)
+    To.backward(cot)
+    mask = torch.tensor([1, 1, 0, 1, 1, 1, 1, 0, 1], dtype=torch.uint8)
+    g = ops.pose_backward(dv(p), dv(cot), mask=mask.to(DEV))
+    expect = po.grad * mask[:, None].float()
+    assert rel(g, expect) < 1e-5
+    assert torch.isfinite(g).all() and float(g[2].abs().max()) == 0.0
+    g2 = ops.pose_backward(dv(p), dv(cot), mask=mask.to(DEV), out=g.clone(), accumulate=True)
+    assert rel(g2, 2 * expect) < 1e-5
+
+
+def test_build_window_rays_equals_per_keyframe_build(ops, golden):
+    g = golden("g1_rays")
+    dirs = [dv(g[f"dirs_g{i}"]) for i in range(3)]
+    dist = [dv(g[f"dist_g{i}"]) for i in range(3)]
+    T = torch.stack([torch.from_numpy(g[f"T{i}"])[:3, :4].reshape(12) for i in range(3)])
+    counts = [300, 64, 500]
+    sky = dv(torch.nn.functional.normalize(torch.randn(3, 40, generator=torch.Generator().manual_seed(1)), dim=0))
+    tab = ops.WindowTables(dirs + [sky], dist + [None], [0.0, 0.0, 0.0, 51.0], counts + [32], [0, 1, 2, 2])
+    gen = torch.Generator().manual_seed(2)
+    idx = torch.cat([torch.randint(0, 700, (c,), generator=gen) for c in counts] + [torch.randint(0, 40, (32,), generator=gen)])
+    rays, depths, keep, src = ops.build_window_rays(tab, dv(T), g["ray_range"], float(g["scale"]), g["shift"], index=idx.to(DEV))
+    assert torch.equal(src.cpu(), idx)
+    lo = 0
+    for s in range(3):
+        r1, d1, k1 = ops.build_lidar_rays(dirs[s], dist[s], idx[lo:lo + counts[s]].to(DEV), dv(T[s]), g["ray_range"], float(g["scale"]), g["shift"])
+        assert torch.equal(rays[lo:lo + counts[s]], r1) and torch.equal(depths[lo:lo + counts[s]], d1) and torch.equal(keep[lo:lo + counts[s]], k1)
+        lo += counts[s]
+    assert torch.allclose(depths[lo:], torch.full((32,), 51.0 / float(g["scale"]), device=DEV))     # sky: constant distance
+    # in-kernel index draw: in range, reproducible per seed, different across seeds
+    r_a = ops.build_window_rays(tab, dv(T), g["ray_range"], float(g["scale"]), g["shift"], seed=5)
+    r_b = ops.build_window_rays(tab, dv(T), g["ray_range"], float(g["scale"]), g["shift"], seed=5)
+    r_c = ops.build_window_rays(tab, dv(T), g["ray_range"], float(g["scale"]), g["shift"], seed=6)
+    assert torch.equal(r_a[3], r_b[3]) and not torch.equal(r_a[3], r_c[3])
+    assert int(r_a[3][:864].min()) >= 0 and int(r_a[3][:864].max()) < 700 and int(r_a[3][864:].max()) < 40
+    assert len(torch.unique(r_a[3][:300])) > 150
