@@ -36,6 +36,13 @@ static inline int lnr_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / 
 __device__ __forceinline__ float lnr_mul_rn(float a, float b) { float r = a * b; asm volatile("" : "+v"(r)); return r; }
 __device__ __forceinline__ float lnr_add_rn(float a, float b) { float r = a + b; asm volatile("" : "+v"(r)); return r; }
 
+// Shifts within a 16-lane row as DPP modifiers (no LDS crossbar traffic, unlike __shfl_* with width 16,
+// which lowers to ds_bpermute).  row_up<N>: lane i reads lane i-N of its row; row_down<N>: lane i reads lane i+N.
+// Lanes whose source falls outside the row read 0 (bound_ctrl) - callers mask those lanes anyway.
+template <int N> __device__ __forceinline__ int row_up_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 + N, 0xF, 0xF, true); }
+template <int N> __device__ __forceinline__ int row_down_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x100 + N, 0xF, 0xF, true); }
+template <int N> __device__ __forceinline__ float row_down_f(float v) { return __int_as_float(row_down_i<N>(__float_as_int(v))); }
+
 // ---------------------------------------------------------------------------------------------
 // wave-level primitives (64 lanes)
 // ---------------------------------------------------------------------------------------------

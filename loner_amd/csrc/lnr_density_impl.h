@@ -105,7 +105,8 @@ __device__ __forceinline__ void stage_level_tables(const LnrNetSpec& spec, float
         u[LNR_MAX_LEVELS + i] = spec.level_res[i];
         u[2 * LNR_MAX_LEVELS + i] = spec.level_size[i];
         u[3 * LNR_MAX_LEVELS + i] = spec.level_offset[i];
-        u[4 * LNR_MAX_LEVELS + i] = spec.level_hashed[i];
+        const uint32_t sz = spec.level_size[i];
+        u[4 * LNR_MAX_LEVELS + i] = (spec.level_hashed[i] & 1u) | ((sz != 0u && (sz & (sz - 1u)) == 0u) ? 2u : 0u);   // bit0 hashed, bit1 size is 2^k
     }
 }
 
@@ -127,10 +128,15 @@ __device__ __forceinline__ LevelCell level_cell(const float* lvt, int lv, const 
     return c;
 }
 
+// kept out of line so that the common power-of-two case really skips the division sequence
+__device__ __noinline__ uint32_t lnr_slow_mod(uint32_t a, uint32_t b) { return a % b; }
+
 __device__ __forceinline__ uint32_t cell_entry(const LevelCell& c, int corner) {
     uint32_t cx = c.base[0] + (corner & 1), cy = c.base[1] + ((corner >> 1) & 1), cz = c.base[2] + ((corner >> 2) & 1);
-    uint32_t idx = c.hashed ? (cx ^ (cy * PRIME_Y) ^ (cz * PRIME_Z)) : (cx + cy * c.res + cz * c.res * c.res);
-    return c.offset + (idx % c.size);
+    uint32_t idx = (c.hashed & 1u) ? (cx ^ (cy * PRIME_Y) ^ (cz * PRIME_Z)) : (cx + cy * c.res + cz * c.res * c.res);
+    // table sizes are powers of two for every level of the usual configurations: mask instead of a ~40-instruction modulo
+    if (c.hashed & 2u) idx &= (c.size - 1u); else idx = lnr_slow_mod(idx, c.size);
+    return c.offset + idx;
 }
 
 __device__ __forceinline__ float corner_weight(const LevelCell& c, int corner) {
@@ -257,19 +263,21 @@ __device__ __forceinline__ void hash_features4_bwd(const LnrNetSpec& spec, const
 #pragma unroll
             for (int f = 0; f < FPL; ++f) v[f] = w * g[f];
             if (combine) {
-                // segmented sum over runs of equal entry along the row
-                const uint32_t prev = __shfl_up(entry, 1, 16);
+                // segmented sum over runs of equal entry along the row (DPP row shifts)
+                const uint32_t prev = (uint32_t)row_up_i<1>((int)entry);
                 const bool head = (c16 == 0) || (prev != entry);
                 int seg = head ? 1 : 0;
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { const int t = __shfl_up(seg, o, 16); if (c16 >= o) seg += t; }
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    const int s2 = __shfl_down(seg, o, 16);
-                    const bool take = (c16 + o < 16) && (s2 == seg);
-#pragma unroll
-                    for (int f = 0; f < FPL; ++f) { const float t = __shfl_down(v[f], o, 16); if (take) v[f] += t; }
-                }
+                { int t;
+                  t = row_up_i<1>(seg); if (c16 >= 1) seg += t;
+                  t = row_up_i<2>(seg); if (c16 >= 2) seg += t;
+                  t = row_up_i<4>(seg); if (c16 >= 4) seg += t;
+                  t = row_up_i<8>(seg); if (c16 >= 8) seg += t; }
+#define LNR_SEG_STEP(O)                                                                          \
+                { const int s2 = row_down_i<O>(seg);                                             \
+                  const bool take = (c16 + O < 16) && (s2 == seg);                               \
+                  _Pragma("unroll") for (int f = 0; f < FPL; ++f) { const float t = row_down_f<O>(v[f]); if (take) v[f] += t; } }
+                LNR_SEG_STEP(1) LNR_SEG_STEP(2) LNR_SEG_STEP(4) LNR_SEG_STEP(8)
+#undef LNR_SEG_STEP
                 if (head) sink_emit<FPL>(sink, e, v);
             } else {
                 sink_emit<FPL>(sink, e, v);
@@ -596,6 +604,7 @@ density_backward_kernel(const LnrNetSpec spec, const float* __restrict__ params,
             const int K = (l == 0) ? in_dim : H;
             float* dWl = (l == 0) ? dW1 : dWh + (l - 1) * H * H;
             if constexpr (DWK > 0) {           // n_hidden == 1, in_dim == 16*DWK: accumulate in registers
+                if (!(sa.debug & 16))
 #pragma unroll
                 for (int kt = 0; kt < DWK; ++kt) {
                     const float4 b4 = *reinterpret_cast<const float4*>(T_p + (16 * kt + c) * 16 + 4 * g);
@@ -642,7 +651,7 @@ density_backward_kernel(const LnrNetSpec spec, const float* __restrict__ params,
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
                                 D = __builtin_amdgcn_mfma_f32_16x16x4f32(W1[(16 * jt + 4 * g + r) * in_dim + 16 * kt + c], dZ[jt][r], D, 0, 0, 0);
-                        {   // all 16 lanes of the row take part (segmented shuffles); dead samples carry zeros
+                        if (!(sa.debug & 8)) {   // all 16 lanes of the row take part (segmented shuffles); dead samples carry zeros
                             const float dfeat[4] = {D.x, D.y, D.z, D.w};
                             features4_bwd<WANT_DX>(spec, lvt, table, sink, x, 16 * kt + 4 * g, lane, dfeat, dx);
                         }
