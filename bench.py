@@ -206,6 +206,18 @@ def main():
             dist.destroy_process_group()
         return
 
+    # quality half of the metric ("at matched L1 depth"): render held-out rays of the first keyframe with the trained
+    # map (Model.forward(testing=True), 2048 samples) and compare with the analytic ranges.  Outside the timed region.
+    l1_depth = None
+    try:
+        from loner_amd.analysis.l1_depth import compute_l1_depth
+        from loner_amd.common.ray_utils import LidarRayDirections
+        kf0 = my_window[0]
+        l1_depth = compute_l1_depth(kf0.get_lidar_pose(), LidarRayDirections(kf0.get_lidar_scan(), chunk_size=2048), opt._model,
+                                    opt._ray_sampler, opt._world_cube, opt._ray_range, opt._device, max_rays=4096)
+    except Exception as e:      # never let the quality probe break the benchmark line
+        l1_depth = f"failed: {e}"
+
     ksum = timer.summary()
     spec = opt._model.nerf_model._model_sigma.spec
     n_local = opt.last_stats["n_valid_rays"] / max(args.steps, 1)          # rays per launch on this rank
@@ -219,12 +231,15 @@ def main():
     if "density_backward" in ksum:
         t = ksum["density_backward"]["avg_ms"] * 1e-3
         ach = flops_bwd / t / 1e12
-        roofline = {"kernel": "density_backward_kernel<4,true>", "bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s",
+        roofline = {"kernel": "density_backward (density_backward_kernel<4,true,true,2> + table_grad_reduce_kernel<1> + reduce_slabs_kernel)",
+                    "bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s",
                     "frac": ach / 157.3, "traffic": None, "avg_launch_ms": ksum["density_backward"]["avg_ms"],
                     "algorithmic_flops_per_launch": flops_bwd, "algorithmic_bytes_per_launch": bytes_bwd,
                     "hbm_achieved_GBps": bytes_bwd / t / 1e9, "hbm_peak_GBps": 8000.0,
-                    "note": "peak = dense fp32 MFMA (v_mfma_f32_16x16x4_f32) rate from MI355X_MICROARCH.md; the kernel is "
-                            "L2-gather/atomic + fp32-MFMA bound, its HBM traffic is far below the 8 TB/s roof"}
+                    "note": "peak = dense fp32 MFMA (v_mfma_f32_16x16x4_f32) rate from MI355X_MICROARCH.md.  The launch is bound by "
+                            "L2 line transactions of random 8-byte gathers / 16-byte record stores (DESIGN.md 4.3), neither by MFMA "
+                            "nor by streaming HBM bandwidth; `traffic` (PMC FETCH_SIZE/WRITE_SIZE, profiles/traffic.json) far above "
+                            "the algorithmic bytes is that line-granular over-fetch"}
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
@@ -242,6 +257,7 @@ def main():
                    "parallelism": f"keyframe-sharded x{world}" if world > 1 else "single GPU"},
         "roofline": roofline, "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in ksum.items()},
         "final_loss": float(opt.last_stats["loss_terms"][-1, 0]),
+        "l1_depth_m": l1_depth, "iterations_trained": args.warmup + args.steps,
     }
     print(json.dumps({k: v for k, v in line.items() if k != "cpu_baseline"}), file=sys.stderr, flush=True)   # progress copy
     if world == 1 and not args.no_cpu_baseline:

@@ -239,6 +239,7 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     sink.regions = (void*)((char*)workspace + L.slabs_bytes + L.counts_bytes);
     sink.nown = L.nown; sink.nown_padded = L.nown_padded; sink.cap = L.cap; sink.shift = L.shift;
     { const char* e = getenv("LNR_DEBUG"); sink.debug = e ? atoi(e) : 0; }
+    if (sink.debug & 32) sink.cap = 0;      // test hook: every record takes the global-atomic fallback path
     sink.combine_scale_max = LNR_COMBINE_SCALE_MAX;   // levels up to ~2^11 cells per axis: consecutive samples of a ray share cells
     float* grad_table = grad_params + spec->n_mlp_params;
     switch (spec->n_neurons / 16) {

@@ -449,3 +449,51 @@ def test_build_window_rays_equals_per_keyframe_build(ops, golden):
     assert torch.equal(r_a[3], r_b[3]) and not torch.equal(r_a[3], r_c[3])
     assert int(r_a[3][:864].min()) >= 0 and int(r_a[3][:864].max()) < 700 and int(r_a[3][864:].max()) < 40
     assert len(torch.unique(r_a[3][:300])) > 150
+
+
+# ------------------------------------------------------------------------------------------- full-size properties
+def test_full_size_iteration_properties(ops):
+    """BASELINE size (4096 rays x 512 samples, default network): size-independent properties of every stage, and the
+    record-partition table gradient against the independent global-atomic accumulation path."""
+    import os
+    from loner_amd import hip
+    from loner_amd.utils import synthetic as SY
+    enc, net = NETS["default"]
+    spec = hip.make_net_spec(enc, net)
+    gen = torch.Generator().manual_seed(0)
+    params = dv(NW.init_params(NW.NetworkSpec.from_config(enc, net), 0))
+    params[spec.n_mlp_params:] *= 2000
+    N, S = 4096, 512
+    dirs, _ = SY.lidar_pattern()
+    scale, shift = SY.world_cube()
+    T = OP.transform_from_pose6(SY.trajectory_pose6(2)[1])
+    dist = SY.scene_ranges(dirs, T)
+    idx = torch.randint(0, dirs.shape[1], (N,), generator=gen)
+    rays, depths, keep = ops.build_lidar_rays(dv(dirs), dv(dist), idx.to(DEV), dv(T[:3, :4].reshape(12)), (1.0, 50.0), scale, shift)
+    assert int(keep.sum()) == N
+    grid = dv(torch.randn(100, 100, 100, generator=gen))
+    z = ops.sample_rays_occ(rays, grid, S, 1.0, seed=3)
+    assert bool((z[:, 1:] >= z[:, :-1]).all()) and bool((z >= rays[:, 11:12]).all()) and bool((z <= rays[:, 12:13]).all())
+    sigma = ops.density_forward(spec, params, rays=rays, z=z)
+    assert torch.isfinite(sigma).all()
+    depth, w, opac, var = ops.render_forward(sigma, z, rays, noise_std=1.0, seed=4)
+    assert bool((w >= 0).all()) and float(opac.max()) <= 1.0 + 1e-5 and bool((var >= 0).all())
+    assert bool((depth >= rays[:, 11] - 1e-6).all()) and bool((depth <= rays[:, 12] + 1e-6).all())    # convex combination of z and far
+    counts = ops.count_opaque(rays, depths)
+    cfg = hip.LossConfig(selection=0, min_js=1.0, max_js=10.0, js_alpha=1.0, los_lambda=1000.0, depth_lambda=0.005, min_eps=0.5, fixed_eps=3.0)
+    loss, d_sigma, d_rays, stats, _ = ops.los_loss_fused(sigma, z, rays, depths, scale, cfg, counts, noise_std=1.0, seed=4, want_stats=True)
+    assert torch.isfinite(loss).all() and abs(float(loss[0]) - float(loss[1] + loss[2] + loss[3])) < 1e-3 * float(loss[0])
+    assert rel(stats[:, 0], depth) < 1e-6                                     # same rendering code, same noise stream
+    # linearity of the backward in d_sigma, and partition path == atomic path
+    g1 = torch.zeros(int(spec.n_params), device=DEV); g2 = torch.zeros_like(g1); g3 = torch.zeros_like(g1)
+    p1 = ops.density_backward(spec, params, d_sigma, g1, rays=rays, z=z, want_d_pts=True)
+    ops.density_backward(spec, params, 2.0 * d_sigma, g2, rays=rays, z=z, want_d_pts=False)
+    assert rel(g2, 2.0 * g1) < 1e-5
+    os.environ["LNR_DEBUG"] = "32"
+    try:
+        p3 = ops.density_backward(spec, params, d_sigma, g3, rays=rays, z=z, want_d_pts=True)
+    finally:
+        del os.environ["LNR_DEBUG"]
+    print("partition vs atomic path: table grad rel", rel(g1, g3), " checksum", float(g1.double().sum()), float(g3.double().sum()))
+    assert rel(g1, g3) < 1e-5 and torch.equal(p1, p3)
+    assert abs(float(g1.double().sum()) - float(g3.double().sum())) < 1e-6 * float(g1.double().abs().sum())

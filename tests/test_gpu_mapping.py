@@ -234,3 +234,27 @@ def test_compute_loss_is_differentiable_like_the_reference(golden):
         assert gp is not None and torch.isfinite(gp).all() and gp.abs().sum() > 0
     opt._step_occupancy_grid()
     assert float(opt._occupancy_grid_model.occupancy_grid.abs().max()) > 0
+
+
+def test_training_reduces_l1_depth_matched_quality_gate():
+    """The quality half of the metric ("training rays/s at matched L1 depth"): map-only optimisation of one synthetic
+    keyframe must pull the rendered depth (Model.forward(testing=True), S=2048) towards the analytic ranges."""
+    from loner_amd.analysis.l1_depth import compute_l1_depth
+    from loner_amd.common.ray_utils import LidarRayDirections
+    from loner_amd.common.settings import default_optimizer_settings
+    from loner_amd.mapping.optimizer import OptimizationSettings, Optimizer
+    from loner_amd.utils import synthetic as SY
+    s = default_optimizer_settings()
+    s["num_samples"]["sky"] = 0
+    torch.manual_seed(0)
+    wc = world_cube()
+    opt = Optimizer(s, None, wc, 0, False, True, False)
+    kf = make_keyframes([SY.trajectory_pose6(1)[0]])[0]
+    rr = torch.tensor([1.0, 50.0])
+    lrd = LidarRayDirections(kf.get_lidar_scan(), chunk_size=2048)
+    args = (kf.get_lidar_pose(), lrd, opt._model, opt._ray_sampler, wc, rr, DEV)
+    before = compute_l1_depth(*args, max_rays=4096)
+    opt._do_iterate_optimizer([kf], [None], optimizer_settings=OptimizationSettings(300, True, False, False, True))
+    after = compute_l1_depth(*args, max_rays=4096)
+    print(f"L1 depth before {before:.3f} m, after 300 iterations {after:.3f} m")
+    assert after < 0.5 * before and after < 2.0
