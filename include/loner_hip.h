@@ -93,27 +93,33 @@ int  lnr_version(void);
 /* ---- density network ------------------------------------------------------------------------- */
 int lnr_net_spec_finalize(LnrNetSpec* spec /*host, in/out*/);
 
+/* Scratch both density calls need, sized for up to n_points points per call: feature planes [enc_dim][n_points],
+ * their gradient, per-level d/dx planes, per-workgroup weight-gradient slabs and the record regions of the
+ * table-gradient partition.  The content between calls only matters for `reuse_features` below. */
+size_t lnr_density_workspace(const LnrNetSpec* spec /*host*/, int64_t n_points);
+
 /* sigma = MLP(enc((xyz+1)/2))[0]           replaces tinycudann forward at nerf_tcnn.py:63-72
  * Points are given either explicitly (pts != NULL, [n_points,3] in the world cube [-1,1]) or
- * implicitly as rays [n_rays,13] + z [n_rays,n_samples] (xyz = o + d*z, rendering_tcnn.py:241). */
+ * implicitly as rays [n_rays,13] + z [n_rays,n_samples] (xyz = o + d*z, rendering_tcnn.py:241).
+ * Two launches: level-major encoding into the workspace's feature planes, then the MLP on those planes. */
 int lnr_density_forward(const LnrNetSpec* spec /*host*/, const float* params,
                         const float* pts, int64_t n_points,
                         const float* rays, const float* z, int32_t n_rays, int32_t n_samples,
                         const int32_t* n_rays_dev,
-                        float* sigma /*[n_points] or [n_rays*n_samples]*/, void* stream);
+                        float* sigma /*[n_points] or [n_rays*n_samples]*/,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* Backward of the above                     replaces tinycudann backward (loss.backward(), optimizer.py:366)
  * grad_params [n_params] is ACCUMULATED into (caller zeroes it; lnr_adam_step can re-zero it).
  * d_pts (nullable) [*,3] receives dL/dxyz per point (needed only when poses are optimised).
- * workspace: lnr_density_backward_workspace(spec, n_points) bytes for up to n_points points per call
- * (per-workgroup weight-gradient slabs + the record regions of the table-gradient partition). */
-size_t lnr_density_backward_workspace(const LnrNetSpec* spec /*host*/, int64_t n_points);
+ * reuse_features != 0: the workspace still holds the feature planes lnr_density_forward wrote for the SAME
+ * spec, params and points (tinycudann keeps its forward activations the same way); 0 re-encodes first. */
 int lnr_density_backward(const LnrNetSpec* spec /*host*/, const float* params,
                          const float* pts, int64_t n_points,
                          const float* rays, const float* z, int32_t n_rays, int32_t n_samples,
                          const int32_t* n_rays_dev,
                          const float* d_sigma, float* grad_params, float* d_pts,
-                         void* workspace, size_t workspace_bytes, void* stream);
+                         int32_t reuse_features, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- rays ------------------------------------------------------------------------------------- */
 /* LidarRayDirections.build_lidar_rays (ray_utils.py:269-322) + get_far_val (:31-60) for one

@@ -1,10 +1,16 @@
-// Density network: host-side dispatch (C ABI), slab reduction and the MFMA layout self-test.
-// The kernels live in lnr_density_impl.h and are instantiated per hidden width in lnr_density_ht.hip.
+// Density network: host-side dispatch (C ABI) of the level-major pipeline
+//   forward : encode (level-major, lnr_encode.hip) -> feature planes -> MLP (fp32 MFMA, lnr_density_impl.h)
+//   backward: [encode] -> MLP backward (weight-gradient slabs + d_feature planes) -> encode backward (table-gradient
+//             records + d/dx planes) -> table_grad_reduce2 (per-owner LDS reduction) -> slab reduce
+// plus the MFMA layout self-test.
 #include <stdlib.h>
 
 #include "lnr_density_api.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LNR_FIX_SCALE 4398046511104.0f /* 2^42 */
+#define LNR_ENC_BWD_MAX_BPG 64
 
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs, int n_mlp, float* __restrict__ grad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -19,56 +25,56 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs
     grad[i] += (s0 + s1) + (s2 + s3);
 }
 
-#define LNR_LV_WORDS_HOST (5 * LNR_MAX_LEVELS)
-#define LNR_FIX_SCALE 4398046511104.0f   /* 2^42 */
-
-// Second half of the table gradient: workgroup `o` owns floats [o << shift, (o+1) << shift) of the table
-// gradient, sums every record addressed to it in LDS and adds the slice to grad_table with plain,
-// coalesced read-modify-writes (it is the only writer of that slice).  PAIR: 16-byte {idx, v0, v1, -}
-// records (n_features >= 2) or 8-byte {idx, v} records.  Four independent loads per lane are kept in
-// flight so that the HBM stream is bandwidth- not latency-bound.
+// Workgroup `o` owns floats [o << shift, (o+1) << shift) of the table gradient.  The encode-backward workgroups of
+// level l (blocks [l*bpg, (l+1)*bpg)) wrote the records addressed to it into region [block][o - first_owner(l)];
+// it streams them (4 x 16-byte loads in flight per lane), sums them in LDS in 64-bit fixed point (LDS float atomics
+// run at < 1 lane/clk/CU on CDNA4, integer ones ~16x faster; 2^-42 resolution, exact and order-independent) and adds
+// the slice to grad_table with coalesced read-modify-writes (it is the only writer of that slice).
+// PAIR: 16-byte {idx, v0, v1, -} records (n_features >= 2) or 8-byte {idx, v} records.
 template <int PAIR>
 __global__ void __launch_bounds__(512)
-table_grad_reduce_kernel(const void* __restrict__ regions_v, const int* __restrict__ counts, int n_src, int nown, int cap,
-                         int shift, float* __restrict__ grad_table, int64_t n_table_floats, int debug) {
-    // LDS float atomics (ds_add_f32) run at < 1 lane/clk/CU on CDNA4, integer ones ~16x faster: the slice is
-    // accumulated in 64-bit fixed point (2^-42 resolution, +-2e6 range; exact and order-independent), converted once.
+table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ regions_v, const int* __restrict__ counts, int bpg, int maxo,
+                          int cap, int shift, float* __restrict__ grad_table, int64_t n_table_floats) {
     extern __shared__ long long acc[];
-    __shared__ int cnt[LNR_BWD_MAX_BLOCKS];
     const int o = blockIdx.x;
     const int slice = 1 << shift;
     const uint32_t base = (uint32_t)o << shift;
     for (int i = threadIdx.x; i < slice; i += blockDim.x) acc[i] = 0ll;
-    for (int b = threadIdx.x; b < n_src; b += blockDim.x) cnt[b] = counts[(size_t)b * nown + o];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    for (int b = wave; b < n_src; b += nwaves) {
-        const int n = cnt[b];
-        const size_t off = ((size_t)b * nown + o) * cap;
-        if (PAIR) {
-            const uint4* r = reinterpret_cast<const uint4*>(regions_v) + off;
-            for (int i0 = 0; i0 < n; i0 += 256) {
-                uint4 rec[4];
+    const int F = spec.n_features;
+    for (int l = 0; l < spec.n_levels; ++l) {
+        const uint64_t lo = (uint64_t)spec.level_offset[l] * F, hi = lo + (uint64_t)spec.level_size[l] * F;   // float range of the level
+        if (hi <= base || lo >= (uint64_t)base + slice) continue;
+        const int local = o - (int)(lo >> shift);
+        if (local < 0 || local >= maxo) continue;
+        for (int b = l * bpg + wave; b < (l + 1) * bpg; b += nwaves) {
+            const int n = counts[(size_t)b * maxo + local];
+            const size_t off = ((size_t)b * maxo + local) * cap;
+            if (PAIR) {
+                const uint4* r = reinterpret_cast<const uint4*>(regions_v) + off;
+                for (int i0 = 0; i0 < n; i0 += 256) {
+                    uint4 rec[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { const int i = i0 + u * 64 + lane; rec[u] = i < n ? r[i] : make_uint4(base, 0u, 0u, 0u); }
+                    for (int u = 0; u < 4; ++u) { const int i = i0 + u * 64 + lane; rec[u] = i < n ? r[i] : make_uint4(base, 0u, 0u, 0u); }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float v0 = __uint_as_float(rec[u].y), v1 = __uint_as_float(rec[u].z);
-                    if (debug & 4) { if (v0 == 1e30f) acc[0] = (long long)v1; continue; }
-                    if (v0 != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[rec[u].x - base]), (unsigned long long)__float2ll_rn(v0 * LNR_FIX_SCALE));
-                    if (v1 != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[rec[u].x - base + 1]), (unsigned long long)__float2ll_rn(v1 * LNR_FIX_SCALE));
+                    for (int u = 0; u < 4; ++u) {
+                        const float v0 = __uint_as_float(rec[u].y), v1 = __uint_as_float(rec[u].z);
+                        if (v0 != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[rec[u].x - base]), (unsigned long long)__float2ll_rn(v0 * LNR_FIX_SCALE));
+                        if (v1 != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[rec[u].x - base + 1]), (unsigned long long)__float2ll_rn(v1 * LNR_FIX_SCALE));
+                    }
                 }
-            }
-        } else {
-            const uint2* r = reinterpret_cast<const uint2*>(regions_v) + off;
-            for (int i0 = 0; i0 < n; i0 += 256) {
-                uint2 rec[4];
+            } else {
+                const uint2* r = reinterpret_cast<const uint2*>(regions_v) + off;
+                for (int i0 = 0; i0 < n; i0 += 256) {
+                    uint2 rec[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { const int i = i0 + u * 64 + lane; rec[u] = i < n ? r[i] : make_uint2(base, 0u); }
+                    for (int u = 0; u < 4; ++u) { const int i = i0 + u * 64 + lane; rec[u] = i < n ? r[i] : make_uint2(base, 0u); }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float v = __uint_as_float(rec[u].y);
-                    if (v != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[rec[u].x - base]), (unsigned long long)__float2ll_rn(v * LNR_FIX_SCALE));
+                    for (int u = 0; u < 4; ++u) {
+                        const float v = __uint_as_float(rec[u].y);
+                        if (v != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[rec[u].x - base]), (unsigned long long)__float2ll_rn(v * LNR_FIX_SCALE));
+                    }
                 }
             }
         }
@@ -81,41 +87,62 @@ table_grad_reduce_kernel(const void* __restrict__ regions_v, const int* __restri
     }
 }
 
-struct SinkLayout {
-    int nown, nown_padded, cap, shift, rec_bytes;
-    size_t slabs_bytes, counts_bytes, regions_bytes;
+// ------------------------------------------------------------------------------------------------
+// workspace layout: [feat enc_dim x m_pad][dfeat enc_dim x m_pad][dxl groups x 3 x m_pad][slabs][counts][regions]
+// ------------------------------------------------------------------------------------------------
+struct Layout {
+    int64_t m_pad;
+    int n_groups, bpg, maxo, cap, shift, nown, rec_bytes;
+    size_t off_feat, off_dfeat, off_dxl, off_slabs, off_counts, off_regions, total;
 };
 
-// Region capacity: an uncombined level of `level_size` entries spreads n_points*8 entry updates over
-// level_size*F/slice owners, i.e. n_points*8*slice/level_size float records per owner (F cancels), divided
-// over the source workgroups; the busiest (smallest uncombined) level sets the capacity, +25 % + 256 slack.
-// Anything beyond that (skewed data) falls back to global atomics, so this is a performance knob only.
-static SinkLayout sink_layout(const LnrNetSpec* spec, int64_t n_points) {
-    SinkLayout L;
-    const int64_t n_table = spec->n_params - spec->n_mlp_params;
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// Region capacity: level l sends n_points*8 corner updates (F/2 pair records each, 1 when F == 1) to the `span`
+// owners its table covers, from bpg workgroups; run-length combined (coarse) levels emit far fewer.  The busiest
+// level sets the capacity (+25 % + 128 slack); anything beyond it (skewed data) falls back to global atomics, so
+// this is a performance knob only.
+static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
+    Layout L;
+    L.m_pad = (n_points + 63) / 64 * 64;
+    if (L.m_pad < 64) L.m_pad = 64;
+    const bool hash = spec->encoding == LNR_ENC_HASHGRID;
+    L.n_groups = hash ? spec->n_levels : 1;
     L.shift = LNR_SLICE_SHIFT;
+    const int64_t n_table = spec->n_params - spec->n_mlp_params;
     L.nown = (int)((n_table + (1 << L.shift) - 1) >> L.shift);
-    L.nown_padded = (L.nown + 3) & ~3;
     L.rec_bytes = spec->n_features >= 2 ? 16 : 8;
-    const double rec_per_touch = spec->n_features >= 4 ? (spec->n_features == 8 ? 2.0 : 2.0) : 1.0;   // F=4/8: two pair-records per 4 features
-    double per_owner = 0.0;
-    if (spec->encoding == LNR_ENC_HASHGRID) {
+    int64_t bpg = (n_points + 256 * 64 - 1) / (256 * 64);
+    if (bpg < 1) bpg = 1;
+    if (bpg > LNR_ENC_BWD_MAX_BPG) bpg = LNR_ENC_BWD_MAX_BPG;
+    L.bpg = (int)bpg;
+    L.maxo = 1;
+    double per_region = 0.0;
+    if (hash) {
+        const int F = spec->n_features;
         for (int l = 0; l < spec->n_levels; ++l) {
-            double owners = (double)spec->level_size[l] * spec->n_features / (double)(1 << L.shift);
-            if (owners < 1.0) owners = 1.0;
-            double r = (double)n_points * 8.0 * rec_per_touch * (spec->n_features == 8 ? 2.0 : 1.0) / owners;
-            if (spec->level_scale[l] < LNR_COMBINE_SCALE_MAX) r *= 0.25;      // run-length combined levels emit far fewer records
-            if (r > per_owner) per_owner = r;
+            const uint64_t lo = (uint64_t)spec->level_offset[l] * F, hi = lo + (uint64_t)spec->level_size[l] * F;
+            const int span = (int)(((hi - 1) >> L.shift) - (lo >> L.shift)) + 1;
+            if (span > L.maxo) L.maxo = span;
+            double r = (double)n_points * 8.0 * (F >= 2 ? F / 2.0 : 1.0) / (double)span / (double)L.bpg;
+            if (spec->level_scale[l] < LNR_COMBINE_SCALE_MAX) r *= 0.25;
+            if (r > per_region) per_region = r;
         }
     }
-    int64_t cap = (int64_t)(per_owner / LNR_BWD_MAX_BLOCKS * 1.25) + 256;
-    const int64_t budget_cap = L.nown > 0 ? (int64_t)(LNR_REGION_BUDGET / ((uint64_t)L.rec_bytes * LNR_BWD_MAX_BLOCKS * (uint64_t)L.nown)) : 0;
+    const int64_t blocks = (int64_t)L.n_groups * L.bpg;
+    int64_t cap = (int64_t)(per_region * 1.25) + 128;
+    const int64_t budget_cap = (int64_t)(LNR_REGION_BUDGET / ((uint64_t)L.rec_bytes * (uint64_t)blocks * (uint64_t)L.maxo));
     if (cap > budget_cap) cap = budget_cap;
     if (cap < 64) cap = 64;
-    L.cap = (int)cap;
-    L.slabs_bytes = (size_t)LNR_BWD_MAX_BLOCKS * (size_t)spec->n_mlp_params * sizeof(float);
-    L.counts_bytes = ((size_t)LNR_BWD_MAX_BLOCKS * (size_t)L.nown * sizeof(int) + 255) & ~(size_t)255;
-    L.regions_bytes = (size_t)LNR_BWD_MAX_BLOCKS * (size_t)L.nown * (size_t)L.cap * (size_t)L.rec_bytes;
+    L.cap = hash ? (int)cap : 0;
+    size_t off = 0;
+    L.off_feat = off; off += align256((size_t)spec->enc_dim * L.m_pad * sizeof(float));
+    L.off_dfeat = off; off += align256((size_t)spec->enc_dim * L.m_pad * sizeof(float));
+    L.off_dxl = off; off += align256((size_t)L.n_groups * 3 * L.m_pad * sizeof(float));
+    L.off_slabs = off; off += align256((size_t)LNR_BWD_MAX_BLOCKS * spec->n_mlp_params * sizeof(float));
+    L.off_counts = off; off += align256(hash ? (size_t)blocks * L.maxo * sizeof(int) : 0);
+    L.off_regions = off; off += hash ? (size_t)blocks * L.maxo * (size_t)L.cap * L.rec_bytes : 0;
+    L.total = off;
     return L;
 }
 
@@ -130,25 +157,21 @@ static int check_spec(const LnrNetSpec* spec, const char* who) {
     return LNR_OK;
 }
 
-static size_t fwd_lds(const LnrNetSpec* s, int w_lds) {
-    return (LNR_LV_WORDS_HOST + (w_lds ? (size_t)s->n_mlp_params : 0)) * sizeof(float);
-}
+static size_t fwd_lds(const LnrNetSpec* s, int w_lds) { return ((w_lds ? (size_t)s->n_mlp_params : 0) + 4) * sizeof(float); }
 static size_t bwd_lds(const LnrNetSpec* s, int w_lds, int waves) {
     const size_t H = s->n_neurons;
-    const size_t scratch = H * 16 + (size_t)s->in_dim * 16 + (s->n_hidden > 1 ? (size_t)(s->n_hidden + 1) * H * 16 : 0);
-    return (LNR_LV_WORDS_HOST + (size_t)sink_layout(s, 0).nown_padded + (w_lds ? 2 : 1) * (size_t)s->n_mlp_params +
-            (size_t)waves * scratch) * sizeof(float);
+    const size_t scratch = H * 16 + (s->n_hidden > 1 ? (size_t)(s->n_hidden + 1) * H * 16 : 0);
+    return ((w_lds ? 2 : 1) * (size_t)s->n_mlp_params + (size_t)waves * scratch) * sizeof(float);
 }
 
-// Pick the launch shape: prefer weights in LDS and 4 waves per workgroup; fall back to fewer waves, then to
-// weights read from global memory, until the workgroup fits the 160 KB LDS of a CDNA4 CU.
+// Launch shape of the MLP kernels: prefer weights in LDS and 4 waves per workgroup; fall back to fewer waves, then to
+// weights read from global memory (L2), until the workgroup fits the 160 KB LDS of a CDNA4 CU.
 static int plan_launch(const LnrNetSpec* spec, int64_t n_points, bool backward, DensityPlan* plan, const char* who) {
     static const int opts[6][2] = {{1, 4}, {1, 2}, {1, 1}, {0, 4}, {0, 2}, {0, 1}};
     for (int o = 0; o < 6; ++o) {
         const int w_lds = opts[o][0], waves = opts[o][1];
         if (!backward && waves != 4) continue;           // forward scratch does not depend on the wave count
         const size_t lds = backward ? bwd_lds(spec, w_lds, waves) : fwd_lds(spec, w_lds);
-        // keep two workgroups per CU resident when the weights are LDS-staged copies (latency hiding for the gathers)
         if (lds > (size_t)LNR_LDS_LIMIT) continue;
         plan->w_lds = w_lds; plan->waves = waves; plan->lds = lds;
         const int64_t tiles = (n_points + 15) / 16;
@@ -165,104 +188,129 @@ static int plan_launch(const LnrNetSpec* spec, int64_t n_points, bool backward, 
     return LNR_ERR_UNSUPPORTED;
 }
 
-static int make_src(PointSrc* s, const float* pts, int64_t n_points, const float* rays, const float* z,
+static int make_src(PointSrc* s, MlpPoints* mp, const float* pts, int64_t n_points, const float* rays, const float* z,
                     int32_t n_rays, int32_t n_samples, const int32_t* n_rays_dev, const char* who) {
     if (pts != nullptr) {
         LNR_REQUIRE(n_points >= 0, "%s: negative n_points", who);
         *s = PointSrc{pts, nullptr, nullptr, 1, n_points, 0, nullptr};
+        *mp = MlpPoints{n_points, nullptr, 0, 1};
     } else {
         LNR_REQUIRE(rays != nullptr && z != nullptr, "%s: need either pts or (rays, z)", who);
         LNR_REQUIRE(n_rays >= 0 && n_samples > 0, "%s: bad n_rays/n_samples", who);
         *s = PointSrc{nullptr, rays, z, n_samples, 0, n_rays, n_rays_dev};
+        *mp = MlpPoints{(int64_t)n_rays * n_samples, n_rays_dev, n_rays, n_samples};
     }
     return LNR_OK;
+}
+
+extern "C" size_t lnr_density_workspace(const LnrNetSpec* spec, int64_t n_points) {
+    if (!spec || n_points < 0) return 0;
+    return make_layout(spec, n_points).total;
 }
 
 extern "C" int lnr_density_forward(const LnrNetSpec* spec, const float* params, const float* pts, int64_t n_points,
                                    const float* rays, const float* z, int32_t n_rays, int32_t n_samples,
-                                   const int32_t* n_rays_dev, float* sigma, void* stream) {
+                                   const int32_t* n_rays_dev, float* sigma, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_spec(spec, "lnr_density_forward");
     if (rc) return rc;
-    LNR_REQUIRE(params && sigma, "lnr_density_forward: null params/sigma");
-    PointSrc src;
-    rc = make_src(&src, pts, n_points, rays, z, n_rays, n_samples, n_rays_dev, "lnr_density_forward");
+    LNR_REQUIRE(params && sigma && workspace, "lnr_density_forward: null params/sigma/workspace");
+    PointSrc src; MlpPoints mp;
+    rc = make_src(&src, &mp, pts, n_points, rays, z, n_rays, n_samples, n_rays_dev, "lnr_density_forward");
     if (rc) return rc;
-    const int64_t cap = pts ? n_points : (int64_t)n_rays * n_samples;
+    const int64_t cap = mp.n_points;
     if (cap == 0) return LNR_OK;
+    const Layout L = make_layout(spec, cap);
+    if (workspace_bytes < L.total) {
+        lnr_set_error("lnr_density_forward: workspace %zu < %zu (lnr_density_workspace)", workspace_bytes, L.total);
+        return LNR_ERR_WORKSPACE;
+    }
     DensityPlan plan;
     rc = plan_launch(spec, cap, false, &plan, "lnr_density_forward");
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    float* feat = (float*)((char*)workspace + L.off_feat);
+    rc = lnr_encode_forward(spec, params, &src, cap, feat, L.m_pad, st);
+    if (rc) return rc;
+    LNR_CHECK_LAUNCH("lnr_density_forward(encode)");
     switch (spec->n_neurons / 16) {
-        case 1: rc = lnr_density_fwd_ht1(spec, params, &src, sigma, &plan, st); break;
-        case 2: rc = lnr_density_fwd_ht2(spec, params, &src, sigma, &plan, st); break;
-        case 4: rc = lnr_density_fwd_ht4(spec, params, &src, sigma, &plan, st); break;
-        case 8: rc = lnr_density_fwd_ht8(spec, params, &src, sigma, &plan, st); break;
-        default: rc = lnr_density_fwd_ht16(spec, params, &src, sigma, &plan, st); break;
+        case 1: rc = lnr_mlp_fwd_ht1(spec, params, feat, L.m_pad, &mp, sigma, &plan, st); break;
+        case 2: rc = lnr_mlp_fwd_ht2(spec, params, feat, L.m_pad, &mp, sigma, &plan, st); break;
+        case 4: rc = lnr_mlp_fwd_ht4(spec, params, feat, L.m_pad, &mp, sigma, &plan, st); break;
+        case 8: rc = lnr_mlp_fwd_ht8(spec, params, feat, L.m_pad, &mp, sigma, &plan, st); break;
+        default: rc = lnr_mlp_fwd_ht16(spec, params, feat, L.m_pad, &mp, sigma, &plan, st); break;
     }
     if (rc) return rc;
-    LNR_CHECK_LAUNCH("lnr_density_forward");
+    LNR_CHECK_LAUNCH("lnr_density_forward(mlp)");
     return LNR_OK;
-}
-
-extern "C" size_t lnr_density_backward_workspace(const LnrNetSpec* spec, int64_t n_points) {
-    if (!spec) return 0;
-    const SinkLayout L = sink_layout(spec, n_points);
-    return L.slabs_bytes + L.counts_bytes + L.regions_bytes;
 }
 
 extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params, const float* pts, int64_t n_points,
                                     const float* rays, const float* z, int32_t n_rays, int32_t n_samples,
                                     const int32_t* n_rays_dev, const float* d_sigma, float* grad_params, float* d_pts,
-                                    void* workspace, size_t workspace_bytes, void* stream) {
+                                    int32_t reuse_features, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_spec(spec, "lnr_density_backward");
     if (rc) return rc;
     LNR_REQUIRE(params && d_sigma && grad_params && workspace, "lnr_density_backward: null argument");
-    const int64_t cap_points = pts ? n_points : (int64_t)n_rays * n_samples;
-    if (workspace_bytes < lnr_density_backward_workspace(spec, cap_points)) {
-        lnr_set_error("lnr_density_backward: workspace %zu < %zu", workspace_bytes, lnr_density_backward_workspace(spec, cap_points));
+    PointSrc src; MlpPoints mp;
+    rc = make_src(&src, &mp, pts, n_points, rays, z, n_rays, n_samples, n_rays_dev, "lnr_density_backward");
+    if (rc) return rc;
+    const int64_t cap = mp.n_points;
+    if (cap == 0) return LNR_OK;
+    const Layout L = make_layout(spec, cap);
+    if (workspace_bytes < L.total) {
+        lnr_set_error("lnr_density_backward: workspace %zu < %zu (lnr_density_workspace)", workspace_bytes, L.total);
         return LNR_ERR_WORKSPACE;
     }
-    PointSrc src;
-    rc = make_src(&src, pts, n_points, rays, z, n_rays, n_samples, n_rays_dev, "lnr_density_backward");
-    if (rc) return rc;
-    const int64_t cap = pts ? n_points : (int64_t)n_rays * n_samples;
-    if (cap == 0) return LNR_OK;
     DensityPlan plan;
     rc = plan_launch(spec, cap, true, &plan, "lnr_density_backward");
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const SinkLayout L = sink_layout(spec, cap_points);
-    float* slabs = (float*)workspace;
-    BwdSinkArgs sink;
-    sink.counts = (int*)((char*)workspace + L.slabs_bytes);
-    sink.regions = (void*)((char*)workspace + L.slabs_bytes + L.counts_bytes);
-    sink.nown = L.nown; sink.nown_padded = L.nown_padded; sink.cap = L.cap; sink.shift = L.shift;
-    { const char* e = getenv("LNR_DEBUG"); sink.debug = e ? atoi(e) : 0; }
-    if (sink.debug & 32) sink.cap = 0;      // test hook: every record takes the global-atomic fallback path
-    sink.combine_scale_max = LNR_COMBINE_SCALE_MAX;   // levels up to ~2^11 cells per axis: consecutive samples of a ray share cells
-    float* grad_table = grad_params + spec->n_mlp_params;
+    char* ws = (char*)workspace;
+    float* feat = (float*)(ws + L.off_feat);
+    float* dfeat = (float*)(ws + L.off_dfeat);
+    float* dxl = (float*)(ws + L.off_dxl);
+    float* slabs = (float*)(ws + L.off_slabs);
+    int* counts = (int*)(ws + L.off_counts);
+    void* regions = (void*)(ws + L.off_regions);
+    const bool hash = spec->encoding == LNR_ENC_HASHGRID;
+    int debug = 0;
+    { const char* e = getenv("LNR_DEBUG"); debug = e ? atoi(e) : 0; }
+    const int cap_rec = (debug & 32) ? 0 : L.cap;          // test hook: every record takes the global-atomic fallback path
+
+    if (!reuse_features) {
+        rc = lnr_encode_forward(spec, params, &src, cap, feat, L.m_pad, st);
+        if (rc) return rc;
+        LNR_CHECK_LAUNCH("lnr_density_backward(encode)");
+    }
+    const int want_dfeat = (hash || d_pts != nullptr) ? 1 : 0;
     switch (spec->n_neurons / 16) {
-        case 1: rc = lnr_density_bwd_ht1(spec, params, &src, d_sigma, grad_table, d_pts, slabs, &sink, &plan, st); break;
-        case 2: rc = lnr_density_bwd_ht2(spec, params, &src, d_sigma, grad_table, d_pts, slabs, &sink, &plan, st); break;
-        case 4: rc = lnr_density_bwd_ht4(spec, params, &src, d_sigma, grad_table, d_pts, slabs, &sink, &plan, st); break;
-        case 8: rc = lnr_density_bwd_ht8(spec, params, &src, d_sigma, grad_table, d_pts, slabs, &sink, &plan, st); break;
-        default: rc = lnr_density_bwd_ht16(spec, params, &src, d_sigma, grad_table, d_pts, slabs, &sink, &plan, st); break;
+        case 1: rc = lnr_mlp_bwd_ht1(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &plan, st); break;
+        case 2: rc = lnr_mlp_bwd_ht2(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &plan, st); break;
+        case 4: rc = lnr_mlp_bwd_ht4(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &plan, st); break;
+        case 8: rc = lnr_mlp_bwd_ht8(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &plan, st); break;
+        default: rc = lnr_mlp_bwd_ht16(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &plan, st); break;
     }
     if (rc) return rc;
-    LNR_CHECK_LAUNCH("lnr_density_backward");
-    if (L.nown > 0) {
+    LNR_CHECK_LAUNCH("lnr_density_backward(mlp)");
+    float* grad_table = grad_params + spec->n_mlp_params;
+    if (want_dfeat) {
+        rc = lnr_encode_backward(spec, params, &src, cap, dfeat, dxl, L.m_pad, grad_table, regions, counts, L.bpg, L.maxo, cap_rec, L.shift,
+                                 debug, d_pts, st);
+        if (rc) return rc;
+        LNR_CHECK_LAUNCH("lnr_density_backward(encode backward)");
+    }
+    if (hash && L.nown > 0 && cap_rec > 0) {
         const size_t lds = ((size_t)1 << L.shift) * sizeof(long long);
-        const int64_t n_table = spec->n_params - spec->n_mlp_params;
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(table_grad_reduce_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(table_grad_reduce_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(table_grad_reduce2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(table_grad_reduce2_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e0 != hipSuccess || e1 != hipSuccess) { lnr_set_error("lnr_density_backward: hipFuncSetAttribute failed"); return LNR_ERR_LAUNCH; }
+        const int64_t n_table = spec->n_params - spec->n_mlp_params;
         if (L.rec_bytes == 16)
-            hipLaunchKernelGGL(table_grad_reduce_kernel<1>, dim3(L.nown), dim3(512), lds, st, sink.regions, sink.counts, plan.grid, L.nown,
-                               L.cap, L.shift, grad_table, n_table, sink.debug);
+            hipLaunchKernelGGL(table_grad_reduce2_kernel<1>, dim3(L.nown), dim3(512), lds, st, *spec, regions, counts, L.bpg, L.maxo, cap_rec,
+                               L.shift, grad_table, n_table);
         else
-            hipLaunchKernelGGL(table_grad_reduce_kernel<0>, dim3(L.nown), dim3(512), lds, st, sink.regions, sink.counts, plan.grid, L.nown,
-                               L.cap, L.shift, grad_table, n_table, sink.debug);
+            hipLaunchKernelGGL(table_grad_reduce2_kernel<0>, dim3(L.nown), dim3(512), lds, st, *spec, regions, counts, L.bpg, L.maxo, cap_rec,
+                               L.shift, grad_table, n_table);
         LNR_CHECK_LAUNCH("lnr_density_backward(table reduce)");
     }
     const int n_mlp = spec->n_mlp_params;

@@ -40,14 +40,28 @@ struct DensityPlan {
     size_t lds;      // dynamic LDS bytes
 };
 
-#define LNR_DECLARE_HT(HT)                                                                                          \
-    int lnr_density_fwd_ht##HT(const LnrNetSpec* spec, const float* params, const PointSrc* src, float* sigma,      \
-                               const DensityPlan* plan, hipStream_t st);                                            \
-    int lnr_density_bwd_ht##HT(const LnrNetSpec* spec, const float* params, const PointSrc* src, const float* d_sigma, \
-                               float* grad_table, float* d_pts, float* slabs, const BwdSinkArgs* sink,         \
-                               const DensityPlan* plan, hipStream_t st);
+// point count description for the MLP kernels (features come from planes)
+struct MlpPoints {
+    int64_t n_points;            // explicit point count (pts mode)
+    const int32_t* n_rays_dev;   // non-null: live ray count on the device (rays mode)
+    int32_t n_rays, n_samples;
+};
+
+#define LNR_DECLARE_HT(HT)                                                                                              \
+    int lnr_mlp_fwd_ht##HT(const LnrNetSpec* spec, const float* params, const float* feat, int64_t m_pad, const MlpPoints* pt, \
+                           float* sigma, const DensityPlan* plan, hipStream_t st);                                      \
+    int lnr_mlp_bwd_ht##HT(const LnrNetSpec* spec, const float* params, const float* feat, int64_t m_pad, const MlpPoints* pt, \
+                           const float* d_sigma, float* dfeat, float* slabs, int want_dfeat, const DensityPlan* plan,   \
+                           hipStream_t st);
 LNR_DECLARE_HT(1)
 LNR_DECLARE_HT(2)
 LNR_DECLARE_HT(4)
 LNR_DECLARE_HT(8)
 LNR_DECLARE_HT(16)
+
+// level-major encoding (lnr_encode.hip)
+int lnr_encode_forward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, float* feat,
+                       int64_t m_pad, hipStream_t st);
+int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, const float* dfeat,
+                        float* dxl, int64_t m_pad, float* grad_table, void* regions, int* counts, int bpg, int maxo, int cap,
+                        int shift, int debug, float* d_pts, hipStream_t st);

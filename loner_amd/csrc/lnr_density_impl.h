@@ -700,3 +700,279 @@ density_backward_kernel(const LnrNetSpec spec, const float* __restrict__ params,
         sa.counts[(size_t)blockIdx.x * sa.nown + i] = cursors[i] < sa.cap ? cursors[i] : sa.cap;
 }
 
+
+
+// ================================================================================================
+// MLP kernels on feature planes (level-major pipeline: lnr_encode.hip produces / consumes the planes)
+//   feat [enc_dim][m_pad]   dfeat [enc_dim][m_pad]     padded inputs (k >= enc_dim) are the constant 1
+// ================================================================================================
+template <int HT>
+__device__ __forceinline__ void layer1_from_planes(const LnrNetSpec& spec, const float* W1, const float* __restrict__ feat,
+                                                   int64_t m_pad, int64_t m, int c, int g, f32x4 Z[HT]) {
+    const int in_dim = spec.in_dim;
+#pragma unroll
+    for (int jt = 0; jt < HT; ++jt) Z[jt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int kt = 0; kt < in_dim / 16; ++kt) {
+        const int k0 = 16 * kt + 4 * g;
+        float xf[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xf[r] = (k0 + r < spec.enc_dim) ? feat[(size_t)(k0 + r) * m_pad + m] : 1.0f;
+#pragma unroll
+        for (int jt = 0; jt < HT; ++jt) {
+            const float4 wa = *reinterpret_cast<const float4*>(W1 + (16 * jt + c) * in_dim + k0);
+            MFMA4(Z[jt], wa, xf[0], xf[1], xf[2], xf[3]);
+        }
+    }
+}
+
+template <int HT, bool W_LDS>
+__global__ void __launch_bounds__(LNR_DENSITY_BLOCK)
+mlp_forward_kernel(const LnrNetSpec spec, const float* __restrict__ params, const float* __restrict__ feat, int64_t m_pad,
+                   int64_t n_points, const int32_t* __restrict__ n_rays_dev, int n_rays, int n_samples, float* __restrict__ sigma) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int H = 16 * HT;
+    const int n_mlp = spec.n_mlp_params;
+    const int nw = blockDim.x >> 6;
+    if (W_LDS) for (int i = threadIdx.x; i < n_mlp; i += blockDim.x) smem[i] = params[i];
+    __syncthreads();
+    const float* W1 = W_LDS ? smem : params;
+    const float* Wh = W1 + H * spec.in_dim;
+    const float* Wo = Wh + (spec.n_hidden - 1) * H * H;
+    const int act = spec.activation;
+    const int64_t M = n_rays_dev ? (int64_t)lnr_live_rays(n_rays, n_rays_dev) * n_samples : n_points;
+    if (M <= 0) return;
+    const int64_t n_tiles = (M + 15) / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < n_tiles; tile += (int64_t)gridDim.x * nw) {
+        int64_t m = tile * 16 + c;
+        const bool valid = m < M;
+        if (!valid) m = M - 1;
+        f32x4 Z[HT];
+        layer1_from_planes<HT>(spec, W1, feat, m_pad, m, c, g, Z);
+        for (int l = 1; l < spec.n_hidden; ++l) {
+            f32x4 Zn[HT];
+            hidden_forward<HT>(Wh + (l - 1) * H * H, H, act, c, g, Z, Zn);
+#pragma unroll
+            for (int jt = 0; jt < HT; ++jt) Z[jt] = Zn[jt];
+        }
+        float part = 0.0f;
+#pragma unroll
+        for (int jt = 0; jt < HT; ++jt) {
+            const float4 wo = *reinterpret_cast<const float4*>(Wo + 16 * jt + 4 * g);
+            part += wo.x * act_fwd(Z[jt].x, act) + wo.y * act_fwd(Z[jt].y, act) + wo.z * act_fwd(Z[jt].z, act) + wo.w * act_fwd(Z[jt].w, act);
+        }
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);
+        if (g == 0 && valid) sigma[m] = part;
+    }
+}
+
+// Backward of the MLP on feature planes: weight gradients (slabs) and dfeat planes.  No gathers, no scatters.
+// LDS map (floats): [W if W_LDS][dW][per-wave: T_dz [H*16] | if n_hidden>1: T_a [H*16] | zsave [n_hidden*H*16]]
+template <int HT, bool W_LDS, int DWK>
+__global__ void __launch_bounds__(LNR_DENSITY_BLOCK)
+mlp_backward_kernel(const LnrNetSpec spec, const float* __restrict__ params, const float* __restrict__ feat, int64_t m_pad,
+                    int64_t n_points, const int32_t* __restrict__ n_rays_dev, int n_rays, int n_samples,
+                    const float* __restrict__ d_sigma, float* __restrict__ dfeat, float* __restrict__ slabs, int want_dfeat) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int H = 16 * HT;
+    const int NH = spec.n_hidden;
+    const int in_dim = spec.in_dim;
+    const int n_mlp = spec.n_mlp_params;
+    const int nw = blockDim.x >> 6;
+    float* dW = smem + (W_LDS ? n_mlp : 0);
+    for (int i = threadIdx.x; i < n_mlp; i += blockDim.x) { if (W_LDS) smem[i] = params[i]; dW[i] = 0.0f; }
+    __syncthreads();
+    const float* W = W_LDS ? smem : params;
+    const float* W1 = W;
+    const float* Wh = W + H * in_dim;
+    const float* Wo = Wh + (NH - 1) * H * H;
+    float* dW1 = dW;
+    float* dWh = dW + H * in_dim;
+    float* dWo = dWh + (NH - 1) * H * H;
+    const int act = spec.activation;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int scratch_per_wave = H * 16 + (NH > 1 ? (NH + 1) * H * 16 : 0);
+    float* T_dz = dW + n_mlp + wave * scratch_per_wave;
+    float* T_a = T_dz + H * 16;
+    float* zsave = T_a + H * 16;
+
+    f32x4 dWo_acc[HT];
+#pragma unroll
+    for (int jt = 0; jt < HT; ++jt) dWo_acc[jt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    constexpr int DWK_N = DWK > 0 ? DWK : 1;
+    f32x4 dW1_acc[HT][DWK_N];
+#pragma unroll
+    for (int jt = 0; jt < HT; ++jt)
+#pragma unroll
+        for (int kt = 0; kt < DWK_N; ++kt) dW1_acc[jt][kt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const int64_t M = n_rays_dev ? (int64_t)lnr_live_rays(n_rays, n_rays_dev) * n_samples : n_points;
+    const int64_t n_tiles = M > 0 ? (M + 15) / 16 : 0;
+    for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < n_tiles; tile += (int64_t)gridDim.x * nw) {
+        int64_t m = tile * 16 + c;
+        const bool valid = m < M;
+        if (!valid) m = M - 1;
+        const float ds = valid ? d_sigma[m] : 0.0f;
+        if (__ballot(ds != 0.0f) == 0ull) {          // nothing flows back into this tile
+            if (want_dfeat && valid) {
+                for (int kt = 0; kt < in_dim / 16; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const int k = 16 * kt + 4 * g + r; if (k < spec.enc_dim) dfeat[(size_t)k * m_pad + m] = 0.0f; }
+            }
+            continue;
+        }
+        f32x4 Z[HT];
+        layer1_from_planes<HT>(spec, W1, feat, m_pad, m, c, g, Z);
+        if (NH > 1) {
+#pragma unroll
+            for (int jt = 0; jt < HT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) zsave[((0 * HT + jt) * 4 + r) * 64 + lane] = Z[jt][r];
+            for (int l = 1; l < NH; ++l) {
+                f32x4 Zn[HT];
+                hidden_forward<HT>(Wh + (l - 1) * H * H, H, act, c, g, Z, Zn);
+#pragma unroll
+                for (int jt = 0; jt < HT; ++jt) {
+                    Z[jt] = Zn[jt];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) zsave[((l * HT + jt) * 4 + r) * 64 + lane] = Zn[jt][r];
+                }
+            }
+        }
+        f32x4 dA[HT];
+#pragma unroll
+        for (int jt = 0; jt < HT; ++jt) {
+            const float4 wo = *reinterpret_cast<const float4*>(Wo + 16 * jt + 4 * g);
+            dA[jt] = f32x4{ds * wo.x, ds * wo.y, ds * wo.z, ds * wo.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dWo_acc[jt][r] += ds * act_fwd(Z[jt][r], act);
+        }
+        for (int l = NH - 1; l >= 0; --l) {
+            f32x4 dZ[HT];
+#pragma unroll
+            for (int jt = 0; jt < HT; ++jt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float zv = (NH > 1) ? zsave[((l * HT + jt) * 4 + r) * 64 + lane] : Z[jt][r];
+                    dZ[jt][r] = dA[jt][r] * act_bwd(zv, act);
+                    T_dz[(16 * jt + 4 * g + r) * 16 + c] = dZ[jt][r];
+                }
+            }
+            if (l > 0) {
+#pragma unroll
+                for (int jt = 0; jt < HT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        T_a[(16 * jt + 4 * g + r) * 16 + c] = act_fwd(zsave[(((l - 1) * HT + jt) * 4 + r) * 64 + lane], act);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+            // weight gradient.  Layer 1: the B operand (X^T, 4 consecutive samples of one feature) is 16 contiguous
+            // bytes of a feature plane - read straight from global memory, no LDS transpose.
+            const int K = (l == 0) ? in_dim : H;
+            float* dWl = (l == 0) ? dW1 : dWh + (l - 1) * H * H;
+            const int64_t tile_base = tile * 16;
+            if (l == 0) {
+                auto load_b = [&](int kt) -> float4 {
+                    const int k = 16 * kt + c;
+                    if (k >= spec.enc_dim) return make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+                    if (tile_base + 16 <= M) return *reinterpret_cast<const float4*>(feat + (size_t)k * m_pad + tile_base + 4 * g);
+                    float4 b;   // ragged last tile: dZ of the padding samples is 0, any finite value will do
+                    const float* p = feat + (size_t)k * m_pad;
+                    b.x = p[min(tile_base + 4 * g + 0, M - 1)]; b.y = p[min(tile_base + 4 * g + 1, M - 1)];
+                    b.z = p[min(tile_base + 4 * g + 2, M - 1)]; b.w = p[min(tile_base + 4 * g + 3, M - 1)];
+                    return b;
+                };
+                if constexpr (DWK > 0) {
+#pragma unroll
+                    for (int kt = 0; kt < DWK; ++kt) {
+                        const float4 b4 = load_b(kt);
+#pragma unroll
+                        for (int jt = 0; jt < HT; ++jt) {
+                            const float4 a4 = *reinterpret_cast<const float4*>(T_dz + (16 * jt + c) * 16 + 4 * g);
+                            MFMA4(dW1_acc[jt][kt], a4, b4.x, b4.y, b4.z, b4.w);
+                        }
+                    }
+                } else {
+                    for (int kt = 0; kt < K / 16; ++kt) {
+                        const float4 b4 = load_b(kt);
+#pragma unroll
+                        for (int jt = 0; jt < HT; ++jt) {
+                            const float4 a4 = *reinterpret_cast<const float4*>(T_dz + (16 * jt + c) * 16 + 4 * g);
+                            f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                            MFMA4(acc, a4, b4.x, b4.y, b4.z, b4.w);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) atomicAdd(dWl + (16 * jt + 4 * g + r) * K + 16 * kt + c, acc[r]);
+                        }
+                    }
+                }
+            } else {
+                for (int kt = 0; kt < K / 16; ++kt) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(T_a + (16 * kt + c) * 16 + 4 * g);
+#pragma unroll
+                    for (int jt = 0; jt < HT; ++jt) {
+                        const float4 a4 = *reinterpret_cast<const float4*>(T_dz + (16 * jt + c) * 16 + 4 * g);
+                        f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                        MFMA4(acc, a4, b4.x, b4.y, b4.z, b4.w);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) atomicAdd(dWl + (16 * jt + 4 * g + r) * K + 16 * kt + c, acc[r]);
+                    }
+                }
+            }
+            // input gradient
+            if (l > 0) {
+                const float* Wl = Wh + (l - 1) * H * H;
+#pragma unroll
+                for (int kt = 0; kt < HT; ++kt) {
+                    f32x4 D = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int jt = 0; jt < HT; ++jt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            D = __builtin_amdgcn_mfma_f32_16x16x4f32(Wl[(16 * jt + 4 * g + r) * H + 16 * kt + c], dZ[jt][r], D, 0, 0, 0);
+                    dA[kt] = D;
+                }
+            } else if (want_dfeat) {
+                for (int kt = 0; kt < in_dim / 16; ++kt) {
+                    f32x4 D = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int jt = 0; jt < HT; ++jt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            D = __builtin_amdgcn_mfma_f32_16x16x4f32(W1[(16 * jt + 4 * g + r) * in_dim + 16 * kt + c], dZ[jt][r], D, 0, 0, 0);
+                    if (valid) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const int k = 16 * kt + 4 * g + r; if (k < spec.enc_dim) dfeat[(size_t)k * m_pad + m] = D[r]; }
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if constexpr (DWK > 0) {
+#pragma unroll
+        for (int jt = 0; jt < HT; ++jt)
+#pragma unroll
+            for (int kt = 0; kt < DWK; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicAdd(dW1 + (16 * jt + 4 * g + r) * in_dim + 16 * kt + c, dW1_acc[jt][kt][r]);
+    }
+#pragma unroll
+    for (int jt = 0; jt < HT; ++jt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = dWo_acc[jt][r];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            if (c == 0) atomicAdd(dWo + 16 * jt + 4 * g + r, v);
+        }
+    }
+    __syncthreads();
+    float* slab = slabs + (size_t)blockIdx.x * n_mlp;
+    for (int i = threadIdx.x; i < n_mlp; i += blockDim.x) slab[i] = dW[i];
+}

@@ -429,7 +429,7 @@ class Optimizer:
             else:
                 grad_params = torch.zeros_like(p)
             d_pts = ops.density_backward(spec, p, d_sigma, grad_params, rays=rays, z=z, n_rays_dev=n_rays_dev,
-                                         want_d_pts=want_ray_grads)
+                                         want_d_pts=want_ray_grads, reuse_features=True)
             if want_ray_grads:
                 ops.points_grad_to_rays(d_pts, z, d_rays, n_rays_dev=n_rays_dev)
             if self._dist is not None and want_param_grads:

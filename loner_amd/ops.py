@@ -33,59 +33,72 @@ def _f32c(t):
 
 
 # ---------------------------------------------------------------- density network
+_workspaces = {}
+
+
+def _workspace(spec, device, n_points):
+    """One scratch buffer per device, grown on demand (feature planes, gradient records, ... - see the header)."""
+    need = load().lnr_density_workspace(C.byref(spec), int(n_points))
+    key = str(device)
+    ent = _workspaces.get(key)
+    if ent is None or ent["buf"].numel() * 4 < need:
+        ent = {"buf": torch.empty((need + 3) // 4, device=device, dtype=torch.float32), "features_of": None}
+        _workspaces[key] = ent
+    return ent, need
+
+
 def density_forward(spec, params, pts=None, rays=None, z=None, n_rays_dev=None):
     require_device(params, pts, rays, z)
     params = _f32c(params)
     if pts is not None:
         pts = _f32c(pts).reshape(-1, 3)
         n = pts.shape[0]
+        ent, need = _workspace(spec, params.device, n)
         sigma = torch.empty(n, device=params.device, dtype=torch.float32)
         check(load().lnr_density_forward(C.byref(spec), _ptr(params), _ptr(pts), n, None, None, 0, 0, None,
-                                         _ptr(sigma), _stream()), "lnr_density_forward")
+                                         _ptr(sigma), _ptr(ent["buf"]), need, _stream()), "lnr_density_forward")
+        ent["features_of"] = (params.data_ptr(), pts.data_ptr(), 0, n)
         return sigma
     rays, z = _f32c(rays), _f32c(z)
     n, s = z.shape
+    ent, need = _workspace(spec, params.device, n * s)
     sigma = torch.empty(n, s, device=params.device, dtype=torch.float32)      # rows >= *n_rays_dev are never read
     check(load().lnr_density_forward(C.byref(spec), _ptr(params), None, 0, _ptr(rays), _ptr(z), n, s,
-                                     _ptr(n_rays_dev), _ptr(sigma), _stream()), "lnr_density_forward")
+                                     _ptr(n_rays_dev), _ptr(sigma), _ptr(ent["buf"]), need, _stream()), "lnr_density_forward")
+    ent["features_of"] = (params.data_ptr(), rays.data_ptr(), z.data_ptr(), n * s)
     return sigma
 
 
-_workspaces = {}
-
-
-def _workspace(spec, device, n_points):
-    need = load().lnr_density_backward_workspace(C.byref(spec), int(n_points))
-    key = str(device)
-    ws = _workspaces.get(key)
-    if ws is None or ws.numel() * 4 < need:
-        ws = torch.empty((need + 3) // 4, device=device, dtype=torch.float32)
-        _workspaces[key] = ws
-    return ws, need
-
-
 def density_backward(spec, params, d_sigma, grad_params, pts=None, rays=None, z=None, n_rays_dev=None,
-                     want_d_pts=False):
-    """Accumulates into grad_params [n_params]; returns d_pts ([...,3]) or None."""
+                     want_d_pts=False, reuse_features=False):
+    """Accumulates into grad_params [n_params]; returns d_pts ([...,3]) or None.
+    reuse_features: the caller asserts that the last density_forward on this device ran on the same params and
+    points (and that neither changed since), so the encoded features still in the workspace are reused."""
     require_device(params, d_sigma, grad_params, pts, rays, z)
     params, d_sigma = _f32c(params), _f32c(d_sigma)
     assert grad_params.dtype == torch.float32 and grad_params.is_contiguous()
     n_points = (pts.numel() // 3) if pts is not None else z.numel()
-    ws, need = _workspace(spec, params.device, n_points)
+    ent, need = _workspace(spec, params.device, n_points)
     if pts is not None:
         pts = _f32c(pts).reshape(-1, 3)
         n = pts.shape[0]
+        reuse = int(bool(reuse_features))
+        if reuse and ent["features_of"] != (params.data_ptr(), pts.data_ptr(), 0, n):
+            raise RuntimeError("density_backward(reuse_features=True): workspace features belong to a different forward call")
         d_pts = torch.empty(n, 3, device=params.device, dtype=torch.float32) if want_d_pts else None
         check(load().lnr_density_backward(C.byref(spec), _ptr(params), _ptr(pts), n, None, None, 0, 0, None,
-                                          _ptr(d_sigma), _ptr(grad_params), _ptr(d_pts), _ptr(ws), need, _stream()),
-              "lnr_density_backward")
+                                          _ptr(d_sigma), _ptr(grad_params), _ptr(d_pts), reuse, _ptr(ent["buf"]), need,
+                                          _stream()), "lnr_density_backward")
         return d_pts
     rays, z = _f32c(rays), _f32c(z)
     n, s = z.shape
+    reuse = int(bool(reuse_features))
+    if reuse and ent["features_of"] != (params.data_ptr(), rays.data_ptr(), z.data_ptr(), n * s):
+        raise RuntimeError("density_backward(reuse_features=True): workspace features belong to a different forward call")
     d_pts = torch.empty(n, s, 3, device=params.device, dtype=torch.float32) if want_d_pts else None
     check(load().lnr_density_backward(C.byref(spec), _ptr(params), None, 0, _ptr(rays), _ptr(z), n, s,
-                                      _ptr(n_rays_dev), _ptr(d_sigma), _ptr(grad_params), _ptr(d_pts), _ptr(ws), need,
-                                      _stream()), "lnr_density_backward")
+                                      _ptr(n_rays_dev), _ptr(d_sigma), _ptr(grad_params), _ptr(d_pts), reuse,
+                                      _ptr(ent["buf"]), need, _stream()), "lnr_density_backward")
     return d_pts
 
 
