@@ -164,9 +164,22 @@ static size_t bwd_lds(const LnrNetSpec* s, int w_lds, int waves) {
     return ((w_lds ? 2 : 1) * (size_t)s->n_mlp_params + (size_t)waves * scratch) * sizeof(float);
 }
 
-// Launch shape of the MLP kernels: prefer weights in LDS and 4 waves per workgroup; fall back to fewer waves, then to
-// weights read from global memory (L2), until the workgroup fits the 160 KB LDS of a CDNA4 CU.
+// Launch shape of the MLP kernels.  The reference's default shape class (32 encoded features -> <= 64 ReLU neurons
+// -> 1) takes the register-resident kernels; everything else prefers weights in LDS and 4 waves per workgroup and
+// falls back to fewer waves, then to weights read from global memory (L2), until the workgroup fits the 160 KB LDS
+// of a CDNA4 CU.
 static int plan_launch(const LnrNetSpec* spec, int64_t n_points, bool backward, DensityPlan* plan, const char* who) {
+    const int64_t tiles = (n_points + 15) / 16;
+    if (spec->activation == LNR_ACT_RELU && spec->n_hidden == 1 && spec->in_dim == 32 && spec->enc_dim == 32 && spec->n_neurons <= 64) {
+        plan->fast32 = 1; plan->w_lds = 1; plan->waves = 4;
+        plan->lds = backward ? (2 * (size_t)spec->n_mlp_params + 4 * (size_t)spec->n_neurons * 20) * sizeof(float)
+                             : (size_t)spec->n_mlp_params * sizeof(float);
+        int64_t blocks = (tiles + 3) / 4;
+        const int64_t max_blocks = backward ? LNR_BWD_MAX_BLOCKS : LNR_DENSITY_MAX_BLOCKS;
+        plan->grid = (int)(blocks > max_blocks ? max_blocks : (blocks < 1 ? 1 : blocks));
+        return LNR_OK;
+    }
+    plan->fast32 = 0;
     static const int opts[6][2] = {{1, 4}, {1, 2}, {1, 1}, {0, 4}, {0, 2}, {0, 1}};
     for (int o = 0; o < 6; ++o) {
         const int w_lds = opts[o][0], waves = opts[o][1];
@@ -174,7 +187,6 @@ static int plan_launch(const LnrNetSpec* spec, int64_t n_points, bool backward, 
         const size_t lds = backward ? bwd_lds(spec, w_lds, waves) : fwd_lds(spec, w_lds);
         if (lds > (size_t)LNR_LDS_LIMIT) continue;
         plan->w_lds = w_lds; plan->waves = waves; plan->lds = lds;
-        const int64_t tiles = (n_points + 15) / 16;
         int64_t blocks = (tiles + waves - 1) / waves;
         const int64_t max_blocks = backward ? LNR_BWD_MAX_BLOCKS : LNR_DENSITY_MAX_BLOCKS;
         if (blocks > max_blocks) blocks = max_blocks;

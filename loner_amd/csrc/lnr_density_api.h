@@ -17,16 +17,6 @@ struct PointSrc {
     const int32_t* n_rays_dev;
 };
 
-// record sink of the backward kernel (see GradSink in lnr_density_impl.h)
-struct BwdSinkArgs {
-    void* regions;         // [grid][nown][cap] records (8 bytes when n_features == 1, else 16)
-    int* counts;           // [grid][nown]
-    int nown, nown_padded; // owners; padded to a multiple of 4 words for LDS alignment
-    int cap, shift;
-    float combine_scale_max;
-    int debug;             // getenv("LNR_DEBUG") bits, profiling experiments only
-};
-
 #define LNR_BWD_MAX_BLOCKS 512
 #define LNR_SLICE_SHIFT 13            // 8192 floats (32 KB of LDS) per owner
 #define LNR_REGION_BUDGET (24ull << 30)
@@ -38,6 +28,7 @@ struct DensityPlan {
     int waves;       // waves per workgroup (1, 2 or 4)
     int w_lds;       // 1: MLP matrices staged in LDS, 0: read from global memory
     size_t lds;      // dynamic LDS bytes
+    int fast32;      // 1: the register-resident kernels for 32 features -> <= 64 ReLU neurons -> 1
 };
 
 // point count description for the MLP kernels (features come from planes)

@@ -17,30 +17,39 @@ static int set_lds(K kernel, size_t bytes, const char* who) {
     return LNR_OK;
 }
 
+#define LNR_LAUNCH_MF(WL, ACT)                                                                                        \
+    do {                                                                                                              \
+        rc = set_lds(mlp_forward_kernel<LNR_HT, WL, ACT>, plan->lds, "lnr_density_forward");                          \
+        if (rc) return rc;                                                                                            \
+        hipLaunchKernelGGL((mlp_forward_kernel<LNR_HT, WL, ACT>), grid, block, plan->lds, st, *spec, params, feat, m_pad, \
+                           pt->n_points, pt->n_rays_dev, pt->n_rays, pt->n_samples, sigma);                           \
+    } while (0)
+
 int LNR_CAT(lnr_mlp_fwd_ht, LNR_HT)(const LnrNetSpec* spec, const float* params, const float* feat, int64_t m_pad, const MlpPoints* pt,
                                      float* sigma, const DensityPlan* plan, hipStream_t st) {
     int rc;
     const dim3 grid(plan->grid), block(64 * plan->waves);
-    if (plan->w_lds) {
-        rc = set_lds(mlp_forward_kernel<LNR_HT, true>, plan->lds, "lnr_density_forward");
+    const bool relu = spec->activation == LNR_ACT_RELU;
+#if LNR_HT <= 4
+    if (plan->fast32) {
+        rc = set_lds(mlp_forward_relu32_kernel<LNR_HT>, plan->lds, "lnr_density_forward");
         if (rc) return rc;
-        hipLaunchKernelGGL((mlp_forward_kernel<LNR_HT, true>), grid, block, plan->lds, st, *spec, params, feat, m_pad, pt->n_points,
+        hipLaunchKernelGGL((mlp_forward_relu32_kernel<LNR_HT>), grid, block, plan->lds, st, *spec, params, feat, m_pad, pt->n_points,
                            pt->n_rays_dev, pt->n_rays, pt->n_samples, sigma);
-    } else {
-        rc = set_lds(mlp_forward_kernel<LNR_HT, false>, plan->lds, "lnr_density_forward");
-        if (rc) return rc;
-        hipLaunchKernelGGL((mlp_forward_kernel<LNR_HT, false>), grid, block, plan->lds, st, *spec, params, feat, m_pad, pt->n_points,
-                           pt->n_rays_dev, pt->n_rays, pt->n_samples, sigma);
+        return LNR_OK;
     }
+#endif
+    if (plan->w_lds) { if (relu) LNR_LAUNCH_MF(true, LNR_ACT_RELU); else LNR_LAUNCH_MF(true, -1); }
+    else { if (relu) LNR_LAUNCH_MF(false, LNR_ACT_RELU); else LNR_LAUNCH_MF(false, -1); }
     return LNR_OK;
 }
 
-#define LNR_LAUNCH_MB(WL, DWK)                                                                                        \
+#define LNR_LAUNCH_MB(WL, DWK, ACT)                                                                                   \
     do {                                                                                                              \
-        rc = set_lds(mlp_backward_kernel<LNR_HT, WL, DWK>, plan->lds, "lnr_density_backward");                        \
+        rc = set_lds(mlp_backward_kernel<LNR_HT, WL, DWK, ACT>, plan->lds, "lnr_density_backward");         \
         if (rc) return rc;                                                                                            \
-        hipLaunchKernelGGL((mlp_backward_kernel<LNR_HT, WL, DWK>), grid, block, plan->lds, st, *spec, params, feat, m_pad, \
-                           pt->n_points, pt->n_rays_dev, pt->n_rays, pt->n_samples, d_sigma, dfeat, slabs, want_dfeat); \
+        hipLaunchKernelGGL((mlp_backward_kernel<LNR_HT, WL, DWK, ACT>), grid, block, plan->lds, st, *spec, params, feat, \
+                           m_pad, pt->n_points, pt->n_rays_dev, pt->n_rays, pt->n_samples, d_sigma, dfeat, slabs, want_dfeat); \
     } while (0)
 
 int LNR_CAT(lnr_mlp_bwd_ht, LNR_HT)(const LnrNetSpec* spec, const float* params, const float* feat, int64_t m_pad, const MlpPoints* pt,
@@ -48,10 +57,17 @@ int LNR_CAT(lnr_mlp_bwd_ht, LNR_HT)(const LnrNetSpec* spec, const float* params,
                                      hipStream_t st) {
     int rc;
     const dim3 grid(plan->grid), block(64 * plan->waves);
+    const bool relu = spec->activation == LNR_ACT_RELU;
 #if LNR_HT <= 4
-    // the reference's default shape class (one hidden layer, 32 encoded features): register-resident dW1
-    if (plan->w_lds && spec->n_hidden == 1 && spec->in_dim == 32) { LNR_LAUNCH_MB(true, 2); return LNR_OK; }
+    if (plan->fast32) {
+        rc = set_lds(mlp_backward_relu32_kernel<LNR_HT>, plan->lds, "lnr_density_backward");
+        if (rc) return rc;
+        hipLaunchKernelGGL((mlp_backward_relu32_kernel<LNR_HT>), grid, block, plan->lds, st, *spec, params, feat, m_pad, pt->n_points,
+                           pt->n_rays_dev, pt->n_rays, pt->n_samples, d_sigma, dfeat, slabs, want_dfeat);
+        return LNR_OK;
+    }
 #endif
-    if (plan->w_lds) LNR_LAUNCH_MB(true, 0); else LNR_LAUNCH_MB(false, 0);
+    if (plan->w_lds) { if (relu) LNR_LAUNCH_MB(true, 0, LNR_ACT_RELU); else LNR_LAUNCH_MB(true, 0, -1); }
+    else { if (relu) LNR_LAUNCH_MB(false, 0, LNR_ACT_RELU); else LNR_LAUNCH_MB(false, 0, -1); }
     return LNR_OK;
 }

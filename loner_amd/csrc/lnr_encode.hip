@@ -9,8 +9,7 @@
 // Backward: one thread per (sample, level) re-derives the cell, turns d_feature into table-gradient records
 // (run-length combined over the 64 consecutive samples of a wave on coarse levels), and writes its contribution to
 // d/dx as one plane per level; records are reduced by table_grad_reduce2_kernel (lnr_density.hip).
-#define LNR_HT 4
-#include "lnr_density_impl.h"
+#include "lnr_encoding.h"
 
 #define ENC_BLOCK 256
 
@@ -48,7 +47,14 @@ encode_forward_kernel(const LnrNetSpec spec, const float* __restrict__ table, co
     __syncthreads();
     const int group = blockIdx.x / bpg, chunk = blockIdx.x % bpg;
     const int64_t M = live_points(src);
-    for (int64_t m = (int64_t)chunk * ENC_BLOCK + threadIdx.x; m < M; m += (int64_t)bpg * ENC_BLOCK) {
+    const int64_t M16 = (M + 15) / 16 * 16;      // the MLP kernels read whole 16-sample tiles: zero the ragged tail
+    const int nf = spec.encoding == LNR_ENC_HASHGRID ? F : 4;
+    for (int64_t m = (int64_t)chunk * ENC_BLOCK + threadIdx.x; m < M16; m += (int64_t)bpg * ENC_BLOCK) {
+        if (m >= M) {
+            for (int f = 0; f < nf; ++f)
+                if (group * nf + f < spec.enc_dim) feat[(size_t)(group * nf + f) * m_pad + m] = 0.0f;
+            continue;
+        }
         float x[3];
         load_unit_point(src, m, x);
         if (spec.encoding == LNR_ENC_HASHGRID) {
