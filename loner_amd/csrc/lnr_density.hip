@@ -9,8 +9,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define LNR_FIX_SCALE 4398046511104.0f /* 2^42 */
-#define LNR_ENC_BWD_MAX_BPG 64
+#define LNR_ENC_BWD_MAX_BPG 512
 
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs, int n_mlp, float* __restrict__ grad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -27,10 +26,23 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs
 
 // Workgroup `o` owns floats [o << shift, (o+1) << shift) of the table gradient.  The encode-backward workgroups of
 // level l (blocks [l*bpg, (l+1)*bpg)) wrote the records addressed to it into region [block][o - first_owner(l)];
-// it streams them (4 x 16-byte loads in flight per lane), sums them in LDS in 64-bit fixed point (LDS float atomics
-// run at < 1 lane/clk/CU on CDNA4, integer ones ~16x faster; 2^-42 resolution, exact and order-independent) and adds
-// the slice to grad_table with coalesced read-modify-writes (it is the only writer of that slice).
-// PAIR: 16-byte {idx, v0, v1, -} records (n_features >= 2) or 8-byte {idx, v} records.
+// it streams them (4 x 16-byte loads = 8 records in flight per lane), sums them in LDS in 64-bit fixed point (LDS
+// float atomics run at < 1 lane/clk/CU on CDNA4, integer ones ~16x faster; 2^-42 resolution, exact and
+// order-independent) and adds the slice to grad_table with coalesced read-modify-writes (it is the only writer of
+// that slice).  PAIR: packed pair records (n_features >= 2) or {idx, v} records - see lnr_density_api.h.
+template <int PAIR>
+__device__ __forceinline__ void reduce_one(long long* acc, uint2 r, uint32_t base) {
+    if (PAIR) {
+        uint32_t pi; float v0, v1;
+        lnr_unpack_pair(r, pi, v0, v1);
+        if (v0 != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[2 * pi]), (unsigned long long)__float2ll_rn(v0 * LNR_FIX_SCALE));
+        if (v1 != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[2 * pi + 1]), (unsigned long long)__float2ll_rn(v1 * LNR_FIX_SCALE));
+    } else {
+        const float v = __uint_as_float(r.y);
+        if (v != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[r.x - base]), (unsigned long long)__float2ll_rn(v * LNR_FIX_SCALE));
+    }
+}
+
 template <int PAIR>
 __global__ void __launch_bounds__(512)
 table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ regions_v, const int* __restrict__ counts, int bpg, int maxo,
@@ -46,35 +58,25 @@ table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ region
     for (int l = 0; l < spec.n_levels; ++l) {
         const uint64_t lo = (uint64_t)spec.level_offset[l] * F, hi = lo + (uint64_t)spec.level_size[l] * F;   // float range of the level
         if (hi <= base || lo >= (uint64_t)base + slice) continue;
+        if (hi - lo <= (uint64_t)LNR_DENSE_LEVEL_FLOATS) continue;          // dense level: arrives through the slabs
         const int local = o - (int)(lo >> shift);
         if (local < 0 || local >= maxo) continue;
-        for (int b = l * bpg + wave; b < (l + 1) * bpg; b += nwaves) {
-            const int n = counts[(size_t)b * maxo + local];
-            const size_t off = ((size_t)b * maxo + local) * cap;
-            if (PAIR) {
-                const uint4* r = reinterpret_cast<const uint4*>(regions_v) + off;
-                for (int i0 = 0; i0 < n; i0 += 256) {
-                    uint4 rec[4];
+        const int b_end = (l + 1) * bpg;
+        int b = l * bpg + wave;
+        int n_next = b < b_end ? counts[(size_t)b * maxo + local] : 0;
+        for (; b < b_end; b += nwaves) {
+            const int n = n_next;
+            if (b + nwaves < b_end) n_next = counts[(size_t)(b + nwaves) * maxo + local];     // fetched behind this region's records
+            const uint4* r = reinterpret_cast<const uint4*>(reinterpret_cast<const uint2*>(regions_v) + ((size_t)b * maxo + local) * cap);   // cap is even
+            for (int i0 = 0; i0 < n; i0 += 512) {
+                uint4 rec[4];       // unconditional 16-byte loads (out-of-range lanes re-read record 0 and ignore it)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) { const int i = i0 + u * 64 + lane; rec[u] = i < n ? r[i] : make_uint4(base, 0u, 0u, 0u); }
+                for (int u = 0; u < 4; ++u) { const int i = i0 + 2 * (u * 64 + lane); rec[u] = r[i < n ? (i >> 1) : 0]; }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float v0 = __uint_as_float(rec[u].y), v1 = __uint_as_float(rec[u].z);
-                        if (v0 != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[rec[u].x - base]), (unsigned long long)__float2ll_rn(v0 * LNR_FIX_SCALE));
-                        if (v1 != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[rec[u].x - base + 1]), (unsigned long long)__float2ll_rn(v1 * LNR_FIX_SCALE));
-                    }
-                }
-            } else {
-                const uint2* r = reinterpret_cast<const uint2*>(regions_v) + off;
-                for (int i0 = 0; i0 < n; i0 += 256) {
-                    uint2 rec[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { const int i = i0 + u * 64 + lane; rec[u] = i < n ? r[i] : make_uint2(base, 0u); }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float v = __uint_as_float(rec[u].y);
-                        if (v != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[rec[u].x - base]), (unsigned long long)__float2ll_rn(v * LNR_FIX_SCALE));
-                    }
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + 2 * (u * 64 + lane);
+                    if (i < n) reduce_one<PAIR>(acc, make_uint2(rec[u].x, rec[u].y), base);
+                    if (i + 1 < n) reduce_one<PAIR>(acc, make_uint2(rec[u].z, rec[u].w), base);
                 }
             }
         }
@@ -93,7 +95,7 @@ table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ region
 struct Layout {
     int64_t m_pad;
     int n_groups, bpg, maxo, cap, shift, nown, rec_bytes;
-    size_t off_feat, off_dfeat, off_dxl, off_slabs, off_counts, off_regions, total;
+    size_t off_feat, off_dfeat, off_dxl, off_slabs, off_dense, off_counts, off_regions, total;
 };
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -111,16 +113,18 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
     L.shift = LNR_SLICE_SHIFT;
     const int64_t n_table = spec->n_params - spec->n_mlp_params;
     L.nown = (int)((n_table + (1 << L.shift) - 1) >> L.shift);
-    L.rec_bytes = spec->n_features >= 2 ? 16 : 8;
-    int64_t bpg = (n_points + 256 * 64 - 1) / (256 * 64);
+    L.rec_bytes = 8;
+    int64_t bpg = (n_points + 256 * 16 - 1) / (256 * 16);      // ~16 batches of 256 samples per encode-backward workgroup
     if (bpg < 1) bpg = 1;
     if (bpg > LNR_ENC_BWD_MAX_BPG) bpg = LNR_ENC_BWD_MAX_BPG;
     L.bpg = (int)bpg;
     L.maxo = 1;
     double per_region = 0.0;
+    size_t dense_total = 0;
     if (hash) {
         const int F = spec->n_features;
         for (int l = 0; l < spec->n_levels; ++l) {
+            if (lnr_level_is_dense(spec, l)) { dense_total += (size_t)spec->level_size[l] * F; continue; }
             const uint64_t lo = (uint64_t)spec->level_offset[l] * F, hi = lo + (uint64_t)spec->level_size[l] * F;
             const int span = (int)(((hi - 1) >> L.shift) - (lo >> L.shift)) + 1;
             if (span > L.maxo) L.maxo = span;
@@ -134,12 +138,14 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
     const int64_t budget_cap = (int64_t)(LNR_REGION_BUDGET / ((uint64_t)L.rec_bytes * (uint64_t)blocks * (uint64_t)L.maxo));
     if (cap > budget_cap) cap = budget_cap;
     if (cap < 64) cap = 64;
+    cap = (cap + 1) & ~(int64_t)1;       // even: regions stay 16-byte aligned
     L.cap = hash ? (int)cap : 0;
     size_t off = 0;
     L.off_feat = off; off += align256((size_t)spec->enc_dim * L.m_pad * sizeof(float));
     L.off_dfeat = off; off += align256((size_t)spec->enc_dim * L.m_pad * sizeof(float));
     L.off_dxl = off; off += align256((size_t)L.n_groups * 3 * L.m_pad * sizeof(float));
     L.off_slabs = off; off += align256((size_t)LNR_BWD_MAX_BLOCKS * spec->n_mlp_params * sizeof(float));
+    L.off_dense = off; off += align256(dense_total * (size_t)L.bpg * sizeof(float));
     L.off_counts = off; off += align256(hash ? (size_t)blocks * L.maxo * sizeof(int) : 0);
     L.off_regions = off; off += hash ? (size_t)blocks * L.maxo * (size_t)L.cap * L.rec_bytes : 0;
     L.total = off;
@@ -282,6 +288,7 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     float* dfeat = (float*)(ws + L.off_dfeat);
     float* dxl = (float*)(ws + L.off_dxl);
     float* slabs = (float*)(ws + L.off_slabs);
+    float* dense_slabs = (float*)(ws + L.off_dense);
     int* counts = (int*)(ws + L.off_counts);
     void* regions = (void*)(ws + L.off_regions);
     const bool hash = spec->encoding == LNR_ENC_HASHGRID;
@@ -306,7 +313,7 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     LNR_CHECK_LAUNCH("lnr_density_backward(mlp)");
     float* grad_table = grad_params + spec->n_mlp_params;
     if (want_dfeat) {
-        rc = lnr_encode_backward(spec, params, &src, cap, dfeat, dxl, L.m_pad, grad_table, regions, counts, L.bpg, L.maxo, cap_rec, L.shift,
+        rc = lnr_encode_backward(spec, params, &src, cap, dfeat, dxl, L.m_pad, grad_table, regions, counts, dense_slabs, L.bpg, L.maxo, cap_rec, L.shift,
                                  debug, d_pts, st);
         if (rc) return rc;
         LNR_CHECK_LAUNCH("lnr_density_backward(encode backward)");
@@ -317,7 +324,7 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
         hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(table_grad_reduce2_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e0 != hipSuccess || e1 != hipSuccess) { lnr_set_error("lnr_density_backward: hipFuncSetAttribute failed"); return LNR_ERR_LAUNCH; }
         const int64_t n_table = spec->n_params - spec->n_mlp_params;
-        if (L.rec_bytes == 16)
+        if (spec->n_features >= 2)
             hipLaunchKernelGGL(table_grad_reduce2_kernel<1>, dim3(L.nown), dim3(512), lds, st, *spec, regions, counts, L.bpg, L.maxo, cap_rec,
                                L.shift, grad_table, n_table);
         else

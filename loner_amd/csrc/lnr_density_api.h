@@ -21,6 +21,28 @@ struct PointSrc {
 #define LNR_SLICE_SHIFT 13            // 8192 floats (32 KB of LDS) per owner
 #define LNR_REGION_BUDGET (24ull << 30)
 #define LNR_COMBINE_SCALE_MAX 3000.0f
+#define LNR_FIX_SCALE 4398046511104.0f /* 2^42: LDS gradient accumulators are 64-bit fixed point */
+
+// Table-gradient records are 8 bytes.  n_features == 1: {float index, fp32 value}.  n_features >= 2: two values of one
+// entry pair, each rounded (to nearest even) to 26 bits = sign, 8 exponent, 17 mantissa bits (relative error <= 2^-18,
+// below the reordering noise of an fp32 sum of the same records), and the pair's index inside its owner slice:
+//   hi = [v0: 31..6][v1 high 6: 5..0]     lo = [v1 low 20: 31..12][pair index: 11..0]
+static_assert(LNR_SLICE_SHIFT == 13, "pair records hold a 12-bit pair index: 8192-float owner slices");
+__host__ __device__ __forceinline__ uint32_t lnr_pack26(float v) {
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    u += 0x1Fu + ((u >> 6) & 1u);
+    return u >> 6;
+}
+__device__ __forceinline__ uint2 lnr_pack_pair(uint32_t pair_idx, float v0, float v1) {
+    const uint32_t a = lnr_pack26(v0), b = lnr_pack26(v1);
+    return make_uint2((b << 12) | (pair_idx & 0xFFFu), (a << 6) | (b >> 20));     // .x = lo, .y = hi
+}
+__device__ __forceinline__ void lnr_unpack_pair(uint2 r, uint32_t& pair_idx, float& v0, float& v1) {
+    pair_idx = r.x & 0xFFFu;
+    v0 = __uint_as_float(r.y & 0xFFFFFFC0u);
+    v1 = __uint_as_float(((r.y & 0x3Fu) << 26) | ((r.x >> 6) & 0x03FFFFC0u));
+}
 
 // launch plan chosen by the dispatcher
 struct DensityPlan {
@@ -50,9 +72,22 @@ LNR_DECLARE_HT(4)
 LNR_DECLARE_HT(8)
 LNR_DECLARE_HT(16)
 
+// Levels whose whole table is at most this many floats are accumulated densely in LDS by the encode-backward
+// workgroups (64-bit fixed point) and leave as per-workgroup slabs instead of records: on those levels every ray
+// crosses the same few thousand entries, which would make their one or two owner slices the tail of the reduce.
+#define LNR_DENSE_LEVEL_FLOATS 12288
+struct LevelList {
+    int n;                          // levels handled by a launch
+    int lv[LNR_MAX_LEVELS];
+    int slab_off[LNR_MAX_LEVELS];   // dense levels: float offset inside one workgroup's slab
+};
+static inline bool lnr_level_is_dense(const LnrNetSpec* s, int l) {
+    return (uint64_t)s->level_size[l] * (uint64_t)s->n_features <= (uint64_t)LNR_DENSE_LEVEL_FLOATS;
+}
+
 // level-major encoding (lnr_encode.hip)
 int lnr_encode_forward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, float* feat,
                        int64_t m_pad, hipStream_t st);
 int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, const float* dfeat,
-                        float* dxl, int64_t m_pad, float* grad_table, void* regions, int* counts, int bpg, int maxo, int cap,
-                        int shift, int debug, float* d_pts, hipStream_t st);
+                        float* dxl, int64_t m_pad, float* grad_table, void* regions, int* counts, float* dense_slabs, int bpg,
+                        int maxo, int cap, int shift, int debug, float* d_pts, hipStream_t st);

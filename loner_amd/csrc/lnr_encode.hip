@@ -73,57 +73,277 @@ encode_forward_kernel(const LnrNetSpec spec, const float* __restrict__ table, co
 }
 
 // ------------------------------------------------------------------------------------------------ backward
+// Table-gradient records.  Float atomics to global memory top out at ~21 G/s on MI355X whatever the scope, locality
+// or table size (profiles/r01_atomic_throughput.txt), and scattered 16-byte stores at ~87 G lines/s
+// (profiles/r01_scatter_transactions.txt) - both far too slow for the 270 M corner updates of one default iteration.
+// Instead each workgroup radix-partitions the records of a batch of 256 samples by owner slice IN LDS (histogram ->
+// scan -> scatter into a staging buffer) and then copies the staging buffer out linearly: records of one owner are
+// contiguous both in LDS and in that owner's (workgroup, owner) region in HBM, so the stores coalesce into full lines.
+// table_grad_reduce2_kernel (lnr_density.hip) sums each owner's regions in LDS.
 struct EncSink {
-    float* grad_table;
-    void* regions;          // [block][maxo][cap] records
+    float* grad_table;      // fallback target for records beyond a region's capacity
+    void* regions;          // [block][maxo][cap] 8-byte records (lnr_density_api.h)
     int* counts;            // [block][maxo]
     int maxo, cap, shift;
     float combine_scale_max;
     int debug;
 };
 
-__device__ __forceinline__ void enc_emit(const EncSink& s, int* cursors, int first_owner, uint32_t fidx, float v0, float v1, bool pair) {
-    if (v0 == 0.0f && (!pair || v1 == 0.0f)) return;
-    const int local = (int)(fidx >> s.shift) - first_owner;
-    int slot = s.cap;
-    if (local >= 0 && local < s.maxo && s.cap > 0) slot = atomicAdd(&cursors[local], 1);
-    if (slot < s.cap) {
-        const size_t at = ((size_t)blockIdx.x * s.maxo + local) * s.cap + slot;
-        if (pair) reinterpret_cast<uint4*>(s.regions)[at] = make_uint4(fidx, __float_as_uint(v0), __float_as_uint(v1), 0u);
-        else reinterpret_cast<uint2*>(s.regions)[at] = make_uint2(fidx, __float_as_uint(v0));
-    } else {
-        atomicAdd(s.grad_table + fidx, v0);
-        if (pair) atomicAdd(s.grad_table + fidx + 1, v1);
-    }
-}
+// Run-length combining on coarse levels: consecutive samples of a ray fall into the same cell there, so their 8 corner
+// updates are summed before they become records.  Runs are confined to the 16-lane DPP rows of a wave: row shifts are
+// plain VALU operands, whereas a 64-lane segmented sum needs ds_bpermute for every step (measured ~3x the cost).
+struct RunMask { bool take1, take2, take4, take8; };
 
-// segmented sum over the 64 lanes of a wave: lanes with equal consecutive `seg` ids are summed into the run head
-__device__ __forceinline__ float wave_run_sum(float v, int seg, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int s2 = __shfl_down(seg, o, 64);
-        const float t = __shfl_down(v, o, 64);
-        if (lane + o < 64 && s2 == seg) v += t;
-    }
+__device__ __forceinline__ float row_run_sum(float v, const RunMask& k) {
+    float t;
+    t = row_down_f<1>(v); if (k.take1) v += t;
+    t = row_down_f<2>(v); if (k.take2) v += t;
+    t = row_down_f<4>(v); if (k.take4) v += t;
+    t = row_down_f<8>(v); if (k.take8) v += t;
     return v;
 }
 
+// d(level features . g)/dx of one sample needs the 8 corner entries again (L2-resident, see the file header).  The
+// gathers are issued by corner_dots_issue() early in an iteration and consumed by dx_from_dots() at its end.
+template <int F>
+__device__ __forceinline__ void corner_entries_load(const LevelCell& c, const float* __restrict__ table, float tv[8][F]) {
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+        const uint32_t e = cell_entry(c, corner) * F;
+        if constexpr (F == 1) tv[corner][0] = table[e];
+        else if constexpr (F == 2) { const float2 t2 = *reinterpret_cast<const float2*>(table + e); tv[corner][0] = t2.x; tv[corner][1] = t2.y; }
+        else {
+#pragma unroll
+            for (int q = 0; q < F / 4; ++q) {
+                const float4 t4 = *reinterpret_cast<const float4*>(table + e + 4 * q);
+                tv[corner][4 * q] = t4.x; tv[corner][4 * q + 1] = t4.y; tv[corner][4 * q + 2] = t4.z; tv[corner][4 * q + 3] = t4.w;
+            }
+        }
+    }
+}
+template <int F>
+__device__ __forceinline__ void dx_from_entries(const LevelCell& c, const float g[F], const float tv[8][F], float dx[3]) {
+    float dfrac[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+        float dot = 0.0f;
+#pragma unroll
+        for (int f = 0; f < F; ++f) dot += g[f] * tv[corner][f];
+        const float wx = (corner & 1) ? c.frac[0] : 1.0f - c.frac[0];
+        const float wy = (corner & 2) ? c.frac[1] : 1.0f - c.frac[1];
+        const float wz = (corner & 4) ? c.frac[2] : 1.0f - c.frac[2];
+        dfrac[0] += ((corner & 1) ? dot : -dot) * wy * wz;
+        dfrac[1] += ((corner & 2) ? dot : -dot) * wx * wz;
+        dfrac[2] += ((corner & 4) ? dot : -dot) * wx * wy;
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) dx[d] = dfrac[d] * c.scale;
+}
+template <int F>
+__device__ __forceinline__ void encode_dx(const LevelCell& c, const float g[F], const float* __restrict__ table, float dx[3]) {
+    float tv[8][F];
+    corner_entries_load<F>(c, table, tv);
+    dx_from_entries<F>(c, g, tv, dx);
+}
+
+// run masks of one 16-lane row: which lanes share the cell of their left neighbour
+__device__ __forceinline__ void cell_runs(const LevelCell& c, int lane, bool& head, RunMask& run) {
+    const int c16 = lane & 15;
+    const int k1 = (int)(c.base[0] | (c.base[1] << 16)), k2 = (int)c.base[2];
+    // the DPP reads must run with all lanes active: evaluate them before (not inside) any short-circuit logic
+    const int p1 = row_up_i<1>(k1), p2 = row_up_i<1>(k2);
+    head = (c16 == 0) | (p1 != k1) | (p2 != k2);
+    int seg = head ? 1 : 0;
+    int t;
+    t = row_up_i<1>(seg); if (c16 >= 1) seg += t;
+    t = row_up_i<2>(seg); if (c16 >= 2) seg += t;
+    t = row_up_i<4>(seg); if (c16 >= 4) seg += t;
+    t = row_up_i<8>(seg); if (c16 >= 8) seg += t;
+    const int s1 = row_down_i<1>(seg), s2 = row_down_i<2>(seg), s4 = row_down_i<4>(seg), s8 = row_down_i<8>(seg);
+    run.take1 = (c16 + 1 < 16) & (s1 == seg);
+    run.take2 = (c16 + 2 < 16) & (s2 == seg);
+    run.take4 = (c16 + 4 < 16) & (s4 == seg);
+    run.take8 = (c16 + 8 < 16) & (s8 == seg);
+}
+
+#define ENC_STAGE_RECORDS (ENC_BLOCK * 8)
+
+// dynamic LDS: int cnt[maxo], scan[maxo], gpos[maxo], gcur[maxo]; then (16-byte aligned) the staging buffer
 template <int F, bool WANT_DX>
 __global__ void __launch_bounds__(ENC_BLOCK)
 encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, const PointSrc src, const float* __restrict__ dfeat,
-                       float* __restrict__ dxl, int64_t m_pad, int bpg, const EncSink sink) {
-    extern __shared__ int cursors[];
+                       float* __restrict__ dxl, int64_t m_pad, int bpg, const LevelList list, const EncSink sink) {
+    extern __shared__ __attribute__((aligned(16))) int dyn[];
+    __shared__ float lvt[LNR_LV_WORDS];
+    __shared__ int s_total;
+    constexpr bool PAIR = F >= 2;
+    constexpr int NPASS = PAIR ? F / 2 : 1;
+    const int maxo = sink.maxo;
+    int* cnt = dyn;
+    int* scan = dyn + maxo;
+    int* gpos = dyn + 2 * maxo;
+    int* gcur = dyn + 3 * maxo;
+    void* stage = reinterpret_cast<void*>(dyn + ((4 * maxo + 3) & ~3));
+    stage_level_tables(spec, lvt);
+    for (int i = threadIdx.x; i < maxo; i += ENC_BLOCK) { cnt[i] = 0; gcur[i] = 0; }
+    __syncthreads();
+    const int lv = list.lv[blockIdx.x / bpg], chunk = blockIdx.x % bpg;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t M = live_points(src);
+    const int first_owner = (int)(((uint64_t)spec.level_offset[lv] * F) >> sink.shift);
+    const bool combine = spec.level_scale[lv] < sink.combine_scale_max && !(sink.debug & 16);
+    const size_t region0 = ((size_t)lv * bpg + chunk) * maxo;
+    const int64_t step = (int64_t)bpg * ENC_BLOCK;
+    const int64_t n_iter = (M + step - 1) / step;          // workgroup-uniform trip count (the loop body has barriers)
+    // Software pipeline: the inputs of iteration it+1 (d_feature values, the point) are loaded while iteration it goes
+    // through its three barriers, and the table gathers of the d/dx term are issued before them and consumed after -
+    // the kernel is bound by the latency chain of one batch, not by any throughput.
+    constexpr bool EARLY_DX = WANT_DX && F <= 2;
+    int64_t m = (int64_t)chunk * ENC_BLOCK + threadIdx.x;
+    float g_next[F];
+    RawPoint p_next;
+    {
+        const int64_t mc = m < M ? m : M - 1;
+#pragma unroll
+        for (int f = 0; f < F; ++f) g_next[f] = dfeat[(size_t)(lv * F + f) * m_pad + mc];
+        load_raw_point(src, mc, p_next);
+    }
+    for (int64_t it = 0; it < n_iter; ++it, m += step) {
+        const bool live = m < M;
+        float g[F];
+        bool any = false;
+#pragma unroll
+        for (int f = 0; f < F; ++f) { g[f] = live ? g_next[f] : 0.0f; any |= (g[f] != 0.0f); }
+        const RawPoint p_cur = p_next;
+        {
+            const int64_t mn = m + step;
+            const int64_t mc = mn < M ? mn : M - 1;          // unconditional (clamped) loads: a static number in flight
+#pragma unroll
+            for (int f = 0; f < F; ++f) g_next[f] = dfeat[(size_t)(lv * F + f) * m_pad + mc];
+            load_raw_point(src, mc, p_next);
+        }
+        const bool wave_any = __ballot(any) != 0ull;
+        LevelCell c;
+        bool head = true;
+        RunMask run = {false, false, false, false};
+        float tv[EARLY_DX ? 8 : 1][F];
+        if (wave_any) {
+            float x[3];
+            unit_point(src, p_cur, x);
+            c = level_cell(lvt, lv, x);
+            // runs = consecutive samples (lanes of one 16-lane row) in the same CELL, not merely the same hashed entry
+            if (combine) cell_runs(c, lane, head, run);
+            if constexpr (EARLY_DX) { if (!(sink.debug & 8)) corner_entries_load<F>(c, table, tv); }
+        }
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            // ---- A: this thread's records of the batch; rank within the owner's bucket from an LDS histogram
+            uint32_t ridx[8]; float rv0[8], rv1[8]; int rrank[8];
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) rrank[corner] = -1;
+            if (wave_any) {
+#pragma unroll
+                for (int corner = 0; corner < 8; ++corner) {
+                    const float w = corner_weight(c, corner);
+                    const uint32_t e = cell_entry(c, corner) * F + (PAIR ? 2 * pass : 0);
+                    float v0 = w * g[PAIR ? 2 * pass : 0], v1 = PAIR ? w * g[2 * pass + 1] : 0.0f;
+                    if (combine) {
+                        v0 = row_run_sum(v0, run);
+                        if (PAIR) v1 = row_run_sum(v1, run);
+                    }
+                    ridx[corner] = e; rv0[corner] = v0; rv1[corner] = v1;
+                    if (head && (v0 != 0.0f || v1 != 0.0f) && !(sink.debug & 2)) {
+                        const int local = (int)(e >> sink.shift) - first_owner;
+                        if (local >= 0 && local < maxo) rrank[corner] = atomicAdd(&cnt[local], 1);
+                        else { atomicAdd(sink.grad_table + e, v0); if (PAIR) atomicAdd(sink.grad_table + e + 1, v1); }
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- B: exclusive scan of the histogram; reserve the slots in the regions
+            if (wave == 0) {
+                int running = 0;
+                for (int o0 = 0; o0 < maxo; o0 += 64) {
+                    const int o = o0 + lane;
+                    const int n = o < maxo ? cnt[o] : 0;
+                    int incl = n;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+                    if (o < maxo) { scan[o] = running + incl - n; gpos[o] = gcur[o]; gcur[o] += n; cnt[o] = 0; }
+                    running += __shfl(incl, 63, 64);
+                }
+                if (lane == 0) s_total = running;
+            }
+            __syncthreads();
+            // ---- C: scatter into the staging buffer, grouped by owner
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) {
+                if (rrank[corner] >= 0) {
+                    const int local = (int)(ridx[corner] >> sink.shift) - first_owner;
+                    const int at = scan[local] + rrank[corner];
+                    if (PAIR) reinterpret_cast<uint4*>(stage)[at] = make_uint4(ridx[corner], __float_as_uint(rv0[corner]), __float_as_uint(rv1[corner]), 0u);
+                    else reinterpret_cast<uint2*>(stage)[at] = make_uint2(ridx[corner], __float_as_uint(rv0[corner]));
+                }
+            }
+            __syncthreads();
+            // ---- D: linear copy-out; neighbouring lanes write neighbouring records of the same region
+            const int total = s_total;
+            for (int i = threadIdx.x; i < total; i += ENC_BLOCK) {
+                uint32_t idx; float v0, v1 = 0.0f;
+                uint4 r4; uint2 r2;
+                if (PAIR) { r4 = reinterpret_cast<const uint4*>(stage)[i]; idx = r4.x; v0 = __uint_as_float(r4.y); v1 = __uint_as_float(r4.z); }
+                else { r2 = reinterpret_cast<const uint2*>(stage)[i]; idx = r2.x; v0 = __uint_as_float(r2.y); }
+                const int local = (int)(idx >> sink.shift) - first_owner;
+                const int slot = gpos[local] + (i - scan[local]);
+                if (sink.debug & 1) { if (v0 == 1e30f) gcur[0] = 1; }
+                else if (slot < sink.cap) {
+                    const size_t at = (region0 + ((sink.debug & 64) ? (local & ~3) : local)) * sink.cap + ((sink.debug & 64) ? (i & 1023) : slot);   // debug 64: timing experiment only
+                    if (PAIR) r2 = lnr_pack_pair((idx & ((1u << LNR_SLICE_SHIFT) - 1u)) >> 1, v0, v1);
+                    reinterpret_cast<uint2*>(sink.regions)[at] = r2;
+                } else {
+                    atomicAdd(sink.grad_table + idx, v0);
+                    if (PAIR) atomicAdd(sink.grad_table + idx + 1, v1);
+                }
+            }
+            // no barrier here: the next histogram only touches cnt[], and its first barrier orders D before the next B/C
+        }
+        if constexpr (WANT_DX) {
+            float dx[3] = {0.0f, 0.0f, 0.0f};
+            if (any && !(sink.debug & 8)) {
+                if constexpr (EARLY_DX) dx_from_entries<F>(c, g, tv, dx);
+                else encode_dx<F>(c, g, table, dx);
+            }
+            if (live) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) dxl[(size_t)(lv * 3 + d) * m_pad + m] = dx[d];
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < maxo; i += ENC_BLOCK)
+        sink.counts[region0 + i] = gcur[i] < sink.cap ? gcur[i] : sink.cap;
+}
+
+// Dense levels (lnr_density_api.h): the workgroup sums its samples' corner updates in an LDS copy of the level's
+// table (64-bit fixed point: LDS integer atomics are ~16x faster than float ones on CDNA4 and order-independent) and
+// writes it out once as a slab; dense_slab_reduce_kernel adds the slabs of all workgroups to the table gradient.
+template <int F, bool WANT_DX>
+__global__ void __launch_bounds__(ENC_BLOCK)
+encode_backward_dense_kernel(const LnrNetSpec spec, const float* __restrict__ table, const PointSrc src, const float* __restrict__ dfeat,
+                             float* __restrict__ dxl, int64_t m_pad, int bpg, const LevelList list, float* __restrict__ slabs,
+                             int dense_total, int debug) {
+    extern __shared__ long long dacc[];
     __shared__ float lvt[LNR_LV_WORDS];
     stage_level_tables(spec, lvt);
-    for (int i = threadIdx.x; i < sink.maxo; i += ENC_BLOCK) cursors[i] = 0;
+    const int slot = blockIdx.x / bpg, chunk = blockIdx.x % bpg;
+    const int lv = list.lv[slot];
+    const int nfl = (int)spec.level_size[lv] * F;
+    const uint32_t level_base = spec.level_offset[lv] * F;
+    for (int i = threadIdx.x; i < nfl; i += ENC_BLOCK) dacc[i] = 0ll;
     __syncthreads();
-    const int lv = blockIdx.x / bpg, chunk = blockIdx.x % bpg;
     const int lane = threadIdx.x & 63;
     const int64_t M = live_points(src);
-    const int64_t m_round = (M + 63) / 64 * 64;
-    const int first_owner = (int)(((uint64_t)spec.level_offset[lv] * F) >> sink.shift);
-    const bool combine = spec.level_scale[lv] < sink.combine_scale_max;
-    constexpr bool PAIR = F >= 2;
+    const int64_t m_round = (M + 63) / 64 * 64;           // whole waves: the run logic uses cross-lane reads
     for (int64_t m = (int64_t)chunk * ENC_BLOCK + threadIdx.x; m < m_round; m += (int64_t)bpg * ENC_BLOCK) {
         const bool live = m < M;
         float g[F];
@@ -131,61 +351,24 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
 #pragma unroll
         for (int f = 0; f < F; ++f) { g[f] = live ? dfeat[(size_t)(lv * F + f) * m_pad + m] : 0.0f; any |= (g[f] != 0.0f); }
         float dx[3] = {0.0f, 0.0f, 0.0f};
-        if (__ballot(any) != 0ull) {                 // wave-uniform
+        if (__ballot(any) != 0ull) {                        // wave-uniform
             float x[3];
             load_unit_point(src, live ? m : M - 1, x);
-            LevelCell c = level_cell(lvt, lv, x);
-            int seg = 0;
-            bool head = true;
-            if (combine) {
-                // runs = consecutive samples in the same CELL (not merely the same hashed entry)
-                const uint32_t k1 = c.base[0] | (c.base[1] << 16), k2 = c.base[2];
-                const uint32_t p1 = __shfl_up(k1, 1, 64), p2 = __shfl_up(k2, 1, 64);
-                head = (lane == 0) || (p1 != k1) || (p2 != k2);
-                seg = head ? 1 : 0;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(seg, o, 64); if (lane >= o) seg += t; }
-            }
-            float dfrac[3] = {0.0f, 0.0f, 0.0f};
+            const LevelCell c = level_cell(lvt, lv, x);
+            bool head; RunMask run;
+            cell_runs(c, lane, head, run);
 #pragma unroll
             for (int corner = 0; corner < 8; ++corner) {
                 const float w = corner_weight(c, corner);
-                const uint32_t e = cell_entry(c, corner) * F;
-                float v[F];
+                const uint32_t e = cell_entry(c, corner) * F - level_base;
 #pragma unroll
-                for (int f = 0; f < F; ++f) v[f] = w * g[f];
-                if (combine) {
-                    // runs are defined by corner 0's entry: within a run all samples share the cell, hence every corner
-#pragma unroll
-                    for (int f = 0; f < F; ++f) v[f] = wave_run_sum(v[f], seg, lane);
-                }
-                if (!combine || head) {
-                    if (!(sink.debug & 2)) {
-                        if constexpr (F == 1) enc_emit(sink, cursors, first_owner, e, v[0], 0.0f, false);
-                        else {
-#pragma unroll
-                            for (int f = 0; f < F; f += 2) enc_emit(sink, cursors, first_owner, e + f, v[f], v[f + 1], true);
-                        }
-                    }
-                }
-                if constexpr (WANT_DX) {
-                    if (any) {
-                        float dot = 0.0f;
-#pragma unroll
-                        for (int f = 0; f < F; ++f) dot += g[f] * table[(size_t)e + f];
-                        const float wx = (corner & 1) ? c.frac[0] : 1.0f - c.frac[0];
-                        const float wy = (corner & 2) ? c.frac[1] : 1.0f - c.frac[1];
-                        const float wz = (corner & 4) ? c.frac[2] : 1.0f - c.frac[2];
-                        dfrac[0] += ((corner & 1) ? dot : -dot) * wy * wz;
-                        dfrac[1] += ((corner & 2) ? dot : -dot) * wx * wz;
-                        dfrac[2] += ((corner & 4) ? dot : -dot) * wx * wy;
-                    }
+                for (int f = 0; f < F; ++f) {
+                    const float v = row_run_sum(w * g[f], run);
+                    if (head && v != 0.0f && !(debug & 2))
+                        atomicAdd(reinterpret_cast<unsigned long long*>(&dacc[e + f]), (unsigned long long)__float2ll_rn(v * LNR_FIX_SCALE));
                 }
             }
-            if constexpr (WANT_DX) {
-#pragma unroll
-                for (int d = 0; d < 3; ++d) dx[d] = dfrac[d] * c.scale;
-            }
+            if constexpr (WANT_DX) { if (any && !(debug & 8)) encode_dx<F>(c, g, table, dx); }
         }
         if constexpr (WANT_DX) {
             if (live) {
@@ -195,8 +378,28 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < sink.maxo; i += ENC_BLOCK)
-        sink.counts[(size_t)blockIdx.x * sink.maxo + i] = cursors[i] < sink.cap ? cursors[i] : sink.cap;
+    float* slab = slabs + (size_t)chunk * dense_total + list.slab_off[slot];
+    for (int i = threadIdx.x; i < nfl; i += ENC_BLOCK) slab[i] = (float)((double)dacc[i] * (1.0 / (double)LNR_FIX_SCALE));
+}
+
+__global__ void __launch_bounds__(ENC_BLOCK)
+dense_slab_reduce_kernel(const LnrNetSpec spec, const LevelList list, const float* __restrict__ slabs, int bpg, int dense_total,
+                         float* __restrict__ grad_table) {
+    const int slot = blockIdx.y;
+    const int lv = list.lv[slot];
+    const int nfl = (int)spec.level_size[lv] * spec.n_features;
+    const int i = blockIdx.x * ENC_BLOCK + threadIdx.x;
+    if (i >= nfl) return;
+    const float* p = slabs + list.slab_off[slot] + i;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int b = 0;
+    for (; b + 3 < bpg; b += 4) {
+        s0 += p[(size_t)b * dense_total]; s1 += p[(size_t)(b + 1) * dense_total];
+        s2 += p[(size_t)(b + 2) * dense_total]; s3 += p[(size_t)(b + 3) * dense_total];
+    }
+    for (; b < bpg; ++b) s0 += p[(size_t)b * dense_total];
+    const float s = (s0 + s1) + (s2 + s3);
+    if (s != 0.0f) grad_table[(size_t)spec.level_offset[lv] * spec.n_features + i] += s;
 }
 
 // Frequency encoding has no table: backward is only the input gradient, one plane group for all features.
@@ -252,29 +455,70 @@ int lnr_encode_forward(const LnrNetSpec* spec, const float* params, const PointS
 }
 
 int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, const float* dfeat,
-                        float* dxl, int64_t m_pad, float* grad_table, void* regions, int* counts, int bpg, int maxo, int cap,
-                        int shift, int debug, float* d_pts, hipStream_t st) {
+                        float* dxl, int64_t m_pad, float* grad_table, void* regions, int* counts, float* dense_slabs, int bpg,
+                        int maxo, int cap, int shift, int debug, float* d_pts, hipStream_t st) {
     const float* table = params + spec->n_mlp_params;
     int n_groups = 1;
     if (spec->encoding == LNR_ENC_HASHGRID) {
         n_groups = spec->n_levels;
-        EncSink sink;
-        sink.grad_table = grad_table; sink.regions = regions; sink.counts = counts; sink.maxo = maxo; sink.cap = cap; sink.shift = shift;
-        sink.combine_scale_max = LNR_COMBINE_SCALE_MAX; sink.debug = debug;
-        const dim3 grid((unsigned)(n_groups * bpg)), block(ENC_BLOCK);
-        const size_t lds = (size_t)maxo * sizeof(int);
-#define LNR_EB(F)                                                                                                             \
-        do {                                                                                                                  \
-            if (d_pts) hipLaunchKernelGGL((encode_backward_kernel<F, true>), grid, block, lds, st, *spec, table, *src, dfeat, dxl, m_pad, bpg, sink); \
-            else hipLaunchKernelGGL((encode_backward_kernel<F, false>), grid, block, lds, st, *spec, table, *src, dfeat, dxl, m_pad, bpg, sink);     \
-        } while (0)
-        switch (spec->n_features) {
-            case 1: LNR_EB(1); break;
-            case 2: LNR_EB(2); break;
-            case 4: LNR_EB(4); break;
-            default: LNR_EB(8); break;
+        LevelList rec_levels, dense_levels;
+        rec_levels.n = dense_levels.n = 0;
+        int dense_total = 0, dense_max = 0;
+        for (int l = 0; l < spec->n_levels; ++l) {
+            if (lnr_level_is_dense(spec, l)) {
+                const int nfl = (int)spec->level_size[l] * spec->n_features;
+                dense_levels.lv[dense_levels.n] = l; dense_levels.slab_off[dense_levels.n] = dense_total; dense_levels.n++;
+                dense_total += nfl;
+                if (nfl > dense_max) dense_max = nfl;
+            } else {
+                rec_levels.lv[rec_levels.n] = l; rec_levels.slab_off[rec_levels.n] = 0; rec_levels.n++;
+            }
         }
+        const dim3 block(ENC_BLOCK);
+        if (rec_levels.n > 0) {
+            EncSink sink;
+            sink.grad_table = grad_table; sink.regions = regions; sink.counts = counts; sink.maxo = maxo; sink.cap = cap; sink.shift = shift;
+            sink.combine_scale_max = LNR_COMBINE_SCALE_MAX; sink.debug = debug;
+            const dim3 grid((unsigned)(rec_levels.n * bpg));
+            const size_t lds = (size_t)((4 * maxo + 3) & ~3) * sizeof(int) + (size_t)ENC_STAGE_RECORDS * (spec->n_features >= 2 ? 16 : 8);
+#define LNR_EB(F)                                                                                                             \
+            do {                                                                                                              \
+                if (d_pts) hipLaunchKernelGGL((encode_backward_kernel<F, true>), grid, block, lds, st, *spec, table, *src, dfeat, dxl, m_pad, bpg, rec_levels, sink); \
+                else hipLaunchKernelGGL((encode_backward_kernel<F, false>), grid, block, lds, st, *spec, table, *src, dfeat, dxl, m_pad, bpg, rec_levels, sink);     \
+            } while (0)
+            switch (spec->n_features) {
+                case 1: LNR_EB(1); break;
+                case 2: LNR_EB(2); break;
+                case 4: LNR_EB(4); break;
+                default: LNR_EB(8); break;
+            }
 #undef LNR_EB
+        }
+        if (dense_levels.n > 0) {
+            const dim3 grid((unsigned)(dense_levels.n * bpg));
+            const size_t lds = (size_t)dense_max * sizeof(long long);
+#define LNR_ED(F)                                                                                                             \
+            do {                                                                                                              \
+                hipError_t e_;                                                                                                \
+                if (d_pts) {                                                                                                  \
+                    e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(encode_backward_dense_kernel<F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                    if (e_ == hipSuccess) hipLaunchKernelGGL((encode_backward_dense_kernel<F, true>), grid, block, lds, st, *spec, table, *src, dfeat, dxl, m_pad, bpg, dense_levels, dense_slabs, dense_total, debug); \
+                } else {                                                                                                      \
+                    e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(encode_backward_dense_kernel<F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                    if (e_ == hipSuccess) hipLaunchKernelGGL((encode_backward_dense_kernel<F, false>), grid, block, lds, st, *spec, table, *src, dfeat, dxl, m_pad, bpg, dense_levels, dense_slabs, dense_total, debug); \
+                }                                                                                                             \
+                if (e_ != hipSuccess) { lnr_set_error("lnr_density_backward: hipFuncSetAttribute(%zu) failed", lds); return LNR_ERR_LAUNCH; } \
+            } while (0)
+            switch (spec->n_features) {
+                case 1: LNR_ED(1); break;
+                case 2: LNR_ED(2); break;
+                case 4: LNR_ED(4); break;
+                default: LNR_ED(8); break;
+            }
+#undef LNR_ED
+            hipLaunchKernelGGL(dense_slab_reduce_kernel, dim3((unsigned)((dense_max + ENC_BLOCK - 1) / ENC_BLOCK), (unsigned)dense_levels.n), block, 0, st,
+                               *spec, dense_levels, dense_slabs, bpg, dense_total, grad_table);
+        }
     } else if (d_pts) {
         int64_t blocks = (cap_points + ENC_BLOCK - 1) / ENC_BLOCK;
         if (blocks > 4096) blocks = 4096;

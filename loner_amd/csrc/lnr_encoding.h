@@ -16,20 +16,38 @@ __device__ __forceinline__ int64_t live_points(const PointSrc& s) {
     return (int64_t)lnr_live_rays(s.n_rays, s.n_rays_dev) * s.n_samples;
 }
 
-// unit-cube coordinates of point m
-__device__ __forceinline__ void load_unit_point(const PointSrc& s, int64_t m, float x[3]) {
-    float p[3];
+// Point m as loaded (no arithmetic yet, so the loads can be issued a whole iteration ahead of their use).
+// pts mode: o = xyz; rays mode: o = origin, d = direction, z = depth.  Scalar fields, all always assigned: an array
+// written differently by the two modes ends up in scratch memory.
+struct RawPoint { float o0, o1, o2, d0, d1, d2, z; };
+
+__device__ __forceinline__ void load_raw_point(const PointSrc& s, int64_t m, RawPoint& r) {
     if (s.pts) {
-        p[0] = s.pts[3 * m + 0]; p[1] = s.pts[3 * m + 1]; p[2] = s.pts[3 * m + 2];
+        r.o0 = s.pts[3 * m + 0]; r.o1 = s.pts[3 * m + 1]; r.o2 = s.pts[3 * m + 2];
+        r.d0 = 0.0f; r.d1 = 0.0f; r.d2 = 0.0f; r.z = 0.0f;
     } else {
-        int64_t ray = m / s.n_samples;
-        float zv = s.z[m];
-        const float* r = s.rays + ray * LNR_RAY_STRIDE;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) p[d] = lnr_add_rn(r[d], lnr_mul_rn(r[3 + d], zv));   // o + d*z, as the reference rounds it
+        const float* ray = s.rays + (m / s.n_samples) * LNR_RAY_STRIDE;
+        r.o0 = ray[0]; r.o1 = ray[1]; r.o2 = ray[2]; r.d0 = ray[3]; r.d1 = ray[4]; r.d2 = ray[5];
+        r.z = s.z[m];
+    }
+}
+
+// unit-cube coordinates
+__device__ __forceinline__ void unit_point(const PointSrc& s, const RawPoint& r, float x[3]) {
+    float p[3] = {r.o0, r.o1, r.o2};
+    if (!s.pts) {                    // o + d*z, as the reference rounds it
+        p[0] = lnr_add_rn(r.o0, lnr_mul_rn(r.d0, r.z));
+        p[1] = lnr_add_rn(r.o1, lnr_mul_rn(r.d1, r.z));
+        p[2] = lnr_add_rn(r.o2, lnr_mul_rn(r.d2, r.z));
     }
 #pragma unroll
     for (int d = 0; d < 3; ++d) x[d] = lnr_mul_rn(lnr_add_rn(p[d], 1.0f), 0.5f);   // (xyz+1)/2 rounded like the reference (no fma)
+}
+
+__device__ __forceinline__ void load_unit_point(const PointSrc& s, int64_t m, float x[3]) {
+    RawPoint r;
+    load_raw_point(s, m, r);
+    unit_point(s, r, x);
 }
 
 // ------------------------------------------------------------------------------------------------
