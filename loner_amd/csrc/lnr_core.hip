@@ -47,7 +47,7 @@ extern "C" int lnr_net_spec_finalize(LnrNetSpec* s) {
             s->level_hashed[l] = dense > size ? 1u : 0u;
             off += size;
         }
-        LNR_REQUIRE(off * (uint64_t)s->n_features < (1ull << 32), "encoding table too large");
+        LNR_REQUIRE(off * (uint64_t)s->n_features < (1ull << 30), "encoding table too large (the kernels address it with 32-bit byte offsets: < 4 GB)");
         s->enc_dim = s->n_levels * s->n_features;
         s->n_params = (int64_t)off * s->n_features;
     } else if (s->encoding == LNR_ENC_FREQUENCY) {

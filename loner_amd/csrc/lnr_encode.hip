@@ -2,37 +2,34 @@
 //
 // Why level-major: the default hash grid is 29.7 MB, the L2 of an XCD 4 MB.  A kernel that walks all 16 levels per
 // sample thrashes L2 (PMC: 3.5 GB of memory-side fetches per forward launch for 0.13 GB of algorithmic bytes).
-// Here the grid is ordered level by level (blockIdx / blocks_per_group = level), so at any moment the whole chip
-// works on ONE level whose table (<= 2 MB) stays resident in every XCD's L2, and each gather is an L2 hit.
+// Here the grid is ordered level by level (blockIdx / blocks_per_group = level), so at any moment the chip works on
+// one or two levels whose tables (<= 2 MB each) stay resident in every XCD's L2, and each gather is an L2 hit.
 // Features travel to the MLP kernels as [feature plane][sample] arrays in HBM (coalesced both ways).
 //
+// With the gathers served by L2 these kernels are bound by VALU issue, so the per-sample code is kept lean: level
+// geometry in SGPRs (the level is wave-uniform), corner hashes/weights from shared per-axis terms, 32-bit offsets
+// from uniform base pointers, the ray index advanced incrementally.
+//
 // Backward: one thread per (sample, level) re-derives the cell, turns d_feature into table-gradient records
-// (run-length combined over the 64 consecutive samples of a wave on coarse levels), and writes its contribution to
-// d/dx as one plane per level; records are reduced by table_grad_reduce2_kernel (lnr_density.hip).
+// (run-length combined over consecutive samples of a ray on coarse levels), and writes its contribution to d/dx as
+// one plane per level; records are reduced by table_grad_reduce2_kernel (lnr_density.hip).
 #include "lnr_encoding.h"
 
 #define ENC_BLOCK 256
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int F>
-__device__ __forceinline__ void encode_level(const float* lvt, const float* __restrict__ table, int lv, const float x[3], float out[F]) {
-    LevelCell c = level_cell(lvt, lv, x);
+__device__ __forceinline__ void gather_entries(const float* __restrict__ table, const uint32_t e[8], float tv[8][F]) {
 #pragma unroll
-    for (int f = 0; f < F; ++f) out[f] = 0.0f;
-#pragma unroll
-    for (int corner = 0; corner < 8; ++corner) {
-        const float w = corner_weight(c, corner);
-        const float* e = table + (size_t)cell_entry(c, corner) * F;
-        if constexpr (F == 1) {
-            out[0] += w * e[0];
-        } else if constexpr (F == 2) {
-            const float2 v = *reinterpret_cast<const float2*>(e);
-            out[0] += w * v.x; out[1] += w * v.y;
-        } else {
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t off = e[k] * (uint32_t)(F * 4);
+        if constexpr (F == 1) tv[k][0] = ld32<float>(table, off);
+        else if constexpr (F == 2) { const float2 t2 = ld32<float2>(table, off); tv[k][0] = t2.x; tv[k][1] = t2.y; }
+        else {
 #pragma unroll
             for (int q = 0; q < F / 4; ++q) {
-                const float4 v = *reinterpret_cast<const float4*>(e + 4 * q);
-                out[4 * q] += w * v.x; out[4 * q + 1] += w * v.y; out[4 * q + 2] += w * v.z; out[4 * q + 3] += w * v.w;
+                const float4 t4 = ld32<float4>(table, off + 16u * q);
+                tv[k][4 * q] = t4.x; tv[k][4 * q + 1] = t4.y; tv[k][4 * q + 2] = t4.z; tv[k][4 * q + 3] = t4.w;
             }
         }
     }
@@ -42,33 +39,53 @@ template <int F>
 __global__ void __launch_bounds__(ENC_BLOCK)
 encode_forward_kernel(const LnrNetSpec spec, const float* __restrict__ table, const PointSrc src, float* __restrict__ feat,
                       int64_t m_pad, int bpg) {
-    __shared__ float lvt[LNR_LV_WORDS];
-    stage_level_tables(spec, lvt);
-    __syncthreads();
-    const int group = blockIdx.x / bpg, chunk = blockIdx.x % bpg;
+    const int lv = blockIdx.x / bpg, chunk = blockIdx.x % bpg;
+    const LevelInfo L = level_info(spec, lv);
+    const uint32_t M = (uint32_t)live_points(src);
+    const uint32_t M16 = (M + 15u) / 16u * 16u;      // the MLP kernels read whole 16-sample tiles: zero the ragged tail
+    float* planes = feat + (size_t)(lv * F) * m_pad;
+    const uint32_t plane_bytes = (uint32_t)m_pad * 4u;
+    SampleCursor cur;
+    cur.init((uint32_t)chunk * ENC_BLOCK + threadIdx.x, (uint32_t)bpg * ENC_BLOCK, src.pts ? 1u : (uint32_t)src.n_samples);
+    for (; cur.m < M16; cur.advance()) {
+        float out[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) out[f] = 0.0f;
+        if (cur.m < M) {
+            RawPoint rp;
+            load_raw_point(src, cur.m, cur.ray, rp);
+            float x[3];
+            unit_point(src, rp, x);
+            const Cell c = cell_of(L, x);
+            uint32_t e[8]; float w[8], tv[8][F];
+            cell_entries(L, c, e);
+            gather_entries<F>(table, e, tv);
+            cell_weights(c, w);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int f = 0; f < F; ++f) out[f] += w[k] * tv[k][f];
+        }
+#pragma unroll
+        for (int f = 0; f < F; ++f) st32<float>(planes, (uint32_t)f * plane_bytes + cur.m * 4u, out[f]);
+    }
+}
+
+__global__ void __launch_bounds__(ENC_BLOCK)
+freq_forward_kernel(const LnrNetSpec spec, const PointSrc src, float* __restrict__ feat, int64_t m_pad, int bpg) {
+    const int group = blockIdx.x / bpg, chunk = blockIdx.x % bpg;       // 4 features per group
     const int64_t M = live_points(src);
-    const int64_t M16 = (M + 15) / 16 * 16;      // the MLP kernels read whole 16-sample tiles: zero the ragged tail
-    const int nf = spec.encoding == LNR_ENC_HASHGRID ? F : 4;
+    const int64_t M16 = (M + 15) / 16 * 16;
     for (int64_t m = (int64_t)chunk * ENC_BLOCK + threadIdx.x; m < M16; m += (int64_t)bpg * ENC_BLOCK) {
-        if (m >= M) {
-            for (int f = 0; f < nf; ++f)
-                if (group * nf + f < spec.enc_dim) feat[(size_t)(group * nf + f) * m_pad + m] = 0.0f;
-            continue;
-        }
-        float x[3];
-        load_unit_point(src, m, x);
-        if (spec.encoding == LNR_ENC_HASHGRID) {
-            float out[F];
-            encode_level<F>(lvt, table, group, x, out);
-#pragma unroll
-            for (int f = 0; f < F; ++f) feat[(size_t)(group * F + f) * m_pad + m] = out[f];
-        } else {
-            float out[4];
+        float out[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (m < M) {
+            float x[3];
+            load_unit_point(src, m, x);
             freq_features4(spec, x, 4 * group, out);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (4 * group + r < spec.enc_dim) feat[(size_t)(4 * group + r) * m_pad + m] = out[r];
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * group + r < spec.enc_dim) feat[(size_t)(4 * group + r) * m_pad + m] = out[r];
     }
 }
 
@@ -82,8 +99,8 @@ encode_forward_kernel(const LnrNetSpec spec, const float* __restrict__ table, co
 // table_grad_reduce2_kernel (lnr_density.hip) sums each owner's regions in LDS.
 struct EncSink {
     float* grad_table;      // fallback target for records beyond a region's capacity
-    void* regions;          // [block][maxo][cap] 8-byte records (lnr_density_api.h)
-    int* counts;            // [block][maxo]
+    void* regions;          // [level][chunk][maxo][cap] 8-byte records (lnr_density_api.h)
+    int* counts;            // [level][chunk][maxo]
     int maxo, cap, shift;
     float combine_scale_max;
     int debug;
@@ -91,7 +108,7 @@ struct EncSink {
 
 // Run-length combining on coarse levels: consecutive samples of a ray fall into the same cell there, so their 8 corner
 // updates are summed before they become records.  Runs are confined to the 16-lane DPP rows of a wave: row shifts are
-// plain VALU operands, whereas a 64-lane segmented sum needs ds_bpermute for every step (measured ~3x the cost).
+// plain VALU operands, whereas a 64-lane segmented sum needs ds_bpermute (LDS crossbar) for every step.
 struct RunMask { bool take1, take2, take4, take8; };
 
 __device__ __forceinline__ float row_run_sum(float v, const RunMask& k) {
@@ -103,53 +120,10 @@ __device__ __forceinline__ float row_run_sum(float v, const RunMask& k) {
     return v;
 }
 
-// d(level features . g)/dx of one sample needs the 8 corner entries again (L2-resident, see the file header).  The
-// gathers are issued by corner_dots_issue() early in an iteration and consumed by dx_from_dots() at its end.
-template <int F>
-__device__ __forceinline__ void corner_entries_load(const LevelCell& c, const float* __restrict__ table, float tv[8][F]) {
-#pragma unroll
-    for (int corner = 0; corner < 8; ++corner) {
-        const uint32_t e = cell_entry(c, corner) * F;
-        if constexpr (F == 1) tv[corner][0] = table[e];
-        else if constexpr (F == 2) { const float2 t2 = *reinterpret_cast<const float2*>(table + e); tv[corner][0] = t2.x; tv[corner][1] = t2.y; }
-        else {
-#pragma unroll
-            for (int q = 0; q < F / 4; ++q) {
-                const float4 t4 = *reinterpret_cast<const float4*>(table + e + 4 * q);
-                tv[corner][4 * q] = t4.x; tv[corner][4 * q + 1] = t4.y; tv[corner][4 * q + 2] = t4.z; tv[corner][4 * q + 3] = t4.w;
-            }
-        }
-    }
-}
-template <int F>
-__device__ __forceinline__ void dx_from_entries(const LevelCell& c, const float g[F], const float tv[8][F], float dx[3]) {
-    float dfrac[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int corner = 0; corner < 8; ++corner) {
-        float dot = 0.0f;
-#pragma unroll
-        for (int f = 0; f < F; ++f) dot += g[f] * tv[corner][f];
-        const float wx = (corner & 1) ? c.frac[0] : 1.0f - c.frac[0];
-        const float wy = (corner & 2) ? c.frac[1] : 1.0f - c.frac[1];
-        const float wz = (corner & 4) ? c.frac[2] : 1.0f - c.frac[2];
-        dfrac[0] += ((corner & 1) ? dot : -dot) * wy * wz;
-        dfrac[1] += ((corner & 2) ? dot : -dot) * wx * wz;
-        dfrac[2] += ((corner & 4) ? dot : -dot) * wx * wy;
-    }
-#pragma unroll
-    for (int d = 0; d < 3; ++d) dx[d] = dfrac[d] * c.scale;
-}
-template <int F>
-__device__ __forceinline__ void encode_dx(const LevelCell& c, const float g[F], const float* __restrict__ table, float dx[3]) {
-    float tv[8][F];
-    corner_entries_load<F>(c, table, tv);
-    dx_from_entries<F>(c, g, tv, dx);
-}
-
 // run masks of one 16-lane row: which lanes share the cell of their left neighbour
-__device__ __forceinline__ void cell_runs(const LevelCell& c, int lane, bool& head, RunMask& run) {
+__device__ __forceinline__ void cell_runs(const Cell& c, int lane, bool& head, RunMask& run) {
     const int c16 = lane & 15;
-    const int k1 = (int)(c.base[0] | (c.base[1] << 16)), k2 = (int)c.base[2];
+    const int k1 = (int)(c.b[0] | (c.b[1] << 16)), k2 = (int)c.b[2];
     // the DPP reads must run with all lanes active: evaluate them before (not inside) any short-circuit logic
     const int p1 = row_up_i<1>(k1), p2 = row_up_i<1>(k2);
     head = (c16 == 0) | (p1 != k1) | (p2 != k2);
@@ -166,96 +140,136 @@ __device__ __forceinline__ void cell_runs(const LevelCell& c, int lane, bool& he
     run.take8 = (c16 + 8 < 16) & (s8 == seg);
 }
 
+// d(level features . g)/dx of one sample from its 8 corner entries
+template <int F>
+__device__ __forceinline__ void dx_from_entries(const LevelInfo& L, const Cell& c, const float g[F], const float tv[8][F], float dx[3]) {
+    float dot[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        dot[k] = 0.0f;
+#pragma unroll
+        for (int f = 0; f < F; ++f) dot[k] += g[f] * tv[k][f];
+    }
+    const float fx = c.frac[0], fy = c.frac[1], fz = c.frac[2];
+    const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
+    // differences along one axis, interpolated along the other two
+    const float dxv = ((dot[1] - dot[0]) * gy + (dot[3] - dot[2]) * fy) * gz + ((dot[5] - dot[4]) * gy + (dot[7] - dot[6]) * fy) * fz;
+    const float dyv = ((dot[2] - dot[0]) * gx + (dot[3] - dot[1]) * fx) * gz + ((dot[6] - dot[4]) * gx + (dot[7] - dot[5]) * fx) * fz;
+    const float dzv = ((dot[4] - dot[0]) * gx + (dot[5] - dot[1]) * fx) * gy + ((dot[6] - dot[2]) * gx + (dot[7] - dot[3]) * fx) * fy;
+    dx[0] = dxv * L.scale; dx[1] = dyv * L.scale; dx[2] = dzv * L.scale;
+}
+
 #define ENC_STAGE_RECORDS (ENC_BLOCK * 8)
 
-// dynamic LDS: int cnt[maxo], scan[maxo], gpos[maxo], gcur[maxo]; then (16-byte aligned) the staging buffer
+// what the copy-out phase needs to know about one owner of the current batch: one 16-byte LDS read per record
+struct OwnerSlot {
+    uint32_t ptr_lo, ptr_hi;    // address of the owner's next free record in its region
+    int scan;                   // first staged record of this owner
+    int room;                   // records the region can still take
+};
+
+// dynamic LDS: int cnt[maxo4], gcur[maxo4]; OwnerSlot slot[maxo] (16-byte aligned); then the staging buffer
 template <int F, bool WANT_DX>
 __global__ void __launch_bounds__(ENC_BLOCK)
 encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, const PointSrc src, const float* __restrict__ dfeat,
                        float* __restrict__ dxl, int64_t m_pad, int bpg, const LevelList list, const EncSink sink) {
     extern __shared__ __attribute__((aligned(16))) int dyn[];
-    __shared__ float lvt[LNR_LV_WORDS];
     __shared__ int s_total;
     constexpr bool PAIR = F >= 2;
     constexpr int NPASS = PAIR ? F / 2 : 1;
     const int maxo = sink.maxo;
+    const int maxo4 = (maxo + 3) & ~3;
     int* cnt = dyn;
-    int* scan = dyn + maxo;
-    int* gpos = dyn + 2 * maxo;
-    int* gcur = dyn + 3 * maxo;
-    void* stage = reinterpret_cast<void*>(dyn + ((4 * maxo + 3) & ~3));
-    stage_level_tables(spec, lvt);
+    int* gcur = dyn + maxo4;
+    OwnerSlot* oslot = reinterpret_cast<OwnerSlot*>(dyn + 2 * maxo4);
+    void* stage = reinterpret_cast<void*>(dyn + 2 * maxo4 + 4 * maxo);
     for (int i = threadIdx.x; i < maxo; i += ENC_BLOCK) { cnt[i] = 0; gcur[i] = 0; }
     __syncthreads();
     const int lv = list.lv[blockIdx.x / bpg], chunk = blockIdx.x % bpg;
+    const LevelInfo L = level_info(spec, lv);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t M = live_points(src);
-    const int first_owner = (int)(((uint64_t)spec.level_offset[lv] * F) >> sink.shift);
-    const bool combine = spec.level_scale[lv] < sink.combine_scale_max && !(sink.debug & 16);
+    const uint32_t M = (uint32_t)live_points(src);
+    const int first_owner = (int)(((uint64_t)L.offset * F) >> sink.shift);
+    const bool combine = L.scale < sink.combine_scale_max && !(sink.debug & 16);
     const size_t region0 = ((size_t)lv * bpg + chunk) * maxo;
-    const int64_t step = (int64_t)bpg * ENC_BLOCK;
-    const int64_t n_iter = (M + step - 1) / step;          // workgroup-uniform trip count (the loop body has barriers)
+    const uint32_t step = (uint32_t)bpg * ENC_BLOCK;
+    const uint32_t n_iter = (M + step - 1u) / step;          // workgroup-uniform trip count (the loop body has barriers)
+    const float* gplanes = dfeat + (size_t)(lv * F) * m_pad;
+    float* dxplanes = dxl + (size_t)(lv * 3) * m_pad;
+    const uint32_t plane_bytes = (uint32_t)m_pad * 4u;
+    if (M == 0u) {                                            // workgroup-uniform
+        for (int i = threadIdx.x; i < maxo; i += ENC_BLOCK) sink.counts[region0 + i] = 0;
+        return;
+    }
+
     // Software pipeline: the inputs of iteration it+1 (d_feature values, the point) are loaded while iteration it goes
-    // through its three barriers, and the table gathers of the d/dx term are issued before them and consumed after -
-    // the kernel is bound by the latency chain of one batch, not by any throughput.
+    // through its three barriers, and the table gathers of the d/dx term are issued before them and consumed after.
     constexpr bool EARLY_DX = WANT_DX && F <= 2;
-    int64_t m = (int64_t)chunk * ENC_BLOCK + threadIdx.x;
+    SampleCursor cur;
+    cur.init((uint32_t)chunk * ENC_BLOCK + threadIdx.x, step, src.pts ? 1u : (uint32_t)src.n_samples);
+    const uint32_t last_ray = src.pts ? 0u : (M - 1u) / cur.S;
     float g_next[F];
     RawPoint p_next;
     {
-        const int64_t mc = m < M ? m : M - 1;
+        const bool in = cur.m < M;
+        const uint32_t mc = in ? cur.m : M - 1u;
 #pragma unroll
-        for (int f = 0; f < F; ++f) g_next[f] = dfeat[(size_t)(lv * F + f) * m_pad + mc];
-        load_raw_point(src, mc, p_next);
+        for (int f = 0; f < F; ++f) g_next[f] = ld32<float>(gplanes, (uint32_t)f * plane_bytes + mc * 4u);
+        load_raw_point(src, mc, in ? cur.ray : last_ray, p_next);
     }
-    for (int64_t it = 0; it < n_iter; ++it, m += step) {
+    for (uint32_t it = 0; it < n_iter; ++it) {
+        const uint32_t m = cur.m;
         const bool live = m < M;
         float g[F];
         bool any = false;
 #pragma unroll
         for (int f = 0; f < F; ++f) { g[f] = live ? g_next[f] : 0.0f; any |= (g[f] != 0.0f); }
         const RawPoint p_cur = p_next;
+        cur.advance();
         {
-            const int64_t mn = m + step;
-            const int64_t mc = mn < M ? mn : M - 1;          // unconditional (clamped) loads: a static number in flight
+            const bool in = cur.m < M;
+            const uint32_t mc = in ? cur.m : M - 1u;          // unconditional (clamped) loads: a static number in flight
 #pragma unroll
-            for (int f = 0; f < F; ++f) g_next[f] = dfeat[(size_t)(lv * F + f) * m_pad + mc];
-            load_raw_point(src, mc, p_next);
+            for (int f = 0; f < F; ++f) g_next[f] = ld32<float>(gplanes, (uint32_t)f * plane_bytes + mc * 4u);
+            load_raw_point(src, mc, in ? cur.ray : last_ray, p_next);
         }
         const bool wave_any = __ballot(any) != 0ull;
-        LevelCell c;
+        Cell c;
+        uint32_t e[8];
+        float w[8];
         bool head = true;
         RunMask run = {false, false, false, false};
         float tv[EARLY_DX ? 8 : 1][F];
         if (wave_any) {
             float x[3];
             unit_point(src, p_cur, x);
-            c = level_cell(lvt, lv, x);
+            c = cell_of(L, x);
+            cell_entries(L, c, e);
+            if constexpr (EARLY_DX) { if (!(sink.debug & 8)) gather_entries<F>(table, e, tv); }
+            cell_weights(c, w);
             // runs = consecutive samples (lanes of one 16-lane row) in the same CELL, not merely the same hashed entry
             if (combine) cell_runs(c, lane, head, run);
-            if constexpr (EARLY_DX) { if (!(sink.debug & 8)) corner_entries_load<F>(c, table, tv); }
         }
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
             // ---- A: this thread's records of the batch; rank within the owner's bucket from an LDS histogram
-            uint32_t ridx[8]; float rv0[8], rv1[8]; int rrank[8];
+            float rv0[8], rv1[8]; int rrank[8];
 #pragma unroll
-            for (int corner = 0; corner < 8; ++corner) rrank[corner] = -1;
+            for (int k = 0; k < 8; ++k) rrank[k] = -1;
             if (wave_any) {
 #pragma unroll
-                for (int corner = 0; corner < 8; ++corner) {
-                    const float w = corner_weight(c, corner);
-                    const uint32_t e = cell_entry(c, corner) * F + (PAIR ? 2 * pass : 0);
-                    float v0 = w * g[PAIR ? 2 * pass : 0], v1 = PAIR ? w * g[2 * pass + 1] : 0.0f;
+                for (int k = 0; k < 8; ++k) {
+                    float v0 = w[k] * g[PAIR ? 2 * pass : 0], v1 = PAIR ? w[k] * g[2 * pass + 1] : 0.0f;
                     if (combine) {
                         v0 = row_run_sum(v0, run);
                         if (PAIR) v1 = row_run_sum(v1, run);
                     }
-                    ridx[corner] = e; rv0[corner] = v0; rv1[corner] = v1;
-                    if (head && (v0 != 0.0f || v1 != 0.0f) && !(sink.debug & 2)) {
-                        const int local = (int)(e >> sink.shift) - first_owner;
-                        if (local >= 0 && local < maxo) rrank[corner] = atomicAdd(&cnt[local], 1);
-                        else { atomicAdd(sink.grad_table + e, v0); if (PAIR) atomicAdd(sink.grad_table + e + 1, v1); }
+                    rv0[k] = v0; rv1[k] = v1;
+                    if (head & ((v0 != 0.0f) | (v1 != 0.0f)) & !(sink.debug & 2)) {
+                        const uint32_t fi = e[k] * F + (PAIR ? 2 * pass : 0);
+                        const int local = (int)(fi >> sink.shift) - first_owner;
+                        if (local >= 0 && local < maxo) rrank[k] = atomicAdd(&cnt[local], 1);
+                        else { atomicAdd(sink.grad_table + fi, v0); if (PAIR) atomicAdd(sink.grad_table + fi + 1, v1); }
                     }
                 }
             }
@@ -269,7 +283,17 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
                     int incl = n;
 #pragma unroll
                     for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
-                    if (o < maxo) { scan[o] = running + incl - n; gpos[o] = gcur[o]; gcur[o] += n; cnt[o] = 0; }
+                    if (o < maxo) {
+                        const int have = gcur[o];
+                        const uint64_t p = reinterpret_cast<uint64_t>(sink.regions) + ((region0 + o) * (size_t)sink.cap + (size_t)have) * 8u;
+                        OwnerSlot os;
+                        os.ptr_lo = (uint32_t)p; os.ptr_hi = (uint32_t)(p >> 32);
+                        os.scan = running + incl - n;
+                        os.room = sink.cap - have;
+                        oslot[o] = os;
+                        gcur[o] = have + n;
+                        cnt[o] = 0;
+                    }
                     running += __shfl(incl, 63, 64);
                 }
                 if (lane == 0) s_total = running;
@@ -277,12 +301,13 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
             __syncthreads();
             // ---- C: scatter into the staging buffer, grouped by owner
 #pragma unroll
-            for (int corner = 0; corner < 8; ++corner) {
-                if (rrank[corner] >= 0) {
-                    const int local = (int)(ridx[corner] >> sink.shift) - first_owner;
-                    const int at = scan[local] + rrank[corner];
-                    if (PAIR) reinterpret_cast<uint4*>(stage)[at] = make_uint4(ridx[corner], __float_as_uint(rv0[corner]), __float_as_uint(rv1[corner]), 0u);
-                    else reinterpret_cast<uint2*>(stage)[at] = make_uint2(ridx[corner], __float_as_uint(rv0[corner]));
+            for (int k = 0; k < 8; ++k) {
+                if (rrank[k] >= 0) {
+                    const uint32_t fi = e[k] * F + (PAIR ? 2 * pass : 0);
+                    const int local = (int)(fi >> sink.shift) - first_owner;
+                    const int at = oslot[local].scan + rrank[k];
+                    if (PAIR) reinterpret_cast<uint4*>(stage)[at] = make_uint4(fi, __float_as_uint(rv0[k]), __float_as_uint(rv1[k]), 0u);
+                    else reinterpret_cast<uint2*>(stage)[at] = make_uint2(fi, __float_as_uint(rv0[k]));
                 }
             }
             __syncthreads();
@@ -290,16 +315,17 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
             const int total = s_total;
             for (int i = threadIdx.x; i < total; i += ENC_BLOCK) {
                 uint32_t idx; float v0, v1 = 0.0f;
-                uint4 r4; uint2 r2;
-                if (PAIR) { r4 = reinterpret_cast<const uint4*>(stage)[i]; idx = r4.x; v0 = __uint_as_float(r4.y); v1 = __uint_as_float(r4.z); }
+                uint2 r2;
+                if (PAIR) { const uint4 r4 = reinterpret_cast<const uint4*>(stage)[i]; idx = r4.x; v0 = __uint_as_float(r4.y); v1 = __uint_as_float(r4.z); }
                 else { r2 = reinterpret_cast<const uint2*>(stage)[i]; idx = r2.x; v0 = __uint_as_float(r2.y); }
                 const int local = (int)(idx >> sink.shift) - first_owner;
-                const int slot = gpos[local] + (i - scan[local]);
+                const OwnerSlot os = oslot[local];
+                const int k = i - os.scan;
                 if (sink.debug & 1) { if (v0 == 1e30f) gcur[0] = 1; }
-                else if (slot < sink.cap) {
-                    const size_t at = (region0 + ((sink.debug & 64) ? (local & ~3) : local)) * sink.cap + ((sink.debug & 64) ? (i & 1023) : slot);   // debug 64: timing experiment only
+                else if (k < os.room) {
                     if (PAIR) r2 = lnr_pack_pair((idx & ((1u << LNR_SLICE_SHIFT) - 1u)) >> 1, v0, v1);
-                    reinterpret_cast<uint2*>(sink.regions)[at] = r2;
+                    uint2* dst = reinterpret_cast<uint2*>(((uint64_t)os.ptr_hi << 32) | os.ptr_lo) + k;
+                    *dst = r2;
                 } else {
                     atomicAdd(sink.grad_table + idx, v0);
                     if (PAIR) atomicAdd(sink.grad_table + idx + 1, v1);
@@ -310,12 +336,12 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
         if constexpr (WANT_DX) {
             float dx[3] = {0.0f, 0.0f, 0.0f};
             if (any && !(sink.debug & 8)) {
-                if constexpr (EARLY_DX) dx_from_entries<F>(c, g, tv, dx);
-                else encode_dx<F>(c, g, table, dx);
+                if constexpr (EARLY_DX) dx_from_entries<F>(L, c, g, tv, dx);
+                else { float tl[8][F]; gather_entries<F>(table, e, tl); dx_from_entries<F>(L, c, g, tl, dx); }
             }
             if (live) {
 #pragma unroll
-                for (int d = 0; d < 3; ++d) dxl[(size_t)(lv * 3 + d) * m_pad + m] = dx[d];
+                for (int d = 0; d < 3; ++d) st32<float>(dxplanes, (uint32_t)d * plane_bytes + m * 4u, dx[d]);
             }
         }
     }
@@ -333,47 +359,59 @@ encode_backward_dense_kernel(const LnrNetSpec spec, const float* __restrict__ ta
                              float* __restrict__ dxl, int64_t m_pad, int bpg, const LevelList list, float* __restrict__ slabs,
                              int dense_total, int debug) {
     extern __shared__ long long dacc[];
-    __shared__ float lvt[LNR_LV_WORDS];
-    stage_level_tables(spec, lvt);
     const int slot = blockIdx.x / bpg, chunk = blockIdx.x % bpg;
     const int lv = list.lv[slot];
-    const int nfl = (int)spec.level_size[lv] * F;
-    const uint32_t level_base = spec.level_offset[lv] * F;
+    const LevelInfo L = level_info(spec, lv);
+    const int nfl = (int)L.size * F;
+    const uint32_t level_base = L.offset * F;
     for (int i = threadIdx.x; i < nfl; i += ENC_BLOCK) dacc[i] = 0ll;
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int64_t M = live_points(src);
-    const int64_t m_round = (M + 63) / 64 * 64;           // whole waves: the run logic uses cross-lane reads
-    for (int64_t m = (int64_t)chunk * ENC_BLOCK + threadIdx.x; m < m_round; m += (int64_t)bpg * ENC_BLOCK) {
+    const uint32_t M = (uint32_t)live_points(src);
+    const uint32_t m_round = (M + 63u) / 64u * 64u;           // whole waves: the run logic uses cross-lane reads
+    const float* gplanes = dfeat + (size_t)(lv * F) * m_pad;
+    float* dxplanes = dxl + (size_t)(lv * 3) * m_pad;
+    const uint32_t plane_bytes = (uint32_t)m_pad * 4u;
+    SampleCursor cur;
+    cur.init((uint32_t)chunk * ENC_BLOCK + threadIdx.x, (uint32_t)bpg * ENC_BLOCK, src.pts ? 1u : (uint32_t)src.n_samples);
+    const uint32_t last_ray = src.pts ? 0u : (M > 0u ? (M - 1u) / cur.S : 0u);
+    for (; cur.m < m_round; cur.advance()) {
+        const uint32_t m = cur.m;
         const bool live = m < M;
         float g[F];
         bool any = false;
 #pragma unroll
-        for (int f = 0; f < F; ++f) { g[f] = live ? dfeat[(size_t)(lv * F + f) * m_pad + m] : 0.0f; any |= (g[f] != 0.0f); }
+        for (int f = 0; f < F; ++f) { g[f] = live ? ld32<float>(gplanes, (uint32_t)f * plane_bytes + m * 4u) : 0.0f; any |= (g[f] != 0.0f); }
         float dx[3] = {0.0f, 0.0f, 0.0f};
         if (__ballot(any) != 0ull) {                        // wave-uniform
+            RawPoint rp;
+            load_raw_point(src, live ? m : M - 1u, live ? cur.ray : last_ray, rp);
             float x[3];
-            load_unit_point(src, live ? m : M - 1, x);
-            const LevelCell c = level_cell(lvt, lv, x);
+            unit_point(src, rp, x);
+            const Cell c = cell_of(L, x);
+            uint32_t e[8]; float w[8];
+            cell_entries(L, c, e);
+            cell_weights(c, w);
             bool head; RunMask run;
             cell_runs(c, lane, head, run);
 #pragma unroll
-            for (int corner = 0; corner < 8; ++corner) {
-                const float w = corner_weight(c, corner);
-                const uint32_t e = cell_entry(c, corner) * F - level_base;
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t el = e[k] * F - level_base;
 #pragma unroll
                 for (int f = 0; f < F; ++f) {
-                    const float v = row_run_sum(w * g[f], run);
+                    const float v = row_run_sum(w[k] * g[f], run);
                     if (head && v != 0.0f && !(debug & 2))
-                        atomicAdd(reinterpret_cast<unsigned long long*>(&dacc[e + f]), (unsigned long long)__float2ll_rn(v * LNR_FIX_SCALE));
+                        atomicAdd(reinterpret_cast<unsigned long long*>(&dacc[el + f]), (unsigned long long)__float2ll_rn(v * LNR_FIX_SCALE));
                 }
             }
-            if constexpr (WANT_DX) { if (any && !(debug & 8)) encode_dx<F>(c, g, table, dx); }
+            if constexpr (WANT_DX) {
+                if (any && !(debug & 8)) { float tv[8][F]; gather_entries<F>(table, e, tv); dx_from_entries<F>(L, c, g, tv, dx); }
+            }
         }
         if constexpr (WANT_DX) {
             if (live) {
 #pragma unroll
-                for (int d = 0; d < 3; ++d) dxl[(size_t)(lv * 3 + d) * m_pad + m] = dx[d];
+                for (int d = 0; d < 3; ++d) st32<float>(dxplanes, (uint32_t)d * plane_bytes + m * 4u, dx[d]);
             }
         }
     }
@@ -439,13 +477,17 @@ sum_dx_planes_kernel(const float* __restrict__ dxl, int n_groups, int64_t m_pad,
 int lnr_encode_forward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, float* feat,
                        int64_t m_pad, hipStream_t st) {
     const float* table = params + spec->n_mlp_params;
-    const int n_groups = spec->encoding == LNR_ENC_HASHGRID ? spec->n_levels : (spec->enc_dim + 3) / 4;
+    const bool hash = spec->encoding == LNR_ENC_HASHGRID;
+    const int n_groups = hash ? spec->n_levels : (spec->enc_dim + 3) / 4;
     int64_t bpg = (cap_points + ENC_BLOCK * 4 - 1) / (ENC_BLOCK * 4);      // ~4 samples per thread
     if (bpg < 1) bpg = 1;
     if (bpg > 2048) bpg = 2048;
     const dim3 grid((unsigned)(n_groups * bpg)), block(ENC_BLOCK);
-    const int F = spec->encoding == LNR_ENC_HASHGRID ? spec->n_features : 1;
-    switch (F) {
+    if (!hash) {
+        hipLaunchKernelGGL(freq_forward_kernel, grid, block, 0, st, *spec, *src, feat, m_pad, (int)bpg);
+        return LNR_OK;
+    }
+    switch (spec->n_features) {
         case 1: hipLaunchKernelGGL(encode_forward_kernel<1>, grid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg); break;
         case 2: hipLaunchKernelGGL(encode_forward_kernel<2>, grid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg); break;
         case 4: hipLaunchKernelGGL(encode_forward_kernel<4>, grid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg); break;
@@ -480,11 +522,19 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
             sink.grad_table = grad_table; sink.regions = regions; sink.counts = counts; sink.maxo = maxo; sink.cap = cap; sink.shift = shift;
             sink.combine_scale_max = LNR_COMBINE_SCALE_MAX; sink.debug = debug;
             const dim3 grid((unsigned)(rec_levels.n * bpg));
-            const size_t lds = (size_t)((4 * maxo + 3) & ~3) * sizeof(int) + (size_t)ENC_STAGE_RECORDS * (spec->n_features >= 2 ? 16 : 8);
+            const int maxo4 = (maxo + 3) & ~3;
+            const size_t lds = (size_t)(2 * maxo4 + 4 * maxo) * sizeof(int) + (size_t)ENC_STAGE_RECORDS * (spec->n_features >= 2 ? 16 : 8);
 #define LNR_EB(F)                                                                                                             \
             do {                                                                                                              \
-                if (d_pts) hipLaunchKernelGGL((encode_backward_kernel<F, true>), grid, block, lds, st, *spec, table, *src, dfeat, dxl, m_pad, bpg, rec_levels, sink); \
-                else hipLaunchKernelGGL((encode_backward_kernel<F, false>), grid, block, lds, st, *spec, table, *src, dfeat, dxl, m_pad, bpg, rec_levels, sink);     \
+                hipError_t e_;                                                                                                \
+                if (d_pts) {                                                                                                  \
+                    e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(encode_backward_kernel<F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                    if (e_ == hipSuccess) hipLaunchKernelGGL((encode_backward_kernel<F, true>), grid, block, lds, st, *spec, table, *src, dfeat, dxl, m_pad, bpg, rec_levels, sink); \
+                } else {                                                                                                      \
+                    e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(encode_backward_kernel<F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                    if (e_ == hipSuccess) hipLaunchKernelGGL((encode_backward_kernel<F, false>), grid, block, lds, st, *spec, table, *src, dfeat, dxl, m_pad, bpg, rec_levels, sink); \
+                }                                                                                                             \
+                if (e_ != hipSuccess) { lnr_set_error("lnr_density_backward: hipFuncSetAttribute(%zu) failed", lds); return LNR_ERR_LAUNCH; } \
             } while (0)
             switch (spec->n_features) {
                 case 1: LNR_EB(1); break;

@@ -16,19 +16,48 @@ __device__ __forceinline__ int64_t live_points(const PointSrc& s) {
     return (int64_t)lnr_live_rays(s.n_rays, s.n_rays_dev) * s.n_samples;
 }
 
-// Point m as loaded (no arithmetic yet, so the loads can be issued a whole iteration ahead of their use).
+// 32-bit byte offsets from wave-uniform base pointers (global_load saddr + voffset): per-lane 64-bit pointer
+// arithmetic costs 3-4 VALU instructions per access, and these kernels are bound by VALU issue, not by memory.
+// The host checks n_points < 2^28 and table bytes < 2^32.
+template <typename T>
+__device__ __forceinline__ T ld32(const void* base, uint32_t byte_off) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (size_t)byte_off);
+}
+template <typename T>
+__device__ __forceinline__ void st32(void* base, uint32_t byte_off, T v) {
+    *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (size_t)byte_off) = v;
+}
+
+// Sample index of a thread that walks m, m+step, m+2*step, ...: the ray index m / n_samples is kept incrementally
+// (one division at the start instead of one per sample).
+struct SampleCursor {
+    uint32_t m, ray, rem;          // m = ray * n_samples + rem
+    uint32_t step, dq, dr, S;      // step = dq * S + dr
+    __device__ __forceinline__ void init(uint32_t m0, uint32_t step_, uint32_t n_samples) {
+        S = n_samples; step = step_; m = m0;
+        ray = m0 / S; rem = m0 - ray * S;
+        dq = step_ / S; dr = step_ - dq * S;
+    }
+    __device__ __forceinline__ void advance() {
+        m += step; ray += dq; rem += dr;
+        if (rem >= S) { rem -= S; ++ray; }
+    }
+};
+
+// Point as loaded (no arithmetic yet, so the loads can be issued a whole iteration ahead of their use).
 // pts mode: o = xyz; rays mode: o = origin, d = direction, z = depth.  Scalar fields, all always assigned: an array
 // written differently by the two modes ends up in scratch memory.
 struct RawPoint { float o0, o1, o2, d0, d1, d2, z; };
 
-__device__ __forceinline__ void load_raw_point(const PointSrc& s, int64_t m, RawPoint& r) {
+__device__ __forceinline__ void load_raw_point(const PointSrc& s, uint32_t m, uint32_t ray, RawPoint& r) {
     if (s.pts) {
-        r.o0 = s.pts[3 * m + 0]; r.o1 = s.pts[3 * m + 1]; r.o2 = s.pts[3 * m + 2];
+        r.o0 = ld32<float>(s.pts, m * 12u); r.o1 = ld32<float>(s.pts, m * 12u + 4u); r.o2 = ld32<float>(s.pts, m * 12u + 8u);
         r.d0 = 0.0f; r.d1 = 0.0f; r.d2 = 0.0f; r.z = 0.0f;
     } else {
-        const float* ray = s.rays + (m / s.n_samples) * LNR_RAY_STRIDE;
-        r.o0 = ray[0]; r.o1 = ray[1]; r.o2 = ray[2]; r.d0 = ray[3]; r.d1 = ray[4]; r.d2 = ray[5];
-        r.z = s.z[m];
+        const uint32_t ro = ray * (uint32_t)(LNR_RAY_STRIDE * 4);
+        r.o0 = ld32<float>(s.rays, ro); r.o1 = ld32<float>(s.rays, ro + 4u); r.o2 = ld32<float>(s.rays, ro + 8u);
+        r.d0 = ld32<float>(s.rays, ro + 12u); r.d1 = ld32<float>(s.rays, ro + 16u); r.d2 = ld32<float>(s.rays, ro + 20u);
+        r.z = ld32<float>(s.z, m * 4u);
     }
 }
 
@@ -46,70 +75,78 @@ __device__ __forceinline__ void unit_point(const PointSrc& s, const RawPoint& r,
 
 __device__ __forceinline__ void load_unit_point(const PointSrc& s, int64_t m, float x[3]) {
     RawPoint r;
-    load_raw_point(s, m, r);
+    load_raw_point(s, (uint32_t)m, s.pts ? 0u : (uint32_t)(m / s.n_samples), r);
     unit_point(s, r, x);
 }
 
 // ------------------------------------------------------------------------------------------------
-// multiresolution hash grid: one level, one point
+// multiresolution hash grid: one level (wave-uniform, its geometry lives in SGPRs), one point per lane
 // ------------------------------------------------------------------------------------------------
-struct LevelCell {
-    uint32_t base[3];   // integer cell
-    float frac[3];
+struct LevelInfo {
     float scale;
-    uint32_t res, size, offset, hashed;
+    uint32_t res, size, offset;     // entries
+    bool hashed, pow2;
 };
 
-// Per-level geometry lives in LDS (5 x 32 words at the start of the dynamic LDS block): the level a
-// lane works on depends on its lane group, and indexing kernel arguments by a VGPR would force the
-// whole spec struct into scratch memory.
-#define LNR_LV_WORDS (5 * LNR_MAX_LEVELS)
-__device__ __forceinline__ void stage_level_tables(const LnrNetSpec& spec, float* lds) {
-    uint32_t* u = reinterpret_cast<uint32_t*>(lds);
-    for (int i = threadIdx.x; i < LNR_MAX_LEVELS; i += blockDim.x) {
-        lds[i] = spec.level_scale[i];
-        u[LNR_MAX_LEVELS + i] = spec.level_res[i];
-        u[2 * LNR_MAX_LEVELS + i] = spec.level_size[i];
-        u[3 * LNR_MAX_LEVELS + i] = spec.level_offset[i];
-        const uint32_t sz = spec.level_size[i];
-        u[4 * LNR_MAX_LEVELS + i] = (spec.level_hashed[i] & 1u) | ((sz != 0u && (sz & (sz - 1u)) == 0u) ? 2u : 0u);   // bit0 hashed, bit1 size is 2^k
-    }
+__device__ __forceinline__ LevelInfo level_info(const LnrNetSpec& spec, int lv) {
+    LevelInfo L;
+    L.scale = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(spec.level_scale[lv])));
+    L.res = __builtin_amdgcn_readfirstlane(spec.level_res[lv]);
+    L.size = __builtin_amdgcn_readfirstlane(spec.level_size[lv]);
+    L.offset = __builtin_amdgcn_readfirstlane(spec.level_offset[lv]);
+    L.hashed = (__builtin_amdgcn_readfirstlane(spec.level_hashed[lv]) & 1u) != 0u;
+    L.pow2 = (L.size & (L.size - 1u)) == 0u;
+    return L;
 }
 
-__device__ __forceinline__ LevelCell level_cell(const float* lvt, int lv, const float x[3]) {
-    LevelCell c;
-    const uint32_t* u = reinterpret_cast<const uint32_t*>(lvt);
-    c.scale = lvt[lv];
-    c.res = u[LNR_MAX_LEVELS + lv];
-    c.size = u[2 * LNR_MAX_LEVELS + lv];
-    c.offset = u[3 * LNR_MAX_LEVELS + lv];
-    c.hashed = u[4 * LNR_MAX_LEVELS + lv];
+struct Cell {
+    uint32_t b[3];      // integer cell
+    float frac[3];
+};
+
+__device__ __forceinline__ Cell cell_of(const LevelInfo& L, const float x[3]) {
+    Cell c;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        float pos = lnr_add_rn(lnr_mul_rn(x[d], c.scale), 0.5f);
-        float fl = floorf(pos);
+        const float pos = lnr_add_rn(lnr_mul_rn(x[d], L.scale), 0.5f);
+        const float fl = floorf(pos);
         c.frac[d] = pos - fl;
-        c.base[d] = (uint32_t)(int32_t)fl;
+        c.b[d] = (uint32_t)(int32_t)fl;
     }
     return c;
 }
 
-// kept out of line so that the common power-of-two case really skips the division sequence
-__device__ __noinline__ uint32_t lnr_slow_mod(uint32_t a, uint32_t b) { return a % b; }
-
-__device__ __forceinline__ uint32_t cell_entry(const LevelCell& c, int corner) {
-    uint32_t cx = c.base[0] + (corner & 1), cy = c.base[1] + ((corner >> 1) & 1), cz = c.base[2] + ((corner >> 2) & 1);
-    uint32_t idx = (c.hashed & 1u) ? (cx ^ (cy * PRIME_Y) ^ (cz * PRIME_Z)) : (cx + cy * c.res + cz * c.res * c.res);
-    // table sizes are powers of two for every level of the usual configurations: mask instead of a ~40-instruction modulo
-    if (c.hashed & 2u) idx &= (c.size - 1u); else idx = lnr_slow_mod(idx, c.size);
-    return c.offset + idx;
+// Table entries (absolute, in entries) of the 8 corners; corner bit 0 = +x, bit 1 = +y, bit 2 = +z.  The per-axis
+// terms are shared between corners: 12 xors (or 8 adds) instead of 8 full hash evaluations.
+__device__ __forceinline__ void cell_entries(const LevelInfo& L, const Cell& c, uint32_t e[8]) {
+    if (L.hashed) {
+        const uint32_t hx0 = c.b[0], hx1 = c.b[0] + 1u;
+        const uint32_t hy0 = c.b[1] * PRIME_Y, hy1 = hy0 + PRIME_Y;
+        const uint32_t hz0 = c.b[2] * PRIME_Z, hz1 = hz0 + PRIME_Z;
+        const uint32_t yz[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = ((k & 1) ? hx1 : hx0) ^ yz[k >> 1];
+    } else {
+        const uint32_t sy = L.res, sz = L.res * L.res;
+        const uint32_t i0 = c.b[0] + c.b[1] * sy + c.b[2] * sz;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = i0 + (uint32_t)(k & 1) + ((k & 2) ? sy : 0u) + ((k & 4) ? sz : 0u);
+    }
+    if (L.pow2) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = (e[k] & (L.size - 1u)) + L.offset;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = e[k] % L.size + L.offset;
+    }
 }
 
-__device__ __forceinline__ float corner_weight(const LevelCell& c, int corner) {
-    float wx = (corner & 1) ? c.frac[0] : 1.0f - c.frac[0];
-    float wy = (corner & 2) ? c.frac[1] : 1.0f - c.frac[1];
-    float wz = (corner & 4) ? c.frac[2] : 1.0f - c.frac[2];
-    return wx * wy * wz;
+// trilinear weights, associated as (wx*wy)*wz
+__device__ __forceinline__ void cell_weights(const Cell& c, float w[8]) {
+    const float wx[2] = {1.0f - c.frac[0], c.frac[0]}, wy[2] = {1.0f - c.frac[1], c.frac[1]}, wz[2] = {1.0f - c.frac[2], c.frac[2]};
+    const float wxy[4] = {wx[0] * wy[0], wx[1] * wy[0], wx[0] * wy[1], wx[1] * wy[1]};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = wxy[k & 3] * wz[k >> 2];
 }
 
 // Frequency encoding: feature k = sin(x[dim]*2^freq*pi + (k&1)*pi/2), order [dim][freq][sin,cos]
