@@ -32,6 +32,7 @@ extern "C" {
 #endif
 
 #define LNR_RAY_STRIDE 13
+#define LNR_LOSS_RAYS_PER_BLOCK 4
 #define LNR_MAX_LEVELS 32
 
 typedef enum LnrStatus {
@@ -229,7 +230,9 @@ int lnr_logits_grad(const float* s /*[n,S]*/, const float* g /*[n]*/, int32_t n_
  * Reproduces the reference's `depth > far[0]` broadcast quirk (:460-461).
  * counts_dev [2] int32: {number of rays, number of opaque rays} over the WHOLE batch the loss is
  * normalised by (all GPUs) -- from lnr_count_opaque, all-reduced by the caller when sharded.
- * loss_out [8] float (accumulated with atomics; caller zeroes): {total, depth, los, opacity, sum of eps, -,-,-};
+ * loss_out [8] float (accumulated; caller zeroes): {total, depth, los, opacity, sum of eps, -,-,-};
+ * block_partials (nullable) [ceil(n_rays / LNR_LOSS_RAYS_PER_BLOCK) * 8] scratch: with it the terms are summed
+ * without atomics (deterministic, and ~0.25 ms faster at 4096 rays than 20 k same-address atomics);
  * ray_stats (nullable) [n,8]: {depth, opacity, variance, mean_m, std_m, js, eps, opaque}.
  * weights_out (nullable) [n,S]. */
 int lnr_count_opaque(const float* rays, const float* depth_gt, int32_t n_rays, const int32_t* n_rays_dev,
@@ -239,7 +242,7 @@ int lnr_los_loss_fused(const float* sigma, const float* z, const float* rays, co
                        const float* noise, float noise_std, uint64_t seed,
                        float scale, const LnrLossConfig* cfg /*host*/, const int32_t* counts_dev,
                        float* loss_out, float* d_sigma, float* d_rays, float* ray_stats,
-                       float* weights_out, void* stream);
+                       float* weights_out, float* block_partials, void* stream);
 
 /* ---- optimisers -------------------------------------------------------------------------------------- */
 /* torch.optim.Adam step (optimizer.py:257-269,376-380): betas (b1,b2), eps, no weight decay,

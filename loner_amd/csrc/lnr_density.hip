@@ -11,17 +11,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define LNR_ENC_BWD_MAX_BPG 512
 
+// grad[i] += sum over workgroup slabs; blockIdx.y splits the slabs so that a few thousand threads (not n_mlp) share the reads
+#define LNR_SLAB_GROUPS 16
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs, int n_mlp, float* __restrict__ grad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_mlp) return;
+    const int per = (n_slabs + LNR_SLAB_GROUPS - 1) / LNR_SLAB_GROUPS;
+    int b = blockIdx.y * per;
+    const int b_end = min(n_slabs, b + per);
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    int b = 0;
-    for (; b + 3 < n_slabs; b += 4) {
+    for (; b + 3 < b_end; b += 4) {
         s0 += slabs[(size_t)b * n_mlp + i]; s1 += slabs[(size_t)(b + 1) * n_mlp + i];
         s2 += slabs[(size_t)(b + 2) * n_mlp + i]; s3 += slabs[(size_t)(b + 3) * n_mlp + i];
     }
-    for (; b < n_slabs; ++b) s0 += slabs[(size_t)b * n_mlp + i];
-    grad[i] += (s0 + s1) + (s2 + s3);
+    for (; b < b_end; ++b) s0 += slabs[(size_t)b * n_mlp + i];
+    const float s = (s0 + s1) + (s2 + s3);
+    if (s != 0.0f) atomicAdd(grad + i, s);
 }
 
 // Workgroup `o` owns floats [o << shift, (o+1) << shift) of the table gradient.  The encode-backward workgroups of
@@ -44,7 +49,7 @@ __device__ __forceinline__ void reduce_one(long long* acc, uint2 r, uint32_t bas
 }
 
 template <int PAIR>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(1024)
 table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ regions_v, const int* __restrict__ counts, int bpg, int maxo,
                           int cap, int shift, float* __restrict__ grad_table, int64_t n_table_floats) {
     extern __shared__ long long acc[];
@@ -325,15 +330,15 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
         if (e0 != hipSuccess || e1 != hipSuccess) { lnr_set_error("lnr_density_backward: hipFuncSetAttribute failed"); return LNR_ERR_LAUNCH; }
         const int64_t n_table = spec->n_params - spec->n_mlp_params;
         if (spec->n_features >= 2)
-            hipLaunchKernelGGL(table_grad_reduce2_kernel<1>, dim3(L.nown), dim3(512), lds, st, *spec, regions, counts, L.bpg, L.maxo, cap_rec,
+            hipLaunchKernelGGL(table_grad_reduce2_kernel<1>, dim3(L.nown), dim3(1024), lds, st, *spec, regions, counts, L.bpg, L.maxo, cap_rec,
                                L.shift, grad_table, n_table);
         else
-            hipLaunchKernelGGL(table_grad_reduce2_kernel<0>, dim3(L.nown), dim3(512), lds, st, *spec, regions, counts, L.bpg, L.maxo, cap_rec,
+            hipLaunchKernelGGL(table_grad_reduce2_kernel<0>, dim3(L.nown), dim3(1024), lds, st, *spec, regions, counts, L.bpg, L.maxo, cap_rec,
                                L.shift, grad_table, n_table);
         LNR_CHECK_LAUNCH("lnr_density_backward(table reduce)");
     }
     const int n_mlp = spec->n_mlp_params;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(lnr_div_up(n_mlp, 256)), dim3(256), 0, st, slabs, plan.grid, n_mlp, grad_params);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(lnr_div_up(n_mlp, 256), LNR_SLAB_GROUPS), dim3(256), 0, st, slabs, plan.grid, n_mlp, grad_params);
     LNR_CHECK_LAUNCH("lnr_density_backward(reduce)");
     return LNR_OK;
 }

@@ -16,6 +16,7 @@
 
 #define RENDER_BLOCK 256
 #define RAYS_PER_BLOCK (RENDER_BLOCK / 64)
+static_assert(RAYS_PER_BLOCK == LNR_LOSS_RAYS_PER_BLOCK, "header constant out of date");
 
 __device__ __forceinline__ float wave_excl_suffix_sum(float v, int lane) {
     float inc = v;
@@ -224,16 +225,13 @@ __device__ __forceinline__ float gaussian_js(float m1, float s1, float m2, float
     return 0.5f * gaussian_kl(m1, s1, mm, sm) + 0.5f * gaussian_kl(m2, s2, mm, sm);
 }
 
+// one ray of Optimizer.compute_loss held by one wave; terms[0..4] += {total, depth, los, opacity, eps}
 template <int C>
-__global__ void __launch_bounds__(RENDER_BLOCK)
-los_loss_fused_kernel(const float* __restrict__ sigma, const float* __restrict__ z, const float* __restrict__ rays,
-                      const float* __restrict__ depth_gt, int n_rays, const int32_t* __restrict__ n_rays_dev, int S,
-                      const float* __restrict__ noise, float noise_std, uint64_t seed, float scale, const LnrLossConfig cfg,
-                      const int32_t* __restrict__ counts, float* __restrict__ loss_out, float* __restrict__ d_sigma,
-                      float* __restrict__ d_rays, float* __restrict__ ray_stats, float* __restrict__ weights_out) {
-    const int lane = threadIdx.x & 63;
-    const int ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
-    if (ray >= lnr_live_rays(n_rays, n_rays_dev)) return;
+__device__ __forceinline__ void los_loss_ray(const float* __restrict__ sigma, const float* __restrict__ z, const float* __restrict__ rays,
+                                             const float* __restrict__ depth_gt, int S, const float* __restrict__ noise, float noise_std,
+                                             uint64_t seed, float scale, const LnrLossConfig& cfg, const int32_t* __restrict__ counts,
+                                             float* terms, bool terms_atomic, float* __restrict__ d_sigma, float* __restrict__ d_rays,
+                                             float* __restrict__ ray_stats, float* __restrict__ weights_out, int ray, int lane) {
     const float* rr = rays + (size_t)ray * LNR_RAY_STRIDE;
     RayState<C> st;
     render_ray<C>(st, sigma, z, noise, noise_std, seed, ray, S, lane, rr);
@@ -304,17 +302,57 @@ los_loss_fused_kernel(const float* __restrict__ sigma, const float* __restrict__
         const float l_depth = opaque ? cfg.depth_lambda * (depth_m - g) * (depth_m - g) / n_op : 0.0f;
         const float l_los = cfg.los_lambda * los_sum / n_all;
         const float l_op = opaque ? fabsf(st.opacity - 1.0f) / n_op : 0.0f;
-        atomicAdd(loss_out + 0, l_depth + l_los + l_op);
-        atomicAdd(loss_out + 1, l_depth);
-        atomicAdd(loss_out + 2, l_los);
-        atomicAdd(loss_out + 3, l_op);
-        atomicAdd(loss_out + 4, eps);                 // sum of the per-ray margins (-> _depth_eps = mean)
+        const float t5[5] = {l_depth + l_los + l_op, l_depth, l_los, l_op, eps};     // eps: sum of the per-ray margins (-> _depth_eps = mean)
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { if (terms_atomic) atomicAdd(terms + q, t5[q]); else terms[q] = t5[q]; }
         if (ray_stats) {
             float* o = ray_stats + (size_t)ray * 8;
             o[0] = st.depth; o[1] = st.opacity; o[2] = st.variance; o[3] = mean; o[4] = sd_pred; o[5] = js; o[6] = eps;
             o[7] = opaque ? 1.0f : 0.0f;
         }
     }
+}
+
+
+template <int C>
+__global__ void __launch_bounds__(RENDER_BLOCK)
+los_loss_fused_kernel(const float* __restrict__ sigma, const float* __restrict__ z, const float* __restrict__ rays,
+                      const float* __restrict__ depth_gt, int n_rays, const int32_t* __restrict__ n_rays_dev, int S,
+                      const float* __restrict__ noise, float noise_std, uint64_t seed, float scale, const LnrLossConfig cfg,
+                      const int32_t* __restrict__ counts, float* __restrict__ loss_out, float* __restrict__ d_sigma,
+                      float* __restrict__ d_rays, float* __restrict__ ray_stats, float* __restrict__ weights_out,
+                      float* __restrict__ block_partials) {
+    // Loss terms: 20 k same-address float atomics (5 per ray) serialise in one L2 channel and cost ~0.25 ms - more than
+    // the rest of the kernel.  With block_partials each workgroup stores its 5 sums and loss_reduce_kernel adds them up.
+    __shared__ float s_terms[RAYS_PER_BLOCK][5];
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    const bool alive = ray < lnr_live_rays(n_rays, n_rays_dev);         // wave-uniform
+    if (block_partials) {
+        if (lane < 5) s_terms[threadIdx.x >> 6][lane] = 0.0f;
+        if (alive) los_loss_ray<C>(sigma, z, rays, depth_gt, S, noise, noise_std, seed, scale, cfg, counts, s_terms[threadIdx.x >> 6], false,
+                                   d_sigma, d_rays, ray_stats, weights_out, ray, lane);
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            float v = 0.0f;
+            if (threadIdx.x < 5) for (int r = 0; r < RAYS_PER_BLOCK; ++r) v += s_terms[r][threadIdx.x];
+            block_partials[(size_t)blockIdx.x * 8 + threadIdx.x] = v;
+        }
+    } else if (alive) {
+        los_loss_ray<C>(sigma, z, rays, depth_gt, S, noise, noise_std, seed, scale, cfg, counts, loss_out, true,
+                        d_sigma, d_rays, ray_stats, weights_out, ray, lane);
+    }
+}
+
+__global__ void loss_reduce_kernel(const float* __restrict__ block_partials, int n_blocks, float* __restrict__ loss_out) {
+    __shared__ float part[4][8];
+    const int term = threadIdx.x & 7, slice = threadIdx.x >> 3;          // 256 threads = 32 slices x 8 terms
+    float v = 0.0f;
+    for (int b = slice; b < n_blocks; b += 32) v += block_partials[(size_t)b * 8 + term];
+    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    if ((threadIdx.x & 63) < 8) part[threadIdx.x >> 6][term] = v;
+    __syncthreads();
+    if (threadIdx.x < 5) loss_out[threadIdx.x] += part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
 }
 
 __global__ void count_opaque_kernel(const float* __restrict__ rays, const float* __restrict__ depth_gt, int n_rays,
@@ -451,7 +489,7 @@ extern "C" int lnr_count_opaque(const float* rays, const float* depth_gt, int32_
 extern "C" int lnr_los_loss_fused(const float* sigma, const float* z, const float* rays, const float* depth_gt, int32_t n_rays,
                                   const int32_t* n_rays_dev, int32_t n_samples, const float* noise, float noise_std, uint64_t seed,
                                   float scale, const LnrLossConfig* cfg, const int32_t* counts_dev, float* loss_out, float* d_sigma,
-                                  float* d_rays, float* ray_stats, float* weights_out, void* stream) {
+                                  float* d_rays, float* ray_stats, float* weights_out, float* block_partials, void* stream) {
     LNR_REQUIRE(sigma && z && rays && depth_gt && cfg && counts_dev && loss_out && d_sigma && d_rays, "lnr_los_loss_fused: null argument");
     LNR_REQUIRE(cfg->selection >= 0 && cfg->selection <= 3, "lnr_los_loss_fused: unknown loss selection %d", cfg->selection);
     LNR_REQUIRE(n_rays >= 0 && n_samples >= 2, "lnr_los_loss_fused: bad sizes");
@@ -460,8 +498,12 @@ extern "C" int lnr_los_loss_fused(const float* sigma, const float* z, const floa
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_C(n_samples, hipLaunchKernelGGL(los_loss_fused_kernel<C>, grid, block, 0, st, sigma, z, rays, depth_gt, n_rays, n_rays_dev,
                                              n_samples, noise, noise_std, seed, scale, *cfg, counts_dev, loss_out, d_sigma, d_rays,
-                                             ray_stats, weights_out));
+                                             ray_stats, weights_out, block_partials));
     LNR_CHECK_LAUNCH("lnr_los_loss_fused");
+    if (block_partials) {
+        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, block_partials, (int)grid.x, loss_out);
+        LNR_CHECK_LAUNCH("lnr_los_loss_fused(reduce)");
+    }
     return LNR_OK;
 }
 

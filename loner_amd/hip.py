@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "_lib", "libloner_hip.so")
 
 MAX_LEVELS = 32
 RAY_STRIDE = 13
+LOSS_RAYS_PER_BLOCK = 4      # LNR_LOSS_RAYS_PER_BLOCK
 
 ENCODINGS = {"HashGrid": 0, "Grid": 0, "Frequency": 1}
 ACTIVATIONS = {"None": 0, "ReLU": 1, "Sine": 2, "LeakyReLU": 3, "Exponential": 4, "Sigmoid": 5,
@@ -72,7 +73,7 @@ _SIGNATURES = {
     "lnr_logits_grad": (C.c_int, [P, P, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, P, P]),
     "lnr_count_opaque": (C.c_int, [P, P, C.c_int32, P, P, P]),
     "lnr_los_loss_fused": (C.c_int, [P, P, P, P, C.c_int32, P, C.c_int32, P, C.c_float, C.c_uint64, C.c_float,
-                                     C.POINTER(LossConfig), P, P, P, P, P, P, P]),
+                                     C.POINTER(LossConfig), P, P, P, P, P, P, P, P]),
     "lnr_adam_step": (C.c_int, [P, P, P, P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                 C.c_float, C.c_int32, P]),
     "lnr_occ_grid_step": (C.c_int, [P, C.c_int32, P, P, P, C.c_int32, P, C.c_int32, C.c_float, C.c_float, C.c_float,

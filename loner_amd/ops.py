@@ -339,9 +339,10 @@ def los_loss_fused(sigma, z, rays, depth_gt, scale, cfg: hip.LossConfig, counts,
     d_rays = torch.zeros(n, hip.RAY_STRIDE, device=dev)
     stats = torch.zeros(n, 8, device=dev) if want_stats else None
     w = torch.zeros(n, s, device=dev) if want_weights else None
+    partials = torch.empty(((n + hip.LOSS_RAYS_PER_BLOCK - 1) // hip.LOSS_RAYS_PER_BLOCK) * 8, device=dev)
     check(load().lnr_los_loss_fused(_ptr(sigma), _ptr(z), _ptr(rays), _ptr(depth_gt), n, _ptr(n_rays_dev), s,
                                     _ptr(_f32c(noise)), float(noise_std), int(seed), float(scale), C.byref(cfg), _ptr(counts),
-                                    _ptr(loss_out), _ptr(d_sigma), _ptr(d_rays), _ptr(stats), _ptr(w), _stream()),
+                                    _ptr(loss_out), _ptr(d_sigma), _ptr(d_rays), _ptr(stats), _ptr(w), _ptr(partials), _stream()),
           "lnr_los_loss_fused")
     return loss_out, d_sigma, d_rays, stats, w
 
