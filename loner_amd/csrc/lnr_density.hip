@@ -51,7 +51,7 @@ __device__ __forceinline__ void reduce_one(long long* acc, uint2 r, uint32_t bas
 template <int PAIR>
 __global__ void __launch_bounds__(1024)
 table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ regions_v, const int* __restrict__ counts, int bpg, int maxo,
-                          int cap, int shift, float* __restrict__ grad_table, int64_t n_table_floats) {
+                          int cap, int shift, float* __restrict__ grad_table, int64_t n_table_floats, int debug) {
     extern __shared__ long long acc[];
     const int o = blockIdx.x;
     const int slice = 1 << shift;
@@ -66,22 +66,45 @@ table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ region
         if (hi - lo <= (uint64_t)LNR_DENSE_LEVEL_FLOATS) continue;          // dense level: arrives through the slabs
         const int local = o - (int)(lo >> shift);
         if (local < 0 || local >= maxo) continue;
-        const int b_end = (l + 1) * bpg;
-        int b = l * bpg + wave;
-        int n_next = b < b_end ? counts[(size_t)b * maxo + local] : 0;
-        for (; b < b_end; b += nwaves) {
-            const int n = n_next;
-            if (b + nwaves < b_end) n_next = counts[(size_t)(b + nwaves) * maxo + local];     // fetched behind this region's records
-            const uint4* r = reinterpret_cast<const uint4*>(reinterpret_cast<const uint2*>(regions_v) + ((size_t)b * maxo + local) * cap);   // cap is even
-            for (int i0 = 0; i0 < n; i0 += 512) {
-                uint4 rec[4];       // unconditional 16-byte loads (out-of-range lanes re-read record 0 and ignore it)
+        // This wave's regions of the level: b = l*bpg + wave + r*nwaves.  Their record counts are fetched with one load
+        // (lane r holds region r's count), and the first 512 records of region r+1 are loaded before region r is summed:
+        // per region the wave would otherwise sit through two dependent HBM round trips for ~4 KB of data.
+        const int n_regions = (bpg - wave + nwaves - 1) / nwaves;
+        for (int r0 = 0; r0 < n_regions; r0 += 64) {
+            const int my_r = r0 + lane;
+            const int my_n = my_r < n_regions ? counts[(size_t)(l * bpg + wave + my_r * nwaves) * maxo + local] : 0;
+            const int r_end = min(64, n_regions - r0);
+            uint4 rec[4], nxt[4];
+            {
+                const int n0 = __shfl(my_n, 0, 64);
+                const uint4* rg = reinterpret_cast<const uint4*>(reinterpret_cast<const uint2*>(regions_v) + ((size_t)(l * bpg + wave + r0 * nwaves) * maxo + local) * cap);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { const int i = i0 + 2 * (u * 64 + lane); rec[u] = r[i < n ? (i >> 1) : 0]; }
+                for (int u = 0; u < 4; ++u) { const int i = 2 * (u * 64 + lane); nxt[u] = rg[i < n0 ? (i >> 1) : 0]; }
+            }
+            for (int rr = 0; rr < r_end; ++rr) {
+                const int n = __shfl(my_n, rr, 64);
+                const size_t bb = (size_t)(l * bpg + wave + (r0 + rr) * nwaves);
+                const uint4* rg = reinterpret_cast<const uint4*>(reinterpret_cast<const uint2*>(regions_v) + (bb * maxo + local) * cap);   // cap is even
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = i0 + 2 * (u * 64 + lane);
-                    if (i < n) reduce_one<PAIR>(acc, make_uint2(rec[u].x, rec[u].y), base);
-                    if (i + 1 < n) reduce_one<PAIR>(acc, make_uint2(rec[u].z, rec[u].w), base);
+                for (int u = 0; u < 4; ++u) rec[u] = nxt[u];
+                if (rr + 1 < r_end) {
+                    const int n1 = __shfl(my_n, rr + 1, 64);
+                    const uint4* rg1 = reinterpret_cast<const uint4*>(reinterpret_cast<const uint2*>(regions_v) + ((bb + nwaves) * maxo + local) * cap);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const int i = 2 * (u * 64 + lane); nxt[u] = rg1[i < n1 ? (i >> 1) : 0]; }
+                }
+                for (int i0 = 0; i0 < n; i0 += 512) {
+                    if (i0 > 0) {     // long region: the rest is loaded on demand (out-of-range lanes re-read record 0 and ignore it)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { const int i = i0 + 2 * (u * 64 + lane); rec[u] = rg[i < n ? (i >> 1) : 0]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = i0 + 2 * (u * 64 + lane);
+                        if (debug & 4) { if (rec[u].x == 0xFFFFFFFFu && rec[u].z == 0xFFFFFFFFu) acc[0] = 1; continue; }    // timing experiment: loads only
+                        if (i < n) reduce_one<PAIR>(acc, make_uint2(rec[u].x, rec[u].y), base);
+                        if (i + 1 < n) reduce_one<PAIR>(acc, make_uint2(rec[u].z, rec[u].w), base);
+                    }
                 }
             }
         }
@@ -331,10 +354,10 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
         const int64_t n_table = spec->n_params - spec->n_mlp_params;
         if (spec->n_features >= 2)
             hipLaunchKernelGGL(table_grad_reduce2_kernel<1>, dim3(L.nown), dim3(1024), lds, st, *spec, regions, counts, L.bpg, L.maxo, cap_rec,
-                               L.shift, grad_table, n_table);
+                               L.shift, grad_table, n_table, debug);
         else
             hipLaunchKernelGGL(table_grad_reduce2_kernel<0>, dim3(L.nown), dim3(1024), lds, st, *spec, regions, counts, L.bpg, L.maxo, cap_rec,
-                               L.shift, grad_table, n_table);
+                               L.shift, grad_table, n_table, debug);
         LNR_CHECK_LAUNCH("lnr_density_backward(table reduce)");
     }
     const int n_mlp = spec->n_mlp_params;
