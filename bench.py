@@ -184,6 +184,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     timer.enabled = True
+    ops.profile_enable(True)
     t0 = time.perf_counter()
     opt._do_iterate_optimizer(my_window, [None], optimizer_settings=phase(args.steps))
     torch.cuda.synchronize()
@@ -201,6 +202,8 @@ def main():
     else:
         total_rays = float(n_valid[0])
 
+    kprof = ops.profile_read()                     # kernels inside lnr_density_forward / _backward, HIP events in the library
+    ops.profile_enable(False)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -222,30 +225,55 @@ def main():
     spec = opt._model.nerf_model._model_sigma.spec
     n_local = opt.last_stats["n_valid_rays"] / max(args.steps, 1)          # rays per launch on this rank
     pts = n_local * args.samples
-    # algorithmic work of the dominant kernel: fp32 MFMA flops of the density backward
+    F = int(spec.n_features)
+    n_rec = sum(1 for l in range(int(spec.n_levels)) if int(spec.level_size[l]) * F > 12288)      # levels of the record kernel
+    rec_table_floats = sum(int(spec.level_size[l]) * F for l in range(int(spec.n_levels)) if int(spec.level_size[l]) * F > 12288)
     h, ind, nh = spec.n_neurons, spec.in_dim, spec.n_hidden
     mac = h * ind + (nh - 1) * h * h
-    flops_bwd = pts * 2.0 * (3 * mac + h)         # recompute fwd + input grad + weight grad (+ output layer)
-    bytes_bwd = pts * 20.0 + n_local * 52.0 + float(spec.n_params) * 4.0 * 3.0
+    # Algorithmic work per launch:
+    #   encode_backward: d_feature planes in, d/dx planes out (poses train), z and the ray records once, the table gradient once
+    #   mlp_backward:    forward recompute + input gradient + weight gradient GEMMs of the fp32 MLP
+    alg = {
+        "encode_backward": {"bytes": pts * (n_rec * F * 4.0 + 4.0 + n_rec * 12.0) + n_local * 24.0 + rec_table_floats * 4.0},
+        "encode_forward": {"bytes": pts * (4.0 + int(spec.n_levels) * F * 4.0) + n_local * 24.0 + (float(spec.n_params) - spec.n_mlp_params) * 4.0},
+        "table_grad_reduce": {"bytes": rec_table_floats * 8.0},
+        "mlp_backward": {"flops": pts * 2.0 * (3 * mac + h), "bytes": pts * (3 * spec.enc_dim * 4.0 + 4.0)},
+        "mlp_forward": {"flops": pts * 2.0 * (mac + h), "bytes": pts * (spec.enc_dim * 4.0 + 4.0)},
+    }
+    traffic = {}
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf))
+        except Exception:
+            traffic = {}
+    kernels = {}
+    for name, v in kprof.items():
+        ent = {"avg_ms": round(v["avg_ms"], 4), "calls": v["calls"]}
+        a_ = alg.get(name)
+        if a_:
+            t = v["avg_ms"] * 1e-3
+            if "bytes" in a_:
+                ent["hbm_GBps"] = round(a_["bytes"] / t / 1e9, 1); ent["hbm_frac"] = round(a_["bytes"] / t / 8e12, 4)
+            if "flops" in a_:
+                ent["fp32_mfma_TFLOPs"] = round(a_["flops"] / t / 1e12, 2); ent["mfma_frac"] = round(a_["flops"] / t / 157.3e12, 4)
+        kernels[name] = ent
+    for name, v in ksum.items():
+        if name not in ("density_forward", "density_backward"):
+            kernels[name] = {"avg_ms": round(v["avg_ms"], 4), "calls": v["calls"]}
     roofline = None
-    if "density_backward" in ksum:
-        t = ksum["density_backward"]["avg_ms"] * 1e-3
-        ach = flops_bwd / t / 1e12
-        roofline = {"kernel": "density_backward (density_backward_kernel<4,true,true,2> + table_grad_reduce_kernel<1> + reduce_slabs_kernel)",
-                    "bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s",
-                    "frac": ach / 157.3, "traffic": None, "avg_launch_ms": ksum["density_backward"]["avg_ms"],
-                    "algorithmic_flops_per_launch": flops_bwd, "algorithmic_bytes_per_launch": bytes_bwd,
-                    "hbm_achieved_GBps": bytes_bwd / t / 1e9, "hbm_peak_GBps": 8000.0,
-                    "note": "peak = dense fp32 MFMA (v_mfma_f32_16x16x4_f32) rate from MI355X_MICROARCH.md.  The launch is bound by "
-                            "L2 line transactions of random 8-byte gathers / 16-byte record stores (DESIGN.md 4.3), neither by MFMA "
-                            "nor by streaming HBM bandwidth; `traffic` (PMC FETCH_SIZE/WRITE_SIZE, profiles/traffic.json) far above "
-                            "the algorithmic bytes is that line-granular over-fetch"}
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
-            try:
-                roofline["traffic"] = json.load(open(tf)).get("density_backward_bytes_per_launch")
-            except Exception:
-                pass
+    if kprof:
+        dom = max(kprof, key=lambda k: kprof[k]["total_ms"])
+        t = kprof[dom]["avg_ms"] * 1e-3
+        a_ = alg.get(dom, {"bytes": 0.0})
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": a_.get("bytes", 0.0) / t / 1e9, "peak": 8000.0, "unit": "GB/s",
+                    "frac": a_.get("bytes", 0.0) / t / 8e12, "traffic": traffic.get(dom + "_bytes_per_launch"),
+                    "avg_launch_ms": kprof[dom]["avg_ms"], "algorithmic_bytes_per_launch": a_.get("bytes", 0.0),
+                    "note": "dominant kernel by total time over the timed region, timed with HIP events recorded by the library on the "
+                            "launch stream (lnr_profile_*).  It moves few algorithmic bytes: its time goes to L1 line lookups of the "
+                            "random 8-byte table gathers, VALU work of the in-LDS radix partition and the 8-byte gradient records it "
+                            "streams to HBM (DESIGN.md 4.3); `traffic` = PMC FETCH_SIZE+WRITE_SIZE bytes per launch (profiles/traffic.json)",
+                    "secondary": {k: v for k, v in kernels.items() if k in ("mlp_backward", "mlp_forward", "encode_forward", "table_grad_reduce")}}
     line = {
         "metric": "training rays/sec", "value": total_rays / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True,
@@ -255,7 +283,8 @@ def main():
                                "synthetic 64x1024 scans (stand-in for Fusion Portable canteen, BASELINE configs[1])",
                    "keyframes": args.keyframes, "rays_per_keyframe": args.rays, "samples_per_ray": args.samples,
                    "parallelism": f"keyframe-sharded x{world}" if world > 1 else "single GPU"},
-        "roofline": roofline, "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in ksum.items()},
+        "roofline": roofline, "kernels_ms": {k: v["avg_ms"] for k, v in kernels.items()},
+        "ops_ms": {k: round(v["avg_ms"], 4) for k, v in ksum.items()},
         "final_loss": float(opt.last_stats["loss_terms"][-1, 0]),
         "l1_depth_m": l1_depth, "iterations_trained": args.warmup + args.steps,
     }

@@ -91,6 +91,13 @@ typedef struct LnrLossConfig {
 const char* lnr_last_error(void);          /* host; thread-local text for the last negative status */
 int  lnr_version(void);
 
+/* Optional per-kernel timing of the entry points that launch several kernels (density forward / backward): when
+ * enabled, HIP events are recorded on the caller's stream around each internal launch.  lnr_profile_read waits for the
+ * recorded events, returns the number of distinct kernels (names [n][name_stride] chars, summed milliseconds, calls)
+ * and clears the log.  Diagnostics only; off by default. */
+int lnr_profile_enable(int32_t on);
+int lnr_profile_read(char* names, int32_t name_stride, float* total_ms, int32_t* calls, int32_t capacity);
+
 /* ---- density network ------------------------------------------------------------------------- */
 int lnr_net_spec_finalize(LnrNetSpec* spec /*host, in/out*/);
 

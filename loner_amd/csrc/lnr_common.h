@@ -28,6 +28,15 @@ void lnr_set_error(const char* fmt, ...);
         }                                                                             \
     } while (0)
 
+// per-kernel timing hooks (lnr_core.hip); a scope records one HIP event before and one after the launches it encloses
+int lnr_profile_begin(const char* name, hipStream_t st);
+void lnr_profile_end(int span, hipStream_t st);
+struct LnrProfScope {
+    int span; hipStream_t st;
+    LnrProfScope(const char* name, hipStream_t s) : span(lnr_profile_begin(name, s)), st(s) {}
+    ~LnrProfScope() { lnr_profile_end(span, st); }
+};
+
 static inline int lnr_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // Separately rounded float multiply / add.  __fmul_rn/__fadd_rn inline to plain fmul/fadd, which the backend may

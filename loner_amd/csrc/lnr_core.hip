@@ -2,6 +2,10 @@
 #include <math.h>
 #include <stdarg.h>
 
+#include <mutex>
+#include <string>
+#include <vector>
+
 #include "lnr_common.h"
 
 static thread_local char g_err[512] = "";
@@ -14,6 +18,74 @@ void lnr_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* lnr_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------------
+// Optional per-kernel timing of the entry points that launch several kernels (lnr_density_forward / _backward):
+// HIP events recorded on the caller's stream around every internal launch.  Off by default (no events, no cost).
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct ProfSpan { int name; hipEvent_t start, stop; };
+std::mutex g_prof_mutex;
+bool g_prof_on = false;
+std::vector<std::string> g_prof_names;
+std::vector<ProfSpan> g_prof_spans;
+std::vector<hipEvent_t> g_prof_pool;
+
+hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+}  // namespace
+
+bool lnr_profile_active() { return g_prof_on; }
+
+int lnr_profile_begin(const char* name, hipStream_t st) {
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    if (!g_prof_on) return -1;
+    int id = -1;
+    for (size_t i = 0; i < g_prof_names.size(); ++i) if (g_prof_names[i] == name) { id = (int)i; break; }
+    if (id < 0) { g_prof_names.push_back(name); id = (int)g_prof_names.size() - 1; }
+    ProfSpan sp; sp.name = id; sp.start = prof_event(); sp.stop = prof_event();
+    if (!sp.start || !sp.stop) return -1;
+    hipEventRecord(sp.start, st);
+    g_prof_spans.push_back(sp);
+    return (int)g_prof_spans.size() - 1;
+}
+
+void lnr_profile_end(int span, hipStream_t st) {
+    if (span < 0) return;
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    if (span < (int)g_prof_spans.size()) hipEventRecord(g_prof_spans[span].stop, st);
+}
+
+extern "C" int lnr_profile_enable(int32_t on) {
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    g_prof_on = on != 0;
+    return LNR_OK;
+}
+
+extern "C" int lnr_profile_read(char* names, int32_t name_stride, float* total_ms, int32_t* calls, int32_t capacity) {
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    std::vector<double> ms(g_prof_names.size(), 0.0);
+    std::vector<int> n(g_prof_names.size(), 0);
+    for (const ProfSpan& sp : g_prof_spans) {
+        float t = 0.0f;
+        if (hipEventSynchronize(sp.stop) == hipSuccess && hipEventElapsedTime(&t, sp.start, sp.stop) == hipSuccess) { ms[sp.name] += t; n[sp.name]++; }
+        g_prof_pool.push_back(sp.start); g_prof_pool.push_back(sp.stop);
+    }
+    g_prof_spans.clear();
+    int out = 0;
+    for (size_t i = 0; i < g_prof_names.size() && out < capacity; ++i) {
+        if (n[i] == 0) continue;
+        if (names && name_stride > 0) { strncpy(names + (size_t)out * name_stride, g_prof_names[i].c_str(), name_stride - 1); names[(size_t)out * name_stride + name_stride - 1] = 0; }
+        if (total_ms) total_ms[out] = (float)ms[i];
+        if (calls) calls[out] = n[i];
+        ++out;
+    }
+    return out;
+}
 extern "C" int lnr_version(void) { return 100; }
 
 // Level geometry of the multiresolution grid, as published for tiny-cuda-nn's GridEncoding:

@@ -275,9 +275,13 @@ extern "C" int lnr_density_forward(const LnrNetSpec* spec, const float* params, 
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     float* feat = (float*)((char*)workspace + L.off_feat);
-    rc = lnr_encode_forward(spec, params, &src, cap, feat, L.m_pad, st);
+    {
+        LnrProfScope prof("encode_forward", st);
+        rc = lnr_encode_forward(spec, params, &src, cap, feat, L.m_pad, st);
+    }
     if (rc) return rc;
     LNR_CHECK_LAUNCH("lnr_density_forward(encode)");
+    LnrProfScope prof_mlp("mlp_forward", st);
     switch (spec->n_neurons / 16) {
         case 1: rc = lnr_mlp_fwd_ht1(spec, params, feat, L.m_pad, &mp, sigma, &plan, st); break;
         case 2: rc = lnr_mlp_fwd_ht2(spec, params, feat, L.m_pad, &mp, sigma, &plan, st); break;
@@ -325,17 +329,21 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     const int cap_rec = (debug & 32) ? 0 : L.cap;          // test hook: every record takes the global-atomic fallback path
 
     if (!reuse_features) {
+        LnrProfScope prof("encode_forward", st);
         rc = lnr_encode_forward(spec, params, &src, cap, feat, L.m_pad, st);
         if (rc) return rc;
         LNR_CHECK_LAUNCH("lnr_density_backward(encode)");
     }
     const int want_dfeat = (hash || d_pts != nullptr) ? 1 : 0;
+    {
+    LnrProfScope prof("mlp_backward", st);
     switch (spec->n_neurons / 16) {
         case 1: rc = lnr_mlp_bwd_ht1(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &plan, st); break;
         case 2: rc = lnr_mlp_bwd_ht2(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &plan, st); break;
         case 4: rc = lnr_mlp_bwd_ht4(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &plan, st); break;
         case 8: rc = lnr_mlp_bwd_ht8(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &plan, st); break;
         default: rc = lnr_mlp_bwd_ht16(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &plan, st); break;
+    }
     }
     if (rc) return rc;
     LNR_CHECK_LAUNCH("lnr_density_backward(mlp)");
@@ -352,6 +360,7 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
         hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(table_grad_reduce2_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e0 != hipSuccess || e1 != hipSuccess) { lnr_set_error("lnr_density_backward: hipFuncSetAttribute failed"); return LNR_ERR_LAUNCH; }
         const int64_t n_table = spec->n_params - spec->n_mlp_params;
+        LnrProfScope prof("table_grad_reduce", st);
         if (spec->n_features >= 2)
             hipLaunchKernelGGL(table_grad_reduce2_kernel<1>, dim3(L.nown), dim3(1024), lds, st, *spec, regions, counts, L.bpg, L.maxo, cap_rec,
                                L.shift, grad_table, n_table, debug);
@@ -361,6 +370,7 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
         LNR_CHECK_LAUNCH("lnr_density_backward(table reduce)");
     }
     const int n_mlp = spec->n_mlp_params;
+    LnrProfScope prof_slabs("reduce_slabs", st);
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(lnr_div_up(n_mlp, 256), LNR_SLAB_GROUPS), dim3(256), 0, st, slabs, plan.grid, n_mlp, grad_params);
     LNR_CHECK_LAUNCH("lnr_density_backward(reduce)");
     return LNR_OK;

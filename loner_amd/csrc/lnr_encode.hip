@@ -522,6 +522,7 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
             sink.grad_table = grad_table; sink.regions = regions; sink.counts = counts; sink.maxo = maxo; sink.cap = cap; sink.shift = shift;
             sink.combine_scale_max = LNR_COMBINE_SCALE_MAX; sink.debug = debug;
             const dim3 grid((unsigned)(rec_levels.n * bpg));
+            LnrProfScope prof("encode_backward", st);
             const int maxo4 = (maxo + 3) & ~3;
             const size_t lds = (size_t)(2 * maxo4 + 4 * maxo) * sizeof(int) + (size_t)ENC_STAGE_RECORDS * (spec->n_features >= 2 ? 16 : 8);
 #define LNR_EB(F)                                                                                                             \
@@ -546,6 +547,7 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
         }
         if (dense_levels.n > 0) {
             const dim3 grid((unsigned)(dense_levels.n * bpg));
+            LnrProfScope prof("encode_backward_dense", st);
             const size_t lds = (size_t)dense_max * sizeof(long long);
 #define LNR_ED(F)                                                                                                             \
             do {                                                                                                              \
@@ -577,6 +579,7 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
     if (d_pts) {
         int64_t blocks = (cap_points + ENC_BLOCK - 1) / ENC_BLOCK;
         if (blocks > 4096) blocks = 4096;
+        LnrProfScope prof("sum_dx_planes", st);
         hipLaunchKernelGGL(sum_dx_planes_kernel, dim3((unsigned)blocks), dim3(ENC_BLOCK), 0, st, dxl, n_groups, m_pad, *src, d_pts);
     }
     return LNR_OK;

@@ -47,6 +47,8 @@ P = C.c_void_p
 _SIGNATURES = {
     "lnr_last_error": (C.c_char_p, []),
     "lnr_version": (C.c_int, []),
+    "lnr_profile_enable": (C.c_int, [C.c_int32]),
+    "lnr_profile_read": (C.c_int, [P, C.c_int32, P, P, C.c_int32]),
     "lnr_net_spec_finalize": (C.c_int, [C.POINTER(NetSpec)]),
     "lnr_density_workspace": (C.c_size_t, [C.POINTER(NetSpec), C.c_int64]),
     "lnr_density_forward": (C.c_int, [C.POINTER(NetSpec), P, P, C.c_int64, P, P, C.c_int32, C.c_int32, P, P, P, C.c_size_t, P]),

@@ -32,6 +32,26 @@ def _f32c(t):
     return t.contiguous()
 
 
+# ---------------------------------------------------------------- diagnostics
+def profile_enable(on=True):
+    """Per-kernel HIP-event timing inside lnr_density_forward / lnr_density_backward (off by default)."""
+    check(load().lnr_profile_enable(1 if on else 0), "lnr_profile_enable")
+
+
+def profile_read():
+    """-> {kernel: {"calls": n, "total_ms": t, "avg_ms": t / n}}; waits for the recorded events and clears the log."""
+    cap, stride = 64, 48
+    names = C.create_string_buffer(cap * stride)
+    ms = (C.c_float * cap)()
+    calls = (C.c_int32 * cap)()
+    n = load().lnr_profile_read(names, stride, ms, calls, cap)
+    out = {}
+    for i in range(max(n, 0)):
+        name = names.raw[i * stride:(i + 1) * stride].split(b"\0", 1)[0].decode()
+        out[name] = {"calls": int(calls[i]), "total_ms": float(ms[i]), "avg_ms": float(ms[i]) / max(int(calls[i]), 1)}
+    return out
+
+
 # ---------------------------------------------------------------- density network
 _workspaces = {}
 
