@@ -9,7 +9,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define LNR_ENC_BWD_MAX_BPG 512
+#define LNR_ENC_BWD_MAX_BPG 2048
 
 // grad[i] += sum over workgroup slabs; blockIdx.y splits the slabs so that a few thousand threads (not n_mlp) share the reads
 #define LNR_SLAB_GROUPS 16
@@ -30,7 +30,7 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs
 }
 
 // Workgroup `o` owns floats [o << shift, (o+1) << shift) of the table gradient.  The encode-backward workgroups of
-// level l (blocks [l*bpg, (l+1)*bpg)) wrote the records addressed to it into region [block][o - first_owner(l)];
+// level l (bpg of them) wrote the records addressed to it into regions [l][o - first_owner(l)][chunk];
 // it streams them (4 x 16-byte loads = 8 records in flight per lane), sums them in LDS in 64-bit fixed point (LDS
 // float atomics run at < 1 lane/clk/CU on CDNA4, integer ones ~16x faster; 2^-42 resolution, exact and
 // order-independent) and adds the slice to grad_table with coalesced read-modify-writes (it is the only writer of
@@ -66,45 +66,53 @@ table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ region
         if (hi - lo <= (uint64_t)LNR_DENSE_LEVEL_FLOATS) continue;          // dense level: arrives through the slabs
         const int local = o - (int)(lo >> shift);
         if (local < 0 || local >= maxo) continue;
-        // This wave's regions of the level: b = l*bpg + wave + r*nwaves.  Their record counts are fetched with one load
-        // (lane r holds region r's count), and the first 512 records of region r+1 are loaded before region r is summed:
-        // per region the wave would otherwise sit through two dependent HBM round trips for ~4 KB of data.
-        const int n_regions = (bpg - wave + nwaves - 1) / nwaves;
+        // The regions of (level, owner) lie back to back, one per encode-backward workgroup (chunk); a wave takes a
+        // contiguous run of them.  Their record counts are fetched with one load (lane r holds region r's count) and cut
+        // into pieces of 128 records (= one 16-byte load per lane); the wave walks the flattened piece list four pieces per
+        // step and loads the next four before it sums the current ones, so the many short regions (one encode-backward
+        // batch appends ~30 records per owner) never serialise on HBM latency.
+        const int per_wave = (bpg + nwaves - 1) / nwaves;
+        const int first = wave * per_wave;
+        const int n_regions = min(per_wave, bpg - first);
+        const size_t owner_regions = ((size_t)l * maxo + local) * bpg + first;
+        const uint2* level_regions = reinterpret_cast<const uint2*>(regions_v) + owner_regions * cap;
+        const size_t region_stride = (size_t)cap;                          // records between consecutive regions of this wave
         for (int r0 = 0; r0 < n_regions; r0 += 64) {
             const int my_r = r0 + lane;
-            const int my_n = my_r < n_regions ? counts[(size_t)(l * bpg + wave + my_r * nwaves) * maxo + local] : 0;
-            const int r_end = min(64, n_regions - r0);
+            const int my_n = my_r < n_regions ? counts[owner_regions + my_r] : 0;
+            const int my_chunks = (my_n + 127) >> 7;
+            int incl = my_chunks;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+            const int excl = incl - my_chunks;
+            const int total = __shfl(incl, 63, 64);
+            if (total == 0) continue;
             uint4 rec[4], nxt[4];
-            {
-                const int n0 = __shfl(my_n, 0, 64);
-                const uint4* rg = reinterpret_cast<const uint4*>(reinterpret_cast<const uint2*>(regions_v) + ((size_t)(l * bpg + wave + r0 * nwaves) * maxo + local) * cap);
+            int rem[4], nrem[4];                      // records of the chunk (<= 128), wave-uniform
+            auto load4 = [&](int c0, uint4 out[4], int left[4]) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { const int i = 2 * (u * 64 + lane); nxt[u] = rg[i < n0 ? (i >> 1) : 0]; }
-            }
-            for (int rr = 0; rr < r_end; ++rr) {
-                const int n = __shfl(my_n, rr, 64);
-                const size_t bb = (size_t)(l * bpg + wave + (r0 + rr) * nwaves);
-                const uint4* rg = reinterpret_cast<const uint4*>(reinterpret_cast<const uint2*>(regions_v) + (bb * maxo + local) * cap);   // cap is even
-#pragma unroll
-                for (int u = 0; u < 4; ++u) rec[u] = nxt[u];
-                if (rr + 1 < r_end) {
-                    const int n1 = __shfl(my_n, rr + 1, 64);
-                    const uint4* rg1 = reinterpret_cast<const uint4*>(reinterpret_cast<const uint2*>(regions_v) + ((bb + nwaves) * maxo + local) * cap);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { const int i = 2 * (u * 64 + lane); nxt[u] = rg1[i < n1 ? (i >> 1) : 0]; }
+                for (int u = 0; u < 4; ++u) {
+                    const int c = c0 + u < total ? c0 + u : total - 1;                       // clamp: unconditional loads
+                    // the region holding chunk c = the last lane with chunks whose first chunk is at or before c
+                    const unsigned long long starts = __ballot(excl <= c && my_chunks > 0);
+                    const int qq = __builtin_amdgcn_readfirstlane(starts ? 63 - __clzll((long long)starts) : 0);
+                    const int off = (c - __shfl(excl, qq, 64)) << 7;
+                    const int n = __shfl(my_n, qq, 64) - off;
+                    left[u] = c0 + u < total ? (n < 128 ? n : 128) : 0;
+                    const uint4* rg = reinterpret_cast<const uint4*>(level_regions + (size_t)(r0 + qq) * region_stride + off);   // cap is even
+                    out[u] = rg[2 * lane < left[u] ? lane : 0];
                 }
-                for (int i0 = 0; i0 < n; i0 += 512) {
-                    if (i0 > 0) {     // long region: the rest is loaded on demand (out-of-range lanes re-read record 0 and ignore it)
+            };
+            load4(0, nxt, nrem);
+            for (int c0 = 0; c0 < total; c0 += 4) {
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) { const int i = i0 + 2 * (u * 64 + lane); rec[u] = rg[i < n ? (i >> 1) : 0]; }
-                    }
+                for (int u = 0; u < 4; ++u) { rec[u] = nxt[u]; rem[u] = nrem[u]; }
+                if (c0 + 4 < total) load4(c0 + 4, nxt, nrem);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int i = i0 + 2 * (u * 64 + lane);
-                        if (debug & 4) { if (rec[u].x == 0xFFFFFFFFu && rec[u].z == 0xFFFFFFFFu) acc[0] = 1; continue; }    // timing experiment: loads only
-                        if (i < n) reduce_one<PAIR>(acc, make_uint2(rec[u].x, rec[u].y), base);
-                        if (i + 1 < n) reduce_one<PAIR>(acc, make_uint2(rec[u].z, rec[u].w), base);
-                    }
+                for (int u = 0; u < 4; ++u) {
+                    if (debug & 4) { if (rec[u].x == 0xFFFFFFFFu && rec[u].z == 0xFFFFFFFFu) acc[0] = 1; continue; }    // timing experiment: loads only
+                    if (2 * lane < rem[u]) reduce_one<PAIR>(acc, make_uint2(rec[u].x, rec[u].y), base);
+                    if (2 * lane + 1 < rem[u]) reduce_one<PAIR>(acc, make_uint2(rec[u].z, rec[u].w), base);
                 }
             }
         }
@@ -142,7 +150,7 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
     const int64_t n_table = spec->n_params - spec->n_mlp_params;
     L.nown = (int)((n_table + (1 << L.shift) - 1) >> L.shift);
     L.rec_bytes = 8;
-    int64_t bpg = (n_points + 256 * 16 - 1) / (256 * 16);      // ~16 batches of 256 samples per encode-backward workgroup
+    int64_t bpg = (n_points + 256 * 4 - 1) / (256 * 4);        // ~4 batches of 256 samples per encode-backward workgroup
     if (bpg < 1) bpg = 1;
     if (bpg > LNR_ENC_BWD_MAX_BPG) bpg = LNR_ENC_BWD_MAX_BPG;
     L.bpg = (int)bpg;
@@ -173,7 +181,7 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
     L.off_dfeat = off; off += align256((size_t)spec->enc_dim * L.m_pad * sizeof(float));
     L.off_dxl = off; off += align256((size_t)L.n_groups * 3 * L.m_pad * sizeof(float));
     L.off_slabs = off; off += align256((size_t)LNR_BWD_MAX_BLOCKS * spec->n_mlp_params * sizeof(float));
-    L.off_dense = off; off += align256(dense_total * (size_t)L.bpg * sizeof(float));
+    L.off_dense = off; off += align256(dense_total * (size_t)lnr_dense_bpg(L.bpg) * sizeof(float));
     L.off_counts = off; off += align256(hash ? (size_t)blocks * L.maxo * sizeof(int) : 0);
     L.off_regions = off; off += hash ? (size_t)blocks * L.maxo * (size_t)L.cap * L.rec_bytes : 0;
     L.total = off;

@@ -81,6 +81,8 @@ struct LevelList {
     int lv[LNR_MAX_LEVELS];
     int slab_off[LNR_MAX_LEVELS];   // dense levels: float offset inside one workgroup's slab
 };
+// workgroups per dense level: each pays for zeroing and writing out an LDS copy of the level, so fewer than for the record levels
+static inline int lnr_dense_bpg(int bpg) { return bpg < 512 ? bpg : 512; }
 static inline bool lnr_level_is_dense(const LnrNetSpec* s, int l) {
     return (uint64_t)s->level_size[l] * (uint64_t)s->n_features <= (uint64_t)LNR_DENSE_LEVEL_FLOATS;
 }

@@ -99,8 +99,8 @@ freq_forward_kernel(const LnrNetSpec spec, const PointSrc src, float* __restrict
 // table_grad_reduce2_kernel (lnr_density.hip) sums each owner's regions in LDS.
 struct EncSink {
     float* grad_table;      // fallback target for records beyond a region's capacity
-    void* regions;          // [level][chunk][maxo][cap] 8-byte records (lnr_density_api.h)
-    int* counts;            // [level][chunk][maxo]
+    void* regions;          // [level][maxo][chunk][cap] 8-byte records (lnr_density_api.h)
+    int* counts;            // [level][maxo][chunk]
     int maxo, cap, shift;
     float combine_scale_max;
     int debug;
@@ -191,14 +191,16 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
     const uint32_t M = (uint32_t)live_points(src);
     const int first_owner = (int)(((uint64_t)L.offset * F) >> sink.shift);
     const bool combine = L.scale < sink.combine_scale_max && !(sink.debug & 16);
-    const size_t region0 = ((size_t)lv * bpg + chunk) * maxo;
+    // region of (level, owner o, chunk): [level][owner][chunk] - the reduce of one owner streams its chunks' regions back to back
+    const size_t region0 = (size_t)lv * maxo * bpg + chunk;
+    const size_t region_step = (size_t)bpg;          // between consecutive owners
     const uint32_t step = (uint32_t)bpg * ENC_BLOCK;
     const uint32_t n_iter = (M + step - 1u) / step;          // workgroup-uniform trip count (the loop body has barriers)
     const float* gplanes = dfeat + (size_t)(lv * F) * m_pad;
     float* dxplanes = dxl + (size_t)(lv * 3) * m_pad;
     const uint32_t plane_bytes = (uint32_t)m_pad * 4u;
     if (M == 0u) {                                            // workgroup-uniform
-        for (int i = threadIdx.x; i < maxo; i += ENC_BLOCK) sink.counts[region0 + i] = 0;
+        for (int i = threadIdx.x; i < maxo; i += ENC_BLOCK) sink.counts[region0 + i * region_step] = 0;
         return;
     }
 
@@ -285,7 +287,7 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
                     for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
                     if (o < maxo) {
                         const int have = gcur[o];
-                        const uint64_t p = reinterpret_cast<uint64_t>(sink.regions) + ((region0 + o) * (size_t)sink.cap + (size_t)have) * 8u;
+                        const uint64_t p = reinterpret_cast<uint64_t>(sink.regions) + ((region0 + o * region_step) * (size_t)sink.cap + (size_t)have) * 8u;
                         OwnerSlot os;
                         os.ptr_lo = (uint32_t)p; os.ptr_hi = (uint32_t)(p >> 32);
                         os.scan = running + incl - n;
@@ -347,7 +349,7 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
     }
     __syncthreads();
     for (int i = threadIdx.x; i < maxo; i += ENC_BLOCK)
-        sink.counts[region0 + i] = gcur[i] < sink.cap ? gcur[i] : sink.cap;
+        sink.counts[region0 + i * region_step] = gcur[i] < sink.cap ? gcur[i] : sink.cap;
 }
 
 // Dense levels (lnr_density_api.h): the workgroup sums its samples' corner updates in an LDS copy of the level's
@@ -546,7 +548,8 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
 #undef LNR_EB
         }
         if (dense_levels.n > 0) {
-            const dim3 grid((unsigned)(dense_levels.n * bpg));
+            const int dbpg = lnr_dense_bpg(bpg);
+            const dim3 grid((unsigned)(dense_levels.n * dbpg));
             LnrProfScope prof("encode_backward_dense", st);
             const size_t lds = (size_t)dense_max * sizeof(long long);
 #define LNR_ED(F)                                                                                                             \
@@ -554,10 +557,10 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
                 hipError_t e_;                                                                                                \
                 if (d_pts) {                                                                                                  \
                     e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(encode_backward_dense_kernel<F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                    if (e_ == hipSuccess) hipLaunchKernelGGL((encode_backward_dense_kernel<F, true>), grid, block, lds, st, *spec, table, *src, dfeat, dxl, m_pad, bpg, dense_levels, dense_slabs, dense_total, debug); \
+                    if (e_ == hipSuccess) hipLaunchKernelGGL((encode_backward_dense_kernel<F, true>), grid, block, lds, st, *spec, table, *src, dfeat, dxl, m_pad, dbpg, dense_levels, dense_slabs, dense_total, debug); \
                 } else {                                                                                                      \
                     e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(encode_backward_dense_kernel<F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                    if (e_ == hipSuccess) hipLaunchKernelGGL((encode_backward_dense_kernel<F, false>), grid, block, lds, st, *spec, table, *src, dfeat, dxl, m_pad, bpg, dense_levels, dense_slabs, dense_total, debug); \
+                    if (e_ == hipSuccess) hipLaunchKernelGGL((encode_backward_dense_kernel<F, false>), grid, block, lds, st, *spec, table, *src, dfeat, dxl, m_pad, dbpg, dense_levels, dense_slabs, dense_total, debug); \
                 }                                                                                                             \
                 if (e_ != hipSuccess) { lnr_set_error("lnr_density_backward: hipFuncSetAttribute(%zu) failed", lds); return LNR_ERR_LAUNCH; } \
             } while (0)
@@ -569,7 +572,7 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
             }
 #undef LNR_ED
             hipLaunchKernelGGL(dense_slab_reduce_kernel, dim3((unsigned)((dense_max + ENC_BLOCK - 1) / ENC_BLOCK), (unsigned)dense_levels.n), block, 0, st,
-                               *spec, dense_levels, dense_slabs, bpg, dense_total, grad_table);
+                               *spec, dense_levels, dense_slabs, dbpg, dense_total, grad_table);
         }
     } else if (d_pts) {
         int64_t blocks = (cap_points + ENC_BLOCK - 1) / ENC_BLOCK;
