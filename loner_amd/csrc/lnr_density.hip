@@ -267,12 +267,14 @@ extern "C" int lnr_density_forward(const LnrNetSpec* spec, const float* params, 
                                    const int32_t* n_rays_dev, float* sigma, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_spec(spec, "lnr_density_forward");
     if (rc) return rc;
-    LNR_REQUIRE(params && sigma && workspace, "lnr_density_forward: null params/sigma/workspace");
+    if (n_points == 0 && (pts != nullptr || n_rays == 0)) return LNR_OK;          // empty batch: nothing to do, nothing to check
     PointSrc src; MlpPoints mp;
     rc = make_src(&src, &mp, pts, n_points, rays, z, n_rays, n_samples, n_rays_dev, "lnr_density_forward");
     if (rc) return rc;
     const int64_t cap = mp.n_points;
     if (cap == 0) return LNR_OK;
+    LNR_REQUIRE(params && sigma && workspace, "lnr_density_forward: null params/sigma/workspace");
+    LNR_REQUIRE(cap < (1ll << 28), "lnr_density_forward: more than 2^28 points per call (32-bit sample offsets)");
     const Layout L = make_layout(spec, cap);
     if (workspace_bytes < L.total) {
         lnr_set_error("lnr_density_forward: workspace %zu < %zu (lnr_density_workspace)", workspace_bytes, L.total);
@@ -308,12 +310,14 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
                                     int32_t reuse_features, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_spec(spec, "lnr_density_backward");
     if (rc) return rc;
-    LNR_REQUIRE(params && d_sigma && grad_params && workspace, "lnr_density_backward: null argument");
+    if (n_points == 0 && (pts != nullptr || n_rays == 0)) return LNR_OK;          // empty batch: nothing to do, nothing to check
     PointSrc src; MlpPoints mp;
     rc = make_src(&src, &mp, pts, n_points, rays, z, n_rays, n_samples, n_rays_dev, "lnr_density_backward");
     if (rc) return rc;
     const int64_t cap = mp.n_points;
     if (cap == 0) return LNR_OK;
+    LNR_REQUIRE(params && d_sigma && grad_params && workspace, "lnr_density_backward: null argument");
+    LNR_REQUIRE(cap < (1ll << 28), "lnr_density_backward: more than 2^28 points per call (32-bit sample offsets)");
     const Layout L = make_layout(spec, cap);
     if (workspace_bytes < L.total) {
         lnr_set_error("lnr_density_backward: workspace %zu < %zu (lnr_density_workspace)", workspace_bytes, L.total);

@@ -248,6 +248,64 @@ def test_density_rays_form_equals_points_form(ops, golden):
     assert rel(s1, s2) < 1e-5
 
 
+@pytest.mark.parametrize("name", ["small_hash", "hash_f1", "freq_siren"])
+@pytest.mark.parametrize("n", [1, 15, 17, 255, 257, 1000])
+def test_density_ragged_point_counts(ops, name, n):
+    """Tile (16), wave (64) and workgroup (256) boundaries of the level-major pipeline: forward, gradients, and the
+    feature planes kept by the forward (reuse_features) against a fresh backward."""
+    spec_o, spec_h, params = _net(name, seed=5, table_gain=3000.0)
+    gen = torch.Generator().manual_seed(100 + n)
+    pts = torch.rand(n, 3, generator=gen) * 1.9 - 0.95
+    d_sigma = torch.randn(n, generator=gen)
+    p_dev, x_dev = dv(params), dv(pts)
+    sig = ops.density_forward(spec_h, p_dev, pts=x_dev)
+    grad = torch.zeros(int(spec_h.n_params), device=DEV)
+    d_pts = ops.density_backward(spec_h, p_dev, dv(d_sigma), grad, pts=x_dev, want_d_pts=True, reuse_features=True)
+    p32 = params.clone().requires_grad_(True)
+    x32 = pts.clone().requires_grad_(True)
+    out = NW.density(spec_o, p32, x32)
+    (out * d_sigma).sum().backward()
+    assert rel(sig, out.detach()) < 1e-5
+    assert rel(grad, p32.grad) < 2e-5 and rel(d_pts, x32.grad) < 2e-4
+    grad2 = torch.zeros_like(grad)
+    ops.density_forward(spec_h, p_dev, pts=dv(torch.zeros(max(n // 2, 1), 3)))          # clobber the kept feature planes
+    d_pts2 = ops.density_backward(spec_h, p_dev, dv(d_sigma), grad2, pts=x_dev, want_d_pts=True, reuse_features=False)
+    assert rel(grad2, grad) < 1e-6 and rel(d_pts2, d_pts) < 1e-6
+    with pytest.raises(RuntimeError):                                                     # stale planes are refused, not used
+        ops.density_backward(spec_h, p_dev, dv(d_sigma), grad2, pts=x_dev, reuse_features=True)
+
+
+def test_density_dead_rays_and_empty_batches(ops, golden):
+    """n_rays_dev < n_rays (rays dropped by the cube clip without a host sync): live rows equal a call on the live rows
+    only, dead rows are never touched; zero live rays and zero points are no-ops."""
+    g = golden("g4_samplers")
+    spec_o, spec_h, params = _net("default", seed=3, table_gain=3000.0)
+    rays, z = dv(g["rays"]), dv(g["zero_z128"])
+    n, S = z.shape
+    live = n // 3
+    p_dev = dv(params)
+    gen = torch.Generator().manual_seed(9)
+    d_sigma = dv(torch.randn(n, S, generator=gen))
+    n_dev = torch.tensor([live], dtype=torch.int32, device=DEV)
+    sig = torch.full((n, S), 7.0, device=DEV)
+    sig_live = ops.density_forward(spec_h, p_dev, rays=rays, z=z, n_rays_dev=n_dev)
+    ref = ops.density_forward(spec_h, p_dev, rays=rays[:live].contiguous(), z=z[:live].contiguous())
+    assert torch.equal(sig_live[:live], ref)
+    g1 = torch.zeros(int(spec_h.n_params), device=DEV); g2 = torch.zeros_like(g1)
+    d1 = ops.density_backward(spec_h, p_dev, d_sigma, g1, rays=rays, z=z, n_rays_dev=n_dev, want_d_pts=True)
+    d2 = ops.density_backward(spec_h, p_dev, d_sigma[:live].contiguous(), g2, rays=rays[:live].contiguous(), z=z[:live].contiguous(),
+                              want_d_pts=True)
+    assert rel(g1, g2) < 1e-6 and rel(d1[:live], d2) < 1e-6
+    # nothing alive / nothing to do
+    zero = torch.zeros(1, dtype=torch.int32, device=DEV)
+    g3 = torch.zeros_like(g1)
+    ops.density_forward(spec_h, p_dev, rays=rays, z=z, n_rays_dev=zero)
+    ops.density_backward(spec_h, p_dev, d_sigma, g3, rays=rays, z=z, n_rays_dev=zero, want_d_pts=True)
+    assert float(g3.abs().max()) == 0.0
+    assert ops.density_forward(spec_h, p_dev, pts=torch.zeros(0, 3, device=DEV)).numel() == 0
+    del sig
+
+
 # ------------------------------------------------------------------------------------------- rendering
 def test_render_forward_backward_matches_golden(ops, golden):
     g = golden("g5_render")
