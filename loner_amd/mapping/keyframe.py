@@ -49,6 +49,8 @@ class KeyFrame:
     def get_pose_state(self) -> dict:
         return {
             "timestamp": torch.as_tensor(self.get_time()).detach().cpu().clone(),
+            "lidar_to_camera": (self._frame._lidar_to_camera.get_pose_tensor().detach().cpu().clone()
+                                if self._frame._lidar_to_camera is not None else None),
             "lidar_pose": self._frame.get_lidar_pose().get_pose_tensor().detach().cpu().clone(),
             "gt_lidar_pose": (self._frame._gt_lidar_pose.get_pose_tensor().detach().cpu().clone()
                               if self._frame._gt_lidar_pose is not None else None),

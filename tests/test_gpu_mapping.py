@@ -260,6 +260,57 @@ def test_training_reduces_l1_depth_matched_quality_gate():
     assert after < 0.5 * before and after < 2.0
 
 
+def test_checkpoint_round_trip_as_the_mapper_writes_it(tmp_path):
+    """On-disk contract either side of the path: the reference's Mapper.build_ckpt (mapper.py:161-175)
+    reads _model / _optimizer / _occupancy_grid_model / _occupancy_grid_optimizer / _global_step off the Optimizer and
+    torch.save()s them; its analysis scripts (compute_l1_depth.py:140-155, renderer_lidar.py:170-182) rebuild Model and
+    OccupancyGridModel from the config and load_state_dict() the two model entries.  Same steps here, then the restored
+    map must render exactly what the trained one renders."""
+    from loner_amd.analysis.l1_depth import compute_l1_depth
+    from loner_amd.common.ray_utils import LidarRayDirections
+    from loner_amd.mapping.optimizer import OptimizationSettings, Optimizer
+    from loner_amd.models.model_tcnn import Model, OccupancyGridModel
+    from loner_amd.models.ray_sampling import OccGridRaySampler
+    from loner_amd.utils import synthetic as SY
+    s = small_settings(128, 64)
+    torch.manual_seed(0)
+    wc = world_cube()
+    opt = Optimizer(s, None, wc, 0, False, True, False)
+    kfs = make_keyframes(list(SY.trajectory_pose6(2)))
+    opt._do_iterate_optimizer(kfs, [None], optimizer_settings=OptimizationSettings(25, False, False, False, True))
+    ckpt = {"global_step": opt._global_step,
+            "network_state_dict": opt._model.state_dict(),
+            "optimizer_state_dict": opt._optimizer.state_dict(),
+            "poses": [kf.get_pose_state() for kf in kfs],
+            "occ_model_state_dict": opt._occupancy_grid_model.state_dict(),
+            "occ_optimizer_state_dict": opt._occupancy_grid_optimizer.state_dict()}
+    path = tmp_path / "final.tar"
+    torch.save(ckpt, str(path))
+    back = torch.load(str(path), map_location="cpu", weights_only=False)
+    assert back["global_step"] == 25 and len(back["poses"]) == 2
+    assert set(back["poses"][0]) == {"timestamp", "lidar_to_camera", "lidar_pose", "gt_lidar_pose", "tracked_pose"}
+    assert set(back["network_state_dict"]) >= {"nerf_model._model_sigma.params", "nerf_model._pos_encoding.params",
+                                               "nerf_model._dir_encoding.params", "nerf_model._model_intensity.params"}
+    assert set(back["occ_model_state_dict"]) == {"occupancy_grid"}
+    st = back["optimizer_state_dict"]
+    assert set(st) == {"state", "param_groups"} and st["state"][0]["exp_avg"].shape == opt._model.nerf_model._model_sigma.params.shape
+    # the consumer side, as compute_l1_depth.py does it
+    mc = opt._model_config.model
+    model = Model(mc).to(DEV)
+    occ = OccupancyGridModel(mc.occ_model).to(DEV)
+    model.load_state_dict(back["network_state_dict"])
+    occ.load_state_dict(back["occ_model_state_dict"])
+    sampler = OccGridRaySampler()
+    sampler.update_occ_grid(occ().detach())
+    rr = torch.tensor([1.0, 50.0])
+    lrd = LidarRayDirections(kfs[0].get_lidar_scan(), chunk_size=1024)
+    torch.manual_seed(123)            # the importance samples are random even at test time (ray_sampling.py:86, det=False)
+    a = compute_l1_depth(kfs[0].get_lidar_pose(), lrd, opt._model, opt._ray_sampler, wc, rr, DEV, max_rays=1024)
+    torch.manual_seed(123)
+    b = compute_l1_depth(kfs[0].get_lidar_pose(), lrd, model, sampler, wc, rr, DEV, max_rays=1024)
+    assert a == b and np.isfinite(a)
+
+
 def test_sky_rays_tracking_phase_and_uniform_sampler():
     """The schedule variants around the default path: sky rays (keyframe.py:91-100), the pose-refinement phase
     (latest_kf_only + frozen density net, optimizer.py:239-259) and the UNIFORM sampler / FIXED ray selection."""
