@@ -283,7 +283,13 @@ def main():
                                "synthetic 64x1024 scans (stand-in for Fusion Portable canteen, BASELINE configs[1])",
                    "keyframes": args.keyframes, "rays_per_keyframe": args.rays, "samples_per_ray": args.samples,
                    "parallelism": f"keyframe-sharded x{world}" if world > 1 else "single GPU"},
-        "roofline": roofline, "kernels_ms": {k: v["avg_ms"] for k, v in kernels.items()},
+        "roofline": roofline,
+        # whole-path HBM roofline of SURVEY 8d: B_ray = 72 B (ray record, gt depth, per-ray outputs) + dense Adam traffic
+        # (28 B per parameter: read p,g,m,v, write p,m,v) amortised over the rays of an iteration
+        "path_hbm_roofline": (lambda b: {"algorithmic_bytes_per_ray": b, "rays_per_s_at_8TBps": 8e12 / b * world,
+                                         "frac": (total_rays / elapsed) / (8e12 / b * world)})(
+            72.0 + 28.0 * float(spec.n_params) / max(total_rays / max(args.steps, 1) / world, 1.0)),
+        "kernels_ms": {k: v["avg_ms"] for k, v in kernels.items()},
         "ops_ms": {k: round(v["avg_ms"], 4) for k, v in ksum.items()},
         "final_loss": float(opt.last_stats["loss_terms"][-1, 0]),
         "l1_depth_m": l1_depth, "iterations_trained": args.warmup + args.steps,
