@@ -104,7 +104,7 @@ int lnr_net_spec_finalize(LnrNetSpec* spec /*host, in/out*/);
 /* Scratch both density calls need, sized for up to n_points points per call: feature planes [enc_dim][n_points],
  * their gradient, per-level d/dx planes, per-workgroup weight-gradient slabs and the record regions of the
  * table-gradient partition.  The content between calls only matters for `reuse_features` below.
- * Limits: n_points < 2^28 per call, encoding table < 2^30 floats (the kernels use 32-bit byte offsets). */
+ * Limits: n_points * max(n_features_per_level, 4) < 2^30 per call, encoding table < 2^30 floats (32-bit byte offsets). */
 size_t lnr_density_workspace(const LnrNetSpec* spec /*host*/, int64_t n_points);
 
 /* sigma = MLP(enc((xyz+1)/2))[0]           replaces tinycudann forward at nerf_tcnn.py:63-72

@@ -212,7 +212,9 @@ static size_t bwd_lds(const LnrNetSpec* s, int w_lds, int waves) {
 // of a CDNA4 CU.
 static int plan_launch(const LnrNetSpec* spec, int64_t n_points, bool backward, DensityPlan* plan, const char* who) {
     const int64_t tiles = (n_points + 15) / 16;
-    if (spec->activation == LNR_ACT_RELU && spec->n_hidden == 1 && spec->in_dim == 32 && spec->enc_dim == 32 && spec->n_neurons <= 64) {
+    // (the register-resident kernels address the planes with 32-bit byte offsets up to 17 planes: n_points <= 2^25)
+    if (spec->activation == LNR_ACT_RELU && spec->n_hidden == 1 && spec->in_dim == 32 && spec->enc_dim == 32 && spec->n_neurons <= 64 &&
+        n_points <= (1ll << 25)) {
         plan->fast32 = 1; plan->w_lds = 1; plan->waves = 4;
         plan->lds = backward ? (2 * (size_t)spec->n_mlp_params + 4 * (size_t)spec->n_neurons * 20) * sizeof(float)
                              : (size_t)spec->n_mlp_params * sizeof(float);
@@ -274,7 +276,8 @@ extern "C" int lnr_density_forward(const LnrNetSpec* spec, const float* params, 
     const int64_t cap = mp.n_points;
     if (cap == 0) return LNR_OK;
     LNR_REQUIRE(params && sigma && workspace, "lnr_density_forward: null params/sigma/workspace");
-    LNR_REQUIRE(cap < (1ll << 28), "lnr_density_forward: more than 2^28 points per call (32-bit sample offsets)");
+    LNR_REQUIRE(cap * (spec->n_features > 4 ? spec->n_features : 4) < (1ll << 30),
+                "lnr_density_forward: too many points per call for 32-bit plane offsets (n_points * max(n_features, 4) must be < 2^30)");
     const Layout L = make_layout(spec, cap);
     if (workspace_bytes < L.total) {
         lnr_set_error("lnr_density_forward: workspace %zu < %zu (lnr_density_workspace)", workspace_bytes, L.total);
@@ -317,7 +320,8 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     const int64_t cap = mp.n_points;
     if (cap == 0) return LNR_OK;
     LNR_REQUIRE(params && d_sigma && grad_params && workspace, "lnr_density_backward: null argument");
-    LNR_REQUIRE(cap < (1ll << 28), "lnr_density_backward: more than 2^28 points per call (32-bit sample offsets)");
+    LNR_REQUIRE(cap * (spec->n_features > 4 ? spec->n_features : 4) < (1ll << 30),
+                "lnr_density_backward: too many points per call for 32-bit plane offsets (n_points * max(n_features, 4) must be < 2^30)");
     const Layout L = make_layout(spec, cap);
     if (workspace_bytes < L.total) {
         lnr_set_error("lnr_density_backward: workspace %zu < %zu (lnr_density_workspace)", workspace_bytes, L.total);
