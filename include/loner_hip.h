@@ -121,13 +121,16 @@ int lnr_density_forward(const LnrNetSpec* spec /*host*/, const float* params,
 /* Backward of the above                     replaces tinycudann backward (loss.backward(), optimizer.py:366)
  * grad_params [n_params] is ACCUMULATED into (caller zeroes it; lnr_adam_step can re-zero it).
  * d_pts (nullable) [*,3] receives dL/dxyz per point (needed only when poses are optimised).
+ * d_rays (nullable, rays form only, instead of d_pts) [n_rays,13]: dL/dxyz is reduced over the samples of each ray and
+ * ADDED to the ray-record gradient (origin cols 0:3 += sum dL/dxyz, direction cols 3:6 += sum z dL/dxyz) - what
+ * lnr_points_grad_to_rays does with d_pts, without materialising d_pts (float atomics: summation order not fixed).
  * reuse_features != 0: the workspace still holds the feature planes lnr_density_forward wrote for the SAME
  * spec, params and points (tinycudann keeps its forward activations the same way); 0 re-encodes first. */
 int lnr_density_backward(const LnrNetSpec* spec /*host*/, const float* params,
                          const float* pts, int64_t n_points,
                          const float* rays, const float* z, int32_t n_rays, int32_t n_samples,
                          const int32_t* n_rays_dev,
-                         const float* d_sigma, float* grad_params, float* d_pts,
+                         const float* d_sigma, float* grad_params, float* d_pts, float* d_rays,
                          int32_t reuse_features, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- rays ------------------------------------------------------------------------------------- */

@@ -65,6 +65,19 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+// Sum over the 64 lanes with DPP only (quad swaps, half-row and row mirrors: plain VALU operands) plus four readlanes
+// for the rows; __shfl_xor lowers to ds_bpermute (an LDS round trip per step).  The result is wave-uniform.  Must be
+// called with all lanes active.  Association differs from wave_sum (mirror tree instead of xor butterfly).
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
+    const int vi = __float_as_int(v);
+    return (__int_as_float(__builtin_amdgcn_readlane(vi, 0)) + __int_as_float(__builtin_amdgcn_readlane(vi, 16))) +
+           (__int_as_float(__builtin_amdgcn_readlane(vi, 32)) + __int_as_float(__builtin_amdgcn_readlane(vi, 48)));
+}
+
 // exclusive prefix product / inclusive helpers over 64 lanes
 __device__ __forceinline__ float wave_excl_prod(float v, int lane) {
     float inc = v;

@@ -131,7 +131,7 @@ table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ region
 struct Layout {
     int64_t m_pad;
     int n_groups, bpg, maxo, cap, shift, nown, rec_bytes;
-    size_t off_feat, off_dfeat, off_dxl, off_slabs, off_dense, off_counts, off_regions, total;
+    size_t off_feat, off_dfeat, off_dxl, off_dpts, off_slabs, off_dense, off_counts, off_regions, total;
 };
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -180,6 +180,7 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
     L.off_feat = off; off += align256((size_t)spec->enc_dim * L.m_pad * sizeof(float));
     L.off_dfeat = off; off += align256((size_t)spec->enc_dim * L.m_pad * sizeof(float));
     L.off_dxl = off; off += align256((size_t)L.n_groups * 3 * L.m_pad * sizeof(float));
+    L.off_dpts = off; off += align256((size_t)3 * L.m_pad * sizeof(float));      // d_pts scratch of the general d_rays route
     L.off_slabs = off; off += align256((size_t)LNR_BWD_MAX_BLOCKS * spec->n_mlp_params * sizeof(float));
     L.off_dense = off; off += align256(dense_total * (size_t)lnr_dense_bpg(L.bpg) * sizeof(float));
     L.off_counts = off; off += align256(hash ? (size_t)blocks * L.maxo * sizeof(int) : 0);
@@ -309,7 +310,7 @@ extern "C" int lnr_density_forward(const LnrNetSpec* spec, const float* params, 
 
 extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params, const float* pts, int64_t n_points,
                                     const float* rays, const float* z, int32_t n_rays, int32_t n_samples,
-                                    const int32_t* n_rays_dev, const float* d_sigma, float* grad_params, float* d_pts,
+                                    const int32_t* n_rays_dev, const float* d_sigma, float* grad_params, float* d_pts, float* d_rays,
                                     int32_t reuse_features, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_spec(spec, "lnr_density_backward");
     if (rc) return rc;
@@ -350,7 +351,15 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
         if (rc) return rc;
         LNR_CHECK_LAUNCH("lnr_density_backward(encode)");
     }
-    const int want_dfeat = (hash || d_pts != nullptr) ? 1 : 0;
+    // d_rays (rays form only): the input gradient goes straight into the ray records.  When a wave's 64 samples lie on one
+    // ray (n_samples % 64 == 0) and there is a table to walk, the encode kernels accumulate it themselves; otherwise it
+    // takes the general route (d/dx planes -> d_pts scratch in the workspace -> lnr_points_grad_to_rays).
+    LNR_REQUIRE(!(d_rays && pts), "lnr_density_backward: d_rays needs the rays form");
+    LNR_REQUIRE(!(d_rays && d_pts), "lnr_density_backward: pass d_pts or d_rays, not both");
+    const bool ray_accum = d_rays != nullptr && hash && (n_samples % 64 == 0);
+    float* d_pts_eff = d_pts;
+    if (d_rays && !ray_accum) d_pts_eff = (float*)(ws + L.off_dpts);
+    const int want_dfeat = (hash || d_pts_eff != nullptr) ? 1 : 0;
     {
     LnrProfScope prof("mlp_backward", st);
     switch (spec->n_neurons / 16) {
@@ -366,9 +375,13 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     float* grad_table = grad_params + spec->n_mlp_params;
     if (want_dfeat) {
         rc = lnr_encode_backward(spec, params, &src, cap, dfeat, dxl, L.m_pad, grad_table, regions, counts, dense_slabs, L.bpg, L.maxo, cap_rec, L.shift,
-                                 debug, d_pts, st);
+                                 debug, d_pts_eff, ray_accum ? d_rays : nullptr, st);
         if (rc) return rc;
         LNR_CHECK_LAUNCH("lnr_density_backward(encode backward)");
+    }
+    if (d_rays && !ray_accum) {
+        rc = lnr_points_grad_to_rays(d_pts_eff, z, n_rays, n_rays_dev, n_samples, d_rays, stream);
+        if (rc) return rc;
     }
     if (hash && L.nown > 0 && cap_rec > 0) {
         const size_t lds = ((size_t)1 << L.shift) * sizeof(long long);

@@ -159,6 +159,24 @@ __device__ __forceinline__ void dx_from_entries(const LevelInfo& L, const Cell& 
     dx[0] = dxv * L.scale; dx[1] = dyv * L.scale; dx[2] = dzv * L.scale;
 }
 
+// d/dx modes of the backward kernels
+#define ENC_DX_NONE 0
+#define ENC_DX_PLANES 1       // one d/dx plane per level, summed later by sum_dx_planes_kernel (any point source)
+#define ENC_DX_RAYS 2         // rays form with n_samples % 64 == 0: a wave's 64 samples lie on one ray, so its d/dx sum goes
+                              // straight into that ray's record gradient (origin += dx/2, direction += z dx/2): six atomics per
+                              // wave instead of three plane stores per thread, a 400 MB plane sum and the d_pts round trip
+
+// all lanes active; dx = 0 on lanes without a contribution
+__device__ __forceinline__ void ray_accumulate_dx(float* __restrict__ d_rays, uint32_t ray, float z, const float dx[3], int lane) {
+    float t[6];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { t[d] = wave_sum_dpp(dx[d]); t[3 + d] = wave_sum_dpp(z * dx[d]); }
+    if (lane < 6) {
+        const float v = lane == 0 ? t[0] : lane == 1 ? t[1] : lane == 2 ? t[2] : lane == 3 ? t[3] : lane == 4 ? t[4] : t[5];
+        if (v != 0.0f) atomicAdd(d_rays + (size_t)ray * LNR_RAY_STRIDE + lane, 0.5f * v);      // x = (xyz + 1) / 2
+    }
+}
+
 #define ENC_STAGE_RECORDS (ENC_BLOCK * 8)
 
 // what the copy-out phase needs to know about one owner of the current batch: one 16-byte LDS read per record
@@ -169,10 +187,11 @@ struct OwnerSlot {
 };
 
 // dynamic LDS: int cnt[maxo4], gcur[maxo4]; OwnerSlot slot[maxo] (16-byte aligned); then the staging buffer
-template <int F, bool WANT_DX>
+template <int F, int DXM>
 __global__ void __launch_bounds__(ENC_BLOCK)
 encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, const PointSrc src, const float* __restrict__ dfeat,
                        float* __restrict__ dxl, int64_t m_pad, int bpg, const LevelList list, const EncSink sink) {
+    constexpr bool WANT_DX = DXM != ENC_DX_NONE;          // dxl: the d/dx planes (ENC_DX_PLANES) or d_rays [n_rays,13] (ENC_DX_RAYS)
     extern __shared__ __attribute__((aligned(16))) int dyn[];
     __shared__ int s_total;
     constexpr bool PAIR = F >= 2;
@@ -227,6 +246,7 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
 #pragma unroll
         for (int f = 0; f < F; ++f) { g[f] = live ? g_next[f] : 0.0f; any |= (g[f] != 0.0f); }
         const RawPoint p_cur = p_next;
+        const uint32_t ray_cur = cur.ray;
         cur.advance();
         {
             const bool in = cur.m < M;
@@ -341,7 +361,10 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
                 if constexpr (EARLY_DX) dx_from_entries<F>(L, c, g, tv, dx);
                 else { float tl[8][F]; gather_entries<F>(table, e, tl); dx_from_entries<F>(L, c, g, tl, dx); }
             }
-            if (live) {
+            if constexpr (DXM == ENC_DX_RAYS) {
+                if (wave_any && !(sink.debug & 8))       // wave-uniform; lane 0 holds the wave's first (live) sample
+                    ray_accumulate_dx(dxl, (uint32_t)__builtin_amdgcn_readfirstlane((int)ray_cur), p_cur.z, dx, lane);
+            } else if (live) {
 #pragma unroll
                 for (int d = 0; d < 3; ++d) st32<float>(dxplanes, (uint32_t)d * plane_bytes + m * 4u, dx[d]);
             }
@@ -355,11 +378,12 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
 // Dense levels (lnr_density_api.h): the workgroup sums its samples' corner updates in an LDS copy of the level's
 // table (64-bit fixed point: LDS integer atomics are ~16x faster than float ones on CDNA4 and order-independent) and
 // writes it out once as a slab; dense_slab_reduce_kernel adds the slabs of all workgroups to the table gradient.
-template <int F, bool WANT_DX>
+template <int F, int DXM>
 __global__ void __launch_bounds__(ENC_BLOCK)
 encode_backward_dense_kernel(const LnrNetSpec spec, const float* __restrict__ table, const PointSrc src, const float* __restrict__ dfeat,
                              float* __restrict__ dxl, int64_t m_pad, int bpg, const LevelList list, float* __restrict__ slabs,
                              int dense_total, int debug) {
+    constexpr bool WANT_DX = DXM != ENC_DX_NONE;
     extern __shared__ long long dacc[];
     const int slot = blockIdx.x / bpg, chunk = blockIdx.x % bpg;
     const int lv = list.lv[slot];
@@ -385,8 +409,10 @@ encode_backward_dense_kernel(const LnrNetSpec spec, const float* __restrict__ ta
 #pragma unroll
         for (int f = 0; f < F; ++f) { g[f] = live ? ld32<float>(gplanes, (uint32_t)f * plane_bytes + m * 4u) : 0.0f; any |= (g[f] != 0.0f); }
         float dx[3] = {0.0f, 0.0f, 0.0f};
-        if (__ballot(any) != 0ull) {                        // wave-uniform
-            RawPoint rp;
+        const bool wave_any = __ballot(any) != 0ull;
+        RawPoint rp;
+        rp.z = 0.0f;
+        if (wave_any) {                                     // wave-uniform
             load_raw_point(src, live ? m : M - 1u, live ? cur.ray : last_ray, rp);
             float x[3];
             unit_point(src, rp, x);
@@ -410,7 +436,9 @@ encode_backward_dense_kernel(const LnrNetSpec spec, const float* __restrict__ ta
                 if (any && !(debug & 8)) { float tv[8][F]; gather_entries<F>(table, e, tv); dx_from_entries<F>(L, c, g, tv, dx); }
             }
         }
-        if constexpr (WANT_DX) {
+        if constexpr (DXM == ENC_DX_RAYS) {
+            if (wave_any && !(debug & 8)) ray_accumulate_dx(dxl, (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.ray), rp.z, dx, lane);
+        } else if constexpr (DXM == ENC_DX_PLANES) {
             if (live) {
 #pragma unroll
                 for (int d = 0; d < 3; ++d) st32<float>(dxplanes, (uint32_t)d * plane_bytes + m * 4u, dx[d]);
@@ -500,8 +528,11 @@ int lnr_encode_forward(const LnrNetSpec* spec, const float* params, const PointS
 
 int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, const float* dfeat,
                         float* dxl, int64_t m_pad, float* grad_table, void* regions, int* counts, float* dense_slabs, int bpg,
-                        int maxo, int cap, int shift, int debug, float* d_pts, hipStream_t st) {
+                        int maxo, int cap, int shift, int debug, float* d_pts, float* d_rays_acc, hipStream_t st) {
     const float* table = params + spec->n_mlp_params;
+    // d/dx mode: d_rays_acc (rays form, n_samples % 64 == 0, checked by the caller) > d_pts (planes) > none
+    const int dxm = d_rays_acc ? ENC_DX_RAYS : (d_pts ? ENC_DX_PLANES : ENC_DX_NONE);
+    float* dx_out = d_rays_acc ? d_rays_acc : dxl;
     int n_groups = 1;
     if (spec->encoding == LNR_ENC_HASHGRID) {
         n_groups = spec->n_levels;
@@ -519,6 +550,25 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
             }
         }
         const dim3 block(ENC_BLOCK);
+#define LNR_LAUNCH_DXM(KERNEL, F, ...)                                                                                        \
+        do {                                                                                                                  \
+            hipError_t e_ = hipSuccess;                                                                                       \
+            const void* fn_ = dxm == ENC_DX_RAYS ? reinterpret_cast<const void*>(KERNEL<F, ENC_DX_RAYS>)                      \
+                            : dxm == ENC_DX_PLANES ? reinterpret_cast<const void*>(KERNEL<F, ENC_DX_PLANES>)                  \
+                                                   : reinterpret_cast<const void*>(KERNEL<F, ENC_DX_NONE>);                   \
+            e_ = hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+            if (e_ != hipSuccess) { lnr_set_error("lnr_density_backward: hipFuncSetAttribute(%zu) failed", lds); return LNR_ERR_LAUNCH; } \
+            if (dxm == ENC_DX_RAYS) hipLaunchKernelGGL((KERNEL<F, ENC_DX_RAYS>), grid, block, lds, st, __VA_ARGS__);          \
+            else if (dxm == ENC_DX_PLANES) hipLaunchKernelGGL((KERNEL<F, ENC_DX_PLANES>), grid, block, lds, st, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<F, ENC_DX_NONE>), grid, block, lds, st, __VA_ARGS__);                             \
+        } while (0)
+#define LNR_LAUNCH_F(KERNEL, ...)                                                   \
+        switch (spec->n_features) {                                                 \
+            case 1: LNR_LAUNCH_DXM(KERNEL, 1, __VA_ARGS__); break;                  \
+            case 2: LNR_LAUNCH_DXM(KERNEL, 2, __VA_ARGS__); break;                  \
+            case 4: LNR_LAUNCH_DXM(KERNEL, 4, __VA_ARGS__); break;                  \
+            default: LNR_LAUNCH_DXM(KERNEL, 8, __VA_ARGS__); break;                 \
+        }
         if (rec_levels.n > 0) {
             EncSink sink;
             sink.grad_table = grad_table; sink.regions = regions; sink.counts = counts; sink.maxo = maxo; sink.cap = cap; sink.shift = shift;
@@ -527,59 +577,26 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
             LnrProfScope prof("encode_backward", st);
             const int maxo4 = (maxo + 3) & ~3;
             const size_t lds = (size_t)(2 * maxo4 + 4 * maxo) * sizeof(int) + (size_t)ENC_STAGE_RECORDS * (spec->n_features >= 2 ? 16 : 8);
-#define LNR_EB(F)                                                                                                             \
-            do {                                                                                                              \
-                hipError_t e_;                                                                                                \
-                if (d_pts) {                                                                                                  \
-                    e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(encode_backward_kernel<F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                    if (e_ == hipSuccess) hipLaunchKernelGGL((encode_backward_kernel<F, true>), grid, block, lds, st, *spec, table, *src, dfeat, dxl, m_pad, bpg, rec_levels, sink); \
-                } else {                                                                                                      \
-                    e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(encode_backward_kernel<F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                    if (e_ == hipSuccess) hipLaunchKernelGGL((encode_backward_kernel<F, false>), grid, block, lds, st, *spec, table, *src, dfeat, dxl, m_pad, bpg, rec_levels, sink); \
-                }                                                                                                             \
-                if (e_ != hipSuccess) { lnr_set_error("lnr_density_backward: hipFuncSetAttribute(%zu) failed", lds); return LNR_ERR_LAUNCH; } \
-            } while (0)
-            switch (spec->n_features) {
-                case 1: LNR_EB(1); break;
-                case 2: LNR_EB(2); break;
-                case 4: LNR_EB(4); break;
-                default: LNR_EB(8); break;
-            }
-#undef LNR_EB
+            LNR_LAUNCH_F(encode_backward_kernel, *spec, table, *src, dfeat, dx_out, m_pad, bpg, rec_levels, sink);
         }
         if (dense_levels.n > 0) {
             const int dbpg = lnr_dense_bpg(bpg);
             const dim3 grid((unsigned)(dense_levels.n * dbpg));
             LnrProfScope prof("encode_backward_dense", st);
             const size_t lds = (size_t)dense_max * sizeof(long long);
-#define LNR_ED(F)                                                                                                             \
-            do {                                                                                                              \
-                hipError_t e_;                                                                                                \
-                if (d_pts) {                                                                                                  \
-                    e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(encode_backward_dense_kernel<F, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                    if (e_ == hipSuccess) hipLaunchKernelGGL((encode_backward_dense_kernel<F, true>), grid, block, lds, st, *spec, table, *src, dfeat, dxl, m_pad, dbpg, dense_levels, dense_slabs, dense_total, debug); \
-                } else {                                                                                                      \
-                    e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(encode_backward_dense_kernel<F, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                    if (e_ == hipSuccess) hipLaunchKernelGGL((encode_backward_dense_kernel<F, false>), grid, block, lds, st, *spec, table, *src, dfeat, dxl, m_pad, dbpg, dense_levels, dense_slabs, dense_total, debug); \
-                }                                                                                                             \
-                if (e_ != hipSuccess) { lnr_set_error("lnr_density_backward: hipFuncSetAttribute(%zu) failed", lds); return LNR_ERR_LAUNCH; } \
-            } while (0)
-            switch (spec->n_features) {
-                case 1: LNR_ED(1); break;
-                case 2: LNR_ED(2); break;
-                case 4: LNR_ED(4); break;
-                default: LNR_ED(8); break;
-            }
-#undef LNR_ED
+            LNR_LAUNCH_F(encode_backward_dense_kernel, *spec, table, *src, dfeat, dx_out, m_pad, dbpg, dense_levels, dense_slabs, dense_total, debug);
             hipLaunchKernelGGL(dense_slab_reduce_kernel, dim3((unsigned)((dense_max + ENC_BLOCK - 1) / ENC_BLOCK), (unsigned)dense_levels.n), block, 0, st,
                                *spec, dense_levels, dense_slabs, dbpg, dense_total, grad_table);
         }
-    } else if (d_pts) {
+#undef LNR_LAUNCH_F
+#undef LNR_LAUNCH_DXM
+    } else if (dxm != ENC_DX_NONE) {
+        // frequency encoding: no table, one plane group; the per-ray mode is served through the planes by the caller
         int64_t blocks = (cap_points + ENC_BLOCK - 1) / ENC_BLOCK;
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(freq_backward_kernel, dim3((unsigned)blocks), dim3(ENC_BLOCK), 0, st, *spec, *src, dfeat, dxl, m_pad);
     }
-    if (d_pts) {
+    if (dxm == ENC_DX_PLANES) {
         int64_t blocks = (cap_points + ENC_BLOCK - 1) / ENC_BLOCK;
         if (blocks > 4096) blocks = 4096;
         LnrProfScope prof("sum_dx_planes", st);

@@ -428,10 +428,9 @@ class Optimizer:
                 grad_params = params.grad
             else:
                 grad_params = torch.zeros_like(p)
-            d_pts = ops.density_backward(spec, p, d_sigma, grad_params, rays=rays, z=z, n_rays_dev=n_rays_dev,
-                                         want_d_pts=want_ray_grads, reuse_features=True)
-            if want_ray_grads:
-                ops.points_grad_to_rays(d_pts, z, d_rays, n_rays_dev=n_rays_dev)
+            # the point gradient is reduced per ray inside the backward and added to d_rays (no [N,S,3] tensor)
+            ops.density_backward(spec, p, d_sigma, grad_params, rays=rays, z=z, n_rays_dev=n_rays_dev,
+                                 reuse_features=True, d_rays=d_rays if want_ray_grads else None)
             if self._dist is not None and want_param_grads:
                 self._dist.all_reduce_grads(grad_params)
         self._results_lidar = {"rays": rays, "depths": depths, "samples_fine": z, "n_rays_dev": n_rays_dev, "stats": stats}

@@ -90,10 +90,12 @@ def density_forward(spec, params, pts=None, rays=None, z=None, n_rays_dev=None):
 
 
 def density_backward(spec, params, d_sigma, grad_params, pts=None, rays=None, z=None, n_rays_dev=None,
-                     want_d_pts=False, reuse_features=False):
+                     want_d_pts=False, reuse_features=False, d_rays=None):
     """Accumulates into grad_params [n_params]; returns d_pts ([...,3]) or None.
     reuse_features: the caller asserts that the last density_forward on this device ran on the same params and
-    points (and that neither changed since), so the encoded features still in the workspace are reused."""
+    points (and that neither changed since), so the encoded features still in the workspace are reused.
+    d_rays [n_rays,13] (rays form, instead of want_d_pts): the point gradient is reduced per ray and added to it."""
+    assert not (want_d_pts and d_rays is not None)
     require_device(params, d_sigma, grad_params, pts, rays, z)
     params, d_sigma = _f32c(params), _f32c(d_sigma)
     assert grad_params.dtype == torch.float32 and grad_params.is_contiguous()
@@ -107,7 +109,7 @@ def density_backward(spec, params, d_sigma, grad_params, pts=None, rays=None, z=
             raise RuntimeError("density_backward(reuse_features=True): workspace features belong to a different forward call")
         d_pts = torch.empty(n, 3, device=params.device, dtype=torch.float32) if want_d_pts else None
         check(load().lnr_density_backward(C.byref(spec), _ptr(params), _ptr(pts), n, None, None, 0, 0, None,
-                                          _ptr(d_sigma), _ptr(grad_params), _ptr(d_pts), reuse, _ptr(ent["buf"]), need,
+                                          _ptr(d_sigma), _ptr(grad_params), _ptr(d_pts), None, reuse, _ptr(ent["buf"]), need,
                                           _stream()), "lnr_density_backward")
         return d_pts
     rays, z = _f32c(rays), _f32c(z)
@@ -117,7 +119,7 @@ def density_backward(spec, params, d_sigma, grad_params, pts=None, rays=None, z=
         raise RuntimeError("density_backward(reuse_features=True): workspace features belong to a different forward call")
     d_pts = torch.empty(n, s, 3, device=params.device, dtype=torch.float32) if want_d_pts else None
     check(load().lnr_density_backward(C.byref(spec), _ptr(params), None, 0, _ptr(rays), _ptr(z), n, s,
-                                      _ptr(n_rays_dev), _ptr(d_sigma), _ptr(grad_params), _ptr(d_pts), reuse,
+                                      _ptr(n_rays_dev), _ptr(d_sigma), _ptr(grad_params), _ptr(d_pts), _ptr(d_rays), reuse,
                                       _ptr(ent["buf"]), need, _stream()), "lnr_density_backward")
     return d_pts
 

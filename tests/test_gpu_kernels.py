@@ -306,6 +306,32 @@ def test_density_dead_rays_and_empty_batches(ops, golden):
     del sig
 
 
+@pytest.mark.parametrize("name,S", [("default", 128), ("default", 100), ("small_hash", 64), ("hash_f4_2hidden", 128), ("freq_siren", 128)])
+def test_density_backward_ray_gradient_mode(ops, golden, name, S):
+    """d_rays mode of lnr_density_backward (the per-ray reduction of dL/dxyz inside the encode kernels when a wave's 64
+    samples share a ray, the planes + lnr_points_grad_to_rays route otherwise) == d_pts followed by lnr_points_grad_to_rays,
+    with identical parameter gradients; rays dropped on the device (n_rays_dev) stay untouched."""
+    g = golden("g4_samplers")
+    spec_o, spec_h, params = _net(name, seed=7, table_gain=3000.0)
+    rays = dv(g["rays"])
+    n = rays.shape[0]
+    gen = torch.Generator().manual_seed(S)
+    z = dv(torch.sort(torch.rand(n, S, generator=gen) * 0.5 + 0.01, dim=1).values)
+    d_sigma = dv(torch.randn(n, S, generator=gen))
+    p_dev = dv(params)
+    live = n - 5
+    n_dev = torch.tensor([live], dtype=torch.int32, device=DEV)
+    g1 = torch.zeros(int(spec_h.n_params), device=DEV); g2 = torch.zeros_like(g1)
+    base = dv(torch.randn(n, 13, generator=gen))                      # d_rays is accumulated into, not overwritten
+    d_pts = ops.density_backward(spec_h, p_dev, d_sigma, g1, rays=rays, z=z, n_rays_dev=n_dev, want_d_pts=True)
+    ref = base.clone()
+    ops.points_grad_to_rays(d_pts, z, ref, n_rays_dev=n_dev)
+    out = base.clone()
+    assert ops.density_backward(spec_h, p_dev, d_sigma, g2, rays=rays, z=z, n_rays_dev=n_dev, d_rays=out) is None
+    assert rel(g2, g1) < 1e-6
+    assert rel(out[:live, :6], ref[:live, :6]) < 2e-5 and torch.equal(out[:, 6:], base[:, 6:]) and torch.equal(out[live:], base[live:])
+
+
 # ------------------------------------------------------------------------------------------- rendering
 def test_render_forward_backward_matches_golden(ops, golden):
     g = golden("g5_render")
