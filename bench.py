@@ -231,10 +231,10 @@ def main():
     h, ind, nh = spec.n_neurons, spec.in_dim, spec.n_hidden
     mac = h * ind + (nh - 1) * h * h
     # Algorithmic work per launch:
-    #   encode_backward: d_feature planes in, d/dx planes out (poses train), z and the ray records once, the table gradient once
+    #   encode_backward: d_feature planes in, z and the ray records once, 6 ray-gradient floats out, the table gradient once
     #   mlp_backward:    forward recompute + input gradient + weight gradient GEMMs of the fp32 MLP
     alg = {
-        "encode_backward": {"bytes": pts * (n_rec * F * 4.0 + 4.0 + n_rec * 12.0) + n_local * 24.0 + rec_table_floats * 4.0},
+        "encode_backward": {"bytes": pts * (n_rec * F * 4.0 + 4.0) + n_local * (24.0 + 24.0) + rec_table_floats * 4.0},
         "encode_forward": {"bytes": pts * (4.0 + int(spec.n_levels) * F * 4.0) + n_local * 24.0 + (float(spec.n_params) - spec.n_mlp_params) * 4.0},
         "table_grad_reduce": {"bytes": rec_table_floats * 8.0},
         "mlp_backward": {"flops": pts * 2.0 * (3 * mac + h), "bytes": pts * (3 * spec.enc_dim * 4.0 + 4.0)},
