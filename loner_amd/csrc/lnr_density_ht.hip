@@ -44,11 +44,11 @@ int LNR_CAT(lnr_mlp_fwd_ht, LNR_HT)(const LnrNetSpec* spec, const float* params,
     return LNR_OK;
 }
 
-#define LNR_LAUNCH_MB(WL, DWK, ACT)                                                                                   \
+#define LNR_LAUNCH_MB(WL, ACT)                                                                                        \
     do {                                                                                                              \
-        rc = set_lds(mlp_backward_kernel<LNR_HT, WL, DWK, ACT>, plan->lds, "lnr_density_backward");         \
+        rc = set_lds(mlp_backward_kernel<LNR_HT, WL, ACT>, plan->lds, "lnr_density_backward");         \
         if (rc) return rc;                                                                                            \
-        hipLaunchKernelGGL((mlp_backward_kernel<LNR_HT, WL, DWK, ACT>), grid, block, plan->lds, st, *spec, params, feat, \
+        hipLaunchKernelGGL((mlp_backward_kernel<LNR_HT, WL, ACT>), grid, block, plan->lds, st, *spec, params, feat, \
                            m_pad, pt->n_points, pt->n_rays_dev, pt->n_rays, pt->n_samples, d_sigma, dfeat, slabs, want_dfeat); \
     } while (0)
 
@@ -67,7 +67,7 @@ int LNR_CAT(lnr_mlp_bwd_ht, LNR_HT)(const LnrNetSpec* spec, const float* params,
         return LNR_OK;
     }
 #endif
-    if (plan->w_lds) { if (relu) LNR_LAUNCH_MB(true, 0, LNR_ACT_RELU); else LNR_LAUNCH_MB(true, 0, -1); }
-    else { if (relu) LNR_LAUNCH_MB(false, 0, LNR_ACT_RELU); else LNR_LAUNCH_MB(false, 0, -1); }
+    if (plan->w_lds) { if (relu) LNR_LAUNCH_MB(true, LNR_ACT_RELU); else LNR_LAUNCH_MB(true, -1); }
+    else { if (relu) LNR_LAUNCH_MB(false, LNR_ACT_RELU); else LNR_LAUNCH_MB(false, -1); }
     return LNR_OK;
 }

@@ -146,8 +146,8 @@ mlp_forward_kernel(const LnrNetSpec spec, const float* __restrict__ params, cons
 
 // Backward of the MLP on feature planes: weight gradients (slabs) and dfeat planes.  No gathers, no scatters.
 // LDS map (floats): [W if W_LDS][dW][per-wave: T_dz [H*16] | if n_hidden>1: T_a [H*16] | zsave [n_hidden*H*16]]
-// General shapes.  DWK > 0: dW1 accumulates in registers over the whole kernel (needs in_dim == 16*DWK).
-template <int HT, bool W_LDS, int DWK, int ACT>
+// General shapes (any depth, width <= 256, any activation): weight gradients are summed into an LDS copy with LDS atomics.
+template <int HT, bool W_LDS, int ACT>
 __global__ void __launch_bounds__(LNR_DENSITY_BLOCK)
 mlp_backward_kernel(const LnrNetSpec spec, const float* __restrict__ params, const float* __restrict__ feat, int64_t m_pad,
                     int64_t n_points, const int32_t* __restrict__ n_rays_dev, int n_rays, int n_samples,
@@ -155,7 +155,7 @@ mlp_backward_kernel(const LnrNetSpec spec, const float* __restrict__ params, con
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = 16 * HT;
     const int NH = spec.n_hidden;
-    const int in_dim = DWK > 0 ? 16 * DWK : spec.in_dim;
+    const int in_dim = spec.in_dim;
     const int n_mlp = spec.n_mlp_params;
     const int nw = blockDim.x >> 6;
     float* dW = smem + (W_LDS ? n_mlp : 0);
@@ -179,12 +179,6 @@ mlp_backward_kernel(const LnrNetSpec spec, const float* __restrict__ params, con
     f32x4 dWo_acc[HT];
 #pragma unroll
     for (int jt = 0; jt < HT; ++jt) dWo_acc[jt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    constexpr int DWK_N = DWK > 0 ? DWK : 1;
-    f32x4 dW1_acc[HT][DWK_N];
-#pragma unroll
-    for (int jt = 0; jt < HT; ++jt)
-#pragma unroll
-        for (int kt = 0; kt < DWK_N; ++kt) dW1_acc[jt][kt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     const int64_t M = n_rays_dev ? (int64_t)lnr_live_rays(n_rays, n_rays_dev) * n_samples : n_points;
     const int64_t n_tiles = M > 0 ? (M + 15) / 16 : 0;
@@ -202,7 +196,7 @@ mlp_backward_kernel(const LnrNetSpec spec, const float* __restrict__ params, con
             continue;
         }
         f32x4 Z[HT];
-        layer1_from_planes<HT, DWK>(spec, W1, feat, m_pad, m, c, g, Z);
+        layer1_from_planes<HT, 0>(spec, W1, feat, m_pad, m, c, g, Z);
         if (NH > 1) {
 #pragma unroll
             for (int jt = 0; jt < HT; ++jt)
@@ -265,27 +259,15 @@ mlp_backward_kernel(const LnrNetSpec spec, const float* __restrict__ params, con
                     b.z = p[min(tile_base + 4 * g + 2, M - 1)]; b.w = p[min(tile_base + 4 * g + 3, M - 1)];
                     return b;
                 };
-                if constexpr (DWK > 0) {
+                for (int kt = 0; kt < K / 16; ++kt) {
+                    const float4 b4 = load_b(kt);
 #pragma unroll
-                    for (int kt = 0; kt < DWK; ++kt) {
-                        const float4 b4 = load_b(kt);
+                    for (int jt = 0; jt < HT; ++jt) {
+                        const float4 a4 = *reinterpret_cast<const float4*>(T_dz + (16 * jt + c) * 16 + 4 * g);
+                        f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                        MFMA4(acc, a4, b4.x, b4.y, b4.z, b4.w);
 #pragma unroll
-                        for (int jt = 0; jt < HT; ++jt) {
-                            const float4 a4 = *reinterpret_cast<const float4*>(T_dz + (16 * jt + c) * 16 + 4 * g);
-                            MFMA4(dW1_acc[jt][kt], a4, b4.x, b4.y, b4.z, b4.w);
-                        }
-                    }
-                } else {
-                    for (int kt = 0; kt < K / 16; ++kt) {
-                        const float4 b4 = load_b(kt);
-#pragma unroll
-                        for (int jt = 0; jt < HT; ++jt) {
-                            const float4 a4 = *reinterpret_cast<const float4*>(T_dz + (16 * jt + c) * 16 + 4 * g);
-                            f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                            MFMA4(acc, a4, b4.x, b4.y, b4.z, b4.w);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) atomicAdd(dWl + (16 * jt + 4 * g + r) * K + 16 * kt + c, acc[r]);
-                        }
+                        for (int r = 0; r < 4; ++r) atomicAdd(dWl + (16 * jt + 4 * g + r) * K + 16 * kt + c, acc[r]);
                     }
                 }
             } else {
@@ -332,14 +314,6 @@ mlp_backward_kernel(const LnrNetSpec spec, const float* __restrict__ params, con
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-    }
-    if constexpr (DWK > 0) {
-#pragma unroll
-        for (int jt = 0; jt < HT; ++jt)
-#pragma unroll
-            for (int kt = 0; kt < DWK; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(dW1 + (16 * jt + 4 * g + r) * in_dim + 16 * kt + c, dW1_acc[jt][kt][r]);
     }
 #pragma unroll
     for (int jt = 0; jt < HT; ++jt) {
