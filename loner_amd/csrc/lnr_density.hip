@@ -51,7 +51,7 @@ __device__ __forceinline__ void reduce_one(long long* acc, uint2 r, uint32_t bas
 template <int PAIR>
 __global__ void __launch_bounds__(1024)
 table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ regions_v, const int* __restrict__ counts, int bpg, int maxo,
-                          int cap, int shift, float* __restrict__ grad_table, int64_t n_table_floats, int debug) {
+                          int cap, int shift, float* __restrict__ grad_table, int64_t n_table_floats) {
     extern __shared__ long long acc[];
     const int o = blockIdx.x;
     const int slice = 1 << shift;
@@ -110,7 +110,6 @@ table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ region
                 if (c0 + 4 < total) load4(c0 + 4, nxt, nrem);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    if (debug & 4) { if (rec[u].x == 0xFFFFFFFFu && rec[u].z == 0xFFFFFFFFu) acc[0] = 1; continue; }    // timing experiment: loads only
                     if (2 * lane < rem[u]) reduce_one<PAIR>(acc, make_uint2(rec[u].x, rec[u].y), base);
                     if (2 * lane + 1 < rem[u]) reduce_one<PAIR>(acc, make_uint2(rec[u].z, rec[u].w), base);
                 }
@@ -341,9 +340,10 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     int* counts = (int*)(ws + L.off_counts);
     void* regions = (void*)(ws + L.off_regions);
     const bool hash = spec->encoding == LNR_ENC_HASHGRID;
-    int debug = 0;
-    { const char* e = getenv("LNR_DEBUG"); debug = e ? atoi(e) : 0; }
-    const int cap_rec = (debug & 32) ? 0 : L.cap;          // test hook: every record takes the global-atomic fallback path
+    // test hook: LNR_TABLE_GRAD_ATOMICS=1 sends every record down the global-atomic fallback path (same result, ~20x slower);
+    // the tests use it as an independent implementation of the record partition
+    const char* env_atomics = getenv("LNR_TABLE_GRAD_ATOMICS");
+    const int cap_rec = (env_atomics && env_atomics[0] == '1') ? 0 : L.cap;
 
     if (!reuse_features) {
         LnrProfScope prof("encode_forward", st);
@@ -375,7 +375,7 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     float* grad_table = grad_params + spec->n_mlp_params;
     if (want_dfeat) {
         rc = lnr_encode_backward(spec, params, &src, cap, dfeat, dxl, L.m_pad, grad_table, regions, counts, dense_slabs, L.bpg, L.maxo, cap_rec, L.shift,
-                                 debug, d_pts_eff, ray_accum ? d_rays : nullptr, st);
+                                 d_pts_eff, ray_accum ? d_rays : nullptr, st);
         if (rc) return rc;
         LNR_CHECK_LAUNCH("lnr_density_backward(encode backward)");
     }
@@ -392,10 +392,10 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
         LnrProfScope prof("table_grad_reduce", st);
         if (spec->n_features >= 2)
             hipLaunchKernelGGL(table_grad_reduce2_kernel<1>, dim3(L.nown), dim3(1024), lds, st, *spec, regions, counts, L.bpg, L.maxo, cap_rec,
-                               L.shift, grad_table, n_table, debug);
+                               L.shift, grad_table, n_table);
         else
             hipLaunchKernelGGL(table_grad_reduce2_kernel<0>, dim3(L.nown), dim3(1024), lds, st, *spec, regions, counts, L.bpg, L.maxo, cap_rec,
-                               L.shift, grad_table, n_table, debug);
+                               L.shift, grad_table, n_table);
         LNR_CHECK_LAUNCH("lnr_density_backward(table reduce)");
     }
     const int n_mlp = spec->n_mlp_params;

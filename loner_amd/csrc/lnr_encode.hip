@@ -103,7 +103,6 @@ struct EncSink {
     int* counts;            // [level][maxo][chunk]
     int maxo, cap, shift;
     float combine_scale_max;
-    int debug;
 };
 
 // Run-length combining on coarse levels: consecutive samples of a ray fall into the same cell there, so their 8 corner
@@ -209,7 +208,7 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t M = (uint32_t)live_points(src);
     const int first_owner = (int)(((uint64_t)L.offset * F) >> sink.shift);
-    const bool combine = L.scale < sink.combine_scale_max && !(sink.debug & 16);
+    const bool combine = L.scale < sink.combine_scale_max;
     // region of (level, owner o, chunk): [level][owner][chunk] - the reduce of one owner streams its chunks' regions back to back
     const size_t region0 = (size_t)lv * maxo * bpg + chunk;
     const size_t region_step = (size_t)bpg;          // between consecutive owners
@@ -267,7 +266,7 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
             unit_point(src, p_cur, x);
             c = cell_of(L, x);
             cell_entries(L, c, e);
-            if constexpr (EARLY_DX) { if (!(sink.debug & 8)) gather_entries<F>(table, e, tv); }
+            if constexpr (EARLY_DX) gather_entries<F>(table, e, tv);
             cell_weights(c, w);
             // runs = consecutive samples (lanes of one 16-lane row) in the same CELL, not merely the same hashed entry
             if (combine) cell_runs(c, lane, head, run);
@@ -287,7 +286,7 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
                         if (PAIR) v1 = row_run_sum(v1, run);
                     }
                     rv0[k] = v0; rv1[k] = v1;
-                    if (head & ((v0 != 0.0f) | (v1 != 0.0f)) & !(sink.debug & 2)) {
+                    if (head & ((v0 != 0.0f) | (v1 != 0.0f))) {
                         const uint32_t fi = e[k] * F + (PAIR ? 2 * pass : 0);
                         const int local = (int)(fi >> sink.shift) - first_owner;
                         if (local >= 0 && local < maxo) rrank[k] = atomicAdd(&cnt[local], 1);
@@ -343,8 +342,7 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
                 const int local = (int)(idx >> sink.shift) - first_owner;
                 const OwnerSlot os = oslot[local];
                 const int k = i - os.scan;
-                if (sink.debug & 1) { if (v0 == 1e30f) gcur[0] = 1; }
-                else if (k < os.room) {
+                if (k < os.room) {
                     if (PAIR) r2 = lnr_pack_pair((idx & ((1u << LNR_SLICE_SHIFT) - 1u)) >> 1, v0, v1);
                     uint2* dst = reinterpret_cast<uint2*>(((uint64_t)os.ptr_hi << 32) | os.ptr_lo) + k;
                     *dst = r2;
@@ -357,12 +355,12 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
         }
         if constexpr (WANT_DX) {
             float dx[3] = {0.0f, 0.0f, 0.0f};
-            if (any && !(sink.debug & 8)) {
+            if (any) {
                 if constexpr (EARLY_DX) dx_from_entries<F>(L, c, g, tv, dx);
                 else { float tl[8][F]; gather_entries<F>(table, e, tl); dx_from_entries<F>(L, c, g, tl, dx); }
             }
             if constexpr (DXM == ENC_DX_RAYS) {
-                if (wave_any && !(sink.debug & 8))       // wave-uniform; lane 0 holds the wave's first (live) sample
+                if (wave_any)                            // wave-uniform; lane 0 holds the wave's first (live) sample
                     ray_accumulate_dx(dxl, (uint32_t)__builtin_amdgcn_readfirstlane((int)ray_cur), p_cur.z, dx, lane);
             } else if (live) {
 #pragma unroll
@@ -382,7 +380,7 @@ template <int F, int DXM>
 __global__ void __launch_bounds__(ENC_BLOCK)
 encode_backward_dense_kernel(const LnrNetSpec spec, const float* __restrict__ table, const PointSrc src, const float* __restrict__ dfeat,
                              float* __restrict__ dxl, int64_t m_pad, int bpg, const LevelList list, float* __restrict__ slabs,
-                             int dense_total, int debug) {
+                             int dense_total) {
     constexpr bool WANT_DX = DXM != ENC_DX_NONE;
     extern __shared__ long long dacc[];
     const int slot = blockIdx.x / bpg, chunk = blockIdx.x % bpg;
@@ -428,16 +426,16 @@ encode_backward_dense_kernel(const LnrNetSpec spec, const float* __restrict__ ta
 #pragma unroll
                 for (int f = 0; f < F; ++f) {
                     const float v = row_run_sum(w[k] * g[f], run);
-                    if (head && v != 0.0f && !(debug & 2))
+                    if (head && v != 0.0f)
                         atomicAdd(reinterpret_cast<unsigned long long*>(&dacc[el + f]), (unsigned long long)__float2ll_rn(v * LNR_FIX_SCALE));
                 }
             }
             if constexpr (WANT_DX) {
-                if (any && !(debug & 8)) { float tv[8][F]; gather_entries<F>(table, e, tv); dx_from_entries<F>(L, c, g, tv, dx); }
+                if (any) { float tv[8][F]; gather_entries<F>(table, e, tv); dx_from_entries<F>(L, c, g, tv, dx); }
             }
         }
         if constexpr (DXM == ENC_DX_RAYS) {
-            if (wave_any && !(debug & 8)) ray_accumulate_dx(dxl, (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.ray), rp.z, dx, lane);
+            if (wave_any) ray_accumulate_dx(dxl, (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.ray), rp.z, dx, lane);
         } else if constexpr (DXM == ENC_DX_PLANES) {
             if (live) {
 #pragma unroll
@@ -528,7 +526,7 @@ int lnr_encode_forward(const LnrNetSpec* spec, const float* params, const PointS
 
 int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, const float* dfeat,
                         float* dxl, int64_t m_pad, float* grad_table, void* regions, int* counts, float* dense_slabs, int bpg,
-                        int maxo, int cap, int shift, int debug, float* d_pts, float* d_rays_acc, hipStream_t st) {
+                        int maxo, int cap, int shift, float* d_pts, float* d_rays_acc, hipStream_t st) {
     const float* table = params + spec->n_mlp_params;
     // d/dx mode: d_rays_acc (rays form, n_samples % 64 == 0, checked by the caller) > d_pts (planes) > none
     const int dxm = d_rays_acc ? ENC_DX_RAYS : (d_pts ? ENC_DX_PLANES : ENC_DX_NONE);
@@ -572,7 +570,7 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
         if (rec_levels.n > 0) {
             EncSink sink;
             sink.grad_table = grad_table; sink.regions = regions; sink.counts = counts; sink.maxo = maxo; sink.cap = cap; sink.shift = shift;
-            sink.combine_scale_max = LNR_COMBINE_SCALE_MAX; sink.debug = debug;
+            sink.combine_scale_max = LNR_COMBINE_SCALE_MAX;
             const dim3 grid((unsigned)(rec_levels.n * bpg));
             LnrProfScope prof("encode_backward", st);
             const int maxo4 = (maxo + 3) & ~3;
@@ -584,7 +582,7 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
             const dim3 grid((unsigned)(dense_levels.n * dbpg));
             LnrProfScope prof("encode_backward_dense", st);
             const size_t lds = (size_t)dense_max * sizeof(long long);
-            LNR_LAUNCH_F(encode_backward_dense_kernel, *spec, table, *src, dfeat, dx_out, m_pad, dbpg, dense_levels, dense_slabs, dense_total, debug);
+            LNR_LAUNCH_F(encode_backward_dense_kernel, *spec, table, *src, dfeat, dx_out, m_pad, dbpg, dense_levels, dense_slabs, dense_total);
             hipLaunchKernelGGL(dense_slab_reduce_kernel, dim3((unsigned)((dense_max + ENC_BLOCK - 1) / ENC_BLOCK), (unsigned)dense_levels.n), block, 0, st,
                                *spec, dense_levels, dense_slabs, dbpg, dense_total, grad_table);
         }

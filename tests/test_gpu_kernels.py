@@ -573,11 +573,11 @@ def test_full_size_iteration_properties(ops):
     p1 = ops.density_backward(spec, params, d_sigma, g1, rays=rays, z=z, want_d_pts=True)
     ops.density_backward(spec, params, 2.0 * d_sigma, g2, rays=rays, z=z, want_d_pts=False)
     assert rel(g2, 2.0 * g1) < 1e-5
-    os.environ["LNR_DEBUG"] = "32"
+    os.environ["LNR_TABLE_GRAD_ATOMICS"] = "1"
     try:
         p3 = ops.density_backward(spec, params, d_sigma, g3, rays=rays, z=z, want_d_pts=True)
     finally:
-        del os.environ["LNR_DEBUG"]
+        del os.environ["LNR_TABLE_GRAD_ATOMICS"]
     print("partition vs atomic path: table grad rel", rel(g1, g3), " checksum", float(g1.double().sum()), float(g3.double().sum()))
     assert rel(g1, g3) < 1e-5 and torch.equal(p1, p3)
     assert abs(float(g1.double().sum()) - float(g3.double().sum())) < 1e-6 * float(g1.double().abs().sum())
