@@ -200,10 +200,10 @@ static int check_spec(const LnrNetSpec* spec, const char* who) {
 }
 
 static size_t fwd_lds(const LnrNetSpec* s, int w_lds) { return ((w_lds ? (size_t)s->n_mlp_params : 0) + 4) * sizeof(float); }
-static size_t bwd_lds(const LnrNetSpec* s, int w_lds, int waves) {
+static size_t bwd_lds(const LnrNetSpec* s, int w_lds, int waves, int dw64) {
     const size_t H = s->n_neurons;
     const size_t scratch = H * 16 + (s->n_hidden > 1 ? (size_t)(s->n_hidden + 1) * H * 16 : 0);
-    return ((w_lds ? 2 : 1) * (size_t)s->n_mlp_params + (size_t)waves * scratch) * sizeof(float);
+    return ((w_lds ? 1 : 0) * (size_t)s->n_mlp_params + (dw64 ? 2 : 1) * (size_t)s->n_mlp_params + (size_t)waves * scratch) * sizeof(float);
 }
 
 // Launch shape of the MLP kernels.  The reference's default shape class (32 encoded features -> <= 64 ReLU neurons
@@ -215,7 +215,7 @@ static int plan_launch(const LnrNetSpec* spec, int64_t n_points, bool backward, 
     // (the register-resident kernels address the planes with 32-bit byte offsets up to 17 planes: n_points <= 2^25)
     if (spec->activation == LNR_ACT_RELU && spec->n_hidden == 1 && spec->in_dim == 32 && spec->enc_dim == 32 && spec->n_neurons <= 64 &&
         n_points <= (1ll << 25)) {
-        plan->fast32 = 1; plan->w_lds = 1; plan->waves = 4;
+        plan->fast32 = 1; plan->w_lds = 1; plan->waves = 4; plan->dw64 = 0;
         plan->lds = backward ? (2 * (size_t)spec->n_mlp_params + 4 * (size_t)spec->n_neurons * 20) * sizeof(float)
                              : (size_t)spec->n_mlp_params * sizeof(float);
         int64_t blocks = (tiles + 3) / 4;
@@ -223,14 +223,17 @@ static int plan_launch(const LnrNetSpec* spec, int64_t n_points, bool backward, 
         plan->grid = (int)(blocks > max_blocks ? max_blocks : (blocks < 1 ? 1 : blocks));
         return LNR_OK;
     }
-    plan->fast32 = 0;
-    static const int opts[6][2] = {{1, 4}, {1, 2}, {1, 1}, {0, 4}, {0, 2}, {0, 1}};
-    for (int o = 0; o < 6; ++o) {
-        const int w_lds = opts[o][0], waves = opts[o][1];
-        if (!backward && waves != 4) continue;           // forward scratch does not depend on the wave count
-        const size_t lds = backward ? bwd_lds(spec, w_lds, waves) : fwd_lds(spec, w_lds);
+    plan->fast32 = 0; plan->dw64 = 0;
+    // {weights in LDS, waves, 64-bit fixed-point weight-gradient accumulators}.  LDS-resident weights matter most (without
+    // them every MFMA operand is a global load), then the integer accumulators (LDS float atomics are ~16x slower), then waves.
+    static const int opts[12][3] = {{1, 4, 1}, {1, 2, 1}, {1, 1, 1}, {1, 4, 0}, {1, 2, 0}, {1, 1, 0},
+                                    {0, 4, 1}, {0, 2, 1}, {0, 1, 1}, {0, 4, 0}, {0, 2, 0}, {0, 1, 0}};
+    for (int o = 0; o < 12; ++o) {
+        const int w_lds = opts[o][0], waves = opts[o][1], dw64 = opts[o][2];
+        if (!backward && (waves != 4 || dw64)) continue;           // forward scratch does not depend on these
+        const size_t lds = backward ? bwd_lds(spec, w_lds, waves, dw64) : fwd_lds(spec, w_lds);
         if (lds > (size_t)LNR_LDS_LIMIT) continue;
-        plan->w_lds = w_lds; plan->waves = waves; plan->lds = lds;
+        plan->w_lds = w_lds; plan->waves = waves; plan->lds = lds; plan->dw64 = backward ? dw64 : 0;
         int64_t blocks = (tiles + waves - 1) / waves;
         const int64_t max_blocks = backward ? LNR_BWD_MAX_BLOCKS : LNR_DENSITY_MAX_BLOCKS;
         if (blocks > max_blocks) blocks = max_blocks;

@@ -51,6 +51,7 @@ struct DensityPlan {
     int w_lds;       // 1: MLP matrices staged in LDS, 0: read from global memory
     size_t lds;      // dynamic LDS bytes
     int fast32;      // 1: the register-resident kernels for 32 features -> <= 64 ReLU neurons -> 1
+    int dw64;        // general backward: weight gradients accumulate in LDS in 64-bit fixed point (1) or fp32 (0)
 };
 
 // point count description for the MLP kernels (features come from planes)

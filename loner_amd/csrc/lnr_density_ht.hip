@@ -44,11 +44,11 @@ int LNR_CAT(lnr_mlp_fwd_ht, LNR_HT)(const LnrNetSpec* spec, const float* params,
     return LNR_OK;
 }
 
-#define LNR_LAUNCH_MB(WL, ACT)                                                                                        \
+#define LNR_LAUNCH_MB2(WL, ACT, D64)                                                                                  \
     do {                                                                                                              \
-        rc = set_lds(mlp_backward_kernel<LNR_HT, WL, ACT>, plan->lds, "lnr_density_backward");         \
+        rc = set_lds(mlp_backward_kernel<LNR_HT, WL, ACT, D64>, plan->lds, "lnr_density_backward");         \
         if (rc) return rc;                                                                                            \
-        hipLaunchKernelGGL((mlp_backward_kernel<LNR_HT, WL, ACT>), grid, block, plan->lds, st, *spec, params, feat, \
+        hipLaunchKernelGGL((mlp_backward_kernel<LNR_HT, WL, ACT, D64>), grid, block, plan->lds, st, *spec, params, feat, \
                            m_pad, pt->n_points, pt->n_rays_dev, pt->n_rays, pt->n_samples, d_sigma, dfeat, slabs, want_dfeat); \
     } while (0)
 
@@ -67,6 +67,7 @@ int LNR_CAT(lnr_mlp_bwd_ht, LNR_HT)(const LnrNetSpec* spec, const float* params,
         return LNR_OK;
     }
 #endif
+#define LNR_LAUNCH_MB(WL, ACT) do { if (plan->dw64) LNR_LAUNCH_MB2(WL, ACT, true); else LNR_LAUNCH_MB2(WL, ACT, false); } while (0)
     if (plan->w_lds) { if (relu) LNR_LAUNCH_MB(true, LNR_ACT_RELU); else LNR_LAUNCH_MB(true, -1); }
     else { if (relu) LNR_LAUNCH_MB(false, LNR_ACT_RELU); else LNR_LAUNCH_MB(false, -1); }
     return LNR_OK;

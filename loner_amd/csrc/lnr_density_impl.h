@@ -146,8 +146,24 @@ mlp_forward_kernel(const LnrNetSpec spec, const float* __restrict__ params, cons
 
 // Backward of the MLP on feature planes: weight gradients (slabs) and dfeat planes.  No gathers, no scatters.
 // LDS map (floats): [W if W_LDS][dW][per-wave: T_dz [H*16] | if n_hidden>1: T_a [H*16] | zsave [n_hidden*H*16]]
-// General shapes (any depth, width <= 256, any activation): weight gradients are summed into an LDS copy with LDS atomics.
-template <int HT, bool W_LDS, int ACT>
+// General shapes (any depth, width <= 256, any activation): weight gradients are summed into an LDS copy with LDS atomics -
+// DW64: in 64-bit fixed point (integer LDS atomics run ~16x faster than float ones on CDNA4) when that copy fits,
+// else in fp32.
+template <bool DW64> struct DwAcc;
+template <> struct DwAcc<true> {
+    typedef long long type;
+    static __device__ __forceinline__ void add(long long* p, float v) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__float2ll_rn(v * LNR_FIX_SCALE));
+    }
+    static __device__ __forceinline__ float get(long long v) { return (float)((double)v * (1.0 / (double)LNR_FIX_SCALE)); }
+};
+template <> struct DwAcc<false> {
+    typedef float type;
+    static __device__ __forceinline__ void add(float* p, float v) { atomicAdd(p, v); }
+    static __device__ __forceinline__ float get(float v) { return v; }
+};
+
+template <int HT, bool W_LDS, int ACT, bool DW64>
 __global__ void __launch_bounds__(LNR_DENSITY_BLOCK)
 mlp_backward_kernel(const LnrNetSpec spec, const float* __restrict__ params, const float* __restrict__ feat, int64_t m_pad,
                     int64_t n_points, const int32_t* __restrict__ n_rays_dev, int n_rays, int n_samples,
@@ -158,21 +174,22 @@ mlp_backward_kernel(const LnrNetSpec spec, const float* __restrict__ params, con
     const int in_dim = spec.in_dim;
     const int n_mlp = spec.n_mlp_params;
     const int nw = blockDim.x >> 6;
-    float* dW = smem + (W_LDS ? n_mlp : 0);
-    for (int i = threadIdx.x; i < n_mlp; i += blockDim.x) { if (W_LDS) smem[i] = params[i]; dW[i] = 0.0f; }
+    typedef typename DwAcc<DW64>::type dw_t;
+    dw_t* dW = reinterpret_cast<dw_t*>(smem + (W_LDS ? n_mlp : 0));        // n_mlp is a multiple of 16: 8-byte aligned
+    for (int i = threadIdx.x; i < n_mlp; i += blockDim.x) { if (W_LDS) smem[i] = params[i]; dW[i] = (dw_t)0; }
     __syncthreads();
     const float* W = W_LDS ? smem : params;
     const float* W1 = W;
     const float* Wh = W + H * in_dim;
     const float* Wo = Wh + (NH - 1) * H * H;
-    float* dW1 = dW;
-    float* dWh = dW + H * in_dim;
-    float* dWo = dWh + (NH - 1) * H * H;
+    dw_t* dW1 = dW;
+    dw_t* dWh = dW + H * in_dim;
+    dw_t* dWo = dWh + (NH - 1) * H * H;
     const int act = ACT >= 0 ? ACT : spec.activation;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int scratch_per_wave = H * 16 + (NH > 1 ? (NH + 1) * H * 16 : 0);
-    float* T_dz = dW + n_mlp + wave * scratch_per_wave;
+    float* T_dz = reinterpret_cast<float*>(dW + n_mlp) + wave * scratch_per_wave;
     float* T_a = T_dz + H * 16;
     float* zsave = T_a + H * 16;
 
@@ -246,7 +263,7 @@ mlp_backward_kernel(const LnrNetSpec spec, const float* __restrict__ params, con
             // weight gradient.  Layer 1: the B operand (X^T, 4 consecutive samples of one feature) is 16 contiguous
             // bytes of a feature plane - read straight from global memory, no LDS transpose.
             const int K = (l == 0) ? in_dim : H;
-            float* dWl = (l == 0) ? dW1 : dWh + (l - 1) * H * H;
+            dw_t* dWl = (l == 0) ? dW1 : dWh + (l - 1) * H * H;
             const int64_t tile_base = tile * 16;
             if (l == 0) {
                 auto load_b = [&](int kt) -> float4 {
@@ -267,7 +284,7 @@ mlp_backward_kernel(const LnrNetSpec spec, const float* __restrict__ params, con
                         f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                         MFMA4(acc, a4, b4.x, b4.y, b4.z, b4.w);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) atomicAdd(dWl + (16 * jt + 4 * g + r) * K + 16 * kt + c, acc[r]);
+                        for (int r = 0; r < 4; ++r) DwAcc<DW64>::add(dWl + (16 * jt + 4 * g + r) * K + 16 * kt + c, acc[r]);
                     }
                 }
             } else {
@@ -279,7 +296,7 @@ mlp_backward_kernel(const LnrNetSpec spec, const float* __restrict__ params, con
                         f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                         MFMA4(acc, a4, b4.x, b4.y, b4.z, b4.w);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) atomicAdd(dWl + (16 * jt + 4 * g + r) * K + 16 * kt + c, acc[r]);
+                        for (int r = 0; r < 4; ++r) DwAcc<DW64>::add(dWl + (16 * jt + 4 * g + r) * K + 16 * kt + c, acc[r]);
                     }
                 }
             }
@@ -321,12 +338,12 @@ mlp_backward_kernel(const LnrNetSpec spec, const float* __restrict__ params, con
         for (int r = 0; r < 4; ++r) {
             float v = dWo_acc[jt][r];
             v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-            if (c == 0) atomicAdd(dWo + 16 * jt + 4 * g + r, v);
+            if (c == 0) DwAcc<DW64>::add(dWo + 16 * jt + 4 * g + r, v);
         }
     }
     __syncthreads();
     float* slab = slabs + (size_t)blockIdx.x * n_mlp;
-    for (int i = threadIdx.x; i < n_mlp; i += blockDim.x) slab[i] = dW[i];
+    for (int i = threadIdx.x; i < n_mlp; i += blockDim.x) slab[i] = DwAcc<DW64>::get(dW[i]);
 }
 
 // ================================================================================================
