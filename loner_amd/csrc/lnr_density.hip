@@ -11,22 +11,34 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define LNR_ENC_BWD_MAX_BPG 2048
 
-// grad[i] += sum over workgroup slabs; blockIdx.y splits the slabs so that a few thousand threads (not n_mlp) share the reads
+// grad[i] += sum over workgroup slabs.  A 64 x 16 workgroup: 64 consecutive parameters, the slabs split over 16 thread rows
+// (a thousand threads share the reads instead of one per parameter), rows combined through LDS in a fixed order: no
+// atomics, bit-reproducible.
 #define LNR_SLAB_GROUPS 16
-__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs, int n_mlp, float* __restrict__ grad) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_mlp) return;
+__global__ void __launch_bounds__(64 * LNR_SLAB_GROUPS)
+reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs, int n_mlp, float* __restrict__ grad) {
+    __shared__ float part[LNR_SLAB_GROUPS][64];
+    const int px = threadIdx.x & 63, gy = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + px;
     const int per = (n_slabs + LNR_SLAB_GROUPS - 1) / LNR_SLAB_GROUPS;
-    int b = blockIdx.y * per;
+    int b = gy * per;
     const int b_end = min(n_slabs, b + per);
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    for (; b + 3 < b_end; b += 4) {
-        s0 += slabs[(size_t)b * n_mlp + i]; s1 += slabs[(size_t)(b + 1) * n_mlp + i];
-        s2 += slabs[(size_t)(b + 2) * n_mlp + i]; s3 += slabs[(size_t)(b + 3) * n_mlp + i];
+    if (i < n_mlp) {
+        for (; b + 3 < b_end; b += 4) {
+            s0 += slabs[(size_t)b * n_mlp + i]; s1 += slabs[(size_t)(b + 1) * n_mlp + i];
+            s2 += slabs[(size_t)(b + 2) * n_mlp + i]; s3 += slabs[(size_t)(b + 3) * n_mlp + i];
+        }
+        for (; b < b_end; ++b) s0 += slabs[(size_t)b * n_mlp + i];
     }
-    for (; b < b_end; ++b) s0 += slabs[(size_t)b * n_mlp + i];
-    const float s = (s0 + s1) + (s2 + s3);
-    if (s != 0.0f) atomicAdd(grad + i, s);
+    part[gy][px] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (gy == 0 && i < n_mlp) {
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < LNR_SLAB_GROUPS; ++k) s += part[k][px];
+        grad[i] += s;
+    }
 }
 
 // Workgroup `o` owns floats [o << shift, (o+1) << shift) of the table gradient.  The encode-backward workgroups of
@@ -403,7 +415,7 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     }
     const int n_mlp = spec->n_mlp_params;
     LnrProfScope prof_slabs("reduce_slabs", st);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(lnr_div_up(n_mlp, 256), LNR_SLAB_GROUPS), dim3(256), 0, st, slabs, plan.grid, n_mlp, grad_params);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(lnr_div_up(n_mlp, 64)), dim3(64 * LNR_SLAB_GROUPS), 0, st, slabs, plan.grid, n_mlp, grad_params);
     LNR_CHECK_LAUNCH("lnr_density_backward(reduce)");
     return LNR_OK;
 }
