@@ -545,22 +545,28 @@ mlp_backward_relu32_kernel(const LnrNetSpec spec, const float* __restrict__ para
         cur = nxt;
         tile = nt;
     }
+    // The waves add their register accumulators to the workgroup's LDS copy one after the other (every lane owns distinct
+    // elements): plain read-modify-writes in a fixed order, so the slab - and the weight gradient - is bit-reproducible.
     float* dW1 = dW;
     float* dWo = dW + H * 32;
+    for (int turn = 0; turn < nw; ++turn) {
+        if (wave == turn) {
 #pragma unroll
-    for (int jt = 0; jt < HT; ++jt) {
+            for (int jt = 0; jt < HT; ++jt) {
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+                for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(dW1 + (16 * jt + 4 * g + r) * 32 + 16 * kt + c, dW1_acc[jt][kt][r]);
+                    for (int r = 0; r < 4; ++r) dW1[(16 * jt + 4 * g + r) * 32 + 16 * kt + c] += dW1_acc[jt][kt][r];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = dWo_acc[jt][r];
-            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-            if (c == 0) atomicAdd(dWo + 16 * jt + 4 * g + r, v);
+                for (int r = 0; r < 4; ++r) {
+                    float v = dWo_acc[jt][r];
+                    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                    if (c == 0) dWo[16 * jt + 4 * g + r] += v;
+                }
+            }
         }
+        __syncthreads();
     }
-    __syncthreads();
     float* slab = slabs + (size_t)blockIdx.x * n_mlp;
     for (int i = threadIdx.x; i < n_mlp; i += blockDim.x) slab[i] = dW[i];
 }
