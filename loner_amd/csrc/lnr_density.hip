@@ -63,7 +63,7 @@ __device__ __forceinline__ void reduce_one(long long* acc, uint2 r, uint32_t bas
 template <int PAIR>
 __global__ void __launch_bounds__(1024)
 table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ regions_v, const int* __restrict__ counts, int bpg, int maxo,
-                          int cap, int shift, float* __restrict__ grad_table, int64_t n_table_floats) {
+                          int cap, int shift, const long long* __restrict__ ovf, float* __restrict__ grad_table, int64_t n_table_floats) {
     extern __shared__ long long acc[];
     const int o = blockIdx.x;
     const int slice = 1 << shift;
@@ -72,10 +72,24 @@ table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ region
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int F = spec.n_features;
+    int64_t ovf_off = 0;                                                   // running offset of the coherent levels' overflow accumulators
     for (int l = 0; l < spec.n_levels; ++l) {
         const uint64_t lo = (uint64_t)spec.level_offset[l] * F, hi = lo + (uint64_t)spec.level_size[l] * F;   // float range of the level
+        const bool dense = hi - lo <= (uint64_t)LNR_DENSE_LEVEL_FLOATS;
+        const bool coherent = !dense && (int)(((hi - 1) >> shift) - (lo >> shift)) + 1 <= LNR_OVF_MAX_SPAN;
+        const int64_t my_ovf = ovf_off;
+        if (coherent) ovf_off += (int64_t)(hi - lo);
         if (hi <= base || lo >= (uint64_t)base + slice) continue;
-        if (hi - lo <= (uint64_t)LNR_DENSE_LEVEL_FLOATS) continue;          // dense level: arrives through the slabs
+        if (dense) continue;                                                // dense level: arrives through the slabs
+        if (coherent) {
+            // records that did not fit their region were summed into 64-bit accumulators by the encode kernel: same fixed point,
+            // so region records + overflow add up exactly, whatever the (arrival-order dependent) split between the two was
+            for (int i = threadIdx.x; i < slice; i += blockDim.x) {
+                const uint64_t gi = (uint64_t)base + i;
+                if (gi >= lo && gi < hi) acc[i] += ovf[my_ovf + (int64_t)(gi - lo)];
+            }
+            __syncthreads();
+        }
         const int local = o - (int)(lo >> shift);
         if (local < 0 || local >= maxo) continue;
         // The regions of (level, owner) lie back to back, one per encode-backward workgroup (chunk); a wave takes a
@@ -142,7 +156,7 @@ table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ region
 struct Layout {
     int64_t m_pad;
     int n_groups, bpg, maxo, cap, shift, nown, rec_bytes;
-    size_t off_feat, off_dfeat, off_dxl, off_dpts, off_slabs, off_dense, off_counts, off_regions, total;
+    size_t off_feat, off_dfeat, off_dxl, off_dpts, off_slabs, off_dense, off_ovf, off_counts, off_regions, total;
 };
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -167,11 +181,12 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
     L.bpg = (int)bpg;
     L.maxo = 1;
     double per_region = 0.0;
-    size_t dense_total = 0;
+    size_t dense_total = 0, ovf_total = 0;
     if (hash) {
         const int F = spec->n_features;
         for (int l = 0; l < spec->n_levels; ++l) {
             if (lnr_level_is_dense(spec, l)) { dense_total += (size_t)spec->level_size[l] * F; continue; }
+            if (lnr_level_span(spec, l) <= LNR_OVF_MAX_SPAN) ovf_total += (size_t)spec->level_size[l] * F;
             const uint64_t lo = (uint64_t)spec->level_offset[l] * F, hi = lo + (uint64_t)spec->level_size[l] * F;
             const int span = (int)(((hi - 1) >> L.shift) - (lo >> L.shift)) + 1;
             if (span > L.maxo) L.maxo = span;
@@ -194,6 +209,7 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
     L.off_dpts = off; off += align256((size_t)3 * L.m_pad * sizeof(float));      // d_pts scratch of the general d_rays route
     L.off_slabs = off; off += align256((size_t)LNR_BWD_MAX_BLOCKS * spec->n_mlp_params * sizeof(float));
     L.off_dense = off; off += align256(dense_total * (size_t)lnr_dense_bpg(L.bpg) * sizeof(float));
+    L.off_ovf = off; off += align256(ovf_total * sizeof(long long));
     L.off_counts = off; off += align256(hash ? (size_t)blocks * L.maxo * sizeof(int) : 0);
     L.off_regions = off; off += hash ? (size_t)blocks * L.maxo * (size_t)L.cap * L.rec_bytes : 0;
     L.total = off;
@@ -352,6 +368,7 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     float* dxl = (float*)(ws + L.off_dxl);
     float* slabs = (float*)(ws + L.off_slabs);
     float* dense_slabs = (float*)(ws + L.off_dense);
+    long long* ovf = (long long*)(ws + L.off_ovf);
     int* counts = (int*)(ws + L.off_counts);
     void* regions = (void*)(ws + L.off_regions);
     const bool hash = spec->encoding == LNR_ENC_HASHGRID;
@@ -390,7 +407,7 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     float* grad_table = grad_params + spec->n_mlp_params;
     if (want_dfeat) {
         rc = lnr_encode_backward(spec, params, &src, cap, dfeat, dxl, L.m_pad, grad_table, regions, counts, dense_slabs, L.bpg, L.maxo, cap_rec, L.shift,
-                                 d_pts_eff, ray_accum ? d_rays : nullptr, st);
+                                 ovf, d_pts_eff, ray_accum ? d_rays : nullptr, st);
         if (rc) return rc;
         LNR_CHECK_LAUNCH("lnr_density_backward(encode backward)");
     }
@@ -398,7 +415,7 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
         rc = lnr_points_grad_to_rays(d_pts_eff, z, n_rays, n_rays_dev, n_samples, d_rays, stream);
         if (rc) return rc;
     }
-    if (hash && L.nown > 0 && cap_rec > 0) {
+    if (hash && L.nown > 0) {          // also with cap_rec == 0 (all-atomic test path): it folds in the overflow accumulators
         const size_t lds = ((size_t)1 << L.shift) * sizeof(long long);
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(table_grad_reduce2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(table_grad_reduce2_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -407,10 +424,10 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
         LnrProfScope prof("table_grad_reduce", st);
         if (spec->n_features >= 2)
             hipLaunchKernelGGL(table_grad_reduce2_kernel<1>, dim3(L.nown), dim3(1024), lds, st, *spec, regions, counts, L.bpg, L.maxo, cap_rec,
-                               L.shift, grad_table, n_table);
+                               L.shift, ovf, grad_table, n_table);
         else
             hipLaunchKernelGGL(table_grad_reduce2_kernel<0>, dim3(L.nown), dim3(1024), lds, st, *spec, regions, counts, L.bpg, L.maxo, cap_rec,
-                               L.shift, grad_table, n_table);
+                               L.shift, ovf, grad_table, n_table);
         LNR_CHECK_LAUNCH("lnr_density_backward(table reduce)");
     }
     const int n_mlp = spec->n_mlp_params;

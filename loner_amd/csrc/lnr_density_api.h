@@ -80,8 +80,18 @@ LNR_DECLARE_HT(16)
 struct LevelList {
     int n;                          // levels handled by a launch
     int lv[LNR_MAX_LEVELS];
-    int slab_off[LNR_MAX_LEVELS];   // dense levels: float offset inside one workgroup's slab
+    int slab_off[LNR_MAX_LEVELS];   // dense levels: float offset inside one workgroup's slab;
+                                    // record levels: offset of the level's 64-bit overflow accumulators, or -1 (see below)
 };
+// Record levels that span at most this many owner slices are spatially coherent (dense indexing: an owner is a slab of
+// cells), so a workgroup's half-rays pour into two or three owners and routinely exceed the region capacity that the
+// uniform model predicts.  Their overflow goes to 64-bit fixed-point accumulators in the workspace (integer atomics: exact,
+// order-independent) instead of float atomics, which keeps the table gradient bit-reproducible.
+#define LNR_OVF_MAX_SPAN 16
+static inline int lnr_level_span(const LnrNetSpec* s, int l) {
+    const uint64_t lo = (uint64_t)s->level_offset[l] * s->n_features, hi = lo + (uint64_t)s->level_size[l] * s->n_features;
+    return (int)(((hi - 1) >> LNR_SLICE_SHIFT) - (lo >> LNR_SLICE_SHIFT)) + 1;
+}
 // workgroups per dense level: each pays for zeroing and writing out an LDS copy of the level, so fewer than for the record levels
 static inline int lnr_dense_bpg(int bpg) { return bpg < 512 ? bpg : 512; }
 static inline bool lnr_level_is_dense(const LnrNetSpec* s, int l) {
@@ -93,4 +103,4 @@ int lnr_encode_forward(const LnrNetSpec* spec, const float* params, const PointS
                        int64_t m_pad, hipStream_t st);
 int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, const float* dfeat,
                         float* dxl, int64_t m_pad, float* grad_table, void* regions, int* counts, float* dense_slabs, int bpg,
-                        int maxo, int cap, int shift, float* d_pts, float* d_rays_acc, hipStream_t st);
+                        int maxo, int cap, int shift, long long* ovf, float* d_pts, float* d_rays_acc, hipStream_t st);

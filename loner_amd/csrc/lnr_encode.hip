@@ -98,7 +98,8 @@ freq_forward_kernel(const LnrNetSpec spec, const PointSrc src, float* __restrict
 // contiguous both in LDS and in that owner's (workgroup, owner) region in HBM, so the stores coalesce into full lines.
 // table_grad_reduce2_kernel (lnr_density.hip) sums each owner's regions in LDS.
 struct EncSink {
-    float* grad_table;      // fallback target for records beyond a region's capacity
+    float* grad_table;      // fallback target for records beyond a region's capacity (float atomics) ...
+    long long* ovf;         // ... unless the level has 64-bit overflow accumulators (LevelList::slab_off >= 0)
     void* regions;          // [level][maxo][chunk][cap] 8-byte records (lnr_density_api.h)
     int* counts;            // [level][maxo][chunk]
     int maxo, cap, shift;
@@ -210,6 +211,9 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
     const int first_owner = (int)(((uint64_t)L.offset * F) >> sink.shift);
     const bool combine = L.scale < sink.combine_scale_max;
     // region of (level, owner o, chunk): [level][owner][chunk] - the reduce of one owner streams its chunks' regions back to back
+    const int ovf_off = list.slab_off[blockIdx.x / bpg];
+    long long* ovf = ovf_off >= 0 ? sink.ovf + ovf_off : nullptr;                // indexed by float index inside the level
+    const uint32_t level_base = L.offset * F;
     const size_t region0 = (size_t)lv * maxo * bpg + chunk;
     const size_t region_step = (size_t)bpg;          // between consecutive owners
     const uint32_t step = (uint32_t)bpg * ENC_BLOCK;
@@ -346,6 +350,11 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
                     if (PAIR) r2 = lnr_pack_pair((idx & ((1u << LNR_SLICE_SHIFT) - 1u)) >> 1, v0, v1);
                     uint2* dst = reinterpret_cast<uint2*>(((uint64_t)os.ptr_hi << 32) | os.ptr_lo) + k;
                     *dst = r2;
+                } else if (ovf) {
+                    // same 26-bit rounding as a packed record: which records overflow depends on arrival order, the sum must not
+                    const float q0 = PAIR ? __uint_as_float(lnr_pack26(v0) << 6) : v0, q1 = PAIR ? __uint_as_float(lnr_pack26(v1) << 6) : 0.0f;
+                    if (q0 != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(ovf + (idx - level_base)), (unsigned long long)__float2ll_rn(q0 * LNR_FIX_SCALE));
+                    if (PAIR && q1 != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(ovf + (idx - level_base) + 1), (unsigned long long)__float2ll_rn(q1 * LNR_FIX_SCALE));
                 } else {
                     atomicAdd(sink.grad_table + idx, v0);
                     if (PAIR) atomicAdd(sink.grad_table + idx + 1, v1);
@@ -526,7 +535,7 @@ int lnr_encode_forward(const LnrNetSpec* spec, const float* params, const PointS
 
 int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, const float* dfeat,
                         float* dxl, int64_t m_pad, float* grad_table, void* regions, int* counts, float* dense_slabs, int bpg,
-                        int maxo, int cap, int shift, float* d_pts, float* d_rays_acc, hipStream_t st) {
+                        int maxo, int cap, int shift, long long* ovf, float* d_pts, float* d_rays_acc, hipStream_t st) {
     const float* table = params + spec->n_mlp_params;
     // d/dx mode: d_rays_acc (rays form, n_samples % 64 == 0, checked by the caller) > d_pts (planes) > none
     const int dxm = d_rays_acc ? ENC_DX_RAYS : (d_pts ? ENC_DX_PLANES : ENC_DX_NONE);
@@ -536,7 +545,7 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
         n_groups = spec->n_levels;
         LevelList rec_levels, dense_levels;
         rec_levels.n = dense_levels.n = 0;
-        int dense_total = 0, dense_max = 0;
+        int dense_total = 0, dense_max = 0, ovf_total = 0;
         for (int l = 0; l < spec->n_levels; ++l) {
             if (lnr_level_is_dense(spec, l)) {
                 const int nfl = (int)spec->level_size[l] * spec->n_features;
@@ -544,7 +553,10 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
                 dense_total += nfl;
                 if (nfl > dense_max) dense_max = nfl;
             } else {
-                rec_levels.lv[rec_levels.n] = l; rec_levels.slab_off[rec_levels.n] = 0; rec_levels.n++;
+                const int nfl = (int)spec->level_size[l] * spec->n_features;
+                const bool coherent = lnr_level_span(spec, l) <= LNR_OVF_MAX_SPAN;
+                rec_levels.lv[rec_levels.n] = l; rec_levels.slab_off[rec_levels.n] = coherent ? ovf_total : -1; rec_levels.n++;
+                if (coherent) ovf_total += nfl;
             }
         }
         const dim3 block(ENC_BLOCK);
@@ -569,7 +581,11 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
         }
         if (rec_levels.n > 0) {
             EncSink sink;
-            sink.grad_table = grad_table; sink.regions = regions; sink.counts = counts; sink.maxo = maxo; sink.cap = cap; sink.shift = shift;
+            if (ovf_total > 0 && hipMemsetAsync(ovf, 0, (size_t)ovf_total * sizeof(long long), st) != hipSuccess) {
+                lnr_set_error("lnr_density_backward: hipMemsetAsync failed");
+                return LNR_ERR_LAUNCH;
+            }
+            sink.grad_table = grad_table; sink.ovf = ovf; sink.regions = regions; sink.counts = counts; sink.maxo = maxo; sink.cap = cap; sink.shift = shift;
             sink.combine_scale_max = LNR_COMBINE_SCALE_MAX;
             const dim3 grid((unsigned)(rec_levels.n * bpg));
             LnrProfScope prof("encode_backward", st);

@@ -581,16 +581,13 @@ def test_full_size_iteration_properties(ops):
     print("partition vs atomic path: table grad rel", rel(g1, g3), " checksum", float(g1.double().sum()), float(g3.double().sum()))
     assert rel(g1, g3) < 1e-5 and torch.equal(p1, p3)
     assert abs(float(g1.double().sum()) - float(g3.double().sum())) < 1e-6 * float(g1.double().abs().sum())
-    # run-to-run reproducibility: the weight gradient (ordered slab reduction), the input gradient and the table gradient
-    # (64-bit fixed-point sums) are bit-identical; only records that overflow a region fall back to float atomics - here a
-    # few hundred entries of level 1, whose 8 owner slices each see whole half-rays - and may differ in the last bit
+    # run-to-run reproducibility: weight gradient (ordered slab reduction), input gradient and table gradient (64-bit fixed-point
+    # sums, incl. the overflow accumulators of the coherent levels) are bit-identical; only a statistically skewed hashed level
+    # could still spill into float atomics
     g1b = torch.zeros_like(g1)
     p1b = ops.density_backward(spec, params, d_sigma, g1b, rays=rays, z=z, want_d_pts=True)
-    nm = int(spec.n_mlp_params)
-    n_diff = int((g1b != g1).sum())
-    print("reproducibility: differing table-gradient entries", n_diff, "of", g1.numel() - nm)
-    assert torch.equal(g1b[:nm], g1[:nm]) and torch.equal(p1b, p1)
-    assert n_diff < 1e-3 * g1.numel() and rel(g1b, g1) < 1e-7
+    print("reproducibility: differing gradient entries", int((g1b != g1).sum()))
+    assert torch.equal(g1b, g1) and torch.equal(p1b, p1)
     # the training loop's route for the pose gradient: per-ray reduction inside the backward == d_pts -> lnr_points_grad_to_rays
     ref_rays = d_rays.clone(); ops.points_grad_to_rays(p1, z, ref_rays)
     out_rays = d_rays.clone(); g4 = torch.zeros_like(g1)
