@@ -123,7 +123,7 @@ int lnr_density_forward(const LnrNetSpec* spec /*host*/, const float* params,
  * d_pts (nullable) [*,3] receives dL/dxyz per point (needed only when poses are optimised).
  * d_rays (nullable, rays form only, instead of d_pts) [n_rays,13]: dL/dxyz is reduced over the samples of each ray and
  * ADDED to the ray-record gradient (origin cols 0:3 += sum dL/dxyz, direction cols 3:6 += sum z dL/dxyz) - what
- * lnr_points_grad_to_rays does with d_pts, without materialising d_pts (float atomics: summation order not fixed).
+ * lnr_points_grad_to_rays does with d_pts, without materialising d_pts (64-bit fixed-point sums: reproducible).
  * reuse_features != 0: the workspace still holds the feature planes lnr_density_forward wrote for the SAME
  * spec, params and points (tinycudann keeps its forward activations the same way); 0 re-encodes first. */
 int lnr_density_backward(const LnrNetSpec* spec /*host*/, const float* params,

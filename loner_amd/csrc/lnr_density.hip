@@ -156,7 +156,7 @@ table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ region
 struct Layout {
     int64_t m_pad;
     int n_groups, bpg, maxo, cap, shift, nown, rec_bytes;
-    size_t off_feat, off_dfeat, off_dxl, off_dpts, off_slabs, off_dense, off_ovf, off_counts, off_regions, total;
+    size_t off_feat, off_dfeat, off_dxl, off_dpts, off_rayacc, off_slabs, off_dense, off_ovf, off_counts, off_regions, total;
 };
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -207,6 +207,7 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
     L.off_dfeat = off; off += align256((size_t)spec->enc_dim * L.m_pad * sizeof(float));
     L.off_dxl = off; off += align256((size_t)L.n_groups * 3 * L.m_pad * sizeof(float));
     L.off_dpts = off; off += align256((size_t)3 * L.m_pad * sizeof(float));      // d_pts scratch of the general d_rays route
+    L.off_rayacc = off; off += align256((size_t)(L.m_pad / 64) * 6 * sizeof(long long));   // per-ray sums of the d_rays route (n_samples >= 64 there)
     L.off_slabs = off; off += align256((size_t)LNR_BWD_MAX_BLOCKS * spec->n_mlp_params * sizeof(float));
     L.off_dense = off; off += align256(dense_total * (size_t)lnr_dense_bpg(L.bpg) * sizeof(float));
     L.off_ovf = off; off += align256(ovf_total * sizeof(long long));
@@ -407,7 +408,7 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     float* grad_table = grad_params + spec->n_mlp_params;
     if (want_dfeat) {
         rc = lnr_encode_backward(spec, params, &src, cap, dfeat, dxl, L.m_pad, grad_table, regions, counts, dense_slabs, L.bpg, L.maxo, cap_rec, L.shift,
-                                 ovf, d_pts_eff, ray_accum ? d_rays : nullptr, st);
+                                 ovf, d_pts_eff, ray_accum ? d_rays : nullptr, (long long*)(ws + L.off_rayacc), st);
         if (rc) return rc;
         LNR_CHECK_LAUNCH("lnr_density_backward(encode backward)");
     }

@@ -103,4 +103,4 @@ int lnr_encode_forward(const LnrNetSpec* spec, const float* params, const PointS
                        int64_t m_pad, hipStream_t st);
 int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, const float* dfeat,
                         float* dxl, int64_t m_pad, float* grad_table, void* regions, int* counts, float* dense_slabs, int bpg,
-                        int maxo, int cap, int shift, long long* ovf, float* d_pts, float* d_rays_acc, hipStream_t st);
+                        int maxo, int cap, int shift, long long* ovf, float* d_pts, float* d_rays_acc, long long* ray_acc, hipStream_t st);

@@ -167,14 +167,26 @@ __device__ __forceinline__ void dx_from_entries(const LevelInfo& L, const Cell& 
                               // wave instead of three plane stores per thread, a 400 MB plane sum and the d_pts round trip
 
 // all lanes active; dx = 0 on lanes without a contribution
-__device__ __forceinline__ void ray_accumulate_dx(float* __restrict__ d_rays, uint32_t ray, float z, const float dx[3], int lane) {
+__device__ __forceinline__ void ray_accumulate_dx(float* __restrict__ ray_acc_f, uint32_t ray, float z, const float dx[3], int lane) {
+    long long* ray_acc = reinterpret_cast<long long*>(ray_acc_f);        // [n_rays][6] fixed-point sums (passed through the float* d/dx argument)
     float t[6];
 #pragma unroll
     for (int d = 0; d < 3; ++d) { t[d] = wave_sum_dpp(dx[d]); t[3 + d] = wave_sum_dpp(z * dx[d]); }
     if (lane < 6) {
         const float v = lane == 0 ? t[0] : lane == 1 ? t[1] : lane == 2 ? t[2] : lane == 3 ? t[3] : lane == 4 ? t[4] : t[5];
-        if (v != 0.0f) atomicAdd(d_rays + (size_t)ray * LNR_RAY_STRIDE + lane, 0.5f * v);      // x = (xyz + 1) / 2
+        // 64-bit fixed point: integer atomics add exactly, so the ray gradient does not depend on the order of the waves
+        if (v != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(ray_acc) + (size_t)ray * 6 + lane,
+                                 (unsigned long long)__float2ll_rn(0.5f * v * LNR_FIX_SCALE));             // x = (xyz + 1) / 2
     }
+}
+
+// d_rays[ray, 0:6] += the per-ray sums of ray_accumulate_dx
+__global__ void __launch_bounds__(ENC_BLOCK)
+ray_grad_apply_kernel(const long long* __restrict__ ray_acc, int n_rays, const int32_t* __restrict__ n_rays_dev, float* __restrict__ d_rays) {
+    const int i = blockIdx.x * ENC_BLOCK + threadIdx.x;
+    if (i >= lnr_live_rays(n_rays, n_rays_dev) * 6) return;
+    const long long q = ray_acc[i];
+    if (q != 0ll) d_rays[(size_t)(i / 6) * LNR_RAY_STRIDE + (i % 6)] += (float)((double)q * (1.0 / (double)LNR_FIX_SCALE));
 }
 
 #define ENC_STAGE_RECORDS (ENC_BLOCK * 8)
@@ -535,11 +547,15 @@ int lnr_encode_forward(const LnrNetSpec* spec, const float* params, const PointS
 
 int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, const float* dfeat,
                         float* dxl, int64_t m_pad, float* grad_table, void* regions, int* counts, float* dense_slabs, int bpg,
-                        int maxo, int cap, int shift, long long* ovf, float* d_pts, float* d_rays_acc, hipStream_t st) {
+                        int maxo, int cap, int shift, long long* ovf, float* d_pts, float* d_rays_acc, long long* ray_acc, hipStream_t st) {
     const float* table = params + spec->n_mlp_params;
     // d/dx mode: d_rays_acc (rays form, n_samples % 64 == 0, checked by the caller) > d_pts (planes) > none
     const int dxm = d_rays_acc ? ENC_DX_RAYS : (d_pts ? ENC_DX_PLANES : ENC_DX_NONE);
-    float* dx_out = d_rays_acc ? d_rays_acc : dxl;
+    float* dx_out = d_rays_acc ? reinterpret_cast<float*>(ray_acc) : dxl;
+    if (d_rays_acc && hipMemsetAsync(ray_acc, 0, (size_t)src->n_rays * 6 * sizeof(long long), st) != hipSuccess) {
+        lnr_set_error("lnr_density_backward: hipMemsetAsync failed");
+        return LNR_ERR_LAUNCH;
+    }
     int n_groups = 1;
     if (spec->encoding == LNR_ENC_HASHGRID) {
         n_groups = spec->n_levels;
@@ -609,6 +625,10 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
         int64_t blocks = (cap_points + ENC_BLOCK - 1) / ENC_BLOCK;
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(freq_backward_kernel, dim3((unsigned)blocks), dim3(ENC_BLOCK), 0, st, *spec, *src, dfeat, dxl, m_pad);
+    }
+    if (dxm == ENC_DX_RAYS) {
+        hipLaunchKernelGGL(ray_grad_apply_kernel, dim3((unsigned)((src->n_rays * 6 + ENC_BLOCK - 1) / ENC_BLOCK)), dim3(ENC_BLOCK), 0, st,
+                           ray_acc, src->n_rays, src->n_rays_dev, d_rays_acc);
     }
     if (dxm == ENC_DX_PLANES) {
         int64_t blocks = (cap_points + ENC_BLOCK - 1) / ENC_BLOCK;

@@ -593,3 +593,6 @@ def test_full_size_iteration_properties(ops):
     out_rays = d_rays.clone(); g4 = torch.zeros_like(g1)
     ops.density_backward(spec, params, d_sigma, g4, rays=rays, z=z, d_rays=out_rays)
     assert rel(g4, g1) < 1e-6 and rel(out_rays[:, :6], ref_rays[:, :6]) < 2e-5 and torch.equal(out_rays[:, 6:], d_rays[:, 6:])
+    out_rays2 = d_rays.clone(); g5 = torch.zeros_like(g1)
+    ops.density_backward(spec, params, d_sigma, g5, rays=rays, z=z, d_rays=out_rays2)
+    assert torch.equal(out_rays2, out_rays) and torch.equal(g5, g4)          # fixed-point ray sums: reproducible as well
