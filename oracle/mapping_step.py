@@ -169,7 +169,7 @@ class OracleMapper:
             grads = torch.autograd.grad(loss, tensors, allow_unused=True)
             with torch.no_grad():
                 adam.step(grads)
-            self.trace.append(float(loss))
+            self.trace.append(float(loss.detach()))
             if cfg.use_occupancy and self.global_step % cfg.occ_every == 0:
                 g = depths.reshape(-1, 1) * self.scale
                 self.grid = OC.grid_step(self.grid, aux["xyz"], aux["z"] * self.scale, g, cfg.occ_lr)
