@@ -405,6 +405,10 @@ class Optimizer:
                 u1 = draws.jitter(n, S // 2 if ogm else S).to(dev)
             if ogm:
                 u2 = draws.pdf(n, S // 2).to(dev)
+        # loss normalisers first: in the sharded mode their (2-int) all-reduce is pure latency and runs behind the sampler and
+        # the density forward; it is waited for right before the loss kernel, its first consumer
+        counts = ops.count_opaque(rays, depths, n_rays_dev=n_rays_dev)
+        counts_work = self._dist.all_reduce_counts(counts, async_op=True) if self._dist is not None else None
         if ogm:
             z = ops.sample_rays_occ(rays, self._occupancy_grid.detach(), S, perturb, u_jitter=u1, u_pdf=u2, seed=seed,
                                     n_rays_dev=n_rays_dev)
@@ -412,11 +416,10 @@ class Optimizer:
             z = ops.sample_rays_uniform(rays, S, perturb, u_jitter=u1, seed=seed, n_rays_dev=n_rays_dev)
         if draws is not None and noise_std > 0:
             noise = (draws.noise(n, S) * noise_std).to(dev)
-        counts = ops.count_opaque(rays, depths, n_rays_dev=n_rays_dev)
-        if self._dist is not None:
-            self._dist.all_reduce_counts(counts)
         p = params.detach()
         sigma = ops.density_forward(spec, p, rays=rays, z=z, n_rays_dev=n_rays_dev)
+        if counts_work is not None:
+            counts_work.wait()
         loss, d_sigma, d_rays, stats, _ = ops.los_loss_fused(sigma, z, rays, depths, self._scale_f, self._loss_config(iteration_idx),
                                                             counts, noise=noise, noise_std=noise_std, seed=seed + 1,
                                                             n_rays_dev=n_rays_dev, want_stats=want_stats, loss_out=loss_out)

@@ -39,10 +39,12 @@ class DistContext:
     def owned(self, window: Sequence) -> list:
         return [window[i] for i in shard_window(len(window), self.world_size, self.rank)]
 
-    def all_reduce_counts(self, counts: torch.Tensor) -> torch.Tensor:
-        """counts int32 [2] = {#rays, #opaque} of this rank -> global, in place."""
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group)
-        return counts
+    def all_reduce_counts(self, counts: torch.Tensor, async_op: bool = False):
+        """counts int32 [2] = {#rays, #opaque} of this rank -> global, in place.  With async_op=True the collective's
+        handle is returned instead and the caller `.wait()`s right before the first use: the tiny all-reduce is pure
+        latency and hides behind the sampler and the density forward."""
+        work = dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        return work if async_op else counts
 
     def all_reduce_grads(self, flat: torch.Tensor) -> torch.Tensor:
         """Sum a flat gradient buffer over ranks, in place (one large collective, not per-tensor buckets:
