@@ -249,9 +249,12 @@ class Optimizer:
                 out = self._loss_and_grads(batch["rays"], batch["depths"], sigma_params[0] if sigma_params else
                                            self._model.nerf_model._model_sigma.params, it_idx, want_ray_grads=any_free,
                                            want_param_grads=not os_.freeze_sigma_mlp, n_rays_dev=batch["n_dev"],
-                                           loss_out=loss_log[it_idx], accumulate_into_param_grad=True, want_stats=False)
+                                           loss_out=loss_log[it_idx], accumulate_into_param_grad=True, want_stats=False,
+                                           defer_grad_wait=True)
                 if any_free:
                     self._pose_backward(batch, out["d_rays"], pose_dev, free_rows)
+                if out["grad_work"] is not None:
+                    out["grad_work"].wait()          # sharded mode: the gradient all-reduce ran next to the pose gradient
                 if self._optimizer is not None:
                     for g, lr0 in zip(self._optimizer.param_groups, base_lrs):
                         g['lr'] = lr0 * (gamma ** it_idx)
@@ -389,7 +392,7 @@ class Optimizer:
         return cfg
 
     def _loss_and_grads(self, rays, depths, params, iteration_idx, want_ray_grads, want_param_grads, n_rays_dev=None,
-                        loss_out=None, accumulate_into_param_grad=False, draws=None, want_stats=True):
+                        loss_out=None, accumulate_into_param_grad=False, draws=None, want_stats=True, defer_grad_wait=False):
         """sample -> density -> fused render+loss(+backward) -> density backward.  rays [N,13], depths [N] on device."""
         draws = draws if draws is not None else self._draws
         render = self._model_config.model.render
@@ -424,6 +427,7 @@ class Optimizer:
                                                             counts, noise=noise, noise_std=noise_std, seed=seed + 1,
                                                             n_rays_dev=n_rays_dev, want_stats=want_stats, loss_out=loss_out)
         grad_params = None
+        grad_work = None
         if want_param_grads or want_ray_grads:
             if accumulate_into_param_grad and want_param_grads:
                 if params.grad is None:
@@ -435,10 +439,13 @@ class Optimizer:
             ops.density_backward(spec, p, d_sigma, grad_params, rays=rays, z=z, n_rays_dev=n_rays_dev,
                                  reuse_features=True, d_rays=d_rays if want_ray_grads else None)
             if self._dist is not None and want_param_grads:
-                self._dist.all_reduce_grads(grad_params)
+                grad_work = self._dist.all_reduce_grads(grad_params, async_op=True)
+                if not defer_grad_wait:
+                    grad_work.wait()
+                    grad_work = None
         self._results_lidar = {"rays": rays, "depths": depths, "samples_fine": z, "n_rays_dev": n_rays_dev, "stats": stats}
         return dict(loss=loss, d_rays=d_rays if want_ray_grads else None,
-                    grad_params=grad_params if want_param_grads else None, stats=stats, z=z)
+                    grad_params=grad_params if want_param_grads else None, stats=stats, z=z, grad_work=grad_work)
 
     def compute_loss(self, camera_samples: Tuple[torch.Tensor, torch.Tensor], lidar_samples: Tuple[torch.Tensor, torch.Tensor],
                      iteration_idx: int, override_enables: bool = False, tracking=False) -> torch.Tensor:

@@ -46,11 +46,12 @@ class DistContext:
         work = dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         return work if async_op else counts
 
-    def all_reduce_grads(self, flat: torch.Tensor) -> torch.Tensor:
+    def all_reduce_grads(self, flat: torch.Tensor, async_op: bool = False):
         """Sum a flat gradient buffer over ranks, in place (one large collective, not per-tensor buckets:
-        the whole density gradient is a single 29.7 MB vector)."""
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        return flat
+        the whole density gradient is a single 29.7 MB vector).  async_op=True returns the handle; the training loop
+        waits for it right before the density Adam step, so the pose gradient of this rank runs next to the collective."""
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        return work if async_op else flat
 
     def broadcast_(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
         dist.broadcast(t, src=src, group=self.group)
