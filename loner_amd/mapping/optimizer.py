@@ -58,8 +58,11 @@ class HipAdam(torch.optim.Optimizer):
         super().__init__(param_groups, dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8))
 
     @torch.no_grad()
-    def step(self, zero_grad=True):
-        for group in self.param_groups:
+    def step(self, zero_grad=True, groups=None):
+        """groups: indices of the parameter groups to step (default: all)."""
+        for gi, group in enumerate(self.param_groups):
+            if groups is not None and gi not in groups:
+                continue
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -142,6 +145,7 @@ class Optimizer:
         self._results_lidar = None
         self._depth_eps = None
         self._grad_buf = None
+        self._pending_density = None  # (all-reduce handle or None, group index, lr): density Adam step deferred by the training loop
         self.last_stats = {}
 
     # -------------------------------------------------------------------------------------------
@@ -237,6 +241,7 @@ class Optimizer:
             gamma = float(self._model_config.train.lrate_gamma)
             base_lrs = [g['lr'] for g in groups]
 
+            density_group = 0 if (groups and groups[0]['params'] is sigma_params and not os_.freeze_sigma_mlp) else None
             n_it = os_.num_iterations
             loss_log = torch.zeros(max(n_it, 1), 8, device=self._device)
             valid_log = torch.zeros(max(n_it, 1), device=self._device, dtype=torch.int32)
@@ -253,12 +258,20 @@ class Optimizer:
                                            defer_grad_wait=True)
                 if any_free:
                     self._pose_backward(batch, out["d_rays"], pose_dev, free_rows)
-                if out["grad_work"] is not None:
-                    out["grad_work"].wait()          # sharded mode: the gradient all-reduce ran next to the pose gradient
                 if self._optimizer is not None:
                     for g, lr0 in zip(self._optimizer.param_groups, base_lrs):
                         g['lr'] = lr0 * (gamma ** it_idx)
-                    self._optimizer.step(zero_grad=True)
+                    if density_group is None:
+                        if out["grad_work"] is not None:
+                            out["grad_work"].wait()
+                        self._optimizer.step(zero_grad=True)
+                    else:
+                        # The density step is deferred to just before the next density forward (_flush_density_step): nothing in
+                        # between reads the density parameters - pose gradient and pose step, occupancy step, the next batch's ray
+                        # build, compaction, counts and sampling - so in the sharded mode all of that runs beside the gradient
+                        # all-reduce instead of behind it.  Same arithmetic, same order per parameter group.
+                        self._optimizer.step(zero_grad=True, groups=tuple(i for i in range(len(groups)) if i != density_group))
+                        self._pending_density = (out["grad_work"], density_group, self._optimizer.param_groups[density_group]['lr'])
                 if self.should_enable_lidar() and self._settings.samples_selection.strategy == 'OGM' and \
                         self._global_step % self._model_config.model.occ_model.N_iters_acc == 0:
                     self._step_occupancy_grid()
@@ -268,6 +281,7 @@ class Optimizer:
                 if self._progress_bar is not None:
                     self._progress_bar.update()
 
+            self._flush_density_step()
             # ---- one host sync per phase: checks the reference does every iteration (:368-374,:590) ----
             loss_host = loss_log[:, 0].cpu()
             if n_it and torch.isnan(loss_host).any():
@@ -420,6 +434,7 @@ class Optimizer:
         if draws is not None and noise_std > 0:
             noise = (draws.noise(n, S) * noise_std).to(dev)
         p = params.detach()
+        self._flush_density_step()            # the previous iteration's (deferred) density Adam step lands here
         sigma = ops.density_forward(spec, p, rays=rays, z=z, n_rays_dev=n_rays_dev)
         if counts_work is not None:
             counts_work.wait()
@@ -446,6 +461,17 @@ class Optimizer:
         self._results_lidar = {"rays": rays, "depths": depths, "samples_fine": z, "n_rays_dev": n_rays_dev, "stats": stats}
         return dict(loss=loss, d_rays=d_rays if want_ray_grads else None,
                     grad_params=grad_params if want_param_grads else None, stats=stats, z=z, grad_work=grad_work)
+
+    def _flush_density_step(self):
+        """Apply the density Adam step the training loop deferred (after its gradient all-reduce, if any, has finished)."""
+        if self._pending_density is None:
+            return
+        work, group, lr = self._pending_density
+        self._pending_density = None
+        if work is not None:
+            work.wait()
+        self._optimizer.param_groups[group]['lr'] = lr
+        self._optimizer.step(zero_grad=True, groups=(group,))
 
     def compute_loss(self, camera_samples: Tuple[torch.Tensor, torch.Tensor], lidar_samples: Tuple[torch.Tensor, torch.Tensor],
                      iteration_idx: int, override_enables: bool = False, tracking=False) -> torch.Tensor:
