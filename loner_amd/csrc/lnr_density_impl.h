@@ -51,6 +51,12 @@ __device__ __forceinline__ float act_bwd(float v, int kind) {
     }
 }
 
+// DecoupledNeRF.forward clips non-finite densities (nerf_tcnn.py:74-78: nan_to_num with the dtype's extremes, NaN -> 0)
+__device__ __forceinline__ float finite_or_clipped(float v) {
+    if (__builtin_isfinite(v)) return v;
+    return v != v ? 0.0f : copysignf(3.402823466e+38f, v);
+}
+
 #define MFMA4(acc, a4, b0, b1, b2, b3)                                      \
     do {                                                                    \
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32((a4).x, b0, acc, 0, 0, 0); \
@@ -140,7 +146,7 @@ mlp_forward_kernel(const LnrNetSpec spec, const float* __restrict__ params, cons
         }
         part += __shfl_xor(part, 16, 64);
         part += __shfl_xor(part, 32, 64);
-        if (g == 0 && valid) sigma[m] = part;
+        if (g == 0 && valid) sigma[m] = finite_or_clipped(part);
     }
 }
 
@@ -436,7 +442,7 @@ mlp_forward_relu32_kernel(const LnrNetSpec spec, const float* __restrict__ param
         part += __shfl_xor(part, 16, 64);
         part += __shfl_xor(part, 32, 64);
         const int64_t m = tile * 16 + c;
-        if (g == 0 && m < M) sigma[m] = part;
+        if (g == 0 && m < M) sigma[m] = finite_or_clipped(part);
         cur = nxt;
         tile = nt;
     }

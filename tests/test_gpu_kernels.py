@@ -237,6 +237,24 @@ def test_density_backward_matches_oracle_autograd(ops, name):
     assert rel(grad2, grad) < 1e-6
 
 
+@pytest.mark.parametrize("name", ["default", "freq_siren"])
+def test_density_clips_non_finite_outputs_like_the_reference(ops, name):
+    """nerf_tcnn.py:74-78: non-finite densities are replaced (nan_to_num: NaN -> 0, +-inf -> the dtype's extremes)."""
+    spec_o, spec_h, params = _net(name, seed=1, table_gain=3000.0)
+    gen = torch.Generator().manual_seed(3)
+    pts = torch.rand(500, 3, generator=gen) * 1.9 - 0.95
+    bad = params.clone()
+    h, nh, ind = int(spec_h.n_neurons), int(spec_h.n_hidden), int(spec_h.in_dim)
+    wo = h * ind + (nh - 1) * h * h                     # output layer, row 0 = sigma
+    bad[wo:wo + h] = float("inf")
+    ref = NW.density(spec_o, bad, pts)
+    assert not torch.isfinite(ref).all()                # the oracle (like tinycudann) produces inf / NaN here
+    sig = ops.density_forward(spec_h, dv(bad), pts=dv(pts)).cpu()
+    fmax = torch.finfo(torch.float32).max
+    assert torch.isfinite(sig).all()
+    assert torch.equal(sig, torch.nan_to_num(ref, nan=0.0, posinf=fmax, neginf=-fmax))
+
+
 def test_density_rays_form_equals_points_form(ops, golden):
     g = golden("g4_samplers")
     spec_o, spec_h, params = _net("small_hash", table_gain=3000.0)
