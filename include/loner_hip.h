@@ -265,12 +265,14 @@ int lnr_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq
 
 /* Optimizer._step_occupancy_grid (optimizer.py:598-609): pseudo-gradient per sample
  * (losses.py:54-62) scattered trilinearly into the logit grid, SGD step grid -= lr*grad.
- * grad_buf (nullable [V^3]): if given, the gradient is accumulated there (caller zeroes) and
- * applied by lnr_occ_grid_apply; if NULL the update is applied in place atomically. */
+ * grad_acc (nullable int64 [V^3]): if given, the pseudo-gradient is accumulated there in 64-bit fixed point (2^-42;
+ * caller zeroes; integer atomics: exact, order-independent, and summable over ranks with an integer all-reduce) and
+ * applied by lnr_occ_grid_apply, which re-zeroes what it applied; if NULL the update is applied in place with float
+ * atomics (summation order not fixed). */
 int lnr_occ_grid_step(float* grid, int32_t V, const float* rays, const float* z, const float* depth_gt,
                       int32_t n_rays, const int32_t* n_rays_dev, int32_t n_samples, float scale,
-                      float lr, float margin, float l_free, float l_occ, float* grad_buf, void* stream);
-int lnr_occ_grid_apply(float* grid, float* grad_buf, int64_t count, float lr, int32_t zero_grad, void* stream);
+                      float lr, float margin, float l_free, float l_occ, int64_t* grad_acc, void* stream);
+int lnr_occ_grid_apply(float* grid, int64_t* grad_acc, int64_t count, float lr, int32_t zero_grad, void* stream);
 
 /* ---- self test ------------------------------------------------------------------------------------------ */
 /* Checks the MFMA fragment layout the density kernels rely on; out[0]=max abs error. */

@@ -76,7 +76,7 @@ table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ region
     for (int l = 0; l < spec.n_levels; ++l) {
         const uint64_t lo = (uint64_t)spec.level_offset[l] * F, hi = lo + (uint64_t)spec.level_size[l] * F;   // float range of the level
         const bool dense = hi - lo <= (uint64_t)LNR_DENSE_LEVEL_FLOATS;
-        const bool coherent = !dense && (int)(((hi - 1) >> shift) - (lo >> shift)) + 1 <= LNR_OVF_MAX_SPAN;
+        const bool coherent = !dense && spec.level_hashed[l] == 0;
         const int64_t my_ovf = ovf_off;
         if (coherent) ovf_off += (int64_t)(hi - lo);
         if (hi <= base || lo >= (uint64_t)base + slice) continue;
@@ -186,7 +186,7 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
         const int F = spec->n_features;
         for (int l = 0; l < spec->n_levels; ++l) {
             if (lnr_level_is_dense(spec, l)) { dense_total += (size_t)spec->level_size[l] * F; continue; }
-            if (lnr_level_span(spec, l) <= LNR_OVF_MAX_SPAN) ovf_total += (size_t)spec->level_size[l] * F;
+            if (lnr_level_has_overflow_acc(spec, l)) ovf_total += (size_t)spec->level_size[l] * F;
             const uint64_t lo = (uint64_t)spec->level_offset[l] * F, hi = lo + (uint64_t)spec->level_size[l] * F;
             const int span = (int)(((hi - 1) >> L.shift) - (lo >> L.shift)) + 1;
             if (span > L.maxo) L.maxo = span;

@@ -83,15 +83,12 @@ struct LevelList {
     int slab_off[LNR_MAX_LEVELS];   // dense levels: float offset inside one workgroup's slab;
                                     // record levels: offset of the level's 64-bit overflow accumulators, or -1 (see below)
 };
-// Record levels that span at most this many owner slices are spatially coherent (dense indexing: an owner is a slab of
-// cells), so a workgroup's half-rays pour into two or three owners and routinely exceed the region capacity that the
-// uniform model predicts.  Their overflow goes to 64-bit fixed-point accumulators in the workspace (integer atomics: exact,
-// order-independent) instead of float atomics, which keeps the table gradient bit-reproducible.
-#define LNR_OVF_MAX_SPAN 16
-static inline int lnr_level_span(const LnrNetSpec* s, int l) {
-    const uint64_t lo = (uint64_t)s->level_offset[l] * s->n_features, hi = lo + (uint64_t)s->level_size[l] * s->n_features;
-    return (int)(((hi - 1) >> LNR_SLICE_SHIFT) - (lo >> LNR_SLICE_SHIFT)) + 1;
-}
+// Record levels with dense (non-hashed) indexing are spatially coherent - an owner slice is a slab of cells - so a
+// workgroup's half-rays pour into a few owners and routinely exceed the region capacity that the uniform model predicts.
+// Their overflow goes to 64-bit fixed-point accumulators in the workspace (integer atomics: exact, order-independent)
+// instead of float atomics, which keeps the table gradient bit-reproducible.  (On hashed levels an overflow is a
+// statistical accident.)
+static inline bool lnr_level_has_overflow_acc(const LnrNetSpec* s, int l) { return s->level_hashed[l] == 0; }
 // workgroups per dense level: each pays for zeroing and writing out an LDS copy of the level, so fewer than for the record levels
 static inline int lnr_dense_bpg(int bpg) { return bpg < 512 ? bpg : 512; }
 static inline bool lnr_level_is_dense(const LnrNetSpec* s, int l) {

@@ -570,7 +570,7 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
                 if (nfl > dense_max) dense_max = nfl;
             } else {
                 const int nfl = (int)spec->level_size[l] * spec->n_features;
-                const bool coherent = lnr_level_span(spec, l) <= LNR_OVF_MAX_SPAN;
+                const bool coherent = lnr_level_has_overflow_acc(spec, l);
                 rec_levels.lv[rec_levels.n] = l; rec_levels.slab_off[rec_levels.n] = coherent ? ovf_total : -1; rec_levels.n++;
                 if (coherent) ovf_total += nfl;
             }

@@ -72,7 +72,7 @@ extern "C" int lnr_adam_step(float* params, float* grads, float* exp_avg, float*
 __global__ void __launch_bounds__(256)
 occ_grid_step_kernel(float* __restrict__ grid, int V, const float* __restrict__ rays, const float* __restrict__ z,
                      const float* __restrict__ depth_gt, int n_rays, const int32_t* __restrict__ n_rays_dev, int S, float scale,
-                     float lr, float margin, float l_free, float l_occ, float* __restrict__ grad_buf) {
+                     float lr, float margin, float l_free, float l_occ, long long* __restrict__ grad_acc) {
     const int lane = threadIdx.x & 63;
     const int64_t total = (int64_t)lnr_live_rays(n_rays, n_rays_dev) * S;
     const int64_t n_chunks = (total + 63) / 64;
@@ -117,41 +117,45 @@ occ_grid_step_kernel(float* __restrict__ grid, int V, const float* __restrict__ 
             }
             if (head && inside && v != 0.0f) {
                 const size_t idx = ((size_t)(int)zc * V + (int)yc) * V + (int)xc;
-                if (grad_buf) atomicAdd(grad_buf + idx, v);
+                // 64-bit fixed point (2^-42): integer atomics add exactly, so the step does not depend on the order of the waves
+                if (grad_acc) atomicAdd(reinterpret_cast<unsigned long long*>(grad_acc) + idx, (unsigned long long)__float2ll_rn(v * 4398046511104.0f));
                 else atomicAdd(grid + idx, -lr * v);
             }
         }
     }
 }
 
-__global__ void occ_grid_apply_kernel(float* __restrict__ grid, float* __restrict__ grad, int64_t n, float lr, int zero_grad) {
+__global__ void occ_grid_apply_kernel(float* __restrict__ grid, long long* __restrict__ grad, int64_t n, float lr, int zero_grad) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        grid[i] = grid[i] - lr * grad[i];
-        if (zero_grad) grad[i] = 0.0f;
+        const long long q = grad[i];
+        if (q != 0ll) {
+            grid[i] = grid[i] - lr * (float)((double)q * (1.0 / 4398046511104.0));
+            if (zero_grad) grad[i] = 0ll;
+        }
     }
 }
 
 extern "C" int lnr_occ_grid_step(float* grid, int32_t V, const float* rays, const float* z, const float* depth_gt, int32_t n_rays,
                                  const int32_t* n_rays_dev, int32_t n_samples, float scale, float lr, float margin, float l_free,
-                                 float l_occ, float* grad_buf, void* stream) {
+                                 float l_occ, int64_t* grad_acc, void* stream) {
     LNR_REQUIRE(grid && rays && z && depth_gt && V > 0 && n_rays >= 0 && n_samples > 0, "lnr_occ_grid_step: bad argument");
     const int64_t total = (int64_t)n_rays * n_samples;
     if (total == 0) return LNR_OK;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;
     hipLaunchKernelGGL(occ_grid_step_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, grid, V, rays, z, depth_gt, n_rays,
-                       n_rays_dev, n_samples, scale, lr, margin, l_free, l_occ, grad_buf);
+                       n_rays_dev, n_samples, scale, lr, margin, l_free, l_occ, reinterpret_cast<long long*>(grad_acc));
     LNR_CHECK_LAUNCH("lnr_occ_grid_step");
     return LNR_OK;
 }
 
-extern "C" int lnr_occ_grid_apply(float* grid, float* grad_buf, int64_t count, float lr, int32_t zero_grad, void* stream) {
-    LNR_REQUIRE(grid && grad_buf && count >= 0, "lnr_occ_grid_apply: bad argument");
+extern "C" int lnr_occ_grid_apply(float* grid, int64_t* grad_acc, int64_t count, float lr, int32_t zero_grad, void* stream) {
+    LNR_REQUIRE(grid && grad_acc && count >= 0, "lnr_occ_grid_apply: bad argument");
     if (count == 0) return LNR_OK;
     int64_t blocks = (count + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(occ_grid_apply_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, grid, grad_buf, count, lr, zero_grad);
+    hipLaunchKernelGGL(occ_grid_apply_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, grid, reinterpret_cast<long long*>(grad_acc), count, lr, zero_grad);
     LNR_CHECK_LAUNCH("lnr_occ_grid_apply");
     return LNR_OK;
 }

@@ -500,16 +500,15 @@ class Optimizer:
             raise RuntimeError("_step_occupancy_grid called before compute_loss")
         occ = self._model_config.model.occ_model
         grid = self._occupancy_grid_model.occupancy_grid
+        # the pseudo-gradient is accumulated in 64-bit fixed point (exact integer atomics: the step is reproducible, and in the
+        # sharded mode the ranks' accumulators add up exactly in one integer all-reduce), then applied to the logits
+        if self._grad_buf is None:
+            self._grad_buf = torch.zeros(grid.numel(), device=grid.device, dtype=torch.int64)
+        ops.occ_grid_step(grid.data, res["rays"], res["samples_fine"], res["depths"], self._scale_f, occ.lr,
+                          grad_buf=self._grad_buf, n_rays_dev=res["n_rays_dev"])
         if self._dist is not None:
-            if self._grad_buf is None:
-                self._grad_buf = torch.zeros_like(grid.data)
-            ops.occ_grid_step(grid.data, res["rays"], res["samples_fine"], res["depths"], self._scale_f, occ.lr,
-                              grad_buf=self._grad_buf, n_rays_dev=res["n_rays_dev"])
             self._dist.all_reduce_grads(self._grad_buf)
-            ops.occ_grid_apply(grid.data, self._grad_buf, occ.lr, zero_grad=True)
-        else:
-            ops.occ_grid_step(grid.data, res["rays"], res["samples_fine"], res["depths"], self._scale_f, occ.lr,
-                              n_rays_dev=res["n_rays_dev"])
+        ops.occ_grid_apply(grid.data, self._grad_buf, occ.lr, zero_grad=True)
         self._occupancy_grid = self._occupancy_grid_model()
         self._ray_sampler.update_occ_grid(self._occupancy_grid.detach())
 

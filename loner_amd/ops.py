@@ -378,7 +378,9 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, lr, step, betas=(0.9, 0.999), 
 
 
 def occ_grid_step(grid, rays, z, depth_gt, scale, lr, margin=2.0, l_free=0.25, l_occ=2.5, grad_buf=None, n_rays_dev=None):
+    """grad_buf: int64 [V^3] fixed-point accumulator (see the header) or None for the in-place float-atomic update."""
     require_device(grid, rays, z, depth_gt, grad_buf)
+    assert grad_buf is None or (grad_buf.dtype == torch.int64 and grad_buf.is_contiguous())
     v = grid.shape[-1]
     n, s = z.shape
     check(load().lnr_occ_grid_step(_ptr(grid), v, _ptr(_f32c(rays)), _ptr(_f32c(z)), _ptr(_f32c(depth_gt)), n, _ptr(n_rays_dev),
@@ -388,6 +390,7 @@ def occ_grid_step(grid, rays, z, depth_gt, scale, lr, margin=2.0, l_free=0.25, l
 
 def occ_grid_apply(grid, grad_buf, lr, zero_grad=True):
     require_device(grid, grad_buf)
+    assert grad_buf.dtype == torch.int64 and grad_buf.is_contiguous()
     check(load().lnr_occ_grid_apply(_ptr(grid), _ptr(grad_buf), grid.numel(), float(lr), int(zero_grad), _stream()),
           "lnr_occ_grid_apply")
 

@@ -499,10 +499,15 @@ def test_occ_grid_step_matches_oracle(ops, golden):
     assert float((expect - grid0).abs().max()) > 0
     assert rel(grid.cpu() - grid0, expect - grid0) < 1e-4
     # two-stage form used when the window is sharded
-    grid2, buf = dv(grid0.clone()), torch.zeros(V ** 3, device=DEV)
+    # the form the optimiser uses: 64-bit fixed-point accumulators, then apply - reproducible bit for bit
+    grid2, buf = dv(grid0.clone()), torch.zeros(V ** 3, device=DEV, dtype=torch.int64)
     ops.occ_grid_step(grid2, dv(rays), dv(z), dv(depths), scale, 1e-2, grad_buf=buf)
     ops.occ_grid_apply(grid2, buf, 1e-2)
-    assert rel(grid2.cpu() - grid0, expect - grid0) < 1e-4 and float(buf.abs().max()) == 0.0
+    assert rel(grid2.cpu() - grid0, expect - grid0) < 1e-4 and int(buf.abs().max()) == 0
+    grid3 = dv(grid0.clone())
+    ops.occ_grid_step(grid3, dv(rays), dv(z), dv(depths), scale, 1e-2, grad_buf=buf)
+    ops.occ_grid_apply(grid3, buf, 1e-2)
+    assert torch.equal(grid3, grid2)
 
 
 # ------------------------------------------------------------------------------------------- pose kernels / window build

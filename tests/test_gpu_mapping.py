@@ -311,6 +311,39 @@ def test_checkpoint_round_trip_as_the_mapper_writes_it(tmp_path):
     assert a == b and np.isfinite(a)
 
 
+def test_training_run_is_bit_reproducible():
+    """Same seeds -> same bits: every accumulation that crosses waves (table gradient, weight gradient, ray gradient, occupancy
+    pseudo-gradient, loss terms) is a fixed-order or a 64-bit fixed-point sum, so two runs of the joint map + pose optimisation
+    (incl. two occupancy steps) end with identical parameters, Adam state, poses and occupancy grid.  The reference cannot
+    offer this (tinycudann accumulates with fp16 atomics)."""
+    from loner_amd.common.settings import default_optimizer_settings
+    from loner_amd.mapping.optimizer import OptimizationSettings, Optimizer
+    from loner_amd.utils import synthetic as SY
+
+    def run():
+        s = default_optimizer_settings()
+        s["num_samples"]["sky"] = 0
+        s["num_samples"]["lidar"] = 256
+        s["model_config"]["model"]["render"]["N_samples_train"] = 128
+        torch.manual_seed(0)
+        opt = Optimizer(s, None, world_cube(), 0, False, True, False)
+        base = SY.trajectory_pose6(3)
+        kfs = make_keyframes([base[0], base[1] + torch.tensor([0.02, -0.01, 0.0, 0.0, 0.0, 0.0]), base[2]])
+        kfs[0].is_anchored = True
+        torch.manual_seed(7)
+        opt._do_iterate_optimizer(kfs, [None], optimizer_settings=OptimizationSettings(25, False, False, False, True))
+        p = opt._model.nerf_model._model_sigma.params
+        st = opt._optimizer.state[p]
+        return (p.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(), opt._occupancy_grid_model.occupancy_grid.detach().clone(),
+                torch.stack([kf.get_lidar_pose().get_pose_tensor().detach().cpu() for kf in kfs]), opt.last_stats["loss_terms"].clone())
+
+    a, b = run(), run()
+    names = ["params", "exp_avg", "exp_avg_sq", "occupancy grid", "poses", "loss terms"]
+    for n, x, y in zip(names, a, b):
+        assert torch.equal(x, y), f"{n} differ between two identically seeded runs ({int((x != y).sum())} entries)"
+    assert float((a[3] != 0).sum()) > 0 and float((a[4][1] - a[4][0]).abs().max()) > 0
+
+
 def test_sky_rays_tracking_phase_and_uniform_sampler():
     """The schedule variants around the default path: sky rays (keyframe.py:91-100), the pose-refinement phase
     (latest_kf_only + frozen density net, optimizer.py:239-259) and the UNIFORM sampler / FIXED ray selection."""
