@@ -34,6 +34,9 @@ def parse():
     ap.add_argument("--keyframes", type=int, default=8)
     ap.add_argument("--rays", type=int, default=512)
     ap.add_argument("--samples", type=int, default=512)
+    ap.add_argument("--dtype", choices=["f32", "f16"], default="f32",
+                    help="arithmetic of the density network: f32 (default, stricter than the reference) or f16 "
+                         "(the reference's storage types: fp16 features and weights on MFMA, fp32 accumulation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -169,17 +172,16 @@ def main():
     settings["num_samples"]["lidar"] = args.rays
     settings["num_samples"]["sky"] = 0
     settings["model_config"]["model"]["render"]["N_samples_train"] = args.samples
+    settings["model_config"]["model"]["nerf_config"]["sigma_network"]["precision"] = "fp16" if args.dtype == "f16" else "fp32"
     scale, shift = SY.world_cube()
     torch.manual_seed(0)                                   # identical initial parameters on every rank
     opt = Optimizer(settings, None, WorldCube(torch.tensor(scale), torch.from_numpy(shift)), local, False, True, False)
     window = build_window(args.keyframes)
     if world > 1:
         ctx = DistContext()
-        opt.set_distributed(ctx)
-        my_window = ctx.owned(window)
+        opt.set_distributed(ctx)                           # the optimiser shards the window itself: keyframe i -> rank i mod N
         torch.manual_seed(1000 + rank)                     # different ray draws per rank
-    else:
-        my_window = window
+    my_window = window
     phase = lambda n: OptimizationSettings(n, False, False, False, True)
 
     timer = KernelTimer(ops, ["density_backward", "density_forward", "los_loss_fused", "sample_rays_occ", "adam_step",
@@ -285,7 +287,7 @@ def main():
     line = {
         "metric": "training rays/sec", "value": total_rays / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"mapping iteration, {args.keyframes}-keyframe window x {args.rays} rays x {args.samples} samples, "
                                "default cfg (HashGrid 16x2 T=2^18 -> 64 -> 1, L1_JS loss, OGM sampler), joint map+pose optimisation, "
                                "synthetic 64x1024 scans (stand-in for Fusion Portable canteen, BASELINE configs[1])",

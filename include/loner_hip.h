@@ -45,6 +45,22 @@ typedef enum LnrStatus {
 
 typedef enum LnrEncoding { LNR_ENC_HASHGRID = 0, LNR_ENC_FREQUENCY = 1 } LnrEncoding;
 
+/* Arithmetic of the density network.  The reference runs tinycudann in half precision (fp16 parameters copy, fp16 encoded
+ * features, FullyFusedMLP on tensor cores: cfg/nerf_config/default_nerf_hash.yaml:20-31, src/models/nerf_tcnn.py:35-38).
+ *   LNR_PREC_F32: everything in fp32 (fp32 MFMA = exact fma chains); stricter than the reference, the default.
+ *   LNR_PREC_F16: the reference's storage types - encoded features and MLP weights rounded to fp16, matrix products on
+ *                 v_mfma_f32_16x16x32_f16 with fp32 accumulation (the reference accumulates in fp16), fp32 master
+ *                 parameters and fp32 gradients (the reference: fp16 atomics with a loss scale of 128). */
+typedef enum LnrPrecision { LNR_PREC_F32 = 0, LNR_PREC_F16 = 1 } LnrPrecision;
+
+/* Grid position of the hash-grid lookup, pos = x*scale + 0.5:  LNR_POS_FMA rounds once (tiny-cuda-nn's fmaf, the
+ * default), LNR_POS_MUL_ADD rounds the product and the sum separately (what un-contracted code would do).  The two
+ * differ by one fp32 ulp of pos = 1/32 cell on the finest default level. */
+typedef enum LnrPosRounding { LNR_POS_FMA = 0, LNR_POS_MUL_ADD = 1 } LnrPosRounding;
+
+/* lnr_density_backward flags */
+#define LNR_BWD_TABLE_ATOMICS 1   /* test hook: every table-gradient record takes the global-atomic fallback path */
+
 typedef enum LnrActivation {
     LNR_ACT_NONE = 0, LNR_ACT_RELU = 1, LNR_ACT_SINE = 2, LNR_ACT_LEAKY_RELU = 3,
     LNR_ACT_EXPONENTIAL = 4, LNR_ACT_SIGMOID = 5, LNR_ACT_SQUAREPLUS = 6,
@@ -66,6 +82,8 @@ typedef struct LnrNetSpec {
     int32_t activation;        /* LnrActivation of the hidden layers */
     int32_t n_neurons;         /* hidden width, multiple of 16, <= 256 */
     int32_t n_hidden;          /* hidden layers, >= 1 */
+    int32_t precision;         /* LnrPrecision (0 = fp32) */
+    int32_t pos_rounding;      /* LnrPosRounding (0 = fma) */
     /* -- derived by lnr_net_spec_finalize -- */
     int32_t enc_dim;           /* encoding outputs */
     int32_t in_dim;            /* enc_dim rounded up to 16 (padding inputs are the constant 1) */
@@ -119,7 +137,8 @@ int lnr_density_forward(const LnrNetSpec* spec /*host*/, const float* params,
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* Backward of the above                     replaces tinycudann backward (loss.backward(), optimizer.py:366)
- * grad_params [n_params] is ACCUMULATED into (caller zeroes it; lnr_adam_step can re-zero it).
+ * grad_params [n_params] is ACCUMULATED into (caller zeroes it; lnr_adam_step can re-zero it); NULL = parameters frozen
+ * (tracking phase, optimizer.py:239-259): only the input gradient is computed, no table-gradient records, no reduce.
  * d_pts (nullable) [*,3] receives dL/dxyz per point (needed only when poses are optimised).
  * d_rays (nullable, rays form only, instead of d_pts) [n_rays,13]: dL/dxyz is reduced over the samples of each ray and
  * ADDED to the ray-record gradient (origin cols 0:3 += sum dL/dxyz, direction cols 3:6 += sum z dL/dxyz) - what
@@ -131,7 +150,7 @@ int lnr_density_backward(const LnrNetSpec* spec /*host*/, const float* params,
                          const float* rays, const float* z, int32_t n_rays, int32_t n_samples,
                          const int32_t* n_rays_dev,
                          const float* d_sigma, float* grad_params, float* d_pts, float* d_rays,
-                         int32_t reuse_features, void* workspace, size_t workspace_bytes, void* stream);
+                         int32_t reuse_features, int32_t flags, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- rays ------------------------------------------------------------------------------------- */
 /* LidarRayDirections.build_lidar_rays (ray_utils.py:269-322) + get_far_val (:31-60) for one
@@ -238,7 +257,9 @@ int lnr_logits_grad(const float* s /*[n,S]*/, const float* g /*[n]*/, int32_t n_
  * render (as lnr_render_forward), weighted mean/var, JS divergence (:476-482,:614-626), dynamic
  * margin (:495-503), target weights (:504-506), depth MSE + LOS L1/L2 + opacity terms, then the
  * analytic backward to d_sigma [n,S] and the direct part of d_rays [n,13] (overwritten).
- * Reproduces the reference's `depth > far[0]` broadcast quirk (:460-461).
+ * Reproduces the reference's `depth > far[0]` broadcast quirk (:460-461): every ground-truth depth is compared with the
+ * `far` of the FIRST ray of the batch.  far0_dev (nullable, device float[1]): that value when this call sees only a shard
+ * of the batch (keyframe-sharded window: rank 0's first ray, broadcast by the caller); NULL = this call's own first ray.
  * counts_dev [2] int32: {number of rays, number of opaque rays} over the WHOLE batch the loss is
  * normalised by (all GPUs) -- from lnr_count_opaque, all-reduced by the caller when sharded.
  * loss_out [8] float (accumulated; caller zeroes): {total, depth, los, opacity, sum of eps, -,-,-};
@@ -247,11 +268,11 @@ int lnr_logits_grad(const float* s /*[n,S]*/, const float* g /*[n]*/, int32_t n_
  * ray_stats (nullable) [n,8]: {depth, opacity, variance, mean_m, std_m, js, eps, opaque}.
  * weights_out (nullable) [n,S]. */
 int lnr_count_opaque(const float* rays, const float* depth_gt, int32_t n_rays, const int32_t* n_rays_dev,
-                     int32_t* counts_dev /*[2], overwritten*/, void* stream);
+                     const float* far0_dev, int32_t* counts_dev /*[2], overwritten*/, void* stream);
 int lnr_los_loss_fused(const float* sigma, const float* z, const float* rays, const float* depth_gt,
                        int32_t n_rays, const int32_t* n_rays_dev, int32_t n_samples,
                        const float* noise, float noise_std, uint64_t seed,
-                       float scale, const LnrLossConfig* cfg /*host*/, const int32_t* counts_dev,
+                       float scale, const LnrLossConfig* cfg /*host*/, const int32_t* counts_dev, const float* far0_dev,
                        float* loss_out, float* d_sigma, float* d_rays, float* ray_stats,
                        float* weights_out, float* block_partials, void* stream);
 
@@ -275,8 +296,9 @@ int lnr_occ_grid_step(float* grid, int32_t V, const float* rays, const float* z,
 int lnr_occ_grid_apply(float* grid, int64_t* grad_acc, int64_t count, float lr, int32_t zero_grad, void* stream);
 
 /* ---- self test ------------------------------------------------------------------------------------------ */
-/* Checks the MFMA fragment layout the density kernels rely on; out[0]=max abs error. */
-int lnr_selftest_mfma(float* out /*[1]*/, void* stream);
+/* Checks the MFMA fragment layouts the density kernels rely on (v_mfma_f32_16x16x4_f32 and v_mfma_f32_16x16x32_f16,
+ * asymmetric operands); out[0] = max abs error of the fp32 form, out[1] = of the fp16 form. */
+int lnr_selftest_mfma(float* out /*[2]*/, void* stream);
 
 #ifdef __cplusplus
 }

@@ -228,6 +228,14 @@ static int check_spec(const LnrNetSpec* spec, const char* who) {
     return LNR_OK;
 }
 
+// LNR_PREC_F16 is implemented for the reference's sigma network shape class; anything else must say so, not fall back
+static int check_f16(const LnrNetSpec* spec, const char* who) {
+    if (spec->precision != LNR_PREC_F16 || lnr_f16_supported(spec)) return LNR_OK;
+    lnr_set_error("%s: precision fp16 is implemented for HashGrid (16 levels x 2 features) -> <= 64 ReLU neurons x 1 hidden layer -> 1; "
+                  "use precision fp32 for this network", who);
+    return LNR_ERR_UNSUPPORTED;
+}
+
 static size_t fwd_lds(const LnrNetSpec* s, int w_lds) { return ((w_lds ? (size_t)s->n_mlp_params : 0) + 4) * sizeof(float); }
 static size_t bwd_lds(const LnrNetSpec* s, int w_lds, int waves, int dw64) {
     const size_t H = s->n_neurons;
@@ -315,6 +323,9 @@ extern "C" int lnr_density_forward(const LnrNetSpec* spec, const float* params, 
         lnr_set_error("lnr_density_forward: workspace %zu < %zu (lnr_density_workspace)", workspace_bytes, L.total);
         return LNR_ERR_WORKSPACE;
     }
+    const bool f16 = spec->precision == LNR_PREC_F16;
+    rc = check_f16(spec, "lnr_density_forward");
+    if (rc) return rc;
     DensityPlan plan;
     rc = plan_launch(spec, cap, false, &plan, "lnr_density_forward");
     if (rc) return rc;
@@ -322,11 +333,17 @@ extern "C" int lnr_density_forward(const LnrNetSpec* spec, const float* params, 
     float* feat = (float*)((char*)workspace + L.off_feat);
     {
         LnrProfScope prof("encode_forward", st);
-        rc = lnr_encode_forward(spec, params, &src, cap, feat, L.m_pad, st);
+        rc = lnr_encode_forward(spec, params, &src, cap, feat, L.m_pad, f16, st);
     }
     if (rc) return rc;
     LNR_CHECK_LAUNCH("lnr_density_forward(encode)");
     LnrProfScope prof_mlp("mlp_forward", st);
+    if (f16) {
+        rc = lnr_mlp_fwd_f16(spec, params, feat, L.m_pad, &mp, sigma, st);
+        if (rc) return rc;
+        LNR_CHECK_LAUNCH("lnr_density_forward(mlp f16)");
+        return LNR_OK;
+    }
     switch (spec->n_neurons / 16) {
         case 1: rc = lnr_mlp_fwd_ht1(spec, params, feat, L.m_pad, &mp, sigma, &plan, st); break;
         case 2: rc = lnr_mlp_fwd_ht2(spec, params, feat, L.m_pad, &mp, sigma, &plan, st); break;
@@ -342,7 +359,7 @@ extern "C" int lnr_density_forward(const LnrNetSpec* spec, const float* params, 
 extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params, const float* pts, int64_t n_points,
                                     const float* rays, const float* z, int32_t n_rays, int32_t n_samples,
                                     const int32_t* n_rays_dev, const float* d_sigma, float* grad_params, float* d_pts, float* d_rays,
-                                    int32_t reuse_features, void* workspace, size_t workspace_bytes, void* stream) {
+                                    int32_t reuse_features, int32_t flags, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_spec(spec, "lnr_density_backward");
     if (rc) return rc;
     if (n_points == 0 && (pts != nullptr || n_rays == 0)) return LNR_OK;          // empty batch: nothing to do, nothing to check
@@ -351,7 +368,8 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     if (rc) return rc;
     const int64_t cap = mp.n_points;
     if (cap == 0) return LNR_OK;
-    LNR_REQUIRE(params && d_sigma && grad_params && workspace, "lnr_density_backward: null argument");
+    LNR_REQUIRE(params && d_sigma && workspace, "lnr_density_backward: null argument");
+    LNR_REQUIRE(grad_params || d_pts || d_rays, "lnr_density_backward: nothing to compute (no grad_params, d_pts or d_rays)");
     LNR_REQUIRE(cap * (spec->n_features > 4 ? spec->n_features : 4) < (1ll << 30),
                 "lnr_density_backward: too many points per call for 32-bit plane offsets (n_points * max(n_features, 4) must be < 2^30)");
     const Layout L = make_layout(spec, cap);
@@ -373,14 +391,17 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     int* counts = (int*)(ws + L.off_counts);
     void* regions = (void*)(ws + L.off_regions);
     const bool hash = spec->encoding == LNR_ENC_HASHGRID;
-    // test hook: LNR_TABLE_GRAD_ATOMICS=1 sends every record down the global-atomic fallback path (same result, ~20x slower);
+    // test hook: LNR_BWD_TABLE_ATOMICS sends every record down the global-atomic fallback path (same result, ~20x slower);
     // the tests use it as an independent implementation of the record partition
-    const char* env_atomics = getenv("LNR_TABLE_GRAD_ATOMICS");
-    const int cap_rec = (env_atomics && env_atomics[0] == '1') ? 0 : L.cap;
+    const int cap_rec = (flags & LNR_BWD_TABLE_ATOMICS) ? 0 : L.cap;
+    const bool f16 = spec->precision == LNR_PREC_F16;
+    rc = check_f16(spec, "lnr_density_backward");
+    if (rc) return rc;
+    const bool want_grad = grad_params != nullptr;
 
     if (!reuse_features) {
         LnrProfScope prof("encode_forward", st);
-        rc = lnr_encode_forward(spec, params, &src, cap, feat, L.m_pad, st);
+        rc = lnr_encode_forward(spec, params, &src, cap, feat, L.m_pad, f16, st);
         if (rc) return rc;
         LNR_CHECK_LAUNCH("lnr_density_backward(encode)");
     }
@@ -392,10 +413,12 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     const bool ray_accum = d_rays != nullptr && hash && (n_samples % 64 == 0);
     float* d_pts_eff = d_pts;
     if (d_rays && !ray_accum) d_pts_eff = (float*)(ws + L.off_dpts);
-    const int want_dfeat = (hash || d_pts_eff != nullptr) ? 1 : 0;
+    const int want_dfeat = ((hash && want_grad) || d_pts_eff != nullptr || ray_accum) ? 1 : 0;
+    int n_slabs = plan.grid;
     {
     LnrProfScope prof("mlp_backward", st);
-    switch (spec->n_neurons / 16) {
+    if (f16) rc = lnr_mlp_bwd_f16(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &n_slabs, st);
+    else switch (spec->n_neurons / 16) {
         case 1: rc = lnr_mlp_bwd_ht1(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &plan, st); break;
         case 2: rc = lnr_mlp_bwd_ht2(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &plan, st); break;
         case 4: rc = lnr_mlp_bwd_ht4(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &plan, st); break;
@@ -405,9 +428,10 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     }
     if (rc) return rc;
     LNR_CHECK_LAUNCH("lnr_density_backward(mlp)");
-    float* grad_table = grad_params + spec->n_mlp_params;
+    float* grad_table = want_grad ? grad_params + spec->n_mlp_params : nullptr;
     if (want_dfeat) {
-        rc = lnr_encode_backward(spec, params, &src, cap, dfeat, dxl, L.m_pad, grad_table, regions, counts, dense_slabs, L.bpg, L.maxo, cap_rec, L.shift,
+        rc = lnr_encode_backward(spec, params, &src, cap, dfeat, dxl, L.m_pad, grad_table, want_grad ? regions : nullptr, counts,
+                                 want_grad ? dense_slabs : nullptr, L.bpg, L.maxo, cap_rec, L.shift,
                                  ovf, d_pts_eff, ray_accum ? d_rays : nullptr, (long long*)(ws + L.off_rayacc), st);
         if (rc) return rc;
         LNR_CHECK_LAUNCH("lnr_density_backward(encode backward)");
@@ -416,6 +440,7 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
         rc = lnr_points_grad_to_rays(d_pts_eff, z, n_rays, n_rays_dev, n_samples, d_rays, stream);
         if (rc) return rc;
     }
+    if (!want_grad) return LNR_OK;       // frozen parameters: no table reduce, no weight-gradient fold
     if (hash && L.nown > 0) {          // also with cap_rec == 0 (all-atomic test path): it folds in the overflow accumulators
         const size_t lds = ((size_t)1 << L.shift) * sizeof(long long);
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(table_grad_reduce2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -433,7 +458,7 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     }
     const int n_mlp = spec->n_mlp_params;
     LnrProfScope prof_slabs("reduce_slabs", st);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(lnr_div_up(n_mlp, 64)), dim3(64 * LNR_SLAB_GROUPS), 0, st, slabs, plan.grid, n_mlp, grad_params);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(lnr_div_up(n_mlp, 64)), dim3(64 * LNR_SLAB_GROUPS), 0, st, slabs, n_slabs, n_mlp, grad_params);
     LNR_CHECK_LAUNCH("lnr_density_backward(reduce)");
     return LNR_OK;
 }
@@ -465,6 +490,7 @@ __global__ void selftest_mfma_kernel(float* out) {
 extern "C" int lnr_selftest_mfma(float* out, void* stream) {
     LNR_REQUIRE(out != nullptr, "lnr_selftest_mfma: null out");
     hipLaunchKernelGGL(selftest_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out);
+    lnr_selftest_mfma_f16(out, (hipStream_t)stream);
     LNR_CHECK_LAUNCH("lnr_selftest_mfma");
     return LNR_OK;
 }

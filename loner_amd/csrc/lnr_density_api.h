@@ -97,7 +97,15 @@ static inline bool lnr_level_is_dense(const LnrNetSpec* s, int l) {
 
 // level-major encoding (lnr_encode.hip)
 int lnr_encode_forward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, float* feat,
-                       int64_t m_pad, hipStream_t st);
+                       int64_t m_pad, bool half_planes, hipStream_t st);
+
+// fp16-storage MLP kernels (lnr_density_f16.hip): features arrive as half2 planes [level][m_pad]
+bool lnr_f16_supported(const LnrNetSpec* spec);
+int lnr_mlp_fwd_f16(const LnrNetSpec* spec, const float* params, const void* featp, int64_t m_pad, const MlpPoints* pt, float* sigma,
+                    hipStream_t st);
+int lnr_mlp_bwd_f16(const LnrNetSpec* spec, const float* params, const void* featp, int64_t m_pad, const MlpPoints* pt, const float* d_sigma,
+                    float* dfeat, float* slabs, int want_dfeat, int* n_slabs, hipStream_t st);
+int lnr_selftest_mfma_f16(float* out, hipStream_t st);
 int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, const float* dfeat,
                         float* dxl, int64_t m_pad, float* grad_table, void* regions, int* counts, float* dense_slabs, int bpg,
                         int maxo, int cap, int shift, long long* ovf, float* d_pts, float* d_rays_acc, long long* ray_acc, hipStream_t st);

@@ -35,19 +35,23 @@ __device__ __forceinline__ void gather_entries(const float* __restrict__ table, 
     }
 }
 
-template <int F>
+// H16: the features leave as half2 pairs (F == 2: one dword per sample and level) for the fp16 MLP kernels
+// (lnr_density_f16.hip), rounded to nearest even; the interpolation itself stays fp32.
+template <int F, bool H16>
 __global__ void __launch_bounds__(ENC_BLOCK)
 encode_forward_kernel(const LnrNetSpec spec, const float* __restrict__ table, const PointSrc src, float* __restrict__ feat,
                       int64_t m_pad, int bpg) {
+    static_assert(!H16 || F == 2, "half2 planes hold one level of two features per dword");
     const int lv = blockIdx.x / bpg, chunk = blockIdx.x % bpg;
     const LevelInfo L = level_info(spec, lv);
     const uint32_t M = (uint32_t)live_points(src);
-    const uint32_t M16 = (M + 15u) / 16u * 16u;      // the MLP kernels read whole 16-sample tiles: zero the ragged tail
-    float* planes = feat + (size_t)(lv * F) * m_pad;
+    // the MLP kernels read whole tiles of 16 (fp32) / 32 (fp16) samples: zero the ragged tail
+    const uint32_t Mt = H16 ? (M + 31u) / 32u * 32u : (M + 15u) / 16u * 16u;
+    float* planes = feat + (size_t)(H16 ? lv : lv * F) * m_pad;
     const uint32_t plane_bytes = (uint32_t)m_pad * 4u;
     SampleCursor cur;
     cur.init((uint32_t)chunk * ENC_BLOCK + threadIdx.x, (uint32_t)bpg * ENC_BLOCK, src.pts ? 1u : (uint32_t)src.n_samples);
-    for (; cur.m < M16; cur.advance()) {
+    for (; cur.m < Mt; cur.advance()) {
         float out[F];
 #pragma unroll
         for (int f = 0; f < F; ++f) out[f] = 0.0f;
@@ -66,8 +70,13 @@ encode_forward_kernel(const LnrNetSpec spec, const float* __restrict__ table, co
 #pragma unroll
                 for (int f = 0; f < F; ++f) out[f] += w[k] * tv[k][f];
         }
+        if constexpr (H16) {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            st32<uint32_t>(planes, cur.m * 4u, __builtin_bit_cast(uint32_t, h2{(_Float16)out[0], (_Float16)out[1]}));
+        } else {
 #pragma unroll
-        for (int f = 0; f < F; ++f) st32<float>(planes, (uint32_t)f * plane_bytes + cur.m * 4u, out[f]);
+            for (int f = 0; f < F; ++f) st32<float>(planes, (uint32_t)f * plane_bytes + cur.m * 4u, out[f]);
+        }
     }
 }
 
@@ -233,8 +242,9 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
     const float* gplanes = dfeat + (size_t)(lv * F) * m_pad;
     float* dxplanes = dxl + (size_t)(lv * 3) * m_pad;
     const uint32_t plane_bytes = (uint32_t)m_pad * 4u;
+    const bool emit = sink.regions != nullptr;                // false: parameters frozen, only the input gradient is wanted
     if (M == 0u) {                                            // workgroup-uniform
-        for (int i = threadIdx.x; i < maxo; i += ENC_BLOCK) sink.counts[region0 + i * region_step] = 0;
+        if (emit) for (int i = threadIdx.x; i < maxo; i += ENC_BLOCK) sink.counts[region0 + i * region_step] = 0;
         return;
     }
 
@@ -288,7 +298,7 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
             if (combine) cell_runs(c, lane, head, run);
         }
 #pragma unroll
-        for (int pass = 0; pass < NPASS; ++pass) {
+        for (int pass = 0; pass < (emit ? NPASS : 0); ++pass) {
             // ---- A: this thread's records of the batch; rank within the owner's bucket from an LDS histogram
             float rv0[8], rv1[8]; int rrank[8];
 #pragma unroll
@@ -390,8 +400,9 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < maxo; i += ENC_BLOCK)
-        sink.counts[region0 + i * region_step] = gcur[i] < sink.cap ? gcur[i] : sink.cap;
+    if (emit)
+        for (int i = threadIdx.x; i < maxo; i += ENC_BLOCK)
+            sink.counts[region0 + i * region_step] = gcur[i] < sink.cap ? gcur[i] : sink.cap;
 }
 
 // Dense levels (lnr_density_api.h): the workgroup sums its samples' corner updates in an LDS copy of the level's
@@ -442,7 +453,7 @@ encode_backward_dense_kernel(const LnrNetSpec spec, const float* __restrict__ ta
             bool head; RunMask run;
             cell_runs(c, lane, head, run);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < (slabs ? 8 : 0); ++k) {          // slabs == nullptr: parameters frozen, input gradient only
                 const uint32_t el = e[k] * F - level_base;
 #pragma unroll
                 for (int f = 0; f < F; ++f) {
@@ -465,6 +476,7 @@ encode_backward_dense_kernel(const LnrNetSpec spec, const float* __restrict__ ta
         }
     }
     __syncthreads();
+    if (slabs == nullptr) return;
     float* slab = slabs + (size_t)chunk * dense_total + list.slab_off[slot];
     for (int i = threadIdx.x; i < nfl; i += ENC_BLOCK) slab[i] = (float)((double)dacc[i] * (1.0 / (double)LNR_FIX_SCALE));
 }
@@ -524,7 +536,7 @@ sum_dx_planes_kernel(const float* __restrict__ dxl, int n_groups, int64_t m_pad,
 
 // ------------------------------------------------------------------------------------------------ host launchers
 int lnr_encode_forward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, float* feat,
-                       int64_t m_pad, hipStream_t st) {
+                       int64_t m_pad, bool half_planes, hipStream_t st) {
     const float* table = params + spec->n_mlp_params;
     const bool hash = spec->encoding == LNR_ENC_HASHGRID;
     const int n_groups = hash ? spec->n_levels : (spec->enc_dim + 3) / 4;
@@ -533,14 +545,20 @@ int lnr_encode_forward(const LnrNetSpec* spec, const float* params, const PointS
     if (bpg > 2048) bpg = 2048;
     const dim3 grid((unsigned)(n_groups * bpg)), block(ENC_BLOCK);
     if (!hash) {
+        if (half_planes) { lnr_set_error("fp16 feature planes are implemented for the hash-grid encoding"); return LNR_ERR_UNSUPPORTED; }
         hipLaunchKernelGGL(freq_forward_kernel, grid, block, 0, st, *spec, *src, feat, m_pad, (int)bpg);
         return LNR_OK;
     }
+    if (half_planes) {
+        if (spec->n_features != 2) { lnr_set_error("fp16 feature planes need n_features_per_level == 2"); return LNR_ERR_UNSUPPORTED; }
+        hipLaunchKernelGGL((encode_forward_kernel<2, true>), grid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg);
+        return LNR_OK;
+    }
     switch (spec->n_features) {
-        case 1: hipLaunchKernelGGL(encode_forward_kernel<1>, grid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg); break;
-        case 2: hipLaunchKernelGGL(encode_forward_kernel<2>, grid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg); break;
-        case 4: hipLaunchKernelGGL(encode_forward_kernel<4>, grid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg); break;
-        default: hipLaunchKernelGGL(encode_forward_kernel<8>, grid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg); break;
+        case 1: hipLaunchKernelGGL((encode_forward_kernel<1, false>), grid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg); break;
+        case 2: hipLaunchKernelGGL((encode_forward_kernel<2, false>), grid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg); break;
+        case 4: hipLaunchKernelGGL((encode_forward_kernel<4, false>), grid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg); break;
+        default: hipLaunchKernelGGL((encode_forward_kernel<8, false>), grid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg); break;
     }
     return LNR_OK;
 }
@@ -597,7 +615,7 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
         }
         if (rec_levels.n > 0) {
             EncSink sink;
-            if (ovf_total > 0 && hipMemsetAsync(ovf, 0, (size_t)ovf_total * sizeof(long long), st) != hipSuccess) {
+            if (regions != nullptr && ovf_total > 0 && hipMemsetAsync(ovf, 0, (size_t)ovf_total * sizeof(long long), st) != hipSuccess) {
                 lnr_set_error("lnr_density_backward: hipMemsetAsync failed");
                 return LNR_ERR_LAUNCH;
             }
@@ -615,7 +633,7 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
             LnrProfScope prof("encode_backward_dense", st);
             const size_t lds = (size_t)dense_max * sizeof(long long);
             LNR_LAUNCH_F(encode_backward_dense_kernel, *spec, table, *src, dfeat, dx_out, m_pad, dbpg, dense_levels, dense_slabs, dense_total);
-            hipLaunchKernelGGL(dense_slab_reduce_kernel, dim3((unsigned)((dense_max + ENC_BLOCK - 1) / ENC_BLOCK), (unsigned)dense_levels.n), block, 0, st,
+            if (dense_slabs != nullptr) hipLaunchKernelGGL(dense_slab_reduce_kernel, dim3((unsigned)((dense_max + ENC_BLOCK - 1) / ENC_BLOCK), (unsigned)dense_levels.n), block, 0, st,
                                *spec, dense_levels, dense_slabs, dbpg, dense_total, grad_table);
         }
 #undef LNR_LAUNCH_F

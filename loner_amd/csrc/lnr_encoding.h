@@ -86,6 +86,7 @@ struct LevelInfo {
     float scale;
     uint32_t res, size, offset;     // entries
     bool hashed, pow2;
+    bool pos_fma;                   // grid position rounded once (tiny-cuda-nn's fmaf) or as separate multiply and add
 };
 
 __device__ __forceinline__ LevelInfo level_info(const LnrNetSpec& spec, int lv) {
@@ -96,6 +97,7 @@ __device__ __forceinline__ LevelInfo level_info(const LnrNetSpec& spec, int lv) 
     L.offset = __builtin_amdgcn_readfirstlane(spec.level_offset[lv]);
     L.hashed = (__builtin_amdgcn_readfirstlane(spec.level_hashed[lv]) & 1u) != 0u;
     L.pow2 = (L.size & (L.size - 1u)) == 0u;
+    L.pos_fma = __builtin_amdgcn_readfirstlane(spec.pos_rounding) == LNR_POS_FMA;
     return L;
 }
 
@@ -108,7 +110,7 @@ __device__ __forceinline__ Cell cell_of(const LevelInfo& L, const float x[3]) {
     Cell c;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        const float pos = lnr_add_rn(lnr_mul_rn(x[d], L.scale), 0.5f);
+        const float pos = L.pos_fma ? __builtin_fmaf(x[d], L.scale, 0.5f) : lnr_add_rn(lnr_mul_rn(x[d], L.scale), 0.5f);
         const float fl = floorf(pos);
         c.frac[d] = pos - fl;
         c.b[d] = (uint32_t)(int32_t)fl;

@@ -231,14 +231,16 @@ __device__ __forceinline__ void los_loss_ray(const float* __restrict__ sigma, co
                                              const float* __restrict__ depth_gt, int S, const float* __restrict__ noise, float noise_std,
                                              uint64_t seed, float scale, const LnrLossConfig& cfg, const int32_t* __restrict__ counts,
                                              float* terms, bool terms_atomic, float* __restrict__ d_sigma, float* __restrict__ d_rays,
-                                             float* __restrict__ ray_stats, float* __restrict__ weights_out, int ray, int lane) {
+                                             float* __restrict__ ray_stats, float* __restrict__ weights_out, int ray, int lane,
+                                             const float* __restrict__ far0_dev) {
     const float* rr = rays + (size_t)ray * LNR_RAY_STRIDE;
     RayState<C> st;
     render_ray<C>(st, sigma, z, noise, noise_std, seed, ray, S, lane, rr);
 
-    // masks, incl. the reference's broadcast quirk: every depth is compared with far of ray 0
+    // masks, incl. the reference's broadcast quirk: every depth is compared with far of ray 0 - of the WHOLE batch, which a
+    // sharded caller passes in far0_dev (rank 0's first ray); a single-GPU batch reads its own first ray
     const float dgt = depth_gt[ray];
-    const float far0 = rays[12];
+    const float far0 = far0_dev ? far0_dev[0] : rays[12];
     const bool opaque = (dgt > 0.0f) && !(dgt > far0);
     const float g = dgt * scale;                       // metres
     const float n_all = (float)counts[0] * (float)S;
@@ -321,7 +323,7 @@ los_loss_fused_kernel(const float* __restrict__ sigma, const float* __restrict__
                       const float* __restrict__ noise, float noise_std, uint64_t seed, float scale, const LnrLossConfig cfg,
                       const int32_t* __restrict__ counts, float* __restrict__ loss_out, float* __restrict__ d_sigma,
                       float* __restrict__ d_rays, float* __restrict__ ray_stats, float* __restrict__ weights_out,
-                      float* __restrict__ block_partials) {
+                      float* __restrict__ block_partials, const float* __restrict__ far0_dev) {
     // Loss terms: 20 k same-address float atomics (5 per ray) serialise in one L2 channel and cost ~0.25 ms - more than
     // the rest of the kernel.  With block_partials each workgroup stores its 5 sums and loss_reduce_kernel adds them up.
     __shared__ float s_terms[RAYS_PER_BLOCK][5];
@@ -331,7 +333,7 @@ los_loss_fused_kernel(const float* __restrict__ sigma, const float* __restrict__
     if (block_partials) {
         if (lane < 5) s_terms[threadIdx.x >> 6][lane] = 0.0f;
         if (alive) los_loss_ray<C>(sigma, z, rays, depth_gt, S, noise, noise_std, seed, scale, cfg, counts, s_terms[threadIdx.x >> 6], false,
-                                   d_sigma, d_rays, ray_stats, weights_out, ray, lane);
+                                   d_sigma, d_rays, ray_stats, weights_out, ray, lane, far0_dev);
         __syncthreads();
         if (threadIdx.x < 8) {
             float v = 0.0f;
@@ -340,7 +342,7 @@ los_loss_fused_kernel(const float* __restrict__ sigma, const float* __restrict__
         }
     } else if (alive) {
         los_loss_ray<C>(sigma, z, rays, depth_gt, S, noise, noise_std, seed, scale, cfg, counts, loss_out, true,
-                        d_sigma, d_rays, ray_stats, weights_out, ray, lane);
+                        d_sigma, d_rays, ray_stats, weights_out, ray, lane, far0_dev);
     }
 }
 
@@ -356,10 +358,11 @@ __global__ void loss_reduce_kernel(const float* __restrict__ block_partials, int
 }
 
 __global__ void count_opaque_kernel(const float* __restrict__ rays, const float* __restrict__ depth_gt, int n_rays,
-                                    const int32_t* __restrict__ n_rays_dev, int32_t* __restrict__ counts) {
+                                    const int32_t* __restrict__ n_rays_dev, int32_t* __restrict__ counts,
+                                    const float* __restrict__ far0_dev) {
     __shared__ int partial[16];
     const int n = lnr_live_rays(n_rays, n_rays_dev);
-    const float far0 = n > 0 ? rays[12] : 0.0f;
+    const float far0 = far0_dev ? far0_dev[0] : (n > 0 ? rays[12] : 0.0f);
     int c = 0;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const float d = depth_gt[i];
@@ -479,17 +482,19 @@ extern "C" int lnr_render_backward(const float* sigma, const float* z, const flo
 }
 
 extern "C" int lnr_count_opaque(const float* rays, const float* depth_gt, int32_t n_rays, const int32_t* n_rays_dev,
-                                int32_t* counts_dev, void* stream) {
-    LNR_REQUIRE(rays && depth_gt && counts_dev && n_rays >= 0, "lnr_count_opaque: bad argument");
-    hipLaunchKernelGGL(count_opaque_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, rays, depth_gt, n_rays, n_rays_dev, counts_dev);
+                                const float* far0_dev, int32_t* counts_dev, void* stream) {
+    LNR_REQUIRE(counts_dev && n_rays >= 0 && (n_rays == 0 || (rays && depth_gt)), "lnr_count_opaque: bad argument");
+    hipLaunchKernelGGL(count_opaque_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, rays, depth_gt, n_rays, n_rays_dev, counts_dev,
+                       far0_dev);
     LNR_CHECK_LAUNCH("lnr_count_opaque");
     return LNR_OK;
 }
 
 extern "C" int lnr_los_loss_fused(const float* sigma, const float* z, const float* rays, const float* depth_gt, int32_t n_rays,
                                   const int32_t* n_rays_dev, int32_t n_samples, const float* noise, float noise_std, uint64_t seed,
-                                  float scale, const LnrLossConfig* cfg, const int32_t* counts_dev, float* loss_out, float* d_sigma,
-                                  float* d_rays, float* ray_stats, float* weights_out, float* block_partials, void* stream) {
+                                  float scale, const LnrLossConfig* cfg, const int32_t* counts_dev, const float* far0_dev, float* loss_out,
+                                  float* d_sigma, float* d_rays, float* ray_stats, float* weights_out, float* block_partials,
+                                  void* stream) {
     LNR_REQUIRE(sigma && z && rays && depth_gt && cfg && counts_dev && loss_out && d_sigma && d_rays, "lnr_los_loss_fused: null argument");
     LNR_REQUIRE(cfg->selection >= 0 && cfg->selection <= 3, "lnr_los_loss_fused: unknown loss selection %d", cfg->selection);
     LNR_REQUIRE(n_rays >= 0 && n_samples >= 2, "lnr_los_loss_fused: bad sizes");
@@ -498,7 +503,7 @@ extern "C" int lnr_los_loss_fused(const float* sigma, const float* z, const floa
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_C(n_samples, hipLaunchKernelGGL(los_loss_fused_kernel<C>, grid, block, 0, st, sigma, z, rays, depth_gt, n_rays, n_rays_dev,
                                              n_samples, noise, noise_std, seed, scale, *cfg, counts_dev, loss_out, d_sigma, d_rays,
-                                             ray_stats, weights_out, block_partials));
+                                             ray_stats, weights_out, block_partials, far0_dev));
     LNR_CHECK_LAUNCH("lnr_los_loss_fused");
     if (block_partials) {
         hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, block_partials, (int)grid.x, loss_out);

@@ -23,13 +23,16 @@ ENCODINGS = {"HashGrid": 0, "Grid": 0, "Frequency": 1}
 ACTIVATIONS = {"None": 0, "ReLU": 1, "Sine": 2, "LeakyReLU": 3, "Exponential": 4, "Sigmoid": 5,
                "Squareplus": 6, "Softplus": 7, "Tanh": 8}
 LOSS_SELECTIONS = {"L1_JS": 0, "L2_JS": 1, "L1_LOS": 2, "L2_LOS": 3}
+PRECISIONS = {"fp32": 0, "float32": 0, "fp16": 1, "half": 1, "float16": 1}
+POS_ROUNDINGS = {"fma": 0, "mul_add": 1}
+BWD_TABLE_ATOMICS = 1        # LNR_BWD_TABLE_ATOMICS
 
 
 class NetSpec(C.Structure):
     _fields_ = [("encoding", C.c_int32), ("n_levels", C.c_int32), ("n_features", C.c_int32),
                 ("log2_table", C.c_int32), ("base_res", C.c_int32), ("per_level_scale", C.c_float),
                 ("n_frequencies", C.c_int32), ("activation", C.c_int32), ("n_neurons", C.c_int32),
-                ("n_hidden", C.c_int32),
+                ("n_hidden", C.c_int32), ("precision", C.c_int32), ("pos_rounding", C.c_int32),
                 ("enc_dim", C.c_int32), ("in_dim", C.c_int32), ("n_mlp_params", C.c_int32),
                 ("n_params", C.c_int64),
                 ("level_scale", C.c_float * MAX_LEVELS), ("level_res", C.c_uint32 * MAX_LEVELS),
@@ -53,7 +56,7 @@ _SIGNATURES = {
     "lnr_density_workspace": (C.c_size_t, [C.POINTER(NetSpec), C.c_int64]),
     "lnr_density_forward": (C.c_int, [C.POINTER(NetSpec), P, P, C.c_int64, P, P, C.c_int32, C.c_int32, P, P, P, C.c_size_t, P]),
     "lnr_density_backward": (C.c_int, [C.POINTER(NetSpec), P, P, C.c_int64, P, P, C.c_int32, C.c_int32, P, P, P, P, P,
-                                       C.c_int32, P, C.c_size_t, P]),
+                                       C.c_int32, C.c_int32, P, C.c_size_t, P]),
     "lnr_build_lidar_rays": (C.c_int, [P, P, C.c_int64, P, C.c_int32, P, C.c_float, C.c_float, C.c_float,
                                        C.POINTER(C.c_float), P, P, P, P]),
     "lnr_build_window_rays": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_float), C.POINTER(C.c_int64),
@@ -73,9 +76,9 @@ _SIGNATURES = {
     "lnr_points_grad_to_rays": (C.c_int, [P, P, C.c_int32, P, C.c_int32, P, P]),
     "lnr_weights_gt": (C.c_int, [P, P, P, C.c_float, C.c_int32, C.c_int32, C.c_int32, P, P]),
     "lnr_logits_grad": (C.c_int, [P, P, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, P, P]),
-    "lnr_count_opaque": (C.c_int, [P, P, C.c_int32, P, P, P]),
+    "lnr_count_opaque": (C.c_int, [P, P, C.c_int32, P, P, P, P]),
     "lnr_los_loss_fused": (C.c_int, [P, P, P, P, C.c_int32, P, C.c_int32, P, C.c_float, C.c_uint64, C.c_float,
-                                     C.POINTER(LossConfig), P, P, P, P, P, P, P, P]),
+                                     C.POINTER(LossConfig), P, P, P, P, P, P, P, P, P]),
     "lnr_adam_step": (C.c_int, [P, P, P, P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                 C.c_float, C.c_int32, P]),
     "lnr_occ_grid_step": (C.c_int, [P, C.c_int32, P, P, P, C.c_int32, P, C.c_int32, C.c_float, C.c_float, C.c_float,
@@ -156,5 +159,14 @@ def make_net_spec(encoding_config: dict, network_config: dict) -> NetSpec:
     s.activation = ACTIVATIONS[act]
     s.n_neurons = int(network_config.get("n_neurons", 64))
     s.n_hidden = int(network_config.get("n_hidden_layers", 1))
+    # extensions to the tinycudann schema (absent keys = defaults): arithmetic of the network, grid-position rounding
+    prec = str(network_config.get("precision", "fp32"))
+    if prec not in PRECISIONS:
+        raise RuntimeError(f"unsupported precision {prec!r} (supported: {sorted(PRECISIONS)})")
+    s.precision = PRECISIONS[prec]
+    pos = str(encoding_config.get("pos_rounding", "fma"))
+    if pos not in POS_ROUNDINGS:
+        raise RuntimeError(f"unsupported pos_rounding {pos!r} (supported: {sorted(POS_ROUNDINGS)})")
+    s.pos_rounding = POS_ROUNDINGS[pos]
     check(load().lnr_net_spec_finalize(C.byref(s)), "lnr_net_spec_finalize")
     return s

@@ -146,6 +146,7 @@ class Optimizer:
         self._depth_eps = None
         self._grad_buf = None
         self._pending_density = None  # (all-reduce handle or None, group index, lr): density Adam step deferred by the training loop
+        self._defer_density_step = True   # False: step right away (same arithmetic; the tests compare the two)
         self.last_stats = {}
 
     # -------------------------------------------------------------------------------------------
@@ -188,7 +189,7 @@ class Optimizer:
     # -------------------------------------------------------------------------------------------
     def _do_iterate_optimizer(self, keyframe_window: List, iteration_schedule, profiler=None,
                               optimizer_settings: OptimizationSettings = None) -> float:
-        if len(keyframe_window) == 1 and self._dist is None:     # sharded: anchoring is decided on the whole window
+        if len(keyframe_window) == 1:           # (sharded: every rank is handed the whole window, so all agree)
             keyframe_window[0].is_anchored = True
         if len(iteration_schedule) > 1 and self._settings.skip_pose_refinement:
             iteration_schedule = iteration_schedule[1:]
@@ -215,10 +216,14 @@ class Optimizer:
             self._model.freeze_rgb_head(True)
             optimize_poses = not os_.freeze_poses
 
+            # The phase is decided on the WHOLE window (latest keyframe, anchoring); in the sharded mode every rank is handed the
+            # same window and keeps the keyframes i mod G == rank of the active list (mapping/sharding.py).  A rank may end up
+            # with none (window smaller than the world size: the first keyframes of every run): it still joins every collective.
             if os_.latest_kf_only:
-                active = [max(keyframe_window, key=lambda kf: float(kf.get_time()))]
+                active_all = [max(keyframe_window, key=lambda kf: float(kf.get_time()))]
             else:
-                active = keyframe_window
+                active_all = list(keyframe_window)
+            active = self._dist.owned(active_all) if self._dist is not None else active_all
             for kf in active:
                 if not kf.is_anchored:
                     kf.get_lidar_pose().set_fixed(not optimize_poses)
@@ -226,22 +231,29 @@ class Optimizer:
 
             sigma_params = self._model.get_sigma_parameters()
             groups = []
+            density_group = None
             if not tracking and sigma_params:
+                density_group = len(groups)
                 groups.append({'params': sigma_params, 'lr': self._model_config.train.lrate_sigma_mlp})
             # poses are optimised on the device as one [K,6] tensor (rows of fixed/anchored keyframes get zero gradient)
             pose_cpu = [kf.get_lidar_pose().get_pose_tensor() for kf in active]
-            pose_dev = torch.stack([p.detach().to(self._device, torch.float32) for p in pose_cpu]).contiguous()
+            if active:
+                pose_dev = torch.stack([p.detach().to(self._device, torch.float32) for p in pose_cpu]).contiguous()
+            else:
+                pose_dev = torch.zeros(0, 6, device=self._device)
             free_rows = torch.tensor([(optimize_poses and not kf.is_anchored) for kf in active], device=self._device).to(torch.uint8)
-            tab = self._window_tables(active)
+            tab = self._window_tables(active) if active else None
             any_free = bool(optimize_poses and any(not kf.is_anchored for kf in active))
             pose_dev.requires_grad_(any_free)
             if any_free:
                 groups.append({'params': [pose_dev], 'lr': self._model_config.train.lrate_pose})
-            self._optimizer = HipAdam(groups) if groups else None
+            # always an Adam, like the reference (Mapper.build_ckpt reads its state_dict unconditionally, mapper.py:161-175)
+            self._optimizer = HipAdam(groups if groups else [{'params': []}])
             gamma = float(self._model_config.train.lrate_gamma)
             base_lrs = [g['lr'] for g in groups]
-
-            density_group = 0 if (groups and groups[0]['params'] is sigma_params and not os_.freeze_sigma_mlp) else None
+            # the density step may be deferred (see below) when the density parameters are trained in this phase
+            if os_.freeze_sigma_mlp or not self._defer_density_step:
+                density_group = None
             n_it = os_.num_iterations
             loss_log = torch.zeros(max(n_it, 1), 8, device=self._device)
             valid_log = torch.zeros(max(n_it, 1), device=self._device, dtype=torch.int32)
@@ -249,16 +261,19 @@ class Optimizer:
             for it_idx in range(n_it):
                 if not self.should_enable_lidar():
                     break
-                batch = self._build_window_rays(active, pose_dev, tab)
-                valid_log[it_idx:it_idx + 1] = batch["n_dev"]
-                out = self._loss_and_grads(batch["rays"], batch["depths"], sigma_params[0] if sigma_params else
-                                           self._model.nerf_model._model_sigma.params, it_idx, want_ray_grads=any_free,
-                                           want_param_grads=not os_.freeze_sigma_mlp, n_rays_dev=batch["n_dev"],
-                                           loss_out=loss_log[it_idx], accumulate_into_param_grad=True, want_stats=False,
-                                           defer_grad_wait=True)
+                if active:
+                    batch = self._build_window_rays(active, pose_dev, tab)
+                    valid_log[it_idx:it_idx + 1] = batch["n_dev"]
+                    out = self._loss_and_grads(batch["rays"], batch["depths"], sigma_params[0] if sigma_params else
+                                               self._model.nerf_model._model_sigma.params, it_idx, want_ray_grads=any_free,
+                                               want_param_grads=not os_.freeze_sigma_mlp, n_rays_dev=batch["n_dev"],
+                                               loss_out=loss_log[it_idx], accumulate_into_param_grad=True, want_stats=False,
+                                               defer_grad_wait=True)
+                else:
+                    out = self._join_without_rays(sigma_params[0] if sigma_params else None, want_param_grads=not os_.freeze_sigma_mlp)
                 if any_free:
                     self._pose_backward(batch, out["d_rays"], pose_dev, free_rows)
-                if self._optimizer is not None:
+                if groups:
                     for g, lr0 in zip(self._optimizer.param_groups, base_lrs):
                         g['lr'] = lr0 * (gamma ** it_idx)
                     if density_group is None:
@@ -422,9 +437,12 @@ class Optimizer:
                 u1 = draws.jitter(n, S // 2 if ogm else S).to(dev)
             if ogm:
                 u2 = draws.pdf(n, S // 2).to(dev)
+        # Sharded: the reference compares every ground-truth depth with far[0], the first ray of the WHOLE batch
+        # (optimizer.py:460-461) = rank 0's first ray (it owns the first active keyframe); one float broadcast.
+        far0 = self._dist.broadcast_far0(rays) if self._dist is not None else None
         # loss normalisers first: in the sharded mode their (2-int) all-reduce is pure latency and runs behind the sampler and
         # the density forward; it is waited for right before the loss kernel, its first consumer
-        counts = ops.count_opaque(rays, depths, n_rays_dev=n_rays_dev)
+        counts = ops.count_opaque(rays, depths, n_rays_dev=n_rays_dev, far0=far0)
         counts_work = self._dist.all_reduce_counts(counts, async_op=True) if self._dist is not None else None
         if ogm:
             z = ops.sample_rays_occ(rays, self._occupancy_grid.detach(), S, perturb, u_jitter=u1, u_pdf=u2, seed=seed,
@@ -440,7 +458,7 @@ class Optimizer:
             counts_work.wait()
         loss, d_sigma, d_rays, stats, _ = ops.los_loss_fused(sigma, z, rays, depths, self._scale_f, self._loss_config(iteration_idx),
                                                             counts, noise=noise, noise_std=noise_std, seed=seed + 1,
-                                                            n_rays_dev=n_rays_dev, want_stats=want_stats, loss_out=loss_out)
+                                                            n_rays_dev=n_rays_dev, want_stats=want_stats, loss_out=loss_out, far0=far0)
         grad_params = None
         grad_work = None
         if want_param_grads or want_ray_grads:
@@ -461,6 +479,25 @@ class Optimizer:
         self._results_lidar = {"rays": rays, "depths": depths, "samples_fine": z, "n_rays_dev": n_rays_dev, "stats": stats}
         return dict(loss=loss, d_rays=d_rays if want_ray_grads else None,
                     grad_params=grad_params if want_param_grads else None, stats=stats, z=z, grad_work=grad_work)
+
+    def _join_without_rays(self, params, want_param_grads):
+        """Sharded mode, this rank owns no keyframe of the active window: take part in every collective of an iteration
+        (far[0] broadcast, loss normalisers, density gradient) with zero contributions, in the order _loss_and_grads issues
+        them, so that the other ranks neither block nor see different sums."""
+        dev = self._device
+        self._dist.broadcast_far0(None, device=dev)
+        counts = torch.zeros(2, device=dev, dtype=torch.int32)
+        counts_work = self._dist.all_reduce_counts(counts, async_op=True)
+        self._flush_density_step()
+        counts_work.wait()
+        grad_work = None
+        if want_param_grads and params is not None:
+            if params.grad is None:
+                params.grad = torch.zeros_like(params)
+            grad_work = self._dist.all_reduce_grads(params.grad, async_op=True)
+        self._results_lidar = None
+        return dict(loss=None, d_rays=None, grad_params=params.grad if (want_param_grads and params is not None) else None,
+                    stats=None, z=None, grad_work=grad_work)
 
     def _flush_density_step(self):
         """Apply the density Adam step the training loop deferred (after its gradient all-reduce, if any, has finished)."""
@@ -496,7 +533,7 @@ class Optimizer:
     def _step_occupancy_grid(self):
         """optimizer.py:598-609; must follow a loss evaluation (uses its rays / samples / depths)."""
         res = self._results_lidar
-        if res is None:
+        if res is None and self._dist is None:
             raise RuntimeError("_step_occupancy_grid called before compute_loss")
         occ = self._model_config.model.occ_model
         grid = self._occupancy_grid_model.occupancy_grid
@@ -504,8 +541,9 @@ class Optimizer:
         # sharded mode the ranks' accumulators add up exactly in one integer all-reduce), then applied to the logits
         if self._grad_buf is None:
             self._grad_buf = torch.zeros(grid.numel(), device=grid.device, dtype=torch.int64)
-        ops.occ_grid_step(grid.data, res["rays"], res["samples_fine"], res["depths"], self._scale_f, occ.lr,
-                          grad_buf=self._grad_buf, n_rays_dev=res["n_rays_dev"])
+        if res is not None:            # (None: a rank without rays in the sharded mode contributes zeros to the all-reduce)
+            ops.occ_grid_step(grid.data, res["rays"], res["samples_fine"], res["depths"], self._scale_f, occ.lr,
+                              grad_buf=self._grad_buf, n_rays_dev=res["n_rays_dev"])
         if self._dist is not None:
             self._dist.all_reduce_grads(self._grad_buf)
         ops.occ_grid_apply(grid.data, self._grad_buf, occ.lr, zero_grad=True)

@@ -11,6 +11,8 @@ by keyframe with ONE exchange step per iteration:
   * after backward, the density-parameter gradient is all-reduced (sum) - RCCL over xGMI via
     torch.distributed backend "nccl"; every rank then applies the identical Adam step, so replicas
     stay bit-equal (the reduced buffer is used as produced by the collective on every rank);
+  * the loss compares every ground-truth depth with `far` of the first ray of the batch (the far[0] quirk,
+    optimizer.py:460-461): rank 0 broadcasts that float, so the sharded loss equals the single-GPU one;
   * every N_iters_acc-th step the occupancy-grid pseudo-gradient (V^3 floats) is all-reduced the
     same way so that the samplers do not diverge.
 
@@ -52,6 +54,17 @@ class DistContext:
         waits for it right before the density Adam step, so the pose gradient of this rank runs next to the collective."""
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         return work if async_op else flat
+
+    def broadcast_far0(self, rays, device=None) -> torch.Tensor:
+        """The reference's `depth > far[0]` test (optimizer.py:460-461) uses the first ray of the whole batch.  Rank 0 owns the
+        first active keyframe, hence that ray: it sends `rays[0, 12]`, everyone gets a device float [1] to hand to
+        lnr_count_opaque / lnr_los_loss_fused.  `rays` may be None on ranks without rays."""
+        if self.rank == 0:
+            far0 = rays[0:1, 12].clone()
+        else:
+            far0 = torch.zeros(1, device=rays.device if rays is not None else device, dtype=torch.float32)
+        dist.broadcast(far0, src=0, group=self.group)
+        return far0
 
     def broadcast_(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
         dist.broadcast(t, src=src, group=self.group)

@@ -68,19 +68,6 @@ class Model(nn.Module):
         return results
 
 
-class _OccInterpolate(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, grid, pts):
-        ctx.save_for_backward(pts)
-        ctx.shape = grid.shape
-        return ops.occ_interpolate(grid.detach(), pts.detach())
-
-    @staticmethod
-    def backward(ctx, g):
-        raise NotImplementedError("gradients of OccupancyGridModel.interpolate flow through lnr_occ_grid_step "
-                                  "(Optimizer._step_occupancy_grid), not through autograd")
-
-
 class OccupancyGridModel(nn.Module):
     """V^3 grid of occupancy log-odds (model_tcnn.py:108-131)."""
 

@@ -60,6 +60,9 @@ def render_rays(rays, ray_sampler, nerf_model, ray_range, scale_factor, N_sample
     if not sigma_only:
         raise NotImplementedError("render_rays: colour rendering (camera=True) is not part of the LiDAR mapping path")
     z_vals = ray_sampler.get_samples(rays, N_samples, perturb)
+    draws = getattr(ray_sampler, "_draws", None)
+    if noise is None and draws is not None and raw_noise_std > 0:      # parity hook: the randn of rendering_tcnn.py:104
+        noise = (draws.noise(z_vals.shape[0], N_samples) * raw_noise_std).to(z_vals.device)
     net = nerf_model._model_sigma
     seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (noise is None and raw_noise_std > 0) else 0
     depth, weights, opacity, variance = _RenderRays.apply(rays, net.params, z_vals, net.spec, noise, float(raw_noise_std), seed)

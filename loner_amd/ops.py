@@ -90,15 +90,17 @@ def density_forward(spec, params, pts=None, rays=None, z=None, n_rays_dev=None):
 
 
 def density_backward(spec, params, d_sigma, grad_params, pts=None, rays=None, z=None, n_rays_dev=None,
-                     want_d_pts=False, reuse_features=False, d_rays=None):
-    """Accumulates into grad_params [n_params]; returns d_pts ([...,3]) or None.
+                     want_d_pts=False, reuse_features=False, d_rays=None, table_atomics=False):
+    """Accumulates into grad_params [n_params] (None: parameters frozen, only the input gradient is computed);
+    returns d_pts ([...,3]) or None.  table_atomics: test hook (LNR_BWD_TABLE_ATOMICS).
     reuse_features: the caller asserts that the last density_forward on this device ran on the same params and
     points (and that neither changed since), so the encoded features still in the workspace are reused.
     d_rays [n_rays,13] (rays form, instead of want_d_pts): the point gradient is reduced per ray and added to it."""
     assert not (want_d_pts and d_rays is not None)
     require_device(params, d_sigma, grad_params, pts, rays, z)
     params, d_sigma = _f32c(params), _f32c(d_sigma)
-    assert grad_params.dtype == torch.float32 and grad_params.is_contiguous()
+    assert grad_params is None or (grad_params.dtype == torch.float32 and grad_params.is_contiguous())
+    flags = hip.BWD_TABLE_ATOMICS if table_atomics else 0
     n_points = (pts.numel() // 3) if pts is not None else z.numel()
     ent, need = _workspace(spec, params.device, n_points)
     if pts is not None:
@@ -109,7 +111,7 @@ def density_backward(spec, params, d_sigma, grad_params, pts=None, rays=None, z=
             raise RuntimeError("density_backward(reuse_features=True): workspace features belong to a different forward call")
         d_pts = torch.empty(n, 3, device=params.device, dtype=torch.float32) if want_d_pts else None
         check(load().lnr_density_backward(C.byref(spec), _ptr(params), _ptr(pts), n, None, None, 0, 0, None,
-                                          _ptr(d_sigma), _ptr(grad_params), _ptr(d_pts), None, reuse, _ptr(ent["buf"]), need,
+                                          _ptr(d_sigma), _ptr(grad_params), _ptr(d_pts), None, reuse, flags, _ptr(ent["buf"]), need,
                                           _stream()), "lnr_density_backward")
         return d_pts
     rays, z = _f32c(rays), _f32c(z)
@@ -119,7 +121,7 @@ def density_backward(spec, params, d_sigma, grad_params, pts=None, rays=None, z=
         raise RuntimeError("density_backward(reuse_features=True): workspace features belong to a different forward call")
     d_pts = torch.empty(n, s, 3, device=params.device, dtype=torch.float32) if want_d_pts else None
     check(load().lnr_density_backward(C.byref(spec), _ptr(params), None, 0, _ptr(rays), _ptr(z), n, s,
-                                      _ptr(n_rays_dev), _ptr(d_sigma), _ptr(grad_params), _ptr(d_pts), _ptr(d_rays), reuse,
+                                      _ptr(n_rays_dev), _ptr(d_sigma), _ptr(grad_params), _ptr(d_pts), _ptr(d_rays), reuse, flags,
                                       _ptr(ent["buf"]), need, _stream()), "lnr_density_backward")
     return d_pts
 
@@ -341,17 +343,19 @@ def logits_grad(s, g, margin=2.0, l_free=0.25, l_occ=2.5):
     return out
 
 
-def count_opaque(rays, depth_gt, n_rays_dev=None):
-    require_device(rays, depth_gt)
+def count_opaque(rays, depth_gt, n_rays_dev=None, far0=None):
+    """-> int32 [2] = {#rays, #opaque rays}.  far0 (device float [1], optional): the `far` every depth is compared with
+    (the reference's far[0] quirk) when `rays` is only a shard of the batch."""
+    require_device(rays, depth_gt, far0)
     counts = torch.zeros(2, device=rays.device, dtype=torch.int32)
-    check(load().lnr_count_opaque(_ptr(_f32c(rays)), _ptr(_f32c(depth_gt)), rays.shape[0], _ptr(n_rays_dev), _ptr(counts),
-                                  _stream()), "lnr_count_opaque")
+    check(load().lnr_count_opaque(_ptr(_f32c(rays)), _ptr(_f32c(depth_gt)), rays.shape[0], _ptr(n_rays_dev), _ptr(far0),
+                                  _ptr(counts), _stream()), "lnr_count_opaque")
     return counts
 
 
 def los_loss_fused(sigma, z, rays, depth_gt, scale, cfg: hip.LossConfig, counts, noise=None, noise_std=0.0, seed=0,
-                   n_rays_dev=None, want_stats=False, want_weights=False, loss_out=None):
-    require_device(sigma, z, rays, depth_gt, counts, noise)
+                   n_rays_dev=None, want_stats=False, want_weights=False, loss_out=None, far0=None):
+    require_device(sigma, z, rays, depth_gt, counts, noise, far0)
     sigma, z, rays, depth_gt = _f32c(sigma), _f32c(z), _f32c(rays), _f32c(depth_gt)
     n, s = z.shape
     dev = z.device
@@ -364,7 +368,7 @@ def los_loss_fused(sigma, z, rays, depth_gt, scale, cfg: hip.LossConfig, counts,
     partials = torch.empty(((n + hip.LOSS_RAYS_PER_BLOCK - 1) // hip.LOSS_RAYS_PER_BLOCK) * 8, device=dev)
     check(load().lnr_los_loss_fused(_ptr(sigma), _ptr(z), _ptr(rays), _ptr(depth_gt), n, _ptr(n_rays_dev), s,
                                     _ptr(_f32c(noise)), float(noise_std), int(seed), float(scale), C.byref(cfg), _ptr(counts),
-                                    _ptr(loss_out), _ptr(d_sigma), _ptr(d_rays), _ptr(stats), _ptr(w), _ptr(partials), _stream()),
+                                    _ptr(far0), _ptr(loss_out), _ptr(d_sigma), _ptr(d_rays), _ptr(stats), _ptr(w), _ptr(partials), _stream()),
           "lnr_los_loss_fused")
     return loss_out, d_sigma, d_rays, stats, w
 
@@ -396,6 +400,7 @@ def occ_grid_apply(grid, grad_buf, lr, zero_grad=True):
 
 
 def selftest_mfma(device="cuda"):
-    out = torch.full((1,), -1.0, device=device)
+    """max abs error of the two MFMA fragment-layout checks (fp32 16x16x4 and fp16 16x16x32); 0.0 when both layouts hold."""
+    out = torch.full((2,), -1.0, device=device)
     check(load().lnr_selftest_mfma(_ptr(out), _stream()), "lnr_selftest_mfma")
-    return float(out.item())
+    return float(out.abs().max().item()) if bool((out >= 0).all()) else -1.0

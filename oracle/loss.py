@@ -55,22 +55,24 @@ class LossConfig:
     decay_eps: bool = True
 
 
-def ray_masks(rays: torch.Tensor, depth_gt: torch.Tensor):
+def ray_masks(rays: torch.Tensor, depth_gt: torch.Tensor, far0=None):
     """optimizer.py:460-463 including the broadcast quirk: an [N,1] > [N]
     comparison whose column 0 is kept, i.e. every depth is compared with the
-    FIRST ray's far value."""
-    far0 = rays[0, -1]
+    FIRST ray's far value.  far0: that value when `rays` is only a shard of
+    the batch the reference would have evaluated at once (default: this
+    batch's own first ray)."""
+    far0 = rays[0, -1] if far0 is None else far0
     transparent = depth_gt.reshape(-1) > far0
     opaque = (depth_gt.reshape(-1) > 0) & ~transparent
     return opaque
 
 
 def lidar_loss(rendered: dict, z: torch.Tensor, rays: torch.Tensor, depth_gt: torch.Tensor,
-               scale, cfg: LossConfig, iteration: int = 0):
+               scale, cfg: LossConfig, iteration: int = 0, far0=None):
     """rendered: output of render.composite (grad-carrying); z [N,S] (detached
     sample depths); depth_gt [N].  Returns (loss, aux) where aux carries the
     per-ray intermediates the tests compare."""
-    opaque = ray_masks(rays, depth_gt)
+    opaque = ray_masks(rays, depth_gt, far0)
     s = z * scale
     g = depth_gt.reshape(-1, 1) * scale
     w = rendered["weights"]

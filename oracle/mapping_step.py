@@ -37,6 +37,7 @@ class OracleKeyframe:
     pose6: torch.Tensor                 # [6] = [t, axis-angle]
     anchored: bool = False
     sky_directions: Optional[torch.Tensor] = None
+    time: float = 0.0                   # start time of the scan (Frame.get_time): decides "latest keyframe"
 
 
 class TorchDraws:
@@ -132,11 +133,17 @@ class OracleMapper:
 
     # ---- the optimisation loop ---------------------------------------------------------
     def iterate(self, window: List[OracleKeyframe], n_iters: int, freeze_poses=False,
-                freeze_sigma=False, draws=None):
+                freeze_sigma=False, draws=None, latest_kf_only=False):
         draws = draws or self.draws
         cfg = self.cfg
         if len(window) == 1:
             window[0].anchored = True
+        if latest_kf_only:              # optimizer.py:239-247: first keyframe with the strictly largest start time
+            latest = window[0]
+            for kf in window:
+                if kf.time > latest.time:
+                    latest = kf
+            window = [latest]
         rr = torch.tensor(cfg.ray_range)
         self.params.requires_grad_(not freeze_sigma)
         free = [kf for kf in window if not kf.anchored and not freeze_poses]

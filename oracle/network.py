@@ -15,12 +15,31 @@ kernels are tested against:
   after every hidden layer, none on the output;
 * HashGrid: level l has scale = base*pls^l - 1, res = ceil(scale)+1,
   min(roundup8(res^3), 2^log2_T) entries of F features; lookup position
-  x*scale+0.5, trilinear over the 8 surrounding entries; entry index is the
+  fma(x, scale, 0.5) - ONE rounding, as tiny-cuda-nn's `fmaf(scale, input,
+  0.5f)` (`pos_rounding="mul_add"` rounds product and sum separately, what
+  un-contracted code would do; the two differ by an fp32 ulp of the position,
+  1/32 cell on the finest default level) - trilinear over the 8 surrounding
+  entries; entry index is the
   dense x + y*res + z*res^2 while res^3 <= table size, else the
   coherent-prime hash x ^ y*2654435761 ^ z*805459861 (uint32), always modulo
   the table size;
 * Frequency: feature [dim][k][sin,cos] = sin(2^k*pi*x_dim + {0, pi/2}).
 Inputs are the unit-cube coordinates (xyz+1)/2 (nerf_tcnn.py:63).
+
+precision="fp16" models the storage types the reference actually runs with
+(tinycudann in half precision): encoded features and MLP weights are rounded
+to fp16 (round-to-nearest-even, straight-through for the gradient, i.e. fp32
+master parameters as tinycudann keeps them), products accumulate in fp32 (the
+HIP kernels use v_mfma_f32_16x16x32_f16; tinycudann accumulates in fp16), the
+last hidden activation feeds the 1-row output product unrounded.  It exists so
+that the error of the HIP fp16 mode against the fp32 definition can be split
+into "storage rounding" (this model vs fp32) and "kernel arithmetic" (kernel
+vs this model).
+
+Remaining assumptions about tinycudann that nothing here can verify (the
+package is absent): fused position rounding, padding inputs fed the constant
+1, parameter order "MLP matrices, then tables", `mod T` applied to dense
+levels too, Xavier-uniform / uniform(-1e-4, 1e-4) initialisation.
 """
 import math
 from dataclasses import dataclass, field
@@ -55,6 +74,8 @@ class NetworkSpec:
     activation: str = "ReLU"              # ReLU | Sine | None | ...
     n_neurons: int = 64
     n_hidden: int = 1
+    precision: str = "fp32"               # fp32 | fp16 (storage rounding of features and weights, see the module docstring)
+    pos_rounding: str = "fma"             # fma | mul_add
     levels: List[GridLevel] = field(default_factory=list)
 
     @staticmethod
@@ -68,6 +89,7 @@ class NetworkSpec:
             s.log2_table = int(enc.get("log2_hashmap_size", 19))
             s.base_res = int(enc.get("base_resolution", 16))
             s.per_level_scale = float(enc.get("per_level_scale", 2.0))
+            s.pos_rounding = str(enc.get("pos_rounding", "fma"))
         elif s.enc_type == "Frequency":
             s.n_frequencies = int(enc.get("n_frequencies", 12))
         else:
@@ -75,6 +97,7 @@ class NetworkSpec:
         s.activation = str(net.get("activation", "ReLU"))
         s.n_neurons = int(net.get("n_neurons", 64))
         s.n_hidden = int(net.get("n_hidden_layers", 1))
+        s.precision = {"fp32": "fp32", "float32": "fp32", "fp16": "fp16", "half": "fp16", "float16": "fp16"}[str(net.get("precision", "fp32"))]
         s._build_levels()
         return s
 
@@ -156,12 +179,37 @@ def _activate(x: torch.Tensor, kind: str) -> torch.Tensor:
     raise ValueError(kind)
 
 
+class _RoundF16(torch.autograd.Function):
+    """round to fp16 and back (nearest even); the gradient passes straight through (fp32 master copy)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.float16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def round_f16(x: torch.Tensor) -> torch.Tensor:
+    return _RoundF16.apply(x)
+
+
+def grid_position(spec: NetworkSpec, x: torch.Tensor, scale: float) -> torch.Tensor:
+    """x*scale + 0.5 with the rounding `spec.pos_rounding` asks for (float32 inputs; float64 inputs are exact enough
+    either way).  fma: the product of two fp32 numbers is exact in fp64 and so is adding 0.5 to it at these magnitudes
+    (48 significant bits), so rounding the fp64 result once to fp32 IS the fused multiply-add."""
+    if x.dtype == torch.float32 and spec.pos_rounding == "fma":
+        return (x.double() * float(scale) + 0.5).to(torch.float32)
+    return x * scale + 0.5
+
+
 def encode_hashgrid(spec: NetworkSpec, table: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     """table [E, F] (all levels), x [B,3] in [0,1] -> [B, L*F]; differentiable in both."""
     feats = []
     F = spec.n_features
     for lv in spec.levels:
-        pos = x * lv.scale + 0.5
+        pos = grid_position(spec, x, lv.scale)
         cell = torch.floor(pos)
         frac = pos - cell
         cell = cell.detach().to(torch.int64)
@@ -211,7 +259,10 @@ def density_unit(spec: NetworkSpec, params: torch.Tensor, x: torch.Tensor) -> to
         h = encode_frequency(spec, x)
     if h.shape[1] < spec.in_dim:   # padded inputs are fed the constant 1 (tiny-cuda-nn pads with ones)
         h = torch.cat([h, torch.ones(h.shape[0], spec.in_dim - h.shape[1], dtype=h.dtype)], dim=1)
-    for m in mats[:-1]:
-        h = _activate(h @ m.T, spec.activation)
+    half = spec.precision == "fp16"
+    if half:
+        mats = [round_f16(m) for m in mats]
+    for i, m in enumerate(mats[:-1]):
+        h = _activate((round_f16(h) if half else h) @ m.T, spec.activation)
     out = h @ mats[-1].T
     return out[:, 0]

@@ -442,6 +442,37 @@ def test_fused_loss_matches_reference_compute_loss(ops, golden):
     assert rel(poses[0].grad, g["dpose0"]) < 5e-4 and rel(poses[1].grad, g["dpose1"]) < 5e-4
 
 
+def test_fused_loss_on_shards_with_broadcast_far0_equals_whole_batch(ops, golden):
+    """The keyframe-sharded window: each rank evaluates its rays with the GLOBAL normalisers and with far[0] of the WHOLE
+    batch (the reference's `depth > far[0]` quirk, optimizer.py:460-461).  Two shards evaluated that way must add up to the
+    single-batch loss and reproduce its gradients row for row; with a shard's own first ray they do not."""
+    from loner_amd import hip
+    g, spec_o, spec_h = _g8_setup(golden)
+    rays, z, depths, params = dv(g["rays"]).clone(), dv(g["z"]), dv(g["depths"]), dv(g["params"])
+    noise = dv(g["noise"])
+    n = rays.shape[0]
+    cut = n // 3
+    rays[0, 12] = 0.3 * rays[0, 12] + 0.7 * rays[0, 11]              # first ray of the batch clipped short: many depths exceed far[0]
+    cfg = hip.LossConfig(selection=0, min_js=1.0, max_js=10.0, js_alpha=1.0, los_lambda=1000.0, depth_lambda=0.005, min_eps=0.5, fixed_eps=3.0)
+    sigma = ops.density_forward(spec_h, params, rays=rays, z=z)
+    counts = ops.count_opaque(rays, depths)
+    whole = ops.los_loss_fused(sigma, z, rays, depths, float(g["scale"]), cfg, counts, noise=noise, noise_std=1.0)
+    far0 = rays[0:1, 12].clone()
+    parts, cnt = [], torch.zeros(2, device=DEV, dtype=torch.int32)
+    sl = [slice(0, cut), slice(cut, n)]
+    for s_ in sl:
+        cnt += ops.count_opaque(rays[s_].contiguous(), depths[s_].contiguous(), far0=far0)
+    assert torch.equal(cnt, counts) and 0 < int(counts[1]) < n
+    own = ops.count_opaque(rays[sl[1]].contiguous(), depths[sl[1]].contiguous())          # shard 1 with ITS first ray: a different mask
+    assert int(own[1]) != int(ops.count_opaque(rays[sl[1]].contiguous(), depths[sl[1]].contiguous(), far0=far0)[1])
+    for s_ in sl:
+        parts.append(ops.los_loss_fused(sigma[s_].contiguous(), z[s_].contiguous(), rays[s_].contiguous(), depths[s_].contiguous(),
+                                        float(g["scale"]), cfg, counts, noise=noise[s_].contiguous(), noise_std=1.0, far0=far0))
+    assert rel(parts[0][0][:5] + parts[1][0][:5], whole[0][:5]) < 1e-6
+    assert torch.equal(torch.cat([parts[0][1], parts[1][1]]), whole[1])                   # d_sigma, bit for bit
+    assert torch.equal(torch.cat([parts[0][2], parts[1][2]]), whole[2])                   # direct d_rays
+
+
 @pytest.mark.parametrize("selection", ["L2_JS", "L1_LOS", "L2_LOS"])
 def test_fused_loss_other_selections_match_oracle(ops, golden, selection):
     from loner_amd import hip
@@ -558,6 +589,148 @@ def test_build_window_rays_equals_per_keyframe_build(ops, golden):
     assert len(torch.unique(r_a[3][:300])) > 150
 
 
+# ------------------------------------------------------------------------------------------- precision / rounding modes
+def _default_pair(precision="fp32", pos_rounding="fma", seed=0, gain=2000.0):
+    from loner_amd import hip
+    enc, net = dict(NETS["default"][0]), dict(NETS["default"][1])
+    enc["pos_rounding"] = pos_rounding
+    net["precision"] = precision
+    spec_o = NW.NetworkSpec.from_config(enc, net)
+    spec_h = hip.make_net_spec(enc, net)
+    params = NW.init_params(spec_o, seed)
+    params[spec_o.n_mlp_params:] *= gain
+    return spec_o, spec_h, params
+
+
+@pytest.mark.parametrize("mode", ["fma", "mul_add"])
+def test_grid_position_rounding_convention(ops, mode):
+    """tiny-cuda-nn computes the lookup position with one fused multiply-add; the kernels follow the spec's switch and agree
+    with the oracle in EITHER convention to fp32 noise, while the two conventions differ from each other by much more at the
+    finest levels (one ulp of the position = 1/32 cell at scale 5.2e5)."""
+    spec_o, spec_h, params = _default_pair(pos_rounding=mode)
+    other_o, _, _ = _default_pair(pos_rounding="mul_add" if mode == "fma" else "fma")
+    gen = torch.Generator().manual_seed(11)
+    pts = torch.rand(20000, 3, generator=gen) * 1.9 - 0.95
+    sig = ops.density_forward(spec_h, dv(params), pts=dv(pts)).cpu()
+    ref, ref_other = NW.density(spec_o, params, pts), NW.density(other_o, params, pts)
+    scale = float(ref.abs().max())
+    same, cross = float((sig - ref).abs().max()) / scale, float((sig - ref_other).abs().max()) / scale
+    print(f"pos_rounding={mode}: kernel vs oracle (same convention) {same:.2e}, vs the other convention {cross:.2e}")
+    assert same < 2e-6
+    assert cross > 10 * same            # the switch is observable: the conventions are not interchangeable at fp32 parity
+
+
+def test_hash_known_answer_entries_on_device(ops):
+    """The kernels' index rules against the hand-computed literals of tests/test_host.py: the table gradient of a single point
+    is non-zero exactly at the 8 hand-computed entries of its cell (hashed level 15, dense level 1)."""
+    from tests.test_host import LEVEL15_CELL, LEVEL15_ENTRIES, LEVEL1_CELL, LEVEL1_ENTRIES
+    spec_o, spec_h, params = _default_pair()
+    for level, cell, want in ((15, LEVEL15_CELL, LEVEL15_ENTRIES), (1, LEVEL1_CELL, LEVEL1_ENTRIES)):
+        lv = spec_o.levels[level]
+        x_unit = torch.tensor([[(c + 0.25 - 0.5) / lv.scale for c in cell]], dtype=torch.float32)
+        pts = x_unit * 2 - 1                                         # world cube; (pts + 1) / 2 is exact here
+        assert torch.equal((pts + 1) / 2, x_unit)
+        grad = torch.zeros(int(spec_h.n_params), device=DEV)
+        ops.density_backward(spec_h, dv(params), torch.ones(1, device=DEV), grad, pts=dv(pts))
+        tab = grad[spec_h.n_mlp_params:].reshape(-1, 2).cpu()
+        lo, hi = lv.offset, lv.offset + lv.size
+        touched = sorted(set((tab[lo:hi].abs().sum(1).nonzero().flatten()).tolist()))
+        assert touched == want, (level, touched)
+
+
+def test_fp16_mode_config5_4096x256(ops):
+    """BASELINE configs[4]: 4096 rays x 256 samples, fp16 MLP on MFMA.  sigma, rendered depth and all gradients of the fp16
+    mode against (a) the oracle with the same storage rounding (kernel arithmetic: fp32-accumulating MFMA, per-tile scaled
+    fp16 dZ) and (b) the fp32 definition (error budget of the storage types themselves).  The oracle runs on a 96-ray subset
+    (d_sigma is zero elsewhere, so the gradients only depend on those rays); the launch is full size."""
+    from loner_amd import hip
+    from loner_amd.utils import synthetic as SY
+    o16, h16, params = _default_pair("fp16")
+    o32, h32, _ = _default_pair("fp32")
+    N, S, SUB = 4096, 256, 96
+    gen = torch.Generator().manual_seed(5)
+    dirs, _ = SY.lidar_pattern()
+    scale, shift = SY.world_cube()
+    T = OP.transform_from_pose6(SY.trajectory_pose6(2)[1])
+    dist = SY.scene_ranges(dirs, T)
+    idx = torch.randint(0, dirs.shape[1], (N,), generator=gen)
+    rays, depths, keep = ops.build_lidar_rays(dv(dirs), dv(dist), idx.to(DEV), dv(T[:3, :4].reshape(12)), (1.0, 50.0), scale, shift)
+    assert int(keep.sum()) == N
+    z = ops.sample_rays_occ(rays, dv(torch.randn(100, 100, 100, generator=gen)), S, 1.0, seed=3)
+    P = dv(params)
+    sig16 = ops.density_forward(h16, P, rays=rays, z=z)
+    sub = torch.randperm(N, generator=gen)[:SUB]
+    d_sigma = torch.zeros(N, S)
+    d_sigma[sub] = torch.randn(SUB, S, generator=gen) * torch.logspace(-9, 0, SUB)[:, None]    # nine decades of magnitudes: no underflow
+    d_sigma[sub[:8], ::3] = 0.0
+    g16 = torch.zeros(int(h16.n_params), device=DEV)
+    d_rays16 = torch.zeros(N, 13, device=DEV)
+    ops.density_backward(h16, P, dv(d_sigma), g16, rays=rays, z=z, reuse_features=True, d_rays=d_rays16)
+    depth16 = ops.render_forward(sig16, z, rays)[0]
+    sig32 = ops.density_forward(h32, P, rays=rays, z=z)
+    depth32 = ops.render_forward(sig32, z, rays)[0]
+    # oracle on the subset
+    r_s, z_s = rays[sub.to(DEV)].cpu(), z[sub.to(DEV)].cpu()
+    res = {}
+    for name, so in (("fp16", o16), ("fp32", o32)):
+        p = params.clone().requires_grad_(True)
+        rr = r_s.clone().requires_grad_(True)
+        pts = rr[:, None, 0:3] + rr[:, None, 3:6] * z_s[:, :, None]
+        sg = NW.density(so, p, pts.reshape(-1, 3)).reshape(SUB, S)
+        (sg * d_sigma[sub]).sum().backward()
+        res[name] = (sg.detach(), p.grad, rr.grad)
+    s_scale = float(res["fp32"][0].abs().max())
+    e_sig_model = float((sig16[sub.to(DEV)].cpu() - res["fp16"][0]).abs().max()) / s_scale
+    e_sig_fp32 = float((sig16[sub.to(DEV)].cpu() - res["fp32"][0]).abs().max()) / s_scale
+    e_gp_model, e_gp_fp32 = rel(g16, res["fp16"][1]), rel(g16, res["fp32"][1])
+    e_gr_model, e_gr_fp32 = rel(d_rays16[sub.to(DEV)][:, :6], res["fp16"][2][:, :6]), rel(d_rays16[sub.to(DEV)][:, :6], res["fp32"][2][:, :6])
+    e_depth = float(((depth16 - depth32).abs() / depth32.abs().clamp(min=1e-6)).max())
+    print(f"fp16 mode 4096x256: sigma vs fp16-model {e_sig_model:.2e}, vs fp32 {e_sig_fp32:.2e}; dparams {e_gp_model:.2e} / {e_gp_fp32:.2e}; "
+          f"drays {e_gr_model:.2e} / {e_gr_fp32:.2e}; rendered depth fp16-vs-fp32 rel {e_depth:.2e}")
+    # (a) kernel vs the same storage model: forward is fp32-accumulated either way -> fp32 noise; backward adds the fp16 rounding
+    # of dZ (2^-11 relative per element, averaged down by the sums it enters)
+    assert e_sig_model < 2e-5
+    assert e_gp_model < 1e-3 and e_gr_model < 2e-3
+    # (b) storage error of fp16 features and weights: 2^-11 per rounded operand; sigma sums 32 + 64 rounded products
+    assert e_sig_fp32 < 5e-3 and e_gp_fp32 < 5e-3 and e_gr_fp32 < 1e-2
+    # north_star: depth outputs within 1e-4 relative of the (fp16) reference path - here fp16 mode vs the fp32 definition
+    assert e_depth < 1e-3
+    # gradients of rays without upstream gradient stay exactly zero, tiny d_sigma rows survive (per-tile power-of-two scaling)
+    mask = torch.ones(N, dtype=torch.bool); mask[sub] = False
+    assert float(d_rays16[mask.to(DEV)].abs().max()) == 0.0
+    tiny = sub[:8].to(DEV)
+    assert float(d_rays16[tiny][:, :6].abs().max()) > 0.0
+    # unsupported shapes say so instead of falling back to fp32
+    enc, net = NETS["freq_relu128"]
+    bad = hip.make_net_spec(enc, dict(net, precision="fp16"))
+    with pytest.raises(RuntimeError, match="fp16"):
+        ops.density_forward(bad, torch.zeros(int(bad.n_params), device=DEV), pts=torch.zeros(64, 3, device=DEV))
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_density_backward_with_frozen_parameters(ops, prec):
+    """grad_params=None (tracking phase, optimizer.py:239-259): only the input gradient, identical to the one of a full backward."""
+    _, spec_h, params = _default_pair(prec)
+    gen = torch.Generator().manual_seed(9)
+    n, S = 24, 128
+    rays = torch.zeros(n, 13); rays[:, 0:3] = torch.rand(n, 3, generator=gen) * 0.2 - 0.1
+    d = torch.randn(n, 3, generator=gen); rays[:, 3:6] = d / d.norm(dim=1, keepdim=True); rays[:, 11] = 0.02; rays[:, 12] = 0.55
+    z = torch.sort(torch.rand(n, S, generator=gen) * 0.5 + 0.02, dim=1).values
+    ds = torch.randn(n, S, generator=gen)
+    P, R, Z = dv(params), dv(rays), dv(z)
+    ops.density_forward(spec_h, P, rays=R, z=Z)
+    full, frozen = torch.zeros(n, 13, device=DEV), torch.zeros(n, 13, device=DEV)
+    grad = torch.zeros(int(spec_h.n_params), device=DEV)
+    ops.density_backward(spec_h, P, dv(ds), grad, rays=R, z=Z, reuse_features=True, d_rays=full)
+    ops.density_backward(spec_h, P, dv(ds), None, rays=R, z=Z, reuse_features=True, d_rays=frozen)
+    assert torch.equal(full, frozen) and float(full.abs().max()) > 0
+    p_full = ops.density_backward(spec_h, P, dv(ds), grad, rays=R, z=Z, want_d_pts=True)
+    p_frozen = ops.density_backward(spec_h, P, dv(ds), None, rays=R, z=Z, want_d_pts=True)
+    assert torch.equal(p_full, p_frozen)
+    with pytest.raises(RuntimeError):
+        ops.density_backward(spec_h, P, dv(ds), None, rays=R, z=Z)
+
+
 # ------------------------------------------------------------------------------------------- full-size properties
 def test_full_size_iteration_properties(ops):
     """BASELINE size (4096 rays x 512 samples, default network): size-independent properties of every stage, and the
@@ -596,11 +769,7 @@ def test_full_size_iteration_properties(ops):
     p1 = ops.density_backward(spec, params, d_sigma, g1, rays=rays, z=z, want_d_pts=True)
     ops.density_backward(spec, params, 2.0 * d_sigma, g2, rays=rays, z=z, want_d_pts=False)
     assert rel(g2, 2.0 * g1) < 1e-5
-    os.environ["LNR_TABLE_GRAD_ATOMICS"] = "1"
-    try:
-        p3 = ops.density_backward(spec, params, d_sigma, g3, rays=rays, z=z, want_d_pts=True)
-    finally:
-        del os.environ["LNR_TABLE_GRAD_ATOMICS"]
+    p3 = ops.density_backward(spec, params, d_sigma, g3, rays=rays, z=z, want_d_pts=True, table_atomics=True)
     print("partition vs atomic path: table grad rel", rel(g1, g3), " checksum", float(g1.double().sum()), float(g3.double().sum()))
     assert rel(g1, g3) < 1e-5 and torch.equal(p1, p3)
     assert abs(float(g1.double().sum()) - float(g3.double().sum())) < 1e-6 * float(g1.double().abs().sum())

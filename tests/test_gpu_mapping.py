@@ -21,22 +21,7 @@ def rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
-SMALL_ENC = dict(otype="HashGrid", n_levels=4, n_features_per_level=2, log2_hashmap_size=12, base_resolution=8)
-SMALL_NET = dict(activation="ReLU", n_neurons=32, n_hidden_layers=1, otype="FullyFusedMLP", output_activation="None")
-
-
-def small_settings(n_rays, n_samples, voxel=32):
-    from loner_amd.common.settings import default_optimizer_settings
-    s = default_optimizer_settings()
-    mc = s["model_config"]
-    mc["model"]["nerf_config"]["pos_encoding_sigma"] = dict(SMALL_ENC)
-    mc["model"]["nerf_config"]["sigma_network"] = dict(SMALL_NET)
-    mc["model"]["nerf_config"]["pos_encoding_intensity"]["log2_hashmap_size"] = 10
-    mc["model"]["render"]["N_samples_train"] = n_samples
-    mc["model"]["occ_model"]["voxel_size"] = voxel
-    s["num_samples"]["lidar"] = n_rays
-    s["num_samples"]["sky"] = 0
-    return s
+from tests.support import SMALL_ENC, SMALL_NET, small_settings       # noqa: E402,F401
 
 
 def make_keyframes(pose6_list, device=None):
@@ -385,6 +370,165 @@ def test_sky_rays_tracking_phase_and_uniform_sampler():
         s3 = small_settings(8, 64); s3["rays_selection"]["strategy"] = "NOPE"
         Optimizer(s3, None, world_cube(), 0, False, True, False)._do_iterate_optimizer(
             make_keyframes([base[0]]), [None], optimizer_settings=OptimizationSettings(1, True, False, False, True))
+
+
+def test_sky_rays_and_tracking_phase_reproduce_the_reference(golden):
+    """G11: the reference's Optimizer on three keyframes with sky rays (keyframe.py:91-100) - a joint map + pose phase, then the
+    pose-refinement phase of the default schedule (latest_kf_only, frozen density net: optimizer.py:239-259) - replayed on the
+    HIP path with the reference's recorded draws: loss of every iteration, poses, parameters and occupancy grid."""
+    from loner_amd.mapping.optimizer import OptimizationSettings, Optimizer
+    from tests import support
+    g = golden("g11_sky_tracking")
+    s = small_settings(48, 64)
+    s["num_samples"]["sky"] = 16
+    opt = Optimizer(s, None, world_cube(), 0, False, True, True)
+    with torch.no_grad():
+        opt._model.nerf_model._model_sigma.params.copy_(torch.from_numpy(g["params0"]))
+    kfs = make_keyframes([torch.from_numpy(g[f"pose_init{i}"]) for i in range(3)])
+    for kf in kfs:
+        kf.get_lidar_scan().sky_rays = torch.from_numpy(g["sky"]).clone()
+    assert [float(kf.get_time()) for kf in kfs] == [0.0, 1.0, 2.0]
+    kfs[0].is_anchored = True
+    rp = _Replay(g)
+    opt.set_draws(rp)
+    opt._do_iterate_optimizer(kfs, [None], optimizer_settings=OptimizationSettings(6, False, False, False, True))
+    assert rp.i == int(g["n_draws_a"])
+    loss_a = opt.last_stats["loss_terms"][:, 0].numpy()
+    assert opt.last_stats["n_valid_rays"] == 6 * 3 * (48 + 16)
+    assert rel(opt._model.nerf_model._model_sigma.params, g["params_a"]) < 5e-2            # (Adam: the tolerances of the G9 loop test)
+    assert rel(opt._occupancy_grid_model.occupancy_grid[0, 0], g["grid_a"]) < 2e-3
+    for i in range(3):
+        assert np.abs(kfs[i].get_lidar_pose().get_pose_tensor().detach().cpu().numpy() - g[f"pose_a{i}"]).max() < 5e-4
+    params_a = opt._model.nerf_model._model_sigma.params.detach().clone()
+    opt._do_iterate_optimizer(kfs, [None], optimizer_settings=OptimizationSettings(6, False, True, True, True))
+    assert rp.i == int(g["n_draws"]) and opt._global_step == int(g["global_step"])
+    assert torch.equal(opt._model.nerf_model._model_sigma.params.detach(), params_a)      # frozen density net
+    loss = np.concatenate([loss_a, opt.last_stats["loss_terms"][:, 0].numpy()])
+    print("loss trace vs reference: rel", np.abs(loss - g["losses"]).max() / np.abs(g["losses"]).max())
+    assert np.abs(loss[:6] - g["losses"][:6]).max() < 1e-4 * np.abs(g["losses"]).max()
+    assert np.abs(loss - g["losses"]).max() < 2e-3 * np.abs(g["losses"]).max()            # phase b starts from phase a's (Adam-stepped) map
+    for i in range(3):
+        p = kfs[i].get_lidar_pose().get_pose_tensor().detach().cpu().numpy()
+        assert np.abs(p - g[f"pose_b{i}"]).max() < 5e-4
+    travel = np.abs(g["pose_b2"] - g["pose_a2"]).max()
+    err = np.abs(kfs[2].get_lidar_pose().get_pose_tensor().detach().cpu().numpy() - g["pose_b2"]).max()
+    print(f"tracking phase: latest keyframe moved {travel:.2e}, error vs reference {err:.2e}")
+    assert travel > 1e-3 and err < 0.2 * travel
+    assert rel(opt._occupancy_grid_model.occupancy_grid[0, 0], g["grid_b"]) < 2e-3
+    # the Adam of a tracking phase holds the pose only; its state_dict is what Mapper.build_ckpt saves (mapper.py:161-175)
+    sd = opt._optimizer.state_dict()
+    assert len(sd["param_groups"]) == 1 and sd["state"][0]["step"] == 6
+
+
+def test_checkpoint_written_here_renders_like_the_reference_loading_it(golden, tmp_path):
+    """G12: a checkpoint written by this repo's classes was loaded by the reference's Model / OccupancyGridModel, rendered by
+    its Model.forward(testing=True) and scored by its compute_l1_depth (analysis/compute_l1_depth.py:42-64,140-155).  The same
+    file loaded by OUR consumer side must render the same depths and score the same L1 on the same draws."""
+    from loner_amd.analysis.l1_depth import compute_l1_depth
+    from loner_amd.common.frame import Frame
+    from loner_amd.common.pose import Pose
+    from loner_amd.common.ray_utils import LidarRayDirections
+    from loner_amd.common.sensors import LidarScan
+    from loner_amd.models.model_tcnn import Model, OccupancyGridModel
+    from loner_amd.models.ray_sampling import OccGridRaySampler
+    from loner_amd.utils import synthetic as SY
+    from tests import support
+    g = golden("g12_checkpoint_l1_depth")
+    path = str(tmp_path / "final.tar")
+    meta = support.write_repo_checkpoint(path)
+    assert float(meta["sigma_params"].double().sum()) == float(g["sigma_params_checksum"])
+    mc = support.small_settings(48, 64, n_test=int(g["n_samples_test"])).model_config.model
+    model, occ = Model(mc).to(DEV), OccupancyGridModel(mc.occ_model).to(DEV)
+    back = torch.load(path, map_location="cpu", weights_only=False)
+    model.load_state_dict(back["network_state_dict"])                       # strict
+    occ.load_state_dict(back["occ_model_state_dict"])
+    sampler = OccGridRaySampler()
+    sampler.update_occ_grid(occ().detach())
+    dirs, ts = SY.lidar_pattern()
+    sub = torch.from_numpy(g["scan_subset"])
+    pose6 = torch.from_numpy(g["pose6"])
+    scan = LidarScan(dirs[:, sub].clone(), SY.scene_ranges(dirs, OP.transform_from_pose6(pose6))[sub], ts[sub])
+
+    class Draws:
+        def pdf(self, n, h): return torch.from_numpy(g["u_pdf"])
+        def noise(self, n, s_): return torch.from_numpy(g["noise"])
+    sampler.set_draws(Draws())
+    lrd = LidarRayDirections(scan, chunk_size=4096)
+    wc = world_cube()
+    rays = lrd.fetch_chunk_rays(0, Pose(pose_tensor=pose6.clone(), fixed=True), wc, torch.tensor([1.0, 50.0]))
+    out = model(rays, sampler, wc.scale_factor, testing=True, return_variance=True, camera=False)
+    e_depth = rel(out["depth_fine"], g["depth"])
+    l1 = compute_l1_depth(Pose(pose_tensor=pose6.clone(), fixed=True), lrd, model, sampler, wc, torch.tensor([1.0, 50.0]), DEV)
+    print(f"rendered depth vs reference rel {e_depth:.2e}; L1 depth {l1:.5f} m vs reference {float(g['l1']):.5f} m")
+    assert out["depth_fine"].shape == (512,) and e_depth < 1e-4
+    assert abs(l1 - float(g["l1"])) < 1e-4 * float(g["l1"])
+
+
+def test_optimizer_survives_spawn_pickling_and_mask_ray_selection():
+    """The reference constructs the Optimizer in the parent and hands it to the mapping process through spawn
+    (src/loner.py:59,188,205): a constructed Optimizer must pickle (no live HIP handles) and work after unpickling.  Also the
+    MASK ray-selection strategy (optimizer.py:290-293): every drawn ray index lies inside the scan's mask."""
+    import pickle
+    from loner_amd.mapping.optimizer import OptimizationSettings, Optimizer
+    from loner_amd.utils import synthetic as SY
+    s = small_settings(64, 64)
+    s["rays_selection"]["strategy"] = "MASK"
+    torch.manual_seed(0)
+    opt = Optimizer(s, None, world_cube(), 0, False, True, False)
+    blob = pickle.dumps(opt)
+    opt2 = pickle.loads(blob)
+    assert torch.equal(opt2._model.nerf_model._model_sigma.params.detach().cpu(), opt._model.nerf_model._model_sigma.params.detach().cpu())
+    kf = make_keyframes([SY.trajectory_pose6(1)[0]])
+    n = len(kf[0].get_lidar_scan())
+    mask = torch.zeros(n, dtype=torch.bool)
+    mask[1000:1400] = True
+    kf[0].get_lidar_scan().mask = mask
+    seen = []
+    orig = opt2._draw_window_indices
+
+    def spy(active, tab):
+        idx = orig(active, tab)
+        seen.append(idx.cpu())
+        return idx
+    opt2._draw_window_indices = spy
+    opt2._do_iterate_optimizer(kf, [None], optimizer_settings=OptimizationSettings(5, True, False, False, True))
+    assert torch.isfinite(opt2.last_stats["loss_terms"]).all() and opt2.last_stats["n_valid_rays"] == 5 * 64
+    drawn = torch.cat(seen)
+    assert drawn.numel() == 5 * 64 and int(drawn.min()) >= 1000 and int(drawn.max()) < 1400 and len(torch.unique(drawn)) > 100
+
+
+def test_deferred_density_step_is_taken_and_changes_nothing():
+    """The density Adam step is deferred to just before the next density forward (so that, sharded, the gradient all-reduce
+    overlaps the pose tail and the next batch's ray build).  It must actually be deferred in a joint phase, and the result
+    must be bit-identical to stepping right away."""
+    from loner_amd.mapping import optimizer as OM
+    from loner_amd.utils import synthetic as SY
+
+    def run(defer):
+        torch.manual_seed(0)
+        opt = OM.Optimizer(small_settings(96, 64), None, world_cube(), 0, False, True, False)
+        opt._defer_density_step = defer
+        base = SY.trajectory_pose6(2)
+        kfs = make_keyframes([base[0], base[1] + torch.tensor([0.02, 0.0, -0.01, 0.0, 0.0, 0.0])])
+        kfs[0].is_anchored = True
+        pending_seen = []
+        flush = opt._flush_density_step
+
+        def spy():
+            pending_seen.append(opt._pending_density is not None)
+            return flush()
+        opt._flush_density_step = spy
+        torch.manual_seed(3)
+        opt._do_iterate_optimizer(kfs, [None], optimizer_settings=OM.OptimizationSettings(12, False, False, False, True))
+        p = opt._model.nerf_model._model_sigma.params
+        return p.detach().clone(), opt._optimizer.state[p]["exp_avg"].clone(), kfs[1].get_lidar_pose().get_pose_tensor().detach().clone(), pending_seen
+
+    a = run(True)
+    b = run(False)
+    assert sum(a[3]) >= 11                  # a pending density step was found (and flushed) before (almost) every forward
+    assert sum(b[3]) == 0                   # eager mode never leaves one pending
+    for x, y in zip(a[:3], b[:3]):
+        assert torch.equal(x, y)
 
 
 def test_cfg1_loop_matches_oracle_with_default_network():

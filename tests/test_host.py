@@ -55,6 +55,45 @@ def test_net_spec_matches_oracle_level_geometry(lib_path):
     assert list(h.level_size[:3]) == [4096, 32768, 262144] and list(h.level_hashed[:4]) == [0, 0, 0, 1]
 
 
+# Hand-computed known answers for the two index rules of the grid encoding (tiny-cuda-nn's published grid_index):
+#   hashed: (x ^ y*2654435761 ^ z*805459861) mod 2^32 mod T;  e.g. (1,1,1): 0x9E3779B1 ^ 0x30025795 ^ 1 = 0xAE352E25 = 2922720805
+#   dense:  x + y*res + z*res^2
+HASH_KA = {(1, 1, 1): 2922720805, (0, 0, 0): 0, (5, 0, 0): 5, (0, 1, 0): 2654435761, (0, 0, 1): 805459861,
+           (127, 255, 511): 1307501915, (300000, 1, 2): 4265035131, (300000, 200001, 400002): 3250711227, (524287, 524287, 524287): 2750599643}
+LEVEL15_CELL = (300000, 200001, 400002)                      # hash of the cell's own corner: 3250711227
+LEVEL15_ENTRIES = [87272, 87273, 125626, 125627, 212092, 212093, 229934, 229935]          # its 8 corners, mod 2^18
+LEVEL1_CELL = (13, 14, 15)
+LEVEL1_ENTRIES = [15821, 15822, 15853, 15854, 16845, 16846, 16877, 16878]                # res 32: x + 32 y + 1024 z
+DEFAULT_SCALES = [16.0 * 2 ** l - 1.0 for l in range(16)]                                 # 15, 31, ..., 524287 (exact in fp32)
+
+
+def test_hash_and_level_geometry_known_answers(lib_path):
+    """The oracle's index rules and level geometry against literals computed by hand (not by the oracle's own code), and the
+    oracle's table gradient of single points landing exactly on the hand-computed entries."""
+    import torch
+    from loner_amd import hip
+    from oracle import network as NW
+    m = 0xFFFFFFFF
+    for (x, y, z), want in HASH_KA.items():
+        assert ((x ^ (y * NW.PRIME_Y & m) ^ (z * NW.PRIME_Z & m)) & m) == want
+    enc, net = dict(otype="HashGrid", n_levels=16, n_features_per_level=2, log2_hashmap_size=18, base_resolution=16), dict(n_neurons=64, n_hidden_layers=1)
+    o, h = NW.NetworkSpec.from_config(enc, net), hip.make_net_spec(enc, net)
+    assert [lv.scale for lv in o.levels] == DEFAULT_SCALES == [float(h.level_scale[l]) for l in range(16)]
+    assert [lv.res for lv in o.levels] == [16 * 2 ** l for l in range(16)]
+    assert [lv.offset for lv in o.levels] == [0, 4096, 36864] + [36864 + 262144 * k for k in range(1, 14)]
+    # which table entries does one point touch?  (gradient of sum(features) w.r.t. the table = the 8 corner weights)
+    for level, cell, want in ((15, LEVEL15_CELL, LEVEL15_ENTRIES), (1, LEVEL1_CELL, LEVEL1_ENTRIES)):
+        lv = o.levels[level]
+        x = torch.tensor([[(c + 0.25 - 0.5) / lv.scale for c in cell]], dtype=torch.float32)     # pos = cell + 0.25
+        table = torch.zeros(o.n_enc_params // 2, 2, requires_grad=True)
+        feats = NW.encode_hashgrid(o, table, x)
+        feats[:, 2 * level].sum().backward()
+        touched = sorted((table.grad[:, 0].nonzero().flatten() - lv.offset).tolist())
+        assert touched == want, (level, touched)
+        w = table.grad[lv.offset + torch.tensor(want), 0]
+        assert abs(float(w.sum()) - 1.0) < 1e-6 and abs(float(w.max()) - 0.75 ** 3) < 1e-3   # weights of frac = 0.25: (3/4)^3 at the cell's own corner
+
+
 def test_bad_configs_fail_loudly(lib_path):
     from loner_amd import hip
     with pytest.raises(RuntimeError):

@@ -252,6 +252,69 @@ def test_g9_optimisation_loop(golden):
 
 
 # ---------------------------------------------------------------- G10 pose
+def _g11_replay(g):
+    from tests.test_gpu_mapping import _Replay
+    return _Replay(g)
+
+
+def test_g11_sky_rays_and_tracking_phase(golden):
+    """oracle.mapping_step against the reference's Optimizer on sky rays (keyframe.py:91-100) and the pose-refinement phase
+    (latest_kf_only + frozen density net, optimizer.py:239-259): same draws -> same loss trace, poses, parameters, grid."""
+    from oracle import mapping_step as MS
+    from loner_amd.utils import synthetic as SY
+    from tests import support
+    g = golden("g11_sky_tracking")
+    spec = NW.NetworkSpec.from_config(dict(support.SMALL_ENC), dict(n_neurons=32, n_hidden_layers=1))
+    dirs, _ = SY.lidar_pattern()
+    base = SY.trajectory_pose6(8)
+    sky = torch.from_numpy(g["sky"])
+    kfs = [MS.OracleKeyframe(dirs, SY.scene_ranges(dirs, P.transform_from_pose6(base[i])), torch.from_numpy(g[f"pose_init{i}"]).clone(),
+                             anchored=(i == 0), sky_directions=sky, time=float(i)) for i in range(3)]
+    m = MS.OracleMapper(spec, torch.from_numpy(g["params0"]), float(g["scale"]), g["shift"], MS.MapperConfig(n_rays=48, n_sky=16, n_samples=64),
+                        grid_size=32)
+    rp = _g11_replay(g)
+    m.iterate(kfs, 6, draws=rp)
+    assert rp.i == int(g["n_draws_a"])
+    assert rel_err(m.params, g["params_a"]) < 2e-2 and rel_err(m.grid[0, 0], g["grid_a"]) < 1e-3      # (Adam: the tolerances of G9)
+    for i in range(3):
+        assert np.abs(kfs[i].pose6.detach().numpy() - g[f"pose_a{i}"]).max() < 2e-4
+    params_before = m.params.clone()
+    m.iterate(kfs, 6, freeze_sigma=True, draws=rp, latest_kf_only=True)
+    assert rp.i == int(g["n_draws"]) and m.global_step == int(g["global_step"])
+    assert torch.equal(m.params, params_before)
+    trace = np.array(m.trace)
+    print('loss trace rel err', np.abs(trace - g['losses']).max() / np.abs(g['losses']).max())
+    assert np.abs(trace - g["losses"]).max() < 2e-5 * np.abs(g["losses"]).max()
+    for i in range(3):
+        moved = np.abs(g[f"pose_b{i}"] - g[f"pose_a{i}"]).max()
+        assert (moved > 0) == (i == 2)                                   # only the latest keyframe is refined
+        assert np.abs(kfs[i].pose6.detach().numpy() - g[f"pose_b{i}"]).max() < 2e-4
+        if i == 2:
+            assert moved > 1e-3                                              # and it did move, by far more than the tolerance
+    assert rel_err(m.grid[0, 0], g["grid_b"]) < 1e-3
+
+
+def test_g12_l1_depth_of_a_repo_written_checkpoint(golden, tmp_path):
+    """oracle.analysis (Model.forward(testing=True) + compute_l1_depth) against the reference scoring a checkpoint that the
+    repo's own classes wrote and the reference's Model / OccupancyGridModel loaded (analysis/compute_l1_depth.py:42-64,140-155)."""
+    from oracle import analysis as OA
+    from loner_amd.utils import synthetic as SY
+    from tests import support
+    g = golden("g12_checkpoint_l1_depth")
+    meta = support.write_repo_checkpoint(str(tmp_path / "final.tar"))
+    assert float(meta["sigma_params"].double().sum()) == float(g["sigma_params_checksum"])      # the same checkpoint the reference loaded
+    spec = NW.NetworkSpec.from_config(dict(support.SMALL_ENC), dict(n_neurons=32, n_hidden_layers=1))
+    dirs, _ = SY.lidar_pattern()
+    sub = torch.from_numpy(g["scan_subset"])
+    pose6 = torch.from_numpy(g["pose6"])
+    dist = SY.scene_ranges(dirs, P.transform_from_pose6(pose6))[sub]
+    l1, depth = OA.l1_depth(spec, meta["sigma_params"], meta["occ_grid"][0, 0], dirs[:, sub], dist, pose6, torch.tensor(float(g["scale"])),
+                            torch.from_numpy(g["shift"]), torch.tensor([1.0, 50.0]), int(g["n_samples_test"]), torch.from_numpy(g["u_pdf"]),
+                            torch.from_numpy(g["noise"]) * 1.0)
+    assert rel_err(depth, g["depth"]) < 1e-5
+    assert abs(l1 - float(g["l1"])) < 1e-5 * float(g["l1"])
+
+
 def test_g10_axis_angle(golden):
     g = golden("g10_pose")
     Rm = P.rotation_from_axis_angle(t(g["aa"])).numpy()

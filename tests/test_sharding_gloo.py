@@ -30,13 +30,17 @@ def _window(n_kf=4, n_rays=24, n_samples=32, seed=0):
         if k == 0:
             idx[3] = int((dist_k > 50).nonzero()[0])          # make sure transparent rays exist
         rays, depths, _ = OR.lidar_ray_records(dirs, dist_k, idx, T, torch.tensor([1.0, 50.0]), torch.tensor(scale), torch.from_numpy(shift))
+        if k == 0:
+            # make the reference's far[0] quirk observable: the FIRST ray of the whole batch gets a short `far` (as a ray clipped by
+            # the cube wall has), so that many depths exceed far[0] - while the first rays of the other ranks keep the usual far
+            rays[0, 12] = 0.25 * rays[0, 12] + 0.75 * rays[0, 11]
         z = torch.sort(torch.rand(rays.shape[0], n_samples, generator=gen) * (rays[:, 12:13] - rays[:, 11:12]) + rays[:, 11:12], dim=1).values
         noise = torch.randn(rays.shape[0], n_samples, generator=gen)
         out.append((rays.float(), depths.float(), z.float(), noise))
     return out, scale
 
 
-def _rank_loss(spec, params, items, scale, counts_global):
+def _rank_loss(spec, params, items, scale, counts_global, far0=None):
     """sum over this rank's keyframes of the loss terms re-normalised by the global counts."""
     from oracle import loss as OL
     from oracle import network as NW
@@ -45,7 +49,7 @@ def _rank_loss(spec, params, items, scale, counts_global):
     z = torch.cat([i[2] for i in items]); noise = torch.cat([i[3] for i in items])
     sigma = NW.density(spec, params, ORD.sample_points(rays, z).reshape(-1, 3)).reshape(z.shape)
     out = ORD.composite(sigma, z, rays[:, 3:6], rays[:, 12:13], noise)
-    loss, aux = OL.lidar_loss(out, z, rays, depths, torch.tensor(scale), OL.LossConfig())
+    loss, aux = OL.lidar_loss(out, z, rays, depths, torch.tensor(scale), OL.LossConfig(), far0=far0)
     n_local, op_local = rays.shape[0], int(aux["opaque"].sum())
     td, tl, to = aux["terms"]
     n_glob, op_glob = counts_global
@@ -68,12 +72,15 @@ def _worker(rank, world, port, ret):
     assert [i for i, w in enumerate(window) if any(w is m for m in mine)] == shard_window(len(window), world, rank)
     # local counts -> global counts (the kernels' lnr_count_opaque + all_reduce_counts)
     rays = torch.cat([i[0] for i in mine]); depths = torch.cat([i[1] for i in mine])
-    far0 = window[0][0][0, 12]                                     # every rank's first ray has the same far here
-    assert float(rays[0, 12]) == float(far0)
+    far0 = ctx.broadcast_far0(rays)[0]                               # rank 0's first ray = first ray of the whole batch
+    assert float(far0) == float(window[0][0][0, 12])
+    if rank != 0:
+        assert float(rays[0, 12]) != float(far0)                     # a rank's own first ray would give a different mask
+        assert int((depths > rays[0, 12]).sum()) != int((depths > far0).sum())
     local = torch.tensor([rays.shape[0], int(((depths > 0) & ~(depths > far0)).sum())], dtype=torch.int32)
     counts = ctx.all_reduce_counts(local.clone())
     p = params.clone().requires_grad_(True)
-    loss_r, _ = _rank_loss(spec, p, mine, scale, (int(counts[0]), int(counts[1])))
+    loss_r, _ = _rank_loss(spec, p, mine, scale, (int(counts[0]), int(counts[1])), far0=far0)
     loss_r.backward()
     grad = p.grad.clone()
     ctx.all_reduce_grads(grad)
