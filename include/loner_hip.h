@@ -59,7 +59,7 @@ typedef enum LnrPrecision { LNR_PREC_F32 = 0, LNR_PREC_F16 = 1 } LnrPrecision;
 typedef enum LnrPosRounding { LNR_POS_FMA = 0, LNR_POS_MUL_ADD = 1 } LnrPosRounding;
 
 /* lnr_density_backward flags */
-#define LNR_BWD_TABLE_ATOMICS 1   /* test hook: every table-gradient record takes the global-atomic fallback path */
+#define LNR_BWD_TABLE_ATOMICS 1   /* test hook: every table-gradient record goes to the 64-bit overflow accumulators (atomics) */
 
 typedef enum LnrActivation {
     LNR_ACT_NONE = 0, LNR_ACT_RELU = 1, LNR_ACT_SINE = 2, LNR_ACT_LEAKY_RELU = 3,

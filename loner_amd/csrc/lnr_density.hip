@@ -52,14 +52,16 @@ __device__ __forceinline__ void reduce_one(long long* acc, uint2 r, uint32_t bas
     if (PAIR) {
         uint32_t pi; float v0, v1;
         lnr_unpack_pair(r, pi, v0, v1);
-        if (v0 != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[2 * pi]), (unsigned long long)__float2ll_rn(v0 * LNR_FIX_SCALE));
-        if (v1 != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[2 * pi + 1]), (unsigned long long)__float2ll_rn(v1 * LNR_FIX_SCALE));
+        // no test for zero: a record exists because one of its values is non-zero, and a branch per value costs more than adding 0
+        atomicAdd(reinterpret_cast<unsigned long long*>(&acc[2 * pi]), (unsigned long long)__float2ll_rn(v0 * LNR_FIX_SCALE));
+        atomicAdd(reinterpret_cast<unsigned long long*>(&acc[2 * pi + 1]), (unsigned long long)__float2ll_rn(v1 * LNR_FIX_SCALE));
     } else {
         const float v = __uint_as_float(r.y);
         if (v != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[r.x - base]), (unsigned long long)__float2ll_rn(v * LNR_FIX_SCALE));
     }
 }
 
+#define RED_U 8      // 16-byte loads (= pieces of 128 records) in flight per lane
 template <int PAIR>
 __global__ void __launch_bounds__(1024)
 table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ regions_v, const int* __restrict__ counts, int bpg, int maxo,
@@ -76,7 +78,7 @@ table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ region
     for (int l = 0; l < spec.n_levels; ++l) {
         const uint64_t lo = (uint64_t)spec.level_offset[l] * F, hi = lo + (uint64_t)spec.level_size[l] * F;   // float range of the level
         const bool dense = hi - lo <= (uint64_t)LNR_DENSE_LEVEL_FLOATS;
-        const bool coherent = !dense && spec.level_hashed[l] == 0;
+        const bool coherent = !dense;                                       // every record level has overflow accumulators
         const int64_t my_ovf = ovf_off;
         if (coherent) ovf_off += (int64_t)(hi - lo);
         if (hi <= base || lo >= (uint64_t)base + slice) continue;
@@ -113,11 +115,11 @@ table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ region
             const int excl = incl - my_chunks;
             const int total = __shfl(incl, 63, 64);
             if (total == 0) continue;
-            uint4 rec[4], nxt[4];
-            int rem[4], nrem[4];                      // records of the chunk (<= 128), wave-uniform
-            auto load4 = [&](int c0, uint4 out[4], int left[4]) {
+            uint4 rec[RED_U], nxt[RED_U];
+            int rem[RED_U], nrem[RED_U];              // records of the chunk (<= 128), wave-uniform
+            auto load4 = [&](int c0, uint4 out[RED_U], int left[RED_U]) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < RED_U; ++u) {
                     const int c = c0 + u < total ? c0 + u : total - 1;                       // clamp: unconditional loads
                     // the region holding chunk c = the last lane with chunks whose first chunk is at or before c
                     const unsigned long long starts = __ballot(excl <= c && my_chunks > 0);
@@ -130,12 +132,12 @@ table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ region
                 }
             };
             load4(0, nxt, nrem);
-            for (int c0 = 0; c0 < total; c0 += 4) {
+            for (int c0 = 0; c0 < total; c0 += RED_U) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { rec[u] = nxt[u]; rem[u] = nrem[u]; }
-                if (c0 + 4 < total) load4(c0 + 4, nxt, nrem);
+                for (int u = 0; u < RED_U; ++u) { rec[u] = nxt[u]; rem[u] = nrem[u]; }
+                if (c0 + RED_U < total) load4(c0 + RED_U, nxt, nrem);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < RED_U; ++u) {
                     if (2 * lane < rem[u]) reduce_one<PAIR>(acc, make_uint2(rec[u].x, rec[u].y), base);
                     if (2 * lane + 1 < rem[u]) reduce_one<PAIR>(acc, make_uint2(rec[u].z, rec[u].w), base);
                 }
@@ -178,6 +180,7 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
     int64_t bpg = (n_points + 256 * 4 - 1) / (256 * 4);        // ~4 batches of 256 samples per encode-backward workgroup
     if (bpg < 1) bpg = 1;
     if (bpg > LNR_ENC_BWD_MAX_BPG) bpg = LNR_ENC_BWD_MAX_BPG;
+    bpg = (bpg + 3) & ~(int64_t)3;       // the wave-private partition runs 4 waves (= 4 chunks) per workgroup
     L.bpg = (int)bpg;
     L.maxo = 1;
     double per_region = 0.0;
@@ -283,6 +286,30 @@ static int plan_launch(const LnrNetSpec* spec, int64_t n_points, bool backward, 
                   spec->in_dim, spec->n_mlp_params);
     return LNR_ERR_UNSUPPORTED;
 }
+
+namespace {
+struct ReduceCtx {
+    const LnrNetSpec* spec;
+    const void* regions; const int* counts; const long long* ovf; float* grad_table;
+    int bpg, maxo, cap, shift; int64_t n_table;
+};
+
+int launch_table_reduce(const ReduceCtx& c, int n_owners, hipStream_t st) {
+    const size_t lds = ((size_t)1 << c.shift) * sizeof(long long);
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(table_grad_reduce2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(table_grad_reduce2_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e0 != hipSuccess || e1 != hipSuccess) { lnr_set_error("lnr_density_backward: hipFuncSetAttribute failed"); return LNR_ERR_LAUNCH; }
+    LnrProfScope prof("table_grad_reduce", st);
+    if (c.spec->n_features >= 2)
+        hipLaunchKernelGGL(table_grad_reduce2_kernel<1>, dim3(n_owners), dim3(1024), lds, st, *c.spec, c.regions, c.counts, c.bpg, c.maxo, c.cap,
+                           c.shift, c.ovf, c.grad_table, c.n_table);
+    else
+        hipLaunchKernelGGL(table_grad_reduce2_kernel<0>, dim3(n_owners), dim3(1024), lds, st, *c.spec, c.regions, c.counts, c.bpg, c.maxo, c.cap,
+                           c.shift, c.ovf, c.grad_table, c.n_table);
+    return LNR_OK;
+}
+
+}  // namespace
 
 static int make_src(PointSrc* s, MlpPoints* mp, const float* pts, int64_t n_points, const float* rays, const float* z,
                     int32_t n_rays, int32_t n_samples, const int32_t* n_rays_dev, const char* who) {
@@ -429,6 +456,7 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     if (rc) return rc;
     LNR_CHECK_LAUNCH("lnr_density_backward(mlp)");
     float* grad_table = want_grad ? grad_params + spec->n_mlp_params : nullptr;
+    ReduceCtx rctx{spec, regions, counts, ovf, grad_table, L.bpg, L.maxo, cap_rec, L.shift, spec->n_params - spec->n_mlp_params};
     if (want_dfeat) {
         rc = lnr_encode_backward(spec, params, &src, cap, dfeat, dxl, L.m_pad, grad_table, want_grad ? regions : nullptr, counts,
                                  want_grad ? dense_slabs : nullptr, L.bpg, L.maxo, cap_rec, L.shift,
@@ -442,18 +470,8 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     }
     if (!want_grad) return LNR_OK;       // frozen parameters: no table reduce, no weight-gradient fold
     if (hash && L.nown > 0) {          // also with cap_rec == 0 (all-atomic test path): it folds in the overflow accumulators
-        const size_t lds = ((size_t)1 << L.shift) * sizeof(long long);
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(table_grad_reduce2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(table_grad_reduce2_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e0 != hipSuccess || e1 != hipSuccess) { lnr_set_error("lnr_density_backward: hipFuncSetAttribute failed"); return LNR_ERR_LAUNCH; }
-        const int64_t n_table = spec->n_params - spec->n_mlp_params;
-        LnrProfScope prof("table_grad_reduce", st);
-        if (spec->n_features >= 2)
-            hipLaunchKernelGGL(table_grad_reduce2_kernel<1>, dim3(L.nown), dim3(1024), lds, st, *spec, regions, counts, L.bpg, L.maxo, cap_rec,
-                               L.shift, ovf, grad_table, n_table);
-        else
-            hipLaunchKernelGGL(table_grad_reduce2_kernel<0>, dim3(L.nown), dim3(1024), lds, st, *spec, regions, counts, L.bpg, L.maxo, cap_rec,
-                               L.shift, ovf, grad_table, n_table);
+        rc = launch_table_reduce(rctx, L.nown, st);
+        if (rc) return rc;
         LNR_CHECK_LAUNCH("lnr_density_backward(table reduce)");
     }
     const int n_mlp = spec->n_mlp_params;

@@ -83,12 +83,13 @@ struct LevelList {
     int slab_off[LNR_MAX_LEVELS];   // dense levels: float offset inside one workgroup's slab;
                                     // record levels: offset of the level's 64-bit overflow accumulators, or -1 (see below)
 };
-// Record levels with dense (non-hashed) indexing are spatially coherent - an owner slice is a slab of cells - so a
-// workgroup's half-rays pour into a few owners and routinely exceed the region capacity that the uniform model predicts.
-// Their overflow goes to 64-bit fixed-point accumulators in the workspace (integer atomics: exact, order-independent)
-// instead of float atomics, which keeps the table gradient bit-reproducible.  (On hashed levels an overflow is a
-// statistical accident.)
-static inline bool lnr_level_has_overflow_acc(const LnrNetSpec* s, int l) { return s->level_hashed[l] == 0; }
+// Every record level has 64-bit fixed-point overflow accumulators in the workspace (one per table float of the level): a
+// record that does not fit its staging bin or its region is added there (integer atomics: exact, order-independent) with
+// the same 26-bit rounding as a packed record, and the reduce folds the accumulators into the same fixed-point sum - so the
+// table gradient does not depend on which records happened to overflow.  Levels with dense (non-hashed) indexing overflow
+// routinely (they are spatially coherent: an owner slice is a slab of cells and a ray pours into a few of them), hashed
+// levels only by statistical accident.
+static inline bool lnr_level_has_overflow_acc(const LnrNetSpec* s, int l) { (void)s; (void)l; return true; }
 // workgroups per dense level: each pays for zeroing and writing out an LDS copy of the level, so fewer than for the record levels
 static inline int lnr_dense_bpg(int bpg) { return bpg < 512 ? bpg : 512; }
 static inline bool lnr_level_is_dense(const LnrNetSpec* s, int l) {

@@ -602,9 +602,9 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
                                                    : reinterpret_cast<const void*>(KERNEL<F, ENC_DX_NONE>);                   \
             e_ = hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
             if (e_ != hipSuccess) { lnr_set_error("lnr_density_backward: hipFuncSetAttribute(%zu) failed", lds); return LNR_ERR_LAUNCH; } \
-            if (dxm == ENC_DX_RAYS) hipLaunchKernelGGL((KERNEL<F, ENC_DX_RAYS>), grid, block, lds, st, __VA_ARGS__);          \
+            if (dxm == ENC_DX_RAYS) hipLaunchKernelGGL((KERNEL<F, ENC_DX_RAYS>), grid, block, lds, st, __VA_ARGS__);   \
             else if (dxm == ENC_DX_PLANES) hipLaunchKernelGGL((KERNEL<F, ENC_DX_PLANES>), grid, block, lds, st, __VA_ARGS__); \
-            else hipLaunchKernelGGL((KERNEL<F, ENC_DX_NONE>), grid, block, lds, st, __VA_ARGS__);                             \
+            else hipLaunchKernelGGL((KERNEL<F, ENC_DX_NONE>), grid, block, lds, st, __VA_ARGS__);                      \
         } while (0)
 #define LNR_LAUNCH_F(KERNEL, ...)                                                   \
         switch (spec->n_features) {                                                 \
