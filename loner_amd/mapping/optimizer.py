@@ -58,8 +58,10 @@ class HipAdam(torch.optim.Optimizer):
         super().__init__(param_groups, dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8))
 
     @torch.no_grad()
-    def step(self, zero_grad=True, groups=None):
-        """groups: indices of the parameter groups to step (default: all)."""
+    def step(self, zero_grad=True, groups=None, ranges=None):
+        """groups: indices of the parameter groups to step (default: all).  ranges: [(lo, hi), ...] element ranges of the
+        (flat) parameters to step instead of all of them - the sharded form in which a rank owns a slice of the hash tables
+        (mapping/sharding.py); moments outside the ranges are left alone, the step count advances once."""
         for gi, group in enumerate(self.param_groups):
             if groups is not None and gi not in groups:
                 continue
@@ -72,8 +74,10 @@ class HipAdam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p)
                     st["exp_avg_sq"] = torch.zeros_like(p)
                 st["step"] += 1
-                ops.adam_step(p.data.view(-1), p.grad.view(-1), st["exp_avg"].view(-1), st["exp_avg_sq"].view(-1),
-                              group["lr"], st["step"], betas=group["betas"], eps=group["eps"], zero_grad=zero_grad)
+                flat = (p.data.view(-1), p.grad.view(-1), st["exp_avg"].view(-1), st["exp_avg_sq"].view(-1))
+                for lo, hi in (ranges if ranges is not None else [(0, flat[0].numel())]):
+                    ops.adam_step(flat[0][lo:hi], flat[1][lo:hi], flat[2][lo:hi], flat[3][lo:hi],
+                                  group["lr"], st["step"], betas=group["betas"], eps=group["eps"], zero_grad=zero_grad)
 
 
 class _LidarLossFn(torch.autograd.Function):
@@ -277,9 +281,10 @@ class Optimizer:
                     for g, lr0 in zip(self._optimizer.param_groups, base_lrs):
                         g['lr'] = lr0 * (gamma ** it_idx)
                     if density_group is None:
-                        if out["grad_work"] is not None:
-                            out["grad_work"].wait()
-                        self._optimizer.step(zero_grad=True)
+                        dg = 0 if (sigma_params and not tracking and not os_.freeze_sigma_mlp) else None     # stepped right away
+                        self._optimizer.step(zero_grad=True, groups=tuple(i for i in range(len(groups)) if i != dg))
+                        if dg is not None:
+                            self._step_density(out["grad_work"], dg)
                     else:
                         # The density step is deferred to just before the next density forward (_flush_density_step): nothing in
                         # between reads the density parameters - pose gradient and pose step, occupancy step, the next batch's ray
@@ -472,7 +477,7 @@ class Optimizer:
             ops.density_backward(spec, p, d_sigma, grad_params, rays=rays, z=z, n_rays_dev=n_rays_dev,
                                  reuse_features=True, d_rays=d_rays if want_ray_grads else None)
             if self._dist is not None and want_param_grads:
-                grad_work = self._dist.all_reduce_grads(grad_params, async_op=True)
+                grad_work = self._dist.exchange_grads(grad_params, int(spec.n_mlp_params), async_op=True)
                 if not defer_grad_wait:
                     grad_work.wait()
                     grad_work = None
@@ -494,7 +499,8 @@ class Optimizer:
         if want_param_grads and params is not None:
             if params.grad is None:
                 params.grad = torch.zeros_like(params)
-            grad_work = self._dist.all_reduce_grads(params.grad, async_op=True)
+            spec = self._model.nerf_model._model_sigma.spec
+            grad_work = self._dist.exchange_grads(params.grad, int(spec.n_mlp_params), async_op=True)
         self._results_lidar = None
         return dict(loss=None, d_rays=None, grad_params=params.grad if (want_param_grads and params is not None) else None,
                     stats=None, z=None, grad_work=grad_work)
@@ -505,10 +511,24 @@ class Optimizer:
             return
         work, group, lr = self._pending_density
         self._pending_density = None
+        self._optimizer.param_groups[group]['lr'] = lr
+        self._step_density(work, group)
+
+    def _step_density(self, work, group):
+        """Adam step of the density parameters once their gradient exchange (if any) has finished.  Sharded with the
+        "reduce_scatter" exchange a rank steps the MLP matrices and ITS slice of the hash tables, then the slices are gathered."""
         if work is not None:
             work.wait()
-        self._optimizer.param_groups[group]['lr'] = lr
-        self._optimizer.step(zero_grad=True, groups=(group,))
+        ranges = None
+        if self._dist is not None:
+            params = self._model.nerf_model._model_sigma.params
+            n_mlp = int(self._model.nerf_model._model_sigma.spec.n_mlp_params)
+            sl = self._dist.table_slice(n_mlp, params.numel())
+            if sl is not None:
+                ranges = [(0, n_mlp), sl]
+        self._optimizer.step(zero_grad=True, groups=(group,), ranges=ranges)
+        if ranges is not None:
+            self._dist.gather_params(self._model.nerf_model._model_sigma.params.data.view(-1), n_mlp)
 
     def compute_loss(self, camera_samples: Tuple[torch.Tensor, torch.Tensor], lidar_samples: Tuple[torch.Tensor, torch.Tensor],
                      iteration_idx: int, override_enables: bool = False, tracking=False) -> torch.Tensor:

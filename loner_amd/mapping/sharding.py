@@ -16,6 +16,21 @@ by keyframe with ONE exchange step per iteration:
   * every N_iters_acc-th step the occupancy-grid pseudo-gradient (V^3 floats) is all-reduced the
     same way so that the samplers do not diverge.
 
+Two forms of the gradient exchange (DistContext(exchange=...)):
+
+  "all_reduce"      one all-reduce(sum) of the flat gradient [MLP matrices | tables] (29.7 MB); every rank runs the whole
+                    Adam step (237 MB of HBM traffic, ~25-35 us).  Issued asynchronously and awaited at the deferred
+                    density step, i.e. it overlaps the pose tail, the occupancy step and the next batch's ray build.
+  "reduce_scatter"  the table gradient is reduce-scattered by contiguous slice (rank r receives the sum of slice r), every
+                    rank runs Adam on ITS slice of the table only (parameters and Adam moments of a slice live where the
+                    slice is stepped: 1/G of the Adam traffic per rank), then the stepped parameter slices are all-gathered;
+                    the 3072 MLP weights are all-reduced separately and stepped everywhere.  Same bytes on the wire as a
+                    ring all-reduce (it IS its two halves), but only the first half can hide behind the pose tail - the
+                    all-gather sits directly in front of the next density forward.  Worth it when the dense Adam step is
+                    a visible part of a rank's iteration (large tables, many ranks); the default stays "all_reduce".
+  payload="bf16"    either form can put the gradient on the wire as bf16 (half the bytes; the sum over ranks is then
+                    rounded to 8 mantissa bits - replicas stay bit-identical because every rank receives the same sum).
+
 This module is backend-agnostic (it only calls torch.distributed), which is what lets the
 world_size-2 `gloo` tests exercise it on CPU.
 """
@@ -30,13 +45,75 @@ def shard_window(n_keyframes: int, world_size: int, rank: int) -> List[int]:
     return [i for i in range(n_keyframes) if i % world_size == rank]
 
 
+class _Pending:
+    """handle of an asynchronous gradient exchange: wait() blocks (the stream, for RCCL) and finishes the bookkeeping"""
+
+    def __init__(self, works, finish=None):
+        self._works, self._finish = [w for w in works if w is not None], finish
+
+    def wait(self):
+        for w in self._works:
+            w.wait()
+        if self._finish is not None:
+            self._finish()
+            self._finish = None
+
+
 class DistContext:
-    def __init__(self, group=None):
+    def __init__(self, group=None, exchange: str = "all_reduce", payload: str = "fp32"):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
+        if exchange not in ("all_reduce", "reduce_scatter") or payload not in ("fp32", "bf16"):
+            raise ValueError(f"unknown gradient exchange {exchange!r} / payload {payload!r}")
         self.group = group
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.exchange, self.payload = exchange, payload
+
+    # ---- density gradient --------------------------------------------------------------------------------------------
+    def table_slice(self, n_mlp: int, n_total: int):
+        """(lo, hi) of this rank's slice of the flat parameter vector in the "reduce_scatter" form, or None when the whole
+        vector is all-reduced (form "all_reduce", or a table that does not split into 16-byte aligned equal slices)."""
+        n_table = n_total - n_mlp
+        if self.exchange != "reduce_scatter" or n_table <= 0 or n_table % (4 * self.world_size) or n_mlp % 4:
+            return None
+        chunk = n_table // self.world_size
+        return n_mlp + self.rank * chunk, n_mlp + (self.rank + 1) * chunk
+
+    def exchange_grads(self, flat: torch.Tensor, n_mlp: int, async_op: bool = True):
+        """Sum the flat density gradient [MLP | tables] over the ranks.  After .wait(): form "all_reduce" - `flat` holds the sum
+        everywhere; form "reduce_scatter" - flat[:n_mlp] and flat[lo:hi] (table_slice) hold the sums, the rest of the table
+        gradient is zeroed (it belongs to other ranks)."""
+        bf16 = self.payload == "bf16"
+        sl = self.table_slice(n_mlp, flat.numel())
+        if sl is None:
+            buf = flat.to(torch.bfloat16) if bf16 else flat
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            pending = _Pending([work], (lambda: flat.copy_(buf)) if bf16 else None)
+        else:
+            lo, hi = sl
+            w_mlp = dist.all_reduce(flat[:n_mlp], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            table = flat[n_mlp:]
+            src = table.to(torch.bfloat16) if bf16 else table
+            out = torch.empty(hi - lo, device=flat.device, dtype=src.dtype)
+            w_tab = dist.reduce_scatter_tensor(out, src, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+            def finish():
+                flat[n_mlp:lo].zero_()
+                flat[hi:].zero_()
+                flat[lo:hi].copy_(out)
+            pending = _Pending([w_mlp, w_tab], finish)
+        if not async_op:
+            pending.wait()
+        return pending
+
+    def gather_params(self, flat_params: torch.Tensor, n_mlp: int):
+        """form "reduce_scatter": every rank has stepped its slice of the table; collect the slices (in place)."""
+        sl = self.table_slice(n_mlp, flat_params.numel())
+        if sl is None:
+            return
+        mine = flat_params[sl[0]:sl[1]].clone()
+        dist.all_gather_into_tensor(flat_params[n_mlp:], mine, group=self.group)
 
     def owned(self, window: Sequence) -> list:
         return [window[i] for i in shard_window(len(window), self.world_size, self.rank)]
@@ -49,9 +126,7 @@ class DistContext:
         return work if async_op else counts
 
     def all_reduce_grads(self, flat: torch.Tensor, async_op: bool = False):
-        """Sum a flat gradient buffer over ranks, in place (one large collective, not per-tensor buckets:
-        the whole density gradient is a single 29.7 MB vector).  async_op=True returns the handle; the training loop
-        waits for it right before the density Adam step, so the pose gradient of this rank runs next to the collective."""
+        """Sum a flat buffer over ranks, in place (the occupancy pseudo-gradient: 64-bit fixed-point accumulators, exact)."""
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         return work if async_op else flat
 

@@ -117,6 +117,56 @@ def test_sharded_window_equals_single_process():
     assert np.abs(ret["grad"] - p.grad.numpy()).max() / np.abs(p.grad.numpy()).max() < 1e-4
 
 
+def _exchange_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from loner_amd.mapping.sharding import DistContext
+    n_mlp, n_table = 48, 4096
+    gen = torch.Generator().manual_seed(10 + rank)
+    local = torch.randn(n_mlp + n_table, generator=gen)
+    out = {}
+    for exchange in ("all_reduce", "reduce_scatter"):
+        for payload in ("fp32", "bf16"):
+            ctx = DistContext(exchange=exchange, payload=payload)
+            flat = local.clone()
+            ctx.exchange_grads(flat, n_mlp, async_op=True).wait()
+            sl = ctx.table_slice(n_mlp, flat.numel())
+            assert (sl is None) == (exchange == "all_reduce")
+            # a fake "step": every rank writes rank-independent values derived from the reduced gradient into the part it owns
+            params = torch.zeros_like(flat)
+            if sl is None:
+                params.copy_(flat * 0.5)
+            else:
+                params[:n_mlp] = flat[:n_mlp] * 0.5
+                params[sl[0]:sl[1]] = flat[sl[0]:sl[1]] * 0.5
+                assert float(flat[n_mlp:sl[0]].abs().sum()) == 0.0 and float(flat[sl[1]:].abs().sum()) == 0.0   # other ranks' slices: zeroed
+                ctx.gather_params(params, n_mlp)
+            out[(exchange, payload)] = params
+    ret[rank] = {k: v.numpy() for k, v in out.items()}
+    ret[f"local{rank}"] = local.numpy()
+    dist.destroy_process_group()
+
+
+def test_gradient_exchange_forms_agree():
+    """all_reduce vs reduce_scatter(+all_gather), fp32 vs bf16 payload: every rank ends with the same full vector; the fp32
+    forms equal the plain sum, the bf16 forms equal the sum of the bf16-rounded contributions (rounded to bf16)."""
+    port = 29800 + (os.getpid() % 1000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_exchange_worker, args=(2, port, ret), nprocs=2, join=True)
+    total = torch.from_numpy(ret["local0"]) + torch.from_numpy(ret["local1"])
+    total_bf = (torch.from_numpy(ret["local0"]).bfloat16() + torch.from_numpy(ret["local1"]).bfloat16()).float()
+    for key, v0 in ret[0].items():
+        assert np.array_equal(v0, ret[1][key]), key                       # replicas identical
+        exchange, payload = key
+        want = total.clone()
+        if payload == "bf16":
+            want = total_bf.clone()
+            if exchange == "reduce_scatter":
+                want[:48] = total[:48]                                     # the MLP part always travels in fp32
+        assert np.array_equal(v0, (want * 0.5).numpy()), key
+
+
 def test_shard_window_round_robin():
     from loner_amd.mapping.sharding import shard_window
     assert shard_window(8, 8, 3) == [3]
