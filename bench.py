@@ -49,15 +49,11 @@ def build_window(n_kf, device=None):
     from loner_amd.utils import synthetic as SY
     from loner_amd.common.pose_utils import tensor_to_transform
     dirs, ts = SY.lidar_pattern()
-    base = SY.trajectory_pose6(n_kf)
-    gen = torch.Generator().manual_seed(1)
+    base, init = window_poses(n_kf)
     kfs = []
     for i in range(n_kf):
         dist = SY.scene_ranges(dirs, tensor_to_transform(base[i]))
-        p6 = base[i].clone()
-        if i > 0:                                   # initial pose error N(0, 2 cm / 0.2 deg)
-            p6[:3] += torch.randn(3, generator=gen) * 0.02
-            p6[3:] += torch.randn(3, generator=gen) * 0.2 * 3.14159265 / 180
+        p6 = init[i]
         fr = Frame(None, LidarScan(dirs.clone(), dist, ts + 3.0 * i, sky_rays=torch.Tensor()), Pose())
         fr._lidar_pose = Pose(pose_tensor=p6, fixed=False)
         fr._gt_lidar_pose = Pose(pose_tensor=base[i].clone(), fixed=True)
@@ -66,38 +62,87 @@ def build_window(n_kf, device=None):
     return kfs
 
 
-def cpu_baseline(args, budget_s=12.0):
-    """The oracle (CPU restatement of the reference's mapping iteration, oracle/mapping_step.py) timed on the
-    host cores on a bounded sample of the same workload: ONE keyframe x 512 rays x 512 samples per iteration,
-    default network, as many iterations as fit in ~budget_s seconds (at least 1, at most 40; the every-10th-step
-    occupancy update is part of the sample)."""
+L1_RAYS = 256            # held-out rays of keyframe 0 for the matched-quality probe of the baseline legs
+
+
+def window_poses(n_kf):
+    """(ground-truth pose6, initial pose6) of the synthetic window: N(0, 2 cm / 0.2 deg) error on every keyframe but the first"""
+    from loner_amd.utils import synthetic as SY
+    base = SY.trajectory_pose6(n_kf)
+    gen = torch.Generator().manual_seed(1)
+    init = []
+    for i in range(n_kf):
+        p6 = base[i].clone()
+        if i > 0:
+            p6[:3] += torch.randn(3, generator=gen) * 0.02
+            p6[3:] += torch.randn(3, generator=gen) * 0.2 * 3.14159265 / 180
+        init.append(p6)
+    return base, init
+
+
+def oracle_leg(args, device, budget_s, max_iters, min_iters=2):
+    """A baseline leg: the oracle (oracle/mapping_step.py - the reference's mapping iteration restated op for op in torch, with
+    the reference's own sampler op sequence, oracle/torch_sampling.py) on the SAME workload as the HIP path: the whole
+    keyframe window, joint optimisation of the density field and the non-anchored poses, occupancy step at global steps 0, 10, ...
+    device "cpu": timed on the host cores (cpu_baseline, kind "port").  device "cuda": the same torch ops executed by
+    PyTorch-ROCm on the MI355X (torch_rocm_baseline) - what a straight PyTorch port of the reference would run at, with the
+    hash-grid network written in torch instead of tinycudann.  Bounded: as many iterations as fit in ~budget_s (>= min_iters)."""
+    from oracle import analysis as OA
     from oracle import mapping_step as MS
     from oracle import network as NW
+    from oracle import poses as OP
     from loner_amd.common.settings import default_nerf_config
     from loner_amd.utils import synthetic as SY
-    from oracle import poses as OP
-    threads = min(os.cpu_count() or 1, 16)           # torch CPU ops on [512,512] tensors stop scaling beyond this
-    torch.set_num_threads(threads)
+    dev = torch.device(device)
+    threads = min(os.cpu_count() or 1, 16)           # torch CPU ops on [4096,512] tensors stop scaling beyond this
+    if dev.type == "cpu":
+        torch.set_num_threads(threads)
     nc = default_nerf_config()
     spec = NW.NetworkSpec.from_config(nc["pos_encoding_sigma"], nc["sigma_network"])
     scale, shift = SY.world_cube()
     cfg = MS.MapperConfig(n_rays=args.rays, n_samples=args.samples)
-    m = MS.OracleMapper(spec, NW.init_params(spec, 0), scale, shift, cfg, grid_size=100)
-    m.global_step = 1
     dirs, _ = SY.lidar_pattern()
-    base = SY.trajectory_pose6(1)
-    kfs = [MS.OracleKeyframe(dirs, SY.scene_ranges(dirs, OP.transform_from_pose6(base[0])), base[0].clone(), anchored=True)]
+    base, init = window_poses(args.keyframes)
+    dist0 = None
+
+    def make():
+        nonlocal dist0
+        m = MS.OracleMapper(spec, NW.init_params(spec, 0), scale, shift, cfg, grid_size=100, device=dev, sampler="torch")
+        kfs = []
+        for i in range(args.keyframes):
+            d = SY.scene_ranges(dirs, OP.transform_from_pose6(base[i]))
+            if i == 0:
+                dist0 = d
+            kfs.append(MS.OracleKeyframe(dirs.to(dev), d.to(dev), init[i].clone().to(dev), anchored=(i == 0), time=3.0 * i))
+        return m, kfs
+    sync = (lambda: torch.cuda.synchronize()) if dev.type == "cuda" else (lambda: None)
+    if dev.type == "cuda":                           # one untimed iteration: kernel selection, allocator warm-up
+        m, kfs = make(); torch.manual_seed(0); m.iterate(kfs, 1); sync()
+    m, kfs = make()
     torch.manual_seed(0)
     t0 = time.time()
     n_valid, iters = 0, 0
-    while iters < 40 and (iters == 0 or time.time() - t0 < budget_s):
+    while iters < max_iters and (iters < min_iters or time.time() - t0 < budget_s):
         n_valid += m.iterate(kfs, 1)
+        sync()
         iters += 1
     dt = time.time() - t0
-    return {"value": n_valid / dt, "unit": "rays/s", "cores": threads, "kind": "port",
-            "sample": f"{iters} mapping iterations of 1 keyframe x {args.rays} rays x {args.samples} samples (map-only, pose anchored), "
-                      f"default network, torch CPU fp32, {dt:.1f} s wall",
-            "ms_per_iter": 1e3 * dt / iters}
+    # matched-quality probe (outside the timed region): L1 depth of L1_RAYS held-out rays of keyframe 0, as compute_l1_depth does
+    idx = torch.linspace(0, dirs.shape[1] - 1, L1_RAYS).long()
+    torch.manual_seed(123)
+    l1, _ = OA.l1_depth(spec, m.params, m.grid[0, 0], dirs[:, idx].to(dev), dist0[idx].to(dev), kfs[0].pose6.detach(), m.scale, m.shift,
+                        torch.tensor([1.0, 50.0], device=dev), 2048, torch.rand(L1_RAYS, 1024).to(dev), (torch.randn(L1_RAYS, 2048) * 1.0).to(dev),
+                        sampler="torch")
+    out = {"value": n_valid / dt, "unit": "rays/s", "kind": "port",
+           "sample": f"{iters} mapping iterations of the SAME workload ({args.keyframes} keyframes x {args.rays} rays x {args.samples} samples, joint map + "
+                     f"pose optimisation, default network, occupancy step at global step 0), oracle torch ops in fp32, {dt:.1f} s wall",
+           "ms_per_iter": 1e3 * dt / iters, "iterations": iters, "l1_depth_m_after": l1}
+    if dev.type == "cpu":
+        out["cores"] = threads
+    else:
+        out["device"] = torch.cuda.get_device_name(0)
+        out["kind"] = "port (the oracle's torch ops through PyTorch-ROCm on the same MI355X: a restatement - the reference's density net is tinycudann, CUDA-only)"
+    return out
 
 
 class KernelTimer:
@@ -168,14 +213,22 @@ def main():
     from loner_amd.mapping.sharding import DistContext
     from loner_amd.utils import synthetic as SY
 
-    settings = default_optimizer_settings(log_directory=f"/tmp/loner_amd_bench_{rank}")
-    settings["num_samples"]["lidar"] = args.rays
-    settings["num_samples"]["sky"] = 0
-    settings["model_config"]["model"]["render"]["N_samples_train"] = args.samples
-    settings["model_config"]["model"]["nerf_config"]["sigma_network"]["precision"] = "fp16" if args.dtype == "f16" else "fp32"
     scale, shift = SY.world_cube()
-    torch.manual_seed(0)                                   # identical initial parameters on every rank
-    opt = Optimizer(settings, None, WorldCube(torch.tensor(scale), torch.from_numpy(shift)), local, False, True, False)
+
+    def make_optimizer(dtype, params0=None):
+        settings = default_optimizer_settings(log_directory=f"/tmp/loner_amd_bench_{rank}")
+        settings["num_samples"]["lidar"] = args.rays
+        settings["num_samples"]["sky"] = 0
+        settings["model_config"]["model"]["render"]["N_samples_train"] = args.samples
+        settings["model_config"]["model"]["nerf_config"]["sigma_network"]["precision"] = "fp16" if dtype == "f16" else "fp32"
+        torch.manual_seed(0)                               # identical initial parameters on every rank
+        o = Optimizer(settings, None, WorldCube(torch.tensor(scale), torch.from_numpy(shift)), local, False, True, False)
+        if params0 is not None:
+            with torch.no_grad():
+                o._model.nerf_model._model_sigma.params.copy_(params0.to(o._device))
+        return o
+
+    opt = make_optimizer(args.dtype)
     window = build_window(args.keyframes)
     if world > 1:
         ctx = DistContext()
@@ -221,15 +274,37 @@ def main():
 
     # quality half of the metric ("at matched L1 depth"): render held-out rays of the first keyframe with the trained
     # map (Model.forward(testing=True), 2048 samples) and compare with the analytic ranges.  Outside the timed region.
-    l1_depth = None
-    try:
-        from loner_amd.analysis.l1_depth import compute_l1_depth
-        from loner_amd.common.ray_utils import LidarRayDirections
-        kf0 = my_window[0]
-        l1_depth = compute_l1_depth(kf0.get_lidar_pose(), LidarRayDirections(kf0.get_lidar_scan(), chunk_size=2048), opt._model,
-                                    opt._ray_sampler, opt._world_cube, opt._ray_range, opt._device, max_rays=4096)
-    except Exception as e:      # never let the quality probe break the benchmark line
-        l1_depth = f"failed: {e}"
+    from loner_amd.analysis.l1_depth import compute_l1_depth
+    from loner_amd.common.ray_utils import LidarRayDirections
+
+    def l1_of(o, kf0, max_rays):
+        try:
+            return compute_l1_depth(kf0.get_lidar_pose(), LidarRayDirections(kf0.get_lidar_scan(), chunk_size=2048), o._model,
+                                    o._ray_sampler, o._world_cube, o._ray_range, o._device, max_rays=max_rays)
+        except Exception as e:      # never let the quality probe break the benchmark line
+            return f"failed: {e}"
+    l1_depth = l1_of(opt, my_window[0], 4096)
+
+    # the other arithmetic mode of the density network, same workload, same step counts (outside the headline's timed region)
+    other = None
+    if world == 1:
+        try:
+            od = "f16" if args.dtype == "f32" else "f32"
+            o2, w2 = make_optimizer(od), build_window(args.keyframes)
+            if args.warmup > 0:
+                o2._do_iterate_optimizer(w2, [None], optimizer_settings=phase(args.warmup))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            o2._do_iterate_optimizer(w2, [None], optimizer_settings=phase(args.steps))
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            other = {"dtype": od, "value": o2.last_stats["n_valid_rays"] / dt2, "unit": "rays/s", "ms_per_step": 1e3 * dt2 / max(args.steps, 1),
+                     "final_loss": float(o2.last_stats["loss_terms"][-1, 0]), "l1_depth_m": l1_of(o2, w2[0], 4096),
+                     "note": "f16 = the reference's storage types (tinycudann half precision): fp16 encoded features and MLP weights on "
+                             "v_mfma_f32_16x16x32_f16 with fp32 accumulation, fp32 master parameters and gradients; f32 = everything fp32"}
+            del o2, w2
+        except Exception as e:
+            other = {"error": str(e)}
 
     ksum = timer.summary()
     spec = opt._model.nerf_model._model_sigma.spec
@@ -279,10 +354,12 @@ def main():
         roofline = {"kernel": dom, "bound": "hbm", "achieved": a_.get("bytes", 0.0) / t / 1e9, "peak": 8000.0, "unit": "GB/s",
                     "frac": a_.get("bytes", 0.0) / t / 8e12, "traffic": traffic.get(dom + "_bytes_per_launch"),
                     "avg_launch_ms": kprof[dom]["avg_ms"], "algorithmic_bytes_per_launch": a_.get("bytes", 0.0),
+                    "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command "
+                                      "(tools/pmc.sh), NOT measured by this run; FETCH_SIZE doubled as the microarchitecture guide prescribes for gfx950",
                     "note": "dominant kernel by total time over the timed region, timed with HIP events recorded by the library on the "
-                            "launch stream (lnr_profile_*).  It moves few algorithmic bytes: its time goes to L1 line lookups of the "
-                            "random 8-byte table gathers, VALU work of the in-LDS radix partition and the 8-byte gradient records it "
-                            "streams to HBM (DESIGN.md 4.3); `traffic` = PMC FETCH_SIZE+WRITE_SIZE bytes per launch (profiles/traffic.json)",
+                            "launch stream (lnr_profile_*).  It moves few algorithmic bytes: its time goes to the L2 line rate of the "
+                            "random 8-byte table gathers (one 64-byte line per 2 clocks and CU, tools/gather_bench.hip), VALU work of the "
+                            "in-LDS radix partition and the 8-byte gradient records it streams to HBM (DESIGN.md 4.3)",
                     "secondary": {k: v for k, v in kernels.items() if k in ("mlp_backward", "mlp_forward", "encode_forward", "table_grad_reduce")}}
     line = {
         "metric": "training rays/sec", "value": total_rays / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
@@ -303,10 +380,41 @@ def main():
         "ops_ms": {k: round(v["avg_ms"], 4) for k, v in ksum.items()},
         "final_loss": float(opt.last_stats["loss_terms"][-1, 0]),
         "l1_depth_m": l1_depth, "iterations_trained": args.warmup + args.steps,
+        "other_dtype": other,
+        "disclosures": {
+            "table_gradient_records": "hash-table gradient contributions travel as 8-byte records whose two values are rounded to 26 bits "
+                                      "(sign, 8 exponent, 17 mantissa bits; relative error <= 2^-18) before an exact 64-bit fixed-point sum - a "
+                                      "sub-fp32 step inside the f32 mode (DESIGN.md 4.3; parity vs the fp32 oracle 2e-5)",
+            "grid_position": "fma(x, scale, 0.5) as tiny-cuda-nn (one rounding); spec switch pos_rounding=mul_add for the other convention",
+            "timed_region": "inputs resident in HBM (scans uploaded once per keyframe before the loop); no host sync inside the loop",
+        },
     }
     print(json.dumps({k: v for k, v in line.items() if k != "cpu_baseline"}), file=sys.stderr, flush=True)   # progress copy
     if world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(args)
+        # baseline legs on the SAME workload, each bounded; then the HIP path's L1 after the same number of iterations as the CPU leg
+        cpu = oracle_leg(args, "cpu", budget_s=14.0, max_iters=6)
+        try:
+            rocm = oracle_leg(args, "cuda", budget_s=4.0, max_iters=max(cpu["iterations"], 3), min_iters=cpu["iterations"])
+        except Exception as e:
+            rocm = {"error": str(e)}
+        line["cpu_baseline"] = cpu
+        line["torch_rocm_baseline"] = rocm
+        n_match = cpu["iterations"]
+        o3, w3 = make_optimizer("f32"), build_window(args.keyframes)
+        o3._do_iterate_optimizer(w3, [None], optimizer_settings=phase(n_match))
+        hip_l1 = l1_of(o3, w3[0], L1_RAYS)
+        legs = {"hip_f32": hip_l1, "cpu_oracle": cpu["l1_depth_m_after"], "torch_rocm_oracle": rocm.get("l1_depth_m_after")}
+        vals = [v for v in legs.values() if isinstance(v, float)]
+        line["matched_quality"] = {
+            "iterations": n_match, "l1_depth_m": legs, "rays": L1_RAYS,
+            "agree_within_5pct": bool(len(vals) >= 2 and (max(vals) - min(vals)) <= 0.05 * max(vals)),
+            "note": "L1 depth (analysis/compute_l1_depth.py semantics, Model.forward(testing=True), 2048 samples) of the same held-out rays "
+                    "after the SAME number of iterations from the same initial parameters on every leg (different random draws); the "
+                    "speed-ups below are only quoted when the legs agree within 5 %"}
+        if line["matched_quality"]["agree_within_5pct"]:
+            line["speedup_vs_cpu_oracle"] = line["value"] / cpu["value"] if args.dtype == "f32" else None
+            if isinstance(rocm.get("value"), float):
+                line["speedup_vs_torch_rocm_oracle"] = line["value"] / rocm["value"]
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

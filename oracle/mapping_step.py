@@ -28,6 +28,7 @@ from . import poses as P
 from . import rays as R
 from . import render as RD
 from . import sampling as SP
+from . import torch_sampling as TS
 
 
 @dataclass(eq=False)
@@ -97,12 +98,17 @@ class MapperConfig:
 
 class OracleMapper:
     def __init__(self, spec: NW.NetworkSpec, params: torch.Tensor, scale: float, shift,
-                 cfg: MapperConfig, grid_size: int = 100):
+                 cfg: MapperConfig, grid_size: int = 100, device="cpu", sampler="numpy"):
+        """sampler "numpy": the rounding-exact emulation of torch's CPU kernels (sampling.py; parity tests, CPU only);
+        "torch": the reference's own torch op sequence (torch_sampling.py; any device - the op-for-op baseline legs of bench.py).
+        With device != "cpu" the keyframes' tensors must live on that device too."""
         self.spec, self.cfg = spec, cfg
-        self.params = params.clone().float()
-        self.scale = torch.tensor(float(scale))
-        self.shift = torch.as_tensor(shift, dtype=torch.float32)
-        self.grid = torch.zeros(1, 1, grid_size, grid_size, grid_size)
+        self.device, self.sampler = torch.device(device), sampler
+        assert sampler == "torch" or self.device.type == "cpu"
+        self.params = params.clone().float().to(self.device)
+        self.scale = torch.tensor(float(scale), device=self.device)
+        self.shift = torch.as_tensor(shift, dtype=torch.float32).to(self.device)
+        self.grid = torch.zeros(1, 1, grid_size, grid_size, grid_size, device=self.device)
         self.global_step = 0
         self.draws = TorchDraws()
         self.trace = []
@@ -113,19 +119,29 @@ class OracleMapper:
         cfg = self.cfg
         n = rays.shape[0]
         half = cfg.n_samples // 2
-        rays_np = rays.detach().numpy()
-        if cfg.use_occupancy:
-            u1 = draws.jitter(n, half) if cfg.perturb > 0 else None
-            u2 = draws.pdf(n, half)
-            z = SP.sample_occupancy(rays_np, self.grid[0, 0].numpy(), cfg.n_samples, cfg.perturb,
-                                    None if u1 is None else u1.numpy(), u2.numpy())
+        dev = self.device
+        if self.sampler == "torch":
+            if cfg.use_occupancy:
+                u1 = draws.jitter(n, half).to(dev) if cfg.perturb > 0 else None
+                z = TS.sample_occupancy(rays.detach(), self.grid, cfg.n_samples, cfg.perturb, u1, draws.pdf(n, half).to(dev))
+            else:
+                u1 = draws.jitter(n, cfg.n_samples).to(dev) if cfg.perturb > 0 else None
+                z = TS.sample_uniform(rays.detach(), cfg.n_samples, cfg.perturb, u1)
         else:
-            u1 = draws.jitter(n, cfg.n_samples) if cfg.perturb > 0 else None
-            z = SP.sample_uniform(rays_np, cfg.n_samples, cfg.perturb, None if u1 is None else u1.numpy())
-        z = torch.from_numpy(z) if z_override is None else z_override
+            rays_np = rays.detach().numpy()
+            if cfg.use_occupancy:
+                u1 = draws.jitter(n, half) if cfg.perturb > 0 else None
+                u2 = draws.pdf(n, half)
+                z = SP.sample_occupancy(rays_np, self.grid[0, 0].numpy(), cfg.n_samples, cfg.perturb,
+                                        None if u1 is None else u1.numpy(), u2.numpy())
+            else:
+                u1 = draws.jitter(n, cfg.n_samples) if cfg.perturb > 0 else None
+                z = SP.sample_uniform(rays_np, cfg.n_samples, cfg.perturb, None if u1 is None else u1.numpy())
+            z = torch.from_numpy(z)
+        z = z if z_override is None else z_override
         xyz = RD.sample_points(rays, z)
         sigma = NW.density(self.spec, self.params, xyz.reshape(-1, 3)).reshape(n, cfg.n_samples)
-        noise = draws.noise(n, cfg.n_samples) * cfg.noise_std if cfg.noise_std > 0 else None
+        noise = (draws.noise(n, cfg.n_samples) * cfg.noise_std).to(dev) if cfg.noise_std > 0 else None
         out = RD.composite(sigma, z, rays[:, 3:6], rays[:, -1:], noise)
         loss, aux = L.lidar_loss(out, z, rays, depths, self.scale, cfg.loss, iteration)
         aux.update(z=z, xyz=xyz.detach(), out=out)
@@ -144,7 +160,7 @@ class OracleMapper:
                 if kf.time > latest.time:
                     latest = kf
             window = [latest]
-        rr = torch.tensor(cfg.ray_range)
+        rr = torch.tensor(cfg.ray_range, device=self.device)
         self.params.requires_grad_(not freeze_sigma)
         free = [kf for kf in window if not kf.anchored and not freeze_poses]
         for kf in window:
@@ -159,10 +175,10 @@ class OracleMapper:
         for it in range(n_iters):
             rays_all, depth_all = [], []
             for kf in window:
-                idx = draws.ray_index(kf.distances.shape[0], cfg.n_rays)
+                idx = draws.ray_index(kf.distances.shape[0], cfg.n_rays).to(self.device)
                 sky_idx = None
                 if cfg.n_sky > 0 and kf.sky_directions is not None and kf.sky_directions.numel() > 0:
-                    sky_idx = draws.sky_index(kf.sky_directions.shape[1], cfg.n_sky)
+                    sky_idx = draws.sky_index(kf.sky_directions.shape[1], cfg.n_sky).to(self.device)
                 T = P.transform_from_pose6(kf.pose6) if kf.pose6.requires_grad \
                     else P.transform_from_pose6(kf.pose6.detach())
                 r, d = R.keyframe_ray_records(kf.directions, kf.distances, idx, T, rr, self.scale,

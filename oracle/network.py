@@ -213,7 +213,7 @@ def encode_hashgrid(spec: NetworkSpec, table: torch.Tensor, x: torch.Tensor) -> 
         cell = torch.floor(pos)
         frac = pos - cell
         cell = cell.detach().to(torch.int64)
-        acc = torch.zeros(x.shape[0], F, dtype=x.dtype)
+        acc = torch.zeros(x.shape[0], F, dtype=x.dtype, device=x.device)
         for corner in range(8):
             bx, by, bz = corner & 1, (corner >> 1) & 1, (corner >> 2) & 1
             cx = cell[:, 0] + bx
@@ -234,7 +234,7 @@ def encode_hashgrid(spec: NetworkSpec, table: torch.Tensor, x: torch.Tensor) -> 
 
 def encode_frequency(spec: NetworkSpec, x: torch.Tensor) -> torch.Tensor:
     """x [B,3] -> [B, 3*2*n_freq] ordered [dim][k][sin,cos]."""
-    k = torch.arange(spec.n_frequencies, dtype=x.dtype)
+    k = torch.arange(spec.n_frequencies, dtype=x.dtype, device=x.device)
     phase = x[:, :, None] * torch.exp2(k)[None, None, :] * math.pi        # [B,3,K]
     both = torch.stack([torch.sin(phase), torch.sin(phase + math.pi / 2)], dim=-1)
     return both.reshape(x.shape[0], -1)
@@ -258,7 +258,7 @@ def density_unit(spec: NetworkSpec, params: torch.Tensor, x: torch.Tensor) -> to
     else:
         h = encode_frequency(spec, x)
     if h.shape[1] < spec.in_dim:   # padded inputs are fed the constant 1 (tiny-cuda-nn pads with ones)
-        h = torch.cat([h, torch.ones(h.shape[0], spec.in_dim - h.shape[1], dtype=h.dtype)], dim=1)
+        h = torch.cat([h, torch.ones(h.shape[0], spec.in_dim - h.shape[1], dtype=h.dtype, device=h.device)], dim=1)
     half = spec.precision == "fp16"
     if half:
         mats = [round_f16(m) for m in mats]

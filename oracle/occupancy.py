@@ -63,7 +63,7 @@ def logits_pseudo_grad(s_metres: torch.Tensor, g_metres: torch.Tensor,
     """losses.py:54-62.  +free in front of the surface (s < g-margin), -occ
     within `margin` of it, 0 behind; the step functions are 0 at 0."""
     x = s_metres - g_metres
-    zero = torch.zeros((), dtype=x.dtype)
+    zero = torch.zeros((), dtype=x.dtype, device=x.device)
     step = lambda t: torch.heaviside(t, zero)
     return free * step(-x - margin) - occ * step(x + margin) * step(margin - x)
 

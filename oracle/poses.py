@@ -32,5 +32,5 @@ def transform_from_pose6(p: torch.Tensor) -> torch.Tensor:
     """p [6] = [t(3), axis-angle(3)] -> T [4,4], differentiable."""
     R = rotation_from_axis_angle(p[3:6])
     top = torch.cat([R, p[0:3].reshape(3, 1)], dim=1)
-    bottom = torch.tensor([[0.0, 0.0, 0.0, 1.0]], dtype=p.dtype)
+    bottom = torch.tensor([[0.0, 0.0, 0.0, 1.0]], dtype=p.dtype, device=p.device)
     return torch.cat([top, bottom], dim=0)
