@@ -35,19 +35,19 @@ __device__ __forceinline__ void gather_entries(const float* __restrict__ table, 
     }
 }
 
-// H16: the features leave as half2 pairs (F == 2: one dword per sample and level) for the fp16 MLP kernels
-// (lnr_density_f16.hip), rounded to nearest even; the interpolation itself stays fp32.
+// H16: the features leave as half2 pairs (plane p holds features 2p, 2p+1: one dword per sample; F/2 planes per level) for the
+// fp16 MLP kernels (lnr_density_f16.hip), rounded to nearest even; the interpolation itself stays fp32.
 template <int F, bool H16>
 __global__ void __launch_bounds__(ENC_BLOCK)
 encode_forward_kernel(const LnrNetSpec spec, const float* __restrict__ table, const PointSrc src, float* __restrict__ feat,
                       int64_t m_pad, int bpg) {
-    static_assert(!H16 || F == 2, "half2 planes hold one level of two features per dword");
+    static_assert(!H16 || F >= 2, "half2 planes pair up the features of a level");
     const int lv = blockIdx.x / bpg, chunk = blockIdx.x % bpg;
     const LevelInfo L = level_info(spec, lv);
     const uint32_t M = (uint32_t)live_points(src);
     // the MLP kernels read whole tiles of 16 (fp32) / 32 (fp16) samples: zero the ragged tail
     const uint32_t Mt = H16 ? (M + 31u) / 32u * 32u : (M + 15u) / 16u * 16u;
-    float* planes = feat + (size_t)(H16 ? lv : lv * F) * m_pad;
+    float* planes = feat + (size_t)(H16 ? lv * (F / 2) : lv * F) * m_pad;
     const uint32_t plane_bytes = (uint32_t)m_pad * 4u;
     SampleCursor cur;
     cur.init((uint32_t)chunk * ENC_BLOCK + threadIdx.x, (uint32_t)bpg * ENC_BLOCK, src.pts ? 1u : (uint32_t)src.n_samples);
@@ -72,7 +72,9 @@ encode_forward_kernel(const LnrNetSpec spec, const float* __restrict__ table, co
         }
         if constexpr (H16) {
             typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-            st32<uint32_t>(planes, cur.m * 4u, __builtin_bit_cast(uint32_t, h2{(_Float16)out[0], (_Float16)out[1]}));
+#pragma unroll
+            for (int q = 0; q < F / 2; ++q)
+                st32<uint32_t>(planes, (uint32_t)q * plane_bytes + cur.m * 4u, __builtin_bit_cast(uint32_t, h2{(_Float16)out[2 * q], (_Float16)out[2 * q + 1]}));
         } else {
 #pragma unroll
             for (int f = 0; f < F; ++f) st32<float>(planes, (uint32_t)f * plane_bytes + cur.m * 4u, out[f]);
@@ -80,11 +82,12 @@ encode_forward_kernel(const LnrNetSpec spec, const float* __restrict__ table, co
     }
 }
 
+template <bool H16>
 __global__ void __launch_bounds__(ENC_BLOCK)
 freq_forward_kernel(const LnrNetSpec spec, const PointSrc src, float* __restrict__ feat, int64_t m_pad, int bpg) {
     const int group = blockIdx.x / bpg, chunk = blockIdx.x % bpg;       // 4 features per group
     const int64_t M = live_points(src);
-    const int64_t M16 = (M + 15) / 16 * 16;
+    const int64_t M16 = H16 ? (M + 31) / 32 * 32 : (M + 15) / 16 * 16;
     for (int64_t m = (int64_t)chunk * ENC_BLOCK + threadIdx.x; m < M16; m += (int64_t)bpg * ENC_BLOCK) {
         float out[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (m < M) {
@@ -92,9 +95,18 @@ freq_forward_kernel(const LnrNetSpec spec, const PointSrc src, float* __restrict
             load_unit_point(src, m, x);
             freq_features4(spec, x, 4 * group, out);
         }
+        if constexpr (H16) {                    // half2 pair planes: (sin, cos) of one (dimension, frequency) per dword
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            uint32_t* pairs = reinterpret_cast<uint32_t*>(feat);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (4 * group + r < spec.enc_dim) feat[(size_t)(4 * group + r) * m_pad + m] = out[r];
+            for (int q = 0; q < 2; ++q)
+                if (4 * group + 2 * q < spec.enc_dim)
+                    pairs[(size_t)(2 * group + q) * m_pad + m] = __builtin_bit_cast(uint32_t, h2{(_Float16)out[2 * q], (_Float16)out[2 * q + 1]});
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * group + r < spec.enc_dim) feat[(size_t)(4 * group + r) * m_pad + m] = out[r];
+        }
     }
 }
 
@@ -545,13 +557,17 @@ int lnr_encode_forward(const LnrNetSpec* spec, const float* params, const PointS
     if (bpg > 2048) bpg = 2048;
     const dim3 grid((unsigned)(n_groups * bpg)), block(ENC_BLOCK);
     if (!hash) {
-        if (half_planes) { lnr_set_error("fp16 feature planes are implemented for the hash-grid encoding"); return LNR_ERR_UNSUPPORTED; }
-        hipLaunchKernelGGL(freq_forward_kernel, grid, block, 0, st, *spec, *src, feat, m_pad, (int)bpg);
+        if (half_planes) hipLaunchKernelGGL(freq_forward_kernel<true>, grid, block, 0, st, *spec, *src, feat, m_pad, (int)bpg);
+        else hipLaunchKernelGGL(freq_forward_kernel<false>, grid, block, 0, st, *spec, *src, feat, m_pad, (int)bpg);
         return LNR_OK;
     }
     if (half_planes) {
-        if (spec->n_features != 2) { lnr_set_error("fp16 feature planes need n_features_per_level == 2"); return LNR_ERR_UNSUPPORTED; }
-        hipLaunchKernelGGL((encode_forward_kernel<2, true>), grid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg);
+        switch (spec->n_features) {
+            case 2: hipLaunchKernelGGL((encode_forward_kernel<2, true>), grid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg); break;
+            case 4: hipLaunchKernelGGL((encode_forward_kernel<4, true>), grid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg); break;
+            case 8: hipLaunchKernelGGL((encode_forward_kernel<8, true>), grid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg); break;
+            default: lnr_set_error("fp16 feature planes pair up features: n_features_per_level must be even"); return LNR_ERR_UNSUPPORTED;
+        }
         return LNR_OK;
     }
     switch (spec->n_features) {

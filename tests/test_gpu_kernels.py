@@ -703,11 +703,55 @@ def test_fp16_mode_config5_4096x256(ops):
     assert float(d_rays16[mask.to(DEV)].abs().max()) == 0.0
     tiny = sub[:8].to(DEV)
     assert float(d_rays16[tiny][:, :6].abs().max()) > 0.0
-    # unsupported shapes say so instead of falling back to fp32
-    enc, net = NETS["freq_relu128"]
-    bad = hip.make_net_spec(enc, dict(net, precision="fp16"))
-    with pytest.raises(RuntimeError, match="fp16"):
-        ops.density_forward(bad, torch.zeros(int(bad.n_params), device=DEV), pts=torch.zeros(64, 3, device=DEV))
+
+
+@pytest.mark.parametrize("name", ["hash_f4_2hidden", "hash_f8", "freq_siren", "freq_relu128", "small_hash"])
+def test_fp16_mode_general_networks(ops, name):
+    """precision fp16 beyond the reference's default shape: frequency encoding + SIREN / wide ReLU MLPs, several hidden layers,
+    4 or 8 features per level - forward and every gradient against the oracle with the same storage rounding (fp16 features,
+    weights and inter-layer activations; fp32 accumulation)."""
+    from loner_amd import hip
+    enc, net = NETS[name]
+    net16 = dict(net, precision="fp16")
+    spec_o, spec_h = NW.NetworkSpec.from_config(enc, net16), hip.make_net_spec(enc, net16)
+    params = NW.init_params(spec_o, 3)
+    if spec_o.n_enc_params:
+        params[spec_o.n_mlp_params:] *= 3000.0
+    gen = torch.Generator().manual_seed(8)
+    n = 1000                                                       # not a multiple of the 32-sample tile
+    pts = torch.rand(n, 3, generator=gen) * 1.9 - 0.95
+    d_sigma = torch.randn(n, generator=gen) * torch.logspace(-6, 0, n)
+    d_sigma[torch.rand(n, generator=gen) < 0.2] = 0.0
+    sig = ops.density_forward(spec_h, dv(params), pts=dv(pts)).cpu()
+    grad = torch.zeros(int(spec_h.n_params), device=DEV)
+    d_pts = ops.density_backward(spec_h, dv(params), dv(d_sigma), grad, pts=dv(pts), want_d_pts=True)
+    p = params.clone().requires_grad_(True)
+    x = pts.clone().requires_grad_(True)
+    ref = NW.density(spec_o, p, x)
+    (ref * d_sigma).sum().backward()
+    scale = float(ref.detach().abs().max())
+    e_s = float((sig - ref.detach()).abs().max()) / scale
+    nm = spec_o.n_mlp_params
+    e_w, e_x = rel(grad[:nm], p.grad[:nm]), rel(d_pts, x.grad)
+    e_t = rel(grad[nm:], p.grad[nm:]) if spec_o.n_enc_params else 0.0
+    print(f"fp16 {name}: sigma {e_s:.2e}  dW {e_w:.2e}  dtable {e_t:.2e}  dpts {e_x:.2e}")
+    # forward: identical storage rounding, fp32 accumulation on both sides; an activation that lands on a rounding boundary of fp16 may
+    # round differently after different summation orders (2^-11 of that activation), hence not 1e-6.  backward: + fp16 rounding of dZ.
+    assert e_s < 2e-3 and e_w < 3e-3 and e_t < 3e-3 and e_x < 5e-3
+    # linearity in d_sigma (exact power-of-two scale) and frozen parameters
+    g2 = torch.zeros_like(grad)
+    ops.density_backward(spec_h, dv(params), dv(d_sigma * 4.0), g2, pts=dv(pts))
+    assert rel(g2, 4.0 * grad) < 1e-6
+    assert torch.equal(ops.density_backward(spec_h, dv(params), dv(d_sigma), None, pts=dv(pts), want_d_pts=True), d_pts)
+
+
+def test_fp16_mode_refuses_what_it_does_not_cover(ops):
+    from loner_amd import hip
+    for name in ("hash_f1", "freq_wide256"):                      # odd feature count per level; 256 neurons
+        enc, net = NETS[name]
+        bad = hip.make_net_spec(enc, dict(net, precision="fp16"))
+        with pytest.raises(RuntimeError, match="fp16"):
+            ops.density_forward(bad, torch.zeros(int(bad.n_params), device=DEV), pts=torch.zeros(64, 3, device=DEV))
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16"])

@@ -21,11 +21,17 @@ rays = torch.zeros(N, 13, device='cuda'); rays[:, 0:3] = torch.rand(N, 3, device
 rays[:, 3:6] = torch.nn.functional.normalize(torch.randn(N, 3, device='cuda'), dim=1); rays[:, 11] = 0.0117; rays[:, 12] = 0.58
 z = torch.sort(torch.rand(N, S, device='cuda') * 0.57 + 0.0117, dim=1).values
 ds = torch.randn(N, S, device='cuda'); dr = torch.zeros(N, 13, device='cuda')
-for name, (enc, net) in SHAPES.items():
-    spec = hip.make_net_spec(enc, net)
+PRECS = sys.argv[1:] or ["fp32", "fp16"]
+for name, (enc, net) in [(n + " [" + pr + "]", (e, dict(k, precision=pr))) for n, (e, k) in SHAPES.items() for pr in PRECS]:
+    try:
+        spec = hip.make_net_spec(enc, net)
+        ops.density_forward(spec, torch.zeros(int(spec.n_params), device='cuda'), pts=torch.zeros(64, 3, device='cuda'))
+    except RuntimeError as e:
+        print(f"{name:44s} unsupported: {str(e)[-90:]}")
+        continue
     p = torch.rand(int(spec.n_params), device='cuda') - 0.5
     g = torch.zeros_like(p)
     f = t(lambda: ops.density_forward(spec, p, rays=rays, z=z))
     b = t(lambda: ops.density_backward(spec, p, ds, g, rays=rays, z=z, d_rays=dr))
     mac = spec.n_neurons * spec.in_dim + (spec.n_hidden - 1) * spec.n_neurons ** 2
-    print(f"{name:34s} fwd {f:7.3f} ms ({N*S*2*mac/f/1e9:6.1f} TFLOP/s)   bwd (incl. re-encode) {b:7.3f} ms ({N*S*6*mac/b/1e9:6.1f} TFLOP/s)")
+    print(f"{name:44s} fwd {f:7.3f} ms ({N*S*2*mac/f/1e9:6.1f} TFLOP/s)   bwd (incl. re-encode) {b:7.3f} ms ({N*S*6*mac/b/1e9:6.1f} TFLOP/s)")
