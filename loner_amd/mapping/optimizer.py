@@ -308,6 +308,13 @@ class Optimizer:
                 raise AssertionError("NaN Loss Encountered")
             if any_free and not torch.isfinite(pose_dev.detach()).all():
                 raise RuntimeError("Fatal: Encountered invalid pose tensor.")
+            # the reference asserts on every ray build that the ray origins lie inside the world cube (ray_utils.py:301-303);
+            # here once per phase, on the last batch (all rays of a keyframe share its origin)
+            if active and n_it and self._results_lidar is not None:
+                last = self._results_lidar["rays"]
+                n_live = int(self._results_lidar["n_rays_dev"].item()) if self._results_lidar["n_rays_dev"] is not None else last.shape[0]
+                if n_live and bool((last[:n_live, :3].abs() > 1).any()):
+                    raise AssertionError("ray origins are outside the world cube")
             with torch.no_grad():
                 for k, p in enumerate(pose_cpu):
                     p.data.copy_(pose_dev[k].detach().to(p.device))

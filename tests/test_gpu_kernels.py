@@ -803,6 +803,12 @@ def test_full_size_iteration_properties(ops):
     assert bool((z[:, 1:] >= z[:, :-1]).all()) and bool((z >= rays[:, 11:12]).all()) and bool((z <= rays[:, 12:13]).all())
     sigma = ops.density_forward(spec, params, rays=rays, z=z)
     assert torch.isfinite(sigma).all()
+    # values at full size against the oracle on a 64-ray subset (the launch is the full 4096 x 512; the oracle only visits the subset)
+    sub = torch.randperm(N, generator=gen)[:64]
+    spec_o = NW.NetworkSpec.from_config(enc, net)
+    pts_sub = (rays[sub.to(DEV), None, 0:3] + rays[sub.to(DEV), None, 3:6] * z[sub.to(DEV), :, None]).cpu()
+    ref_sub = NW.density(spec_o, params.cpu(), pts_sub.reshape(-1, 3)).reshape(64, S)
+    assert rel(sigma[sub.to(DEV)], ref_sub) < 1e-5
     depth, w, opac, var = ops.render_forward(sigma, z, rays, noise_std=1.0, seed=4)
     assert bool((w >= 0).all()) and float(opac.max()) <= 1.0 + 1e-5 and bool((var >= 0).all())
     assert bool((depth >= rays[:, 11] - 1e-6).all()) and bool((depth <= rays[:, 12] + 1e-6).all())    # convex combination of z and far
@@ -817,6 +823,14 @@ def test_full_size_iteration_properties(ops):
     ops.density_backward(spec, params, 2.0 * d_sigma, g2, rays=rays, z=z, want_d_pts=False)
     assert rel(g2, 2.0 * g1) < 1e-5
     p3 = ops.density_backward(spec, params, d_sigma, g3, rays=rays, z=z, want_d_pts=True, table_atomics=True)
+    # the full-size gradient against the oracle: d_sigma restricted to the subset rays, so that the oracle only needs those
+    ds_sub = torch.zeros_like(d_sigma); ds_sub[sub.to(DEV)] = d_sigma[sub.to(DEV)]
+    g_sub = torch.zeros_like(g1)
+    ops.density_backward(spec, params, ds_sub, g_sub, rays=rays, z=z)
+    p_o = params.cpu().clone().requires_grad_(True)
+    (NW.density(spec_o, p_o, pts_sub.reshape(-1, 3)).reshape(64, S) * d_sigma[sub.to(DEV)].cpu()).sum().backward()
+    print("full-size launch, subset gradient vs oracle: rel", rel(g_sub, p_o.grad))
+    assert rel(g_sub, p_o.grad) < 5e-5
     print("partition vs atomic path: table grad rel", rel(g1, g3), " checksum", float(g1.double().sum()), float(g3.double().sum()))
     assert rel(g1, g3) < 1e-5 and torch.equal(p1, p3)
     assert abs(float(g1.double().sum()) - float(g3.double().sum())) < 1e-6 * float(g1.double().abs().sum())
