@@ -104,28 +104,70 @@ table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ region
         const int n_regions = min(per_wave, bpg - first);
         const size_t owner_regions = ((size_t)l * maxo + local) * bpg + first;
         const uint2* level_regions = reinterpret_cast<const uint2*>(regions_v) + owner_regions * cap;
-        const size_t region_stride = (size_t)cap;                          // records between consecutive regions of this wave
+        const size_t region_stride = (size_t)cap;                          // 8-byte units between consecutive regions of this wave
+        // x-pair levels (lnr_density_api.h): 12-byte records, pieces of 64 records = one 12-byte load per lane
+        const bool xp = PAIR && lnr_level_uses_xpairs(spec, l);
+        const int psh = xp ? 6 : 7;                                         // log2 records per piece
         for (int r0 = 0; r0 < n_regions; r0 += 64) {
             const int my_r = r0 + lane;
             const int my_n = my_r < n_regions ? counts[owner_regions + my_r] : 0;
-            const int my_chunks = (my_n + 127) >> 7;
+            const int my_chunks = (my_n + (1 << psh) - 1) >> psh;
             int incl = my_chunks;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
             const int excl = incl - my_chunks;
             const int total = __shfl(incl, 63, 64);
             if (total == 0) continue;
+            // the region holding piece c = the last lane with pieces whose first piece is at or before c; -> (region, record offset, records left)
+            auto locate = [&](int c, int& qq, int& off, int& n) {
+                const unsigned long long starts = __ballot(excl <= c && my_chunks > 0);
+                qq = __builtin_amdgcn_readfirstlane(starts ? 63 - __clzll((long long)starts) : 0);
+                off = (c - __shfl(excl, qq, 64)) << psh;
+                n = __shfl(my_n, qq, 64) - off;
+            };
+            if (xp) {
+                LnrXRec rec[RED_U], nxt[RED_U];
+                int rem[RED_U], nrem[RED_U];
+                auto loadx = [&](int c0, LnrXRec out[RED_U], int left[RED_U]) {
+#pragma unroll
+                    for (int u = 0; u < RED_U; ++u) {
+                        const int c = c0 + u < total ? c0 + u : total - 1;                   // clamp: unconditional loads
+                        int qq, off, n;
+                        locate(c, qq, off, n);
+                        left[u] = c0 + u < total ? (n < 64 ? n : 64) : 0;
+                        const char* rg = reinterpret_cast<const char*>(level_regions + (size_t)(r0 + qq) * region_stride) + (size_t)off * 12u;
+                        out[u] = *reinterpret_cast<const LnrXRec*>(rg + (lane < left[u] ? lane : 0) * 12);
+                    }
+                };
+                loadx(0, nxt, nrem);
+                for (int c0 = 0; c0 < total; c0 += RED_U) {
+#pragma unroll
+                    for (int u = 0; u < RED_U; ++u) { rec[u] = nxt[u]; rem[u] = nrem[u]; }
+                    if (c0 + RED_U < total) loadx(c0 + RED_U, nxt, nrem);
+#pragma unroll
+                    for (int u = 0; u < RED_U; ++u) {
+                        if (lane < rem[u]) {
+                            uint32_t pi, t; float a0, a1, fx;
+                            lnr_unpack_xpair(rec[u], pi, t, a0, a1, fx);
+                            const float gx = 1.0f - fx;
+                            const uint32_t pj = pi ^ ((2u << t) - 1u);                        // the (x+1) corner's entry: e ^ (2^(t+1) - 1)
+                            atomicAdd(reinterpret_cast<unsigned long long*>(&acc[2 * pi]), (unsigned long long)__float2ll_rn(gx * a0 * LNR_FIX_SCALE));
+                            atomicAdd(reinterpret_cast<unsigned long long*>(&acc[2 * pi + 1]), (unsigned long long)__float2ll_rn(gx * a1 * LNR_FIX_SCALE));
+                            atomicAdd(reinterpret_cast<unsigned long long*>(&acc[2 * pj]), (unsigned long long)__float2ll_rn(fx * a0 * LNR_FIX_SCALE));
+                            atomicAdd(reinterpret_cast<unsigned long long*>(&acc[2 * pj + 1]), (unsigned long long)__float2ll_rn(fx * a1 * LNR_FIX_SCALE));
+                        }
+                    }
+                }
+                continue;
+            }
             uint4 rec[RED_U], nxt[RED_U];
             int rem[RED_U], nrem[RED_U];              // records of the chunk (<= 128), wave-uniform
             auto load4 = [&](int c0, uint4 out[RED_U], int left[RED_U]) {
 #pragma unroll
                 for (int u = 0; u < RED_U; ++u) {
                     const int c = c0 + u < total ? c0 + u : total - 1;                       // clamp: unconditional loads
-                    // the region holding chunk c = the last lane with chunks whose first chunk is at or before c
-                    const unsigned long long starts = __ballot(excl <= c && my_chunks > 0);
-                    const int qq = __builtin_amdgcn_readfirstlane(starts ? 63 - __clzll((long long)starts) : 0);
-                    const int off = (c - __shfl(excl, qq, 64)) << 7;
-                    const int n = __shfl(my_n, qq, 64) - off;
+                    int qq, off, n;
+                    locate(c, qq, off, n);
                     left[u] = c0 + u < total ? (n < 128 ? n : 128) : 0;
                     const uint4* rg = reinterpret_cast<const uint4*>(level_regions + (size_t)(r0 + qq) * region_stride + off);   // cap is even
                     out[u] = rg[2 * lane < left[u] ? lane : 0];

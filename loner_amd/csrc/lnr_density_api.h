@@ -21,6 +21,7 @@ struct PointSrc {
 #define LNR_SLICE_SHIFT 13            // 8192 floats (32 KB of LDS) per owner
 #define LNR_REGION_BUDGET (24ull << 30)
 #define LNR_COMBINE_SCALE_MAX 3000.0f
+#define LNR_DENSE_LEVEL_FLOATS 12288      /* levels up to this many floats are accumulated densely in LDS (see below) */
 #define LNR_FIX_SCALE 4398046511104.0f /* 2^42: LDS gradient accumulators are 64-bit fixed point */
 
 // Table-gradient records are 8 bytes.  n_features == 1: {float index, fp32 value}.  n_features >= 2: two values of one
@@ -42,6 +43,41 @@ __device__ __forceinline__ void lnr_unpack_pair(uint2 r, uint32_t& pair_idx, flo
     pair_idx = r.x & 0xFFFu;
     v0 = __uint_as_float(r.y & 0xFFFFFFC0u);
     v1 = __uint_as_float(((r.y & 0x3Fu) << 26) | ((r.x >> 6) & 0x03FFFFC0u));
+}
+
+// x-pair records (12 bytes): on hashed power-of-two levels the table index is x ^ (y*P1 ^ z*P2), so the corners (x, y, z) and (x+1, y, z)
+// of a cell differ only in the low bits of the index - e1 = e0 ^ (2^(t+1) - 1), t = trailing one bits of x - and fall into the same
+// owner slice unless t >= 12.  Their four updates (two corners x two features) are a rank-1 product (1-fx, fx) x (a0, a1) with
+// a = wy*wz*g, so ONE record carries both corners: half the records to rank, stage and copy on the fine levels (where nothing is
+// run-length combined) and 12 instead of 16 bytes per corner pair.  Used when n_features == 2 (lnr_level_uses_xpairs).
+//   a = [a0 bits 25..10 :16][t :4][pair index :12]   b = [a0 bits 9..0 :10][a1 bits 25..4 :22]   c = [a1 bits 3..0 :4][fx :28]
+// a0, a1 rounded to 26 bits like the values of a pair record, fx (in [0,1)) to 28 bits; the reduce - and the overflow path, with
+// the same rounding - forms (1-fx)*a and fx*a in fp32.
+struct LnrXRec { uint32_t a, b, c; };
+__device__ __forceinline__ LnrXRec lnr_pack_xpair(uint32_t pair_idx, uint32_t t, float a0, float a1, float fx) {
+    const uint32_t p0 = lnr_pack26(a0), p1 = lnr_pack26(a1);
+    uint32_t fb;
+    memcpy(&fb, &fx, 4);
+    fb = (fb + 8u) >> 4;
+    LnrXRec r;
+    r.a = (pair_idx & 0xFFFu) | ((t & 0xFu) << 12) | ((p0 >> 10) << 16);
+    r.b = ((p0 & 0x3FFu) << 22) | (p1 >> 4);
+    r.c = ((p1 & 0xFu) << 28) | (fb & 0x0FFFFFFFu);
+    return r;
+}
+__device__ __forceinline__ void lnr_unpack_xpair(const LnrXRec& r, uint32_t& pair_idx, uint32_t& t, float& a0, float& a1, float& fx) {
+    pair_idx = r.a & 0xFFFu;
+    t = (r.a >> 12) & 0xFu;
+    a0 = __uint_as_float((((r.a >> 16) << 10) | (r.b >> 22)) << 6);
+    a1 = __uint_as_float((((r.b & 0x3FFFFFu) << 4) | (r.c >> 28)) << 6);
+    fx = __uint_as_float((r.c & 0x0FFFFFFFu) << 4);
+}
+// which levels take x-pair records (must agree between the partition and the reduce)
+static __host__ __device__ __forceinline__ bool lnr_level_uses_xpairs(const LnrNetSpec& s, int l) {
+    const uint32_t size = s.level_size[l];
+    return s.n_features == 2 && s.level_hashed[l] != 0 && (size & (size - 1u)) == 0u && s.level_scale[l] >= LNR_COMBINE_SCALE_MAX &&
+           (uint64_t)size * 2u > (uint64_t)LNR_DENSE_LEVEL_FLOATS &&
+           ((s.level_offset[l] * 2u) & ((1u << LNR_SLICE_SHIFT) - 1u)) == 0u;      // owner slices aligned with the level: low index bits stay inside a slice
 }
 
 // launch plan chosen by the dispatcher
@@ -76,7 +112,6 @@ LNR_DECLARE_HT(16)
 // Levels whose whole table is at most this many floats are accumulated densely in LDS by the encode-backward
 // workgroups (64-bit fixed point) and leave as per-workgroup slabs instead of records: on those levels every ray
 // crosses the same few thousand entries, which would make their one or two owner slices the tail of the reduce.
-#define LNR_DENSE_LEVEL_FLOATS 12288
 struct LevelList {
     int n;                          // levels handled by a launch
     int lv[LNR_MAX_LEVELS];

@@ -219,6 +219,19 @@ struct OwnerSlot {
     int room;                   // records the region can still take
 };
 
+// An x-pair (lnr_density_api.h) that cannot become a record - its region is full, or its two corners straddle owner slices - is
+// added to the level's 64-bit overflow accumulators with exactly the arithmetic the reduce applies to a record.
+__device__ __forceinline__ void xpair_overflow(long long* ovf_level, uint32_t fi0_in_level, uint32_t fi1_in_level, uint32_t t, float a0, float a1, float fx) {
+    uint32_t pi, tt; float q0, q1, qx;
+    lnr_unpack_xpair(lnr_pack_xpair(0u, t, a0, a1, fx), pi, tt, q0, q1, qx);
+    const float gx = 1.0f - qx;
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(ovf_level);
+    atomicAdd(o + fi0_in_level, (unsigned long long)__float2ll_rn(gx * q0 * LNR_FIX_SCALE));
+    atomicAdd(o + fi0_in_level + 1, (unsigned long long)__float2ll_rn(gx * q1 * LNR_FIX_SCALE));
+    atomicAdd(o + fi1_in_level, (unsigned long long)__float2ll_rn(qx * q0 * LNR_FIX_SCALE));
+    atomicAdd(o + fi1_in_level + 1, (unsigned long long)__float2ll_rn(qx * q1 * LNR_FIX_SCALE));
+}
+
 // dynamic LDS: int cnt[maxo4], gcur[maxo4]; OwnerSlot slot[maxo] (16-byte aligned); then the staging buffer
 template <int F, int DXM>
 __global__ void __launch_bounds__(ENC_BLOCK)
@@ -243,6 +256,10 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
     const uint32_t M = (uint32_t)live_points(src);
     const int first_owner = (int)(((uint64_t)L.offset * F) >> sink.shift);
     const bool combine = L.scale < sink.combine_scale_max;
+    // x-pair records (12 bytes for the two x-neighbours of a corner pair) on the fine hashed levels; 8-byte records elsewhere
+    const bool xp = F == 2 && lnr_level_uses_xpairs(spec, lv);
+    const int cap_rec = xp ? (sink.cap * 8) / 12 : sink.cap;               // a region's capacity in records of this level's format
+    const uint32_t rec_bytes = xp ? 12u : 8u;
     // region of (level, owner o, chunk): [level][owner][chunk] - the reduce of one owner streams its chunks' regions back to back
     const int ovf_off = list.slab_off[blockIdx.x / bpg];
     long long* ovf = ovf_off >= 0 ? sink.ovf + ovf_off : nullptr;                // indexed by float index inside the level
@@ -315,7 +332,22 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
             float rv0[8], rv1[8]; int rrank[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) rrank[k] = -1;
-            if (wave_any) {
+            uint32_t xt = 0u;                       // x-pair levels: trailing one bits of the cell's x (e(x+1) = e(x) ^ (2^(t+1) - 1))
+            if (wave_any && xp) {
+                xt = (uint32_t)__builtin_ctz(~c.b[0]);
+                const float wy[2] = {1.0f - c.frac[1], c.frac[1]}, wz[2] = {1.0f - c.frac[2], c.frac[2]};
+#pragma unroll
+                for (int k2 = 0; k2 < 4; ++k2) {
+                    const float wyz = wy[k2 & 1] * wz[k2 >> 1];
+                    const float a0 = wyz * g[0], a1 = wyz * g[F >= 2 ? 1 : 0];
+                    rv0[k2] = a0; rv1[k2] = a1;
+                    if ((a0 != 0.0f) | (a1 != 0.0f)) {
+                        const uint32_t fi = e[2 * k2] * F;
+                        if (xt < 12u) rrank[k2] = atomicAdd(&cnt[(int)(fi >> sink.shift) - first_owner], 1);
+                        else xpair_overflow(ovf, fi - level_base, e[2 * k2 + 1] * F - level_base, xt, a0, a1, c.frac[0]);   // corners in two owner slices
+                    }
+                }
+            } else if (wave_any) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     float v0 = w[k] * g[PAIR ? 2 * pass : 0], v1 = PAIR ? w[k] * g[2 * pass + 1] : 0.0f;
@@ -344,11 +376,11 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
                     for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
                     if (o < maxo) {
                         const int have = gcur[o];
-                        const uint64_t p = reinterpret_cast<uint64_t>(sink.regions) + ((region0 + o * region_step) * (size_t)sink.cap + (size_t)have) * 8u;
+                        const uint64_t p = reinterpret_cast<uint64_t>(sink.regions) + (region0 + o * region_step) * (size_t)sink.cap * 8u + (size_t)have * rec_bytes;
                         OwnerSlot os;
                         os.ptr_lo = (uint32_t)p; os.ptr_hi = (uint32_t)(p >> 32);
                         os.scan = running + incl - n;
-                        os.room = sink.cap - have;
+                        os.room = cap_rec - have;
                         oslot[o] = os;
                         gcur[o] = have + n;
                         cnt[o] = 0;
@@ -359,6 +391,18 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
             }
             __syncthreads();
             // ---- C: scatter into the staging buffer, grouped by owner
+            if (xp) {
+                // x-pair: (float index of the x corner, a0, a1, fx rounded to 28 bits with t in the freed low nibble)
+                const uint32_t fxt = ((__float_as_uint(c.frac[0]) + 8u) & ~0xFu) | xt;
+#pragma unroll
+                for (int k2 = 0; k2 < 4; ++k2) {
+                    if (rrank[k2] >= 0) {
+                        const uint32_t fi = e[2 * k2] * F;
+                        const int at = oslot[(int)(fi >> sink.shift) - first_owner].scan + rrank[k2];
+                        reinterpret_cast<uint4*>(stage)[at] = make_uint4(fi, __float_as_uint(rv0[k2]), __float_as_uint(rv1[k2]), fxt);
+                    }
+                }
+            } else
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 if (rrank[k] >= 0) {
@@ -372,6 +416,22 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
             __syncthreads();
             // ---- D: linear copy-out; neighbouring lanes write neighbouring records of the same region
             const int total = s_total;
+            if (xp) {
+                for (int i = threadIdx.x; i < total; i += ENC_BLOCK) {
+                    const uint4 r4 = reinterpret_cast<const uint4*>(stage)[i];
+                    const uint32_t idx = r4.x, t = r4.w & 0xFu;
+                    const float a0 = __uint_as_float(r4.y), a1 = __uint_as_float(r4.z), fx = __uint_as_float(r4.w & ~0xFu);
+                    const OwnerSlot os = oslot[(int)(idx >> sink.shift) - first_owner];
+                    const int k = i - os.scan;
+                    if (k < os.room) {
+                        LnrXRec* dst = reinterpret_cast<LnrXRec*>((((uint64_t)os.ptr_hi << 32) | os.ptr_lo) + (uint64_t)k * 12u);
+                        *dst = lnr_pack_xpair((idx & ((1u << LNR_SLICE_SHIFT) - 1u)) >> 1, t, a0, a1, fx);
+                    } else {
+                        const uint32_t in_level = idx - level_base;                       // e1 = e0 ^ (2^(t+1) - 1): float index ^ (mask << 1)
+                        xpair_overflow(ovf, in_level, in_level ^ (((2u << t) - 1u) << 1), t, a0, a1, fx);
+                    }
+                }
+            } else
             for (int i = threadIdx.x; i < total; i += ENC_BLOCK) {
                 uint32_t idx; float v0, v1 = 0.0f;
                 uint2 r2;
@@ -414,7 +474,7 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
     __syncthreads();
     if (emit)
         for (int i = threadIdx.x; i < maxo; i += ENC_BLOCK)
-            sink.counts[region0 + i * region_step] = gcur[i] < sink.cap ? gcur[i] : sink.cap;
+            sink.counts[region0 + i * region_step] = gcur[i] < cap_rec ? gcur[i] : cap_rec;
 }
 
 // Dense levels (lnr_density_api.h): the workgroup sums its samples' corner updates in an LDS copy of the level's
