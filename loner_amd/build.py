@@ -21,7 +21,8 @@ MANIFEST = os.path.join(BUILD, "manifest.json")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 ARCH = "gfx950"
-COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value"]
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value"] + \
+         os.environ.get("LNR_EXTRA_HIPCC_FLAGS", "").split()        # development switches, e.g. -DLNR_PHASE_TIMING (tools/README.md)
 # files whose float arithmetic must round exactly like the reference's torch CPU ops
 EXACT = {"lnr_sampler.hip", "lnr_rays.hip"}
 # (source, object name, extra flags); the density kernels are compiled once per hidden width (n_neurons/16)

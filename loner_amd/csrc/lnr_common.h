@@ -152,3 +152,28 @@ __device__ __forceinline__ int lnr_live_rays(int n_rays, const int32_t* n_rays_d
     int v = *n_rays_dev;
     return v < n_rays ? v : n_rays;
 }
+
+// -DLNR_PHASE_TIMING (development builds only, LNR_EXTRA_HIPCC_FLAGS): shader-clock cycles per phase of a kernel, summed over its
+// waves into a __device__ array; the launcher prints and clears them when LNR_PHASE_TIMING is set in the environment.
+#ifdef LNR_PHASE_TIMING
+#include <cstdio>
+#define LNR_N_PHASES 12
+#define PHASE_INIT() unsigned long long ph_acc[LNR_N_PHASES] = {}; unsigned long long ph_last = __builtin_amdgcn_s_memtime()
+#define PHASE(k) do { const unsigned long long ph_now = __builtin_amdgcn_s_memtime(); ph_acc[k] += ph_now - ph_last; ph_last = ph_now; } while (0)
+#define PHASE_FLUSH(sym, base) do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < LNR_N_PHASES; ++k_) if (ph_acc[k_]) atomicAdd(&sym[(base) + k_], ph_acc[k_]); } while (0)
+static inline bool lnr_phase_fetch(const void* symbol, unsigned long long* h, int n, hipStream_t st) {
+    if (hipStreamSynchronize(st) != hipSuccess || hipMemcpyFromSymbol(h, symbol, n * sizeof(unsigned long long)) != hipSuccess) return false;
+    unsigned long long zero[4 * LNR_N_PHASES] = {};
+    return hipMemcpyToSymbol(symbol, zero, n * sizeof(unsigned long long)) == hipSuccess;
+}
+static inline void lnr_phase_print(const char* kernel, const char* const* names, const unsigned long long* h) {
+    unsigned long long sum = 0;
+    for (int k = 0; k < LNR_N_PHASES; ++k) sum += h[k];
+    for (int k = 0; k < LNR_N_PHASES; ++k)
+        if (h[k]) fprintf(stderr, "[lnr phases] %-24s %-28s %6.2f %%  (%llu)\n", kernel, names[k], 100.0 * (double)h[k] / (double)sum, h[k]);
+}
+#else
+#define PHASE_INIT()
+#define PHASE(k)
+#define PHASE_FLUSH(sym, base)
+#endif

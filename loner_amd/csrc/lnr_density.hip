@@ -6,6 +6,9 @@
 #include <stdlib.h>
 
 #include "lnr_density_api.h"
+#include <vector>
+#include <cstdlib>
+#include <cstdio>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -43,155 +46,266 @@ reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs, int n_mlp, flo
 
 // Workgroup `o` owns floats [o << shift, (o+1) << shift) of the table gradient.  The encode-backward workgroups of
 // level l (bpg of them) wrote the records addressed to it into regions [l][o - first_owner(l)][chunk];
-// it streams them (4 x 16-byte loads = 8 records in flight per lane), sums them in LDS in 64-bit fixed point (LDS
-// float atomics run at < 1 lane/clk/CU on CDNA4, integer ones ~16x faster; 2^-42 resolution, exact and
-// order-independent) and adds the slice to grad_table with coalesced read-modify-writes (it is the only writer of
-// that slice).  PAIR: packed pair records (n_features >= 2) or {idx, v} records - see lnr_density_api.h.
+// it streams them, sums them in LDS in 64-bit fixed point (LDS float atomics run at < 1 lane/clk/CU on CDNA4, integer
+// ones ~16x faster; 2^-42 resolution, exact and order-independent) and adds the slice to grad_table with coalesced
+// read-modify-writes (it is the only writer of that slice).  PAIR: packed pair records (n_features >= 2) or {idx, v}
+// records - see lnr_density_api.h.
+//
+// The kernel is bound by instruction issue and latency, not by bytes (ablations in DESIGN.md): a region holds ~30-60 records,
+// so every wave instruction serves one short region.  Hence the shape of the loop: a wave takes a contiguous run of its owner's
+// regions, lane r holds region r's record count, and everything that depends only on the region - its count (v_readlane), its
+// address (scalar arithmetic), the trip count - stays on the scalar unit; the first piece (64 x-pair records or 128 8-byte
+// records, one load per lane) of RED_U regions is in flight while the previous RED_U are summed; the rare longer regions are
+// finished by a second loop.  64 VGPRs, so that two workgroups (2 x 64 KB of accumulators) share a CU.
 template <int PAIR>
 __device__ __forceinline__ void reduce_one(long long* acc, uint2 r, uint32_t base) {
     if (PAIR) {
         uint32_t pi; float v0, v1;
         lnr_unpack_pair(r, pi, v0, v1);
         // no test for zero: a record exists because one of its values is non-zero, and a branch per value costs more than adding 0
-        atomicAdd(reinterpret_cast<unsigned long long*>(&acc[2 * pi]), (unsigned long long)__float2ll_rn(v0 * LNR_FIX_SCALE));
-        atomicAdd(reinterpret_cast<unsigned long long*>(&acc[2 * pi + 1]), (unsigned long long)__float2ll_rn(v1 * LNR_FIX_SCALE));
+        unsigned long long* a = reinterpret_cast<unsigned long long*>(acc) + 2 * pi;
+        if (__builtin_expect(__builtin_fmaxf(__builtin_fabsf(v0), __builtin_fabsf(v1)) < 256.0f, 1)) {
+            atomicAdd(a, (unsigned long long)lnr_to_fix_small(v0));
+            atomicAdd(a + 1, (unsigned long long)lnr_to_fix_small(v1));
+        } else {
+            atomicAdd(a, (unsigned long long)lnr_to_fix(v0));
+            atomicAdd(a + 1, (unsigned long long)lnr_to_fix(v1));
+        }
     } else {
         const float v = __uint_as_float(r.y);
-        if (v != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[r.x - base]), (unsigned long long)__float2ll_rn(v * LNR_FIX_SCALE));
+        if (v != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[r.x - base]), (unsigned long long)lnr_to_fix(v));
+    }
+}
+__device__ __forceinline__ void reduce_xpair(long long* acc, const LnrXRec& r) {
+    uint32_t pi, t; float a0, a1, fx;
+    lnr_unpack_xpair(r, pi, t, a0, a1, fx);
+    const uint32_t pj = pi ^ ((2u << t) - 1u);                        // the (x+1) corner's entry: e ^ (2^(t+1) - 1)
+    long long q[4];
+    lnr_xpair_fix(a0, a1, fx, q);
+    unsigned long long* a = reinterpret_cast<unsigned long long*>(acc);
+    atomicAdd(a + 2 * pi, (unsigned long long)q[0]);
+    atomicAdd(a + 2 * pi + 1, (unsigned long long)q[1]);
+    atomicAdd(a + 2 * pj, (unsigned long long)q[2]);
+    atomicAdd(a + 2 * pj + 1, (unsigned long long)q[3]);
+}
+
+#ifdef LNR_PHASE_TIMING
+__device__ unsigned long long lnr_reduce_phase_cycles[LNR_N_PHASES];
+#endif
+#define RED_SLICE (1 << LNR_SLICE_SHIFT)
+
+// records are read once: streaming (nt) loads
+typedef uint32_t red_u32x3 __attribute__((ext_vector_type(3), aligned(4)));
+typedef uint32_t red_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ LnrXRec load_xrec_stream(const char* p) {
+    const red_u32x3 v = __builtin_nontemporal_load(reinterpret_cast<const red_u32x3*>(p));
+    LnrXRec r; r.a = v.x; r.b = v.y; r.c = v.z;
+    return r;
+}
+__device__ __forceinline__ uint4 load_rec2_stream(const uint4* p) {
+    const red_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const red_u32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// One wave sums the records of n_regions consecutive regions (of one level and owner) into the workgroup's LDS accumulators.
+template <int PAIR, int RED_U>
+__device__ __forceinline__ void reduce_regions(long long* acc, const int* __restrict__ wave_counts, const char* __restrict__ wave_regions, int n_regions,
+                                               uint32_t region_bytes, bool xp, uint32_t base, int lane) {
+    for (int r0 = 0; r0 < n_regions; r0 += 64) {
+        const int nq = min(64, n_regions - r0);                                                      // regions of this round (wave-uniform)
+        const int my_n = lane < nq ? wave_counts[r0 + lane] : 0;
+        const char* round_regions = wave_regions + (size_t)r0 * region_bytes;
+        if (xp) {
+            // x-pair levels (lnr_density_api.h): 12-byte records, a piece = 64 records = one 12-byte load per lane
+            LnrXRec cur[RED_U], nxt[RED_U];
+            auto loadx = [&](int q0, LnrXRec out[RED_U]) {
+#pragma unroll
+                for (int u = 0; u < RED_U; ++u) {
+                    const int q = q0 + u < nq ? q0 + u : nq - 1;                                     // clamp: unconditional loads
+                    const int n = __builtin_amdgcn_readlane(my_n, q);
+                    out[u] = load_xrec_stream(round_regions + (size_t)q * region_bytes + (lane < n ? lane : 0) * 12);
+                }
+            };
+            loadx(0, nxt);
+            for (int q0 = 0; q0 < nq; q0 += RED_U) {
+#pragma unroll
+                for (int u = 0; u < RED_U; ++u) cur[u] = nxt[u];
+                if (q0 + RED_U < nq) loadx(q0 + RED_U, nxt);
+#pragma unroll
+                for (int u = 0; u < RED_U; ++u) {
+                    const int n = q0 + u < nq ? __builtin_amdgcn_readlane(my_n, q0 + u < 64 ? q0 + u : 63) : 0;
+                    if (lane < n) reduce_xpair(acc, cur[u]);
+                }
+            }
+            unsigned long long more = __ballot(my_n > 64);                                           // regions with further pieces: rare
+            while (more) {
+                const int q = __builtin_ctzll(more);
+                more &= more - 1ull;
+                const int n = __builtin_amdgcn_readlane(my_n, q);
+                for (int off = 64; off < n; off += 64)
+                    if (off + lane < n) reduce_xpair(acc, *reinterpret_cast<const LnrXRec*>(round_regions + (size_t)q * region_bytes + (size_t)(off + lane) * 12));
+            }
+            continue;
+        }
+        // 8-byte records: a piece = 128 records = one 16-byte load (two records) per lane
+        uint4 cur[RED_U], nxt[RED_U];
+        auto load4 = [&](int q0, uint4 out[RED_U]) {
+#pragma unroll
+            for (int u = 0; u < RED_U; ++u) {
+                const int q = q0 + u < nq ? q0 + u : nq - 1;
+                const int n = __builtin_amdgcn_readlane(my_n, q);
+                out[u] = load_rec2_stream(reinterpret_cast<const uint4*>(round_regions + (size_t)q * region_bytes) + (2 * lane < n ? lane : 0));   // regions are 16-byte aligned
+            }
+        };
+        load4(0, nxt);
+        for (int q0 = 0; q0 < nq; q0 += RED_U) {
+#pragma unroll
+            for (int u = 0; u < RED_U; ++u) cur[u] = nxt[u];
+            if (q0 + RED_U < nq) load4(q0 + RED_U, nxt);
+#pragma unroll
+            for (int u = 0; u < RED_U; ++u) {
+                const int n = q0 + u < nq ? __builtin_amdgcn_readlane(my_n, q0 + u < 64 ? q0 + u : 63) : 0;
+                if (2 * lane < n) reduce_one<PAIR>(acc, make_uint2(cur[u].x, cur[u].y), base);
+                if (2 * lane + 1 < n) reduce_one<PAIR>(acc, make_uint2(cur[u].z, cur[u].w), base);
+            }
+        }
+        unsigned long long more = __ballot(my_n > 128);
+        while (more) {
+            const int q = __builtin_ctzll(more);
+            more &= more - 1ull;
+            const int n = __builtin_amdgcn_readlane(my_n, q);
+            const uint2* rg = reinterpret_cast<const uint2*>(round_regions + (size_t)q * region_bytes);
+            for (int off = 128; off < n; off += 64)
+                if (off + lane < n) reduce_one<PAIR>(acc, rg[off + lane], base);
+        }
     }
 }
 
-#define RED_U 8      // 16-byte loads (= pieces of 128 records) in flight per lane
-template <int PAIR>
-__global__ void __launch_bounds__(1024)
-table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ regions_v, const int* __restrict__ counts, int bpg, int maxo,
-                          int cap, int shift, const long long* __restrict__ ovf, float* __restrict__ grad_table, int64_t n_table_floats) {
+// float range of level l, its record-level bookkeeping (shared by the two reduce kernels)
+struct RedLevel { uint64_t lo, hi; bool dense; };
+__device__ __forceinline__ RedLevel red_level(const LnrNetSpec& spec, int l) {
+    RedLevel r;
+    r.lo = (uint64_t)spec.level_offset[l] * spec.n_features;
+    r.hi = r.lo + (uint64_t)spec.level_size[l] * spec.n_features;
+    r.dense = r.hi - r.lo <= (uint64_t)LNR_DENSE_LEVEL_FLOATS;
+    return r;
+}
+
+// Spatially coherent levels (RegionPlan::split > 1: dense-indexed ones, where an owner slice is a slab of cells and a scan pours most of
+// the level's records into two or three of them): `split` workgroups share an owner, each sums a run of the owner's regions in LDS and
+// adds its non-zero sums to the level's 64-bit overflow accumulators (integer atomics: exact, order-independent), which the owner's
+// workgroup of table_grad_reduce2_kernel folds in afterwards.  Without it those few owners were the whole kernel's critical path
+// (0.8 ms for level 1 of the default network against 0.2 ms for everything else).
+template <int PAIR, int RED_U, int MINW>
+__global__ void __launch_bounds__(1024, MINW)
+table_grad_reduce_split_kernel(const LnrNetSpec spec, const void* __restrict__ regions_v, const RegionPlan plan, const int* __restrict__ counts, int bpg,
+                               int maxo, long long* __restrict__ ovf) {
+    extern __shared__ long long acc[];
+    constexpr int slice = RED_SLICE, shift = LNR_SLICE_SHIFT;
+    int b = blockIdx.x, l = 0, span = 0;
+    int64_t my_ovf = 0;
+    RedLevel lv;
+    for (;; ++l) {                                                          // the host launched exactly sum(span * split) workgroups
+        lv = red_level(spec, l);
+        span = lv.dense ? 0 : (int)(((lv.hi - 1) >> shift) - (lv.lo >> shift)) + 1;
+        const int n = plan.split[l] > 1 ? span * plan.split[l] : 0;
+        if (b < n) break;
+        b -= n;
+        if (!lv.dense) my_ovf += (int64_t)(lv.hi - lv.lo);
+    }
+    const int parts = plan.split[l], local = b / parts, part = b % parts;
+    const uint32_t base = ((uint32_t)(lv.lo >> shift) + (uint32_t)local) << shift;
+    const uint32_t region_bytes = plan.bytes[l];
+    if (region_bytes == 0u) return;
+#pragma unroll
+    for (int i = threadIdx.x; i < slice; i += 1024) acc[i] = 0ll;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int per_part = (bpg + parts - 1) / parts, part_first = part * per_part, part_n = min(per_part, bpg - part_first);
+    const int per_wave = (part_n + 15) / 16, first = part_first + wave * per_wave, n_regions = min(per_wave, part_first + part_n - first);
+    if (n_regions > 0)
+        reduce_regions<PAIR, RED_U>(acc, counts + ((size_t)l * maxo + local) * bpg + first,
+                                    reinterpret_cast<const char*>(regions_v) + plan.off[l] + ((size_t)local * bpg + first) * (size_t)region_bytes, n_regions,
+                                    region_bytes, PAIR && plan.xp[l] != 0, base, lane);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < slice / 1024; ++k) {
+        const int i = threadIdx.x + k * 1024;
+        const uint64_t gi = (uint64_t)base + i;
+        const long long q = acc[i];
+        if (q != 0ll && gi >= lv.lo && gi < lv.hi) atomicAdd(reinterpret_cast<unsigned long long*>(ovf + my_ovf + (int64_t)(gi - lv.lo)), (unsigned long long)q);
+    }
+}
+
+template <int PAIR, int RED_U, int MINW>
+__global__ void __launch_bounds__(1024, MINW)   // HIP: (max threads, min waves per SIMD)
+table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ regions_v, const RegionPlan plan, const int* __restrict__ counts, int bpg,
+                          int maxo, const long long* __restrict__ ovf, float* __restrict__ grad_table, int64_t n_table_floats) {
     extern __shared__ long long acc[];
     const int o = blockIdx.x;
-    const int slice = 1 << shift;
+    constexpr int slice = RED_SLICE, shift = LNR_SLICE_SHIFT;
     const uint32_t base = (uint32_t)o << shift;
-    for (int i = threadIdx.x; i < slice; i += blockDim.x) acc[i] = 0ll;
+    PHASE_INIT();
+#pragma unroll
+    for (int i = threadIdx.x; i < slice; i += 1024) acc[i] = 0ll;
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    const int F = spec.n_features;
-    int64_t ovf_off = 0;                                                   // running offset of the coherent levels' overflow accumulators
+    PHASE(0);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int nwaves = 16;
+    int64_t ovf_off = 0;                                                   // running offset of the record levels' overflow accumulators
     for (int l = 0; l < spec.n_levels; ++l) {
-        const uint64_t lo = (uint64_t)spec.level_offset[l] * F, hi = lo + (uint64_t)spec.level_size[l] * F;   // float range of the level
-        const bool dense = hi - lo <= (uint64_t)LNR_DENSE_LEVEL_FLOATS;
-        const bool coherent = !dense;                                       // every record level has overflow accumulators
+        const RedLevel lv = red_level(spec, l);
+        const uint64_t lo = lv.lo, hi = lv.hi;
         const int64_t my_ovf = ovf_off;
-        if (coherent) ovf_off += (int64_t)(hi - lo);
+        if (!lv.dense) ovf_off += (int64_t)(hi - lo);                       // every record level has overflow accumulators
         if (hi <= base || lo >= (uint64_t)base + slice) continue;
-        if (dense) continue;                                                // dense level: arrives through the slabs
-        if (coherent) {
-            // records that did not fit their region were summed into 64-bit accumulators by the encode kernel: same fixed point,
-            // so region records + overflow add up exactly, whatever the (arrival-order dependent) split between the two was
-            for (int i = threadIdx.x; i < slice; i += blockDim.x) {
-                const uint64_t gi = (uint64_t)base + i;
-                if (gi >= lo && gi < hi) acc[i] += ovf[my_ovf + (int64_t)(gi - lo)];
+        if (lv.dense) continue;                                             // dense level: arrives through the slabs
+        {
+            // records that did not fit their region were summed into 64-bit accumulators by the encode kernel (and, on split levels, all
+            // records by the split kernel): same fixed point, so region records + overflow add up exactly, whatever the (arrival-order
+            // dependent) split between the two was
+            long long v[slice / 1024];
+#pragma unroll
+            for (int k = 0; k < slice / 1024; ++k) {
+                const uint64_t gi = (uint64_t)base + threadIdx.x + k * 1024;
+                v[k] = (gi >= lo && gi < hi) ? ovf[my_ovf + (int64_t)(gi - lo)] : 0ll;
             }
+#pragma unroll
+            for (int k = 0; k < slice / 1024; ++k) if (v[k] != 0ll) acc[threadIdx.x + k * 1024] += v[k];
             __syncthreads();
+            PHASE(1);
         }
         const int local = o - (int)(lo >> shift);
         if (local < 0 || local >= maxo) continue;
-        // The regions of (level, owner) lie back to back, one per encode-backward workgroup (chunk); a wave takes a
-        // contiguous run of them.  Their record counts are fetched with one load (lane r holds region r's count) and cut
-        // into pieces of 128 records (= one 16-byte load per lane); the wave walks the flattened piece list four pieces per
-        // step and loads the next four before it sums the current ones, so the many short regions (one encode-backward
-        // batch appends ~30 records per owner) never serialise on HBM latency.
+        const uint32_t region_bytes = plan.bytes[l];
+        if (region_bytes == 0u || plan.split[l] > 1) continue;              // every record of this level overflowed / went through the split kernel
         const int per_wave = (bpg + nwaves - 1) / nwaves;
         const int first = wave * per_wave;
         const int n_regions = min(per_wave, bpg - first);
-        const size_t owner_regions = ((size_t)l * maxo + local) * bpg + first;
-        const uint2* level_regions = reinterpret_cast<const uint2*>(regions_v) + owner_regions * cap;
-        const size_t region_stride = (size_t)cap;                          // 8-byte units between consecutive regions of this wave
-        // x-pair levels (lnr_density_api.h): 12-byte records, pieces of 64 records = one 12-byte load per lane
-        const bool xp = PAIR && lnr_level_uses_xpairs(spec, l);
-        const int psh = xp ? 6 : 7;                                         // log2 records per piece
-        for (int r0 = 0; r0 < n_regions; r0 += 64) {
-            const int my_r = r0 + lane;
-            const int my_n = my_r < n_regions ? counts[owner_regions + my_r] : 0;
-            const int my_chunks = (my_n + (1 << psh) - 1) >> psh;
-            int incl = my_chunks;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
-            const int excl = incl - my_chunks;
-            const int total = __shfl(incl, 63, 64);
-            if (total == 0) continue;
-            // the region holding piece c = the last lane with pieces whose first piece is at or before c; -> (region, record offset, records left)
-            auto locate = [&](int c, int& qq, int& off, int& n) {
-                const unsigned long long starts = __ballot(excl <= c && my_chunks > 0);
-                qq = __builtin_amdgcn_readfirstlane(starts ? 63 - __clzll((long long)starts) : 0);
-                off = (c - __shfl(excl, qq, 64)) << psh;
-                n = __shfl(my_n, qq, 64) - off;
-            };
-            if (xp) {
-                LnrXRec rec[RED_U], nxt[RED_U];
-                int rem[RED_U], nrem[RED_U];
-                auto loadx = [&](int c0, LnrXRec out[RED_U], int left[RED_U]) {
-#pragma unroll
-                    for (int u = 0; u < RED_U; ++u) {
-                        const int c = c0 + u < total ? c0 + u : total - 1;                   // clamp: unconditional loads
-                        int qq, off, n;
-                        locate(c, qq, off, n);
-                        left[u] = c0 + u < total ? (n < 64 ? n : 64) : 0;
-                        const char* rg = reinterpret_cast<const char*>(level_regions + (size_t)(r0 + qq) * region_stride) + (size_t)off * 12u;
-                        out[u] = *reinterpret_cast<const LnrXRec*>(rg + (lane < left[u] ? lane : 0) * 12);
-                    }
-                };
-                loadx(0, nxt, nrem);
-                for (int c0 = 0; c0 < total; c0 += RED_U) {
-#pragma unroll
-                    for (int u = 0; u < RED_U; ++u) { rec[u] = nxt[u]; rem[u] = nrem[u]; }
-                    if (c0 + RED_U < total) loadx(c0 + RED_U, nxt, nrem);
-#pragma unroll
-                    for (int u = 0; u < RED_U; ++u) {
-                        if (lane < rem[u]) {
-                            uint32_t pi, t; float a0, a1, fx;
-                            lnr_unpack_xpair(rec[u], pi, t, a0, a1, fx);
-                            const float gx = 1.0f - fx;
-                            const uint32_t pj = pi ^ ((2u << t) - 1u);                        // the (x+1) corner's entry: e ^ (2^(t+1) - 1)
-                            atomicAdd(reinterpret_cast<unsigned long long*>(&acc[2 * pi]), (unsigned long long)__float2ll_rn(gx * a0 * LNR_FIX_SCALE));
-                            atomicAdd(reinterpret_cast<unsigned long long*>(&acc[2 * pi + 1]), (unsigned long long)__float2ll_rn(gx * a1 * LNR_FIX_SCALE));
-                            atomicAdd(reinterpret_cast<unsigned long long*>(&acc[2 * pj]), (unsigned long long)__float2ll_rn(fx * a0 * LNR_FIX_SCALE));
-                            atomicAdd(reinterpret_cast<unsigned long long*>(&acc[2 * pj + 1]), (unsigned long long)__float2ll_rn(fx * a1 * LNR_FIX_SCALE));
-                        }
-                    }
-                }
-                continue;
-            }
-            uint4 rec[RED_U], nxt[RED_U];
-            int rem[RED_U], nrem[RED_U];              // records of the chunk (<= 128), wave-uniform
-            auto load4 = [&](int c0, uint4 out[RED_U], int left[RED_U]) {
-#pragma unroll
-                for (int u = 0; u < RED_U; ++u) {
-                    const int c = c0 + u < total ? c0 + u : total - 1;                       // clamp: unconditional loads
-                    int qq, off, n;
-                    locate(c, qq, off, n);
-                    left[u] = c0 + u < total ? (n < 128 ? n : 128) : 0;
-                    const uint4* rg = reinterpret_cast<const uint4*>(level_regions + (size_t)(r0 + qq) * region_stride + off);   // cap is even
-                    out[u] = rg[2 * lane < left[u] ? lane : 0];
-                }
-            };
-            load4(0, nxt, nrem);
-            for (int c0 = 0; c0 < total; c0 += RED_U) {
-#pragma unroll
-                for (int u = 0; u < RED_U; ++u) { rec[u] = nxt[u]; rem[u] = nrem[u]; }
-                if (c0 + RED_U < total) load4(c0 + RED_U, nxt, nrem);
-#pragma unroll
-                for (int u = 0; u < RED_U; ++u) {
-                    if (2 * lane < rem[u]) reduce_one<PAIR>(acc, make_uint2(rec[u].x, rec[u].y), base);
-                    if (2 * lane + 1 < rem[u]) reduce_one<PAIR>(acc, make_uint2(rec[u].z, rec[u].w), base);
-                }
-            }
-        }
+        if (n_regions > 0)
+            reduce_regions<PAIR, RED_U>(acc, counts + ((size_t)l * maxo + local) * bpg + first,
+                                        reinterpret_cast<const char*>(regions_v) + plan.off[l] + ((size_t)local * bpg + first) * (size_t)region_bytes, n_regions,
+                                        region_bytes, PAIR && plan.xp[l] != 0, base, lane);
+        PHASE(3);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < slice; i += blockDim.x) {
-        const int64_t gi = (int64_t)base + i;
-        const long long q = acc[i];
-        if (gi < n_table_floats && q != 0ll) grad_table[gi] += (float)((double)q * (1.0 / (double)LNR_FIX_SCALE));
+    PHASE(5);
+    {
+        float g[slice / 1024];
+#pragma unroll
+        for (int k = 0; k < slice / 1024; ++k) {
+            const int64_t gi = (int64_t)base + threadIdx.x + k * 1024;
+            g[k] = gi < n_table_floats ? grad_table[gi] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < slice / 1024; ++k) {
+            const int64_t gi = (int64_t)base + threadIdx.x + k * 1024;
+            const long long q = acc[threadIdx.x + k * 1024];
+            if (gi < n_table_floats && q != 0ll) grad_table[gi] = g[k] + (float)((double)q * (1.0 / (double)LNR_FIX_SCALE));
+        }
     }
+    PHASE(6);
+    PHASE_FLUSH(lnr_reduce_phase_cycles, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -199,15 +313,16 @@ table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ region
 // ------------------------------------------------------------------------------------------------
 struct Layout {
     int64_t m_pad;
-    int n_groups, bpg, maxo, cap, shift, nown, rec_bytes;
+    int n_groups, bpg, maxo, shift, nown, n_split;
+    RegionPlan plan;
     size_t off_feat, off_dfeat, off_dxl, off_dpts, off_rayacc, off_slabs, off_dense, off_ovf, off_counts, off_regions, total;
 };
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-// Region capacity: level l sends n_points*8 corner updates (F/2 pair records each, 1 when F == 1) to the `span`
-// owners its table covers, from bpg workgroups; run-length combined (coarse) levels emit far fewer.  The busiest
-// level sets the capacity (+25 % + 128 slack); anything beyond it (skewed data) falls back to global atomics, so
+// Region capacities (RegionPlan, lnr_density_api.h): level l sends n_points*8 corner updates (F/2 pair records each, 1 when
+// F == 1; half as many x-pair records) to the `span` owners its table covers, from bpg workgroups.  Each level's regions hold
+// that expectation + 25 % + 24 records; anything beyond it (skewed data) goes to the level's 64-bit overflow accumulators, so
 // this is a performance knob only.
 static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
     Layout L;
@@ -218,35 +333,51 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
     L.shift = LNR_SLICE_SHIFT;
     const int64_t n_table = spec->n_params - spec->n_mlp_params;
     L.nown = (int)((n_table + (1 << L.shift) - 1) >> L.shift);
-    L.rec_bytes = 8;
     int64_t bpg = (n_points + 256 * 4 - 1) / (256 * 4);        // ~4 batches of 256 samples per encode-backward workgroup
     if (bpg < 1) bpg = 1;
     if (bpg > LNR_ENC_BWD_MAX_BPG) bpg = LNR_ENC_BWD_MAX_BPG;
     bpg = (bpg + 3) & ~(int64_t)3;       // the wave-private partition runs 4 waves (= 4 chunks) per workgroup
     L.bpg = (int)bpg;
     L.maxo = 1;
-    double per_region = 0.0;
     size_t dense_total = 0, ovf_total = 0;
+    uint64_t region_total = 0;
+    for (int l = 0; l < LNR_MAX_LEVELS; ++l) { L.plan.off[l] = 0; L.plan.bytes[l] = 0; L.plan.xp[l] = 0; L.plan.split[l] = 1; }
+    L.n_split = 0;
     if (hash) {
         const int F = spec->n_features;
-        for (int l = 0; l < spec->n_levels; ++l) {
-            if (lnr_level_is_dense(spec, l)) { dense_total += (size_t)spec->level_size[l] * F; continue; }
-            if (lnr_level_has_overflow_acc(spec, l)) ovf_total += (size_t)spec->level_size[l] * F;
-            const uint64_t lo = (uint64_t)spec->level_offset[l] * F, hi = lo + (uint64_t)spec->level_size[l] * F;
-            const int span = (int)(((hi - 1) >> L.shift) - (lo >> L.shift)) + 1;
-            if (span > L.maxo) L.maxo = span;
-            double r = (double)n_points * 8.0 * (F >= 2 ? F / 2.0 : 1.0) / (double)span / (double)L.bpg;
-            if (spec->level_scale[l] < LNR_COMBINE_SCALE_MAX) r *= 0.25;
-            if (r > per_region) per_region = r;
+        for (int pass = 0; pass < 2; ++pass) {                              // pass 1 only if the plan exceeds the budget: scaled down
+            if (pass == 1 && region_total <= LNR_REGION_BUDGET) break;
+            const double shrink = pass == 0 ? 1.0 : (double)LNR_REGION_BUDGET / (double)region_total;
+            region_total = 0; dense_total = 0; ovf_total = 0; L.maxo = 1; L.n_split = 0;
+            for (int l = 0; l < spec->n_levels; ++l) {
+                if (lnr_level_is_dense(spec, l)) { dense_total += (size_t)spec->level_size[l] * F; continue; }
+                ovf_total += (size_t)spec->level_size[l] * F;
+                const uint64_t lo = (uint64_t)spec->level_offset[l] * F, hi = lo + (uint64_t)spec->level_size[l] * F;
+                const int span = (int)(((hi - 1) >> L.shift) - (lo >> L.shift)) + 1;
+                if (span > L.maxo) L.maxo = span;
+                // expected records per (owner, chunk): 8 corner updates per point (F/2 pair records each), spread over the level's owners
+                const bool xp = lnr_level_can_use_xpairs(*spec, l, LNR_XPAIR_SCALE_MIN);
+                L.plan.xp[l] = xp ? 1 : 0;
+                double r = (double)n_points * 8.0 * (F >= 2 ? F / 2.0 : 1.0) / (double)span / (double)L.bpg;
+                if (xp) r *= 0.5;                                           // one record per x-neighbour pair
+                else if (spec->level_scale[l] < LNR_COMBINE_SCALE_MAX) r *= LNR_COMBINE_FILL;   // run-length combined along the rays
+                // twice the expectation + 64 records, in 256-byte units: a record beyond the capacity costs four (two) 64-bit global atomics,
+                // so the capacity is generous (sweep in DESIGN.md; the reduce does not care how full a region is)
+                const double recs = (r * LNR_REGION_HEADROOM + LNR_REGION_SLACK) * shrink;
+                uint64_t bytes = (uint64_t)(recs * (xp ? 12.0 : 8.0));
+                bytes = (bytes + 255u) & ~(uint64_t)255u;
+                // spatially coherent (dense-indexed) levels: several reduce workgroups per owner (table_grad_reduce_split_kernel)
+                int parts = spec->level_hashed[l] == 0 ? LNR_REDUCE_SPLIT : 1;
+                while (parts > 1 && L.bpg / parts < 16) parts >>= 1;      // at least one region per wave
+                L.plan.split[l] = (uint8_t)(parts < 1 ? 1 : parts);
+                if (parts > 1) L.n_split += span * parts;
+                L.plan.off[l] = region_total;
+                L.plan.bytes[l] = (uint32_t)bytes;
+                region_total += (uint64_t)span * (uint64_t)L.bpg * bytes;
+            }
         }
     }
     const int64_t blocks = (int64_t)L.n_groups * L.bpg;
-    int64_t cap = (int64_t)(per_region * 1.25) + 128;
-    const int64_t budget_cap = (int64_t)(LNR_REGION_BUDGET / ((uint64_t)L.rec_bytes * (uint64_t)blocks * (uint64_t)L.maxo));
-    if (cap > budget_cap) cap = budget_cap;
-    if (cap < 64) cap = 64;
-    cap = (cap + 1) & ~(int64_t)1;       // even: regions stay 16-byte aligned
-    L.cap = hash ? (int)cap : 0;
     size_t off = 0;
     L.off_feat = off; off += align256((size_t)spec->enc_dim * L.m_pad * sizeof(float));
     L.off_dfeat = off; off += align256((size_t)spec->enc_dim * L.m_pad * sizeof(float));
@@ -257,9 +388,29 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
     L.off_dense = off; off += align256(dense_total * (size_t)lnr_dense_bpg(L.bpg) * sizeof(float));
     L.off_ovf = off; off += align256(ovf_total * sizeof(long long));
     L.off_counts = off; off += align256(hash ? (size_t)blocks * L.maxo * sizeof(int) : 0);
-    L.off_regions = off; off += hash ? (size_t)blocks * L.maxo * (size_t)L.cap * L.rec_bytes : 0;
+    L.off_regions = off; off += (size_t)region_total;
     L.total = off;
     return L;
+}
+
+// LNR_REPORT_REGIONS=1: how full the record regions ran (diagnostic for sizing RegionPlan; synchronises the stream)
+static void report_regions(const LnrNetSpec* spec, const Layout& L, const RegionPlan& plan, const int* counts, hipStream_t st) {
+    std::vector<int> h((size_t)spec->n_levels * L.maxo * L.bpg);
+    if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(h.data(), counts, h.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return;
+    for (int l = 0; l < spec->n_levels; ++l) {
+        if (lnr_level_is_dense(spec, l)) continue;
+        const int rec = plan.xp[l] ? 12 : 8, cap = (int)(plan.bytes[l] / rec);
+        long long sum = 0, over = 0; int mx = 0;
+        const uint64_t lo = (uint64_t)spec->level_offset[l] * spec->n_features, hi = lo + (uint64_t)spec->level_size[l] * spec->n_features;
+        const int span = (int)(((hi - 1) >> L.shift) - (lo >> L.shift)) + 1;
+        for (int o = 0; o < span; ++o)
+            for (int c = 0; c < L.bpg; ++c) {
+                const int v = h[((size_t)l * L.maxo + o) * L.bpg + c];
+                sum += v; if (v > mx) mx = v; if (v > cap) over += v - cap;
+            }
+        fprintf(stderr, "[lnr regions] level %2d: %d-B records, capacity %d, mean %.1f, max %d, overflowed %lld of %lld\n", l, rec, cap,
+                (double)sum / ((double)span * L.bpg), mx, over, sum);
+    }
 }
 
 static int check_spec(const LnrNetSpec* spec, const char* who) {
@@ -333,22 +484,29 @@ namespace {
 struct ReduceCtx {
     const LnrNetSpec* spec;
     const void* regions; const int* counts; const long long* ovf; float* grad_table;
-    int bpg, maxo, cap, shift; int64_t n_table;
+    RegionPlan plan; int bpg, maxo, shift; int64_t n_table; int n_split;
 };
 
-int launch_table_reduce(const ReduceCtx& c, int n_owners, hipStream_t st) {
-    const size_t lds = ((size_t)1 << c.shift) * sizeof(long long);
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(table_grad_reduce2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(table_grad_reduce2_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e0 != hipSuccess || e1 != hipSuccess) { lnr_set_error("lnr_density_backward: hipFuncSetAttribute failed"); return LNR_ERR_LAUNCH; }
+template <int PAIR, int U, int W>
+static int launch_reduce_variant(const ReduceCtx& c, int n_owners, hipStream_t st) {
+    const size_t lds = (size_t)RED_SLICE * sizeof(long long);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(table_grad_reduce2_kernel<PAIR, U, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(table_grad_reduce_split_kernel<PAIR, U, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        lnr_set_error("lnr_density_backward: hipFuncSetAttribute failed"); return LNR_ERR_LAUNCH;
+    }
     LnrProfScope prof("table_grad_reduce", st);
-    if (c.spec->n_features >= 2)
-        hipLaunchKernelGGL(table_grad_reduce2_kernel<1>, dim3(n_owners), dim3(1024), lds, st, *c.spec, c.regions, c.counts, c.bpg, c.maxo, c.cap,
-                           c.shift, c.ovf, c.grad_table, c.n_table);
-    else
-        hipLaunchKernelGGL(table_grad_reduce2_kernel<0>, dim3(n_owners), dim3(1024), lds, st, *c.spec, c.regions, c.counts, c.bpg, c.maxo, c.cap,
-                           c.shift, c.ovf, c.grad_table, c.n_table);
+    if (c.n_split > 0)
+        hipLaunchKernelGGL((table_grad_reduce_split_kernel<PAIR, U, W>), dim3(c.n_split), dim3(1024), lds, st, *c.spec, c.regions, c.plan, c.counts, c.bpg, c.maxo,
+                           const_cast<long long*>(c.ovf));
+    hipLaunchKernelGGL((table_grad_reduce2_kernel<PAIR, U, W>), dim3(n_owners), dim3(1024), lds, st, *c.spec, c.regions, c.plan, c.counts, c.bpg, c.maxo,
+                       c.ovf, c.grad_table, c.n_table);
     return LNR_OK;
+}
+// 2 regions in flight per wave at 8 waves per SIMD (two workgroups per CU) measured best: 0.35 ms against 0.37 (4 in flight, 8 waves),
+// 0.40 (4, 4 waves) and 0.43 (8, 4 waves) on the bench workload
+int launch_table_reduce(const ReduceCtx& c, int n_owners, hipStream_t st) {
+    if (c.spec->n_features < 2) return launch_reduce_variant<0, 2, 8>(c, n_owners, st);
+    return launch_reduce_variant<1, 2, 8>(c, n_owners, st);
 }
 
 }  // namespace
@@ -462,7 +620,9 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     const bool hash = spec->encoding == LNR_ENC_HASHGRID;
     // test hook: LNR_BWD_TABLE_ATOMICS sends every record down the global-atomic fallback path (same result, ~20x slower);
     // the tests use it as an independent implementation of the record partition
-    const int cap_rec = (flags & LNR_BWD_TABLE_ATOMICS) ? 0 : L.cap;
+    RegionPlan rplan = L.plan;
+    if (flags & LNR_BWD_TABLE_ATOMICS)                       // no room anywhere: every record takes the overflow path
+        for (int l = 0; l < LNR_MAX_LEVELS; ++l) rplan.bytes[l] = 0;
     const bool f16 = spec->precision == LNR_PREC_F16;
     rc = check_f16(spec, "lnr_density_backward");
     if (rc) return rc;
@@ -498,13 +658,15 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     if (rc) return rc;
     LNR_CHECK_LAUNCH("lnr_density_backward(mlp)");
     float* grad_table = want_grad ? grad_params + spec->n_mlp_params : nullptr;
-    ReduceCtx rctx{spec, regions, counts, ovf, grad_table, L.bpg, L.maxo, cap_rec, L.shift, spec->n_params - spec->n_mlp_params};
+    ReduceCtx rctx{spec, regions, counts, ovf, grad_table, rplan, L.bpg, L.maxo, L.shift, spec->n_params - spec->n_mlp_params,
+                   (flags & LNR_BWD_TABLE_ATOMICS) ? 0 : L.n_split};
     if (want_dfeat) {
-        rc = lnr_encode_backward(spec, params, &src, cap, dfeat, dxl, L.m_pad, grad_table, want_grad ? regions : nullptr, counts,
-                                 want_grad ? dense_slabs : nullptr, L.bpg, L.maxo, cap_rec, L.shift,
+        rc = lnr_encode_backward(spec, params, &src, cap, dfeat, dxl, L.m_pad, grad_table, want_grad ? regions : nullptr, &rplan, counts,
+                                 want_grad ? dense_slabs : nullptr, L.bpg, L.maxo, L.shift,
                                  ovf, d_pts_eff, ray_accum ? d_rays : nullptr, (long long*)(ws + L.off_rayacc), st);
         if (rc) return rc;
         LNR_CHECK_LAUNCH("lnr_density_backward(encode backward)");
+        if (want_grad && getenv("LNR_REPORT_REGIONS")) report_regions(spec, L, rplan, counts, st);
     }
     if (d_rays && !ray_accum) {
         rc = lnr_points_grad_to_rays(d_pts_eff, z, n_rays, n_rays_dev, n_samples, d_rays, stream);
@@ -515,6 +677,13 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
         rc = launch_table_reduce(rctx, L.nown, st);
         if (rc) return rc;
         LNR_CHECK_LAUNCH("lnr_density_backward(table reduce)");
+#ifdef LNR_PHASE_TIMING
+        if (getenv("LNR_PHASE_TIMING")) {
+            static const char* names[LNR_N_PHASES] = {"zero LDS", "overflow fold", "-", "records", "-", "final barrier", "write-out"};
+            unsigned long long h[LNR_N_PHASES];
+            if (lnr_phase_fetch(HIP_SYMBOL(lnr_reduce_phase_cycles), h, LNR_N_PHASES, st)) lnr_phase_print("table_grad_reduce", names, h);
+        }
+#endif
     }
     const int n_mlp = spec->n_mlp_params;
     LnrProfScope prof_slabs("reduce_slabs", st);

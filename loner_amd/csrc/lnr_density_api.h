@@ -21,8 +21,26 @@ struct PointSrc {
 #define LNR_SLICE_SHIFT 13            // 8192 floats (32 KB of LDS) per owner
 #define LNR_REGION_BUDGET (24ull << 30)
 #define LNR_COMBINE_SCALE_MAX 3000.0f
+#define LNR_COMBINE_FILL 1.0        // expected records of a run-length combined level, as a fraction of its uncombined count
+#define LNR_REGION_HEADROOM 2.0     // region capacity = expectation x this + LNR_REGION_SLACK records
+#define LNR_REGION_SLACK 64.0
+#define LNR_REDUCE_SPLIT 32         // reduce workgroups per owner of a dense-indexed record level
 #define LNR_DENSE_LEVEL_FLOATS 12288      /* levels up to this many floats are accumulated densely in LDS (see below) */
 #define LNR_FIX_SCALE 4398046511104.0f /* 2^42: LDS gradient accumulators are 64-bit fixed point */
+#define LNR_XPAIR_SCALE_MIN 3000.0f   /* hashed power-of-two levels at least this fine take x-pair records (below: run-length combined 8-byte records) */
+
+// rn(v * 2^42) as a 64-bit integer.  There is no f32 -> i64 convert instruction (the compiler's expansion is ~20 VALU
+// instructions, and these kernels are VALU-issue bound): for |v| < 2^8 the sum (double)v * 2^42 + 1.5 * 2^52 is exact up to
+// its one rounding to an integer (nearest even, like __float2ll_rn) and leaves that integer in the mantissa - a convert, an
+// fp64 fma (full rate on CDNA4) and a 32-bit subtract.  Same result as the generic path wherever both are defined.
+__device__ __forceinline__ long long lnr_to_fix_small(float v) {
+    const double d = __builtin_fma((double)v, 4398046511104.0, 6755399441055744.0);
+    return __double_as_longlong(d) - 0x4338000000000000ll;
+}
+__device__ __forceinline__ long long lnr_to_fix(float v) {
+    if (__builtin_expect(__builtin_fabsf(v) < 256.0f, 1)) return lnr_to_fix_small(v);
+    return __float2ll_rn(v * LNR_FIX_SCALE);
+}
 
 // Table-gradient records are 8 bytes.  n_features == 1: {float index, fp32 value}.  n_features >= 2: two values of one
 // entry pair, each rounded (to nearest even) to 26 bits = sign, 8 exponent, 17 mantissa bits (relative error <= 2^-18,
@@ -72,10 +90,21 @@ __device__ __forceinline__ void lnr_unpack_xpair(const LnrXRec& r, uint32_t& pai
     a1 = __uint_as_float((((r.b & 0x3FFFFFu) << 4) | (r.c >> 28)) << 6);
     fx = __uint_as_float((r.c & 0x0FFFFFFFu) << 4);
 }
-// which levels take x-pair records (must agree between the partition and the reduce)
-static __host__ __device__ __forceinline__ bool lnr_level_uses_xpairs(const LnrNetSpec& s, int l) {
+// the four fixed-point contributions of an (unpacked) x-pair record: (1-fx)*a0, (1-fx)*a1 to the x corner, fx*a0, fx*a1 to the x+1 corner
+// (products rounded to fp32 first; one definition for the reduce and the overflow path, which must agree to the bit)
+__device__ __forceinline__ void lnr_xpair_fix(float a0, float a1, float fx, long long q[4]) {
+    const float gx = 1.0f - fx;
+    if (__builtin_expect(__builtin_fmaxf(__builtin_fabsf(a0), __builtin_fabsf(a1)) < 256.0f, 1)) {
+        q[0] = lnr_to_fix_small(gx * a0); q[1] = lnr_to_fix_small(gx * a1); q[2] = lnr_to_fix_small(fx * a0); q[3] = lnr_to_fix_small(fx * a1);
+    } else {
+        q[0] = __float2ll_rn(gx * a0 * LNR_FIX_SCALE); q[1] = __float2ll_rn(gx * a1 * LNR_FIX_SCALE);
+        q[2] = __float2ll_rn(fx * a0 * LNR_FIX_SCALE); q[3] = __float2ll_rn(fx * a1 * LNR_FIX_SCALE);
+    }
+}
+// which levels can take x-pair records; the host decides once per launch (RegionPlan::xp) and both kernels read the plan
+static inline bool lnr_level_can_use_xpairs(const LnrNetSpec& s, int l, float scale_min) {
     const uint32_t size = s.level_size[l];
-    return s.n_features == 2 && s.level_hashed[l] != 0 && (size & (size - 1u)) == 0u && s.level_scale[l] >= LNR_COMBINE_SCALE_MAX &&
+    return s.n_features == 2 && s.level_hashed[l] != 0 && (size & (size - 1u)) == 0u && s.level_scale[l] >= scale_min &&
            (uint64_t)size * 2u > (uint64_t)LNR_DENSE_LEVEL_FLOATS &&
            ((s.level_offset[l] * 2u) & ((1u << LNR_SLICE_SHIFT) - 1u)) == 0u;      // owner slices aligned with the level: low index bits stay inside a slice
 }
@@ -131,6 +160,18 @@ static inline bool lnr_level_is_dense(const LnrNetSpec* s, int l) {
     return (uint64_t)s->level_size[l] * (uint64_t)s->n_features <= (uint64_t)LNR_DENSE_LEVEL_FLOATS;
 }
 
+// Record regions, sized per level: [owner of the level][chunk (= encode-backward workgroup)] x bytes[l], back to back from off[l].
+// A region is as large as the level's expected records per (owner, chunk) plus 25 % and a small slack, in that level's record
+// format (8-byte pair records, 12-byte x-pair records) - the reduce streams an owner's chunks back to back, so every unused byte
+// of a region is a gap in its HBM stream (with one global capacity, sized for the busiest level, two thirds of the stream were
+// gaps and the reduce ran at 1.6 TB/s whatever its arithmetic cost).
+struct RegionPlan {
+    uint64_t off[LNR_MAX_LEVELS];       // byte offset of the level's regions
+    uint32_t bytes[LNR_MAX_LEVELS];     // bytes per region (multiple of 16); 0: the level emits no records (dense level) or all records overflow
+    uint8_t xp[LNR_MAX_LEVELS];         // 1: the level's records are 12-byte x-pair records, 0: 8-byte records
+    uint8_t split[LNR_MAX_LEVELS];      // > 1: the level's owners are reduced by this many workgroups each (table_grad_reduce_split_kernel)
+};
+
 // level-major encoding (lnr_encode.hip)
 int lnr_encode_forward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, float* feat,
                        int64_t m_pad, bool half_planes, hipStream_t st);
@@ -143,5 +184,5 @@ int lnr_mlp_bwd_f16(const LnrNetSpec* spec, const float* params, const void* fea
                     float* dfeat, float* slabs, int want_dfeat, int* n_slabs, hipStream_t st);
 int lnr_selftest_mfma_f16(float* out, hipStream_t st);
 int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, const float* dfeat,
-                        float* dxl, int64_t m_pad, float* grad_table, void* regions, int* counts, float* dense_slabs, int bpg,
-                        int maxo, int cap, int shift, long long* ovf, float* d_pts, float* d_rays_acc, long long* ray_acc, hipStream_t st);
+                        float* dxl, int64_t m_pad, float* grad_table, void* regions, const RegionPlan* plan, int* counts, float* dense_slabs, int bpg,
+                        int maxo, int shift, long long* ovf, float* d_pts, float* d_rays_acc, long long* ray_acc, hipStream_t st);

@@ -159,7 +159,7 @@ template <bool DW64> struct DwAcc;
 template <> struct DwAcc<true> {
     typedef long long type;
     static __device__ __forceinline__ void add(long long* p, float v) {
-        atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__float2ll_rn(v * LNR_FIX_SCALE));
+        atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)lnr_to_fix(v));
     }
     static __device__ __forceinline__ float get(long long v) { return (float)((double)v * (1.0 / (double)LNR_FIX_SCALE)); }
 };

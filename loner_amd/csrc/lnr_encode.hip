@@ -14,6 +14,8 @@
 // (run-length combined over consecutive samples of a ray on coarse levels), and writes its contribution to d/dx as
 // one plane per level; records are reduced by table_grad_reduce2_kernel (lnr_density.hip).
 #include "lnr_encoding.h"
+#include <cstdio>
+#include <cstdlib>
 
 #define ENC_BLOCK 256
 
@@ -121,9 +123,13 @@ freq_forward_kernel(const LnrNetSpec spec, const PointSrc src, float* __restrict
 struct EncSink {
     float* grad_table;      // fallback target for records beyond a region's capacity (float atomics) ...
     long long* ovf;         // ... unless the level has 64-bit overflow accumulators (LevelList::slab_off >= 0)
-    void* regions;          // [level][maxo][chunk][cap] 8-byte records (lnr_density_api.h)
+    void* regions;          // record regions, laid out by `plan` (lnr_density_api.h)
+    RegionPlan plan;
     int* counts;            // [level][maxo][chunk]
-    int maxo, cap, shift;
+    int maxo, shift;
+#ifdef LNR_ABLATE
+    int dbg;                // ablation bits (LNR_X_DBG), development builds only
+#endif
     float combine_scale_max;
 };
 
@@ -224,13 +230,24 @@ struct OwnerSlot {
 __device__ __forceinline__ void xpair_overflow(long long* ovf_level, uint32_t fi0_in_level, uint32_t fi1_in_level, uint32_t t, float a0, float a1, float fx) {
     uint32_t pi, tt; float q0, q1, qx;
     lnr_unpack_xpair(lnr_pack_xpair(0u, t, a0, a1, fx), pi, tt, q0, q1, qx);
-    const float gx = 1.0f - qx;
+    long long q[4];
+    lnr_xpair_fix(q0, q1, qx, q);
     unsigned long long* o = reinterpret_cast<unsigned long long*>(ovf_level);
-    atomicAdd(o + fi0_in_level, (unsigned long long)__float2ll_rn(gx * q0 * LNR_FIX_SCALE));
-    atomicAdd(o + fi0_in_level + 1, (unsigned long long)__float2ll_rn(gx * q1 * LNR_FIX_SCALE));
-    atomicAdd(o + fi1_in_level, (unsigned long long)__float2ll_rn(qx * q0 * LNR_FIX_SCALE));
-    atomicAdd(o + fi1_in_level + 1, (unsigned long long)__float2ll_rn(qx * q1 * LNR_FIX_SCALE));
+    atomicAdd(o + fi0_in_level, (unsigned long long)q[0]);
+    atomicAdd(o + fi0_in_level + 1, (unsigned long long)q[1]);
+    atomicAdd(o + fi1_in_level, (unsigned long long)q[2]);
+    atomicAdd(o + fi1_in_level + 1, (unsigned long long)q[3]);
 }
+
+#ifdef LNR_PHASE_TIMING
+__device__ unsigned long long lnr_phase_cycles[2 * LNR_N_PHASES];          // [8-byte record levels | x-pair levels]
+#endif
+// -DLNR_ABLATE (development builds only): LNR_X_DBG bits switch parts of encode_backward_kernel off, to time what is left
+#ifdef LNR_ABLATE
+#define DBG_SKIP(bit) ((sink.dbg & (bit)) != 0)
+#else
+#define DBG_SKIP(bit) false
+#endif
 
 // dynamic LDS: int cnt[maxo4], gcur[maxo4]; OwnerSlot slot[maxo] (16-byte aligned); then the staging buffer
 template <int F, int DXM>
@@ -255,11 +272,14 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t M = (uint32_t)live_points(src);
     const int first_owner = (int)(((uint64_t)L.offset * F) >> sink.shift);
-    const bool combine = L.scale < sink.combine_scale_max;
-    // x-pair records (12 bytes for the two x-neighbours of a corner pair) on the fine hashed levels; 8-byte records elsewhere
-    const bool xp = F == 2 && lnr_level_uses_xpairs(spec, lv);
-    const int cap_rec = xp ? (sink.cap * 8) / 12 : sink.cap;               // a region's capacity in records of this level's format
+    // x-pair records (12 bytes for the two x-neighbours of a corner pair) on the hashed power-of-two levels from LNR_XPAIR_SCALE_MIN up;
+    // 8-byte records, run-length combined along the rays, on the coarser ones
+    const bool xp = F == 2 && sink.plan.xp[lv] != 0;
+    const bool combine = !xp && L.scale < sink.combine_scale_max;
     const uint32_t rec_bytes = xp ? 12u : 8u;
+    const uint32_t region_bytes = sink.plan.bytes[lv];
+    const int cap_rec = (int)(region_bytes / rec_bytes);                   // a region's capacity in records of this level's format
+    const char* level_regions = reinterpret_cast<const char*>(sink.regions) + sink.plan.off[lv];
     // region of (level, owner o, chunk): [level][owner][chunk] - the reduce of one owner streams its chunks' regions back to back
     const int ovf_off = list.slab_off[blockIdx.x / bpg];
     long long* ovf = ovf_off >= 0 ? sink.ovf + ovf_off : nullptr;                // indexed by float index inside the level
@@ -289,10 +309,12 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
         const bool in = cur.m < M;
         const uint32_t mc = in ? cur.m : M - 1u;
 #pragma unroll
-        for (int f = 0; f < F; ++f) g_next[f] = ld32<float>(gplanes, (uint32_t)f * plane_bytes + mc * 4u);
+        for (int f = 0; f < F; ++f) g_next[f] = ld32_stream<float>(gplanes, (uint32_t)f * plane_bytes + mc * 4u);
         load_raw_point(src, mc, in ? cur.ray : last_ray, p_next);
     }
+    PHASE_INIT();
     for (uint32_t it = 0; it < n_iter; ++it) {
+        PHASE(11);
         const uint32_t m = cur.m;
         const bool live = m < M;
         float g[F];
@@ -306,10 +328,11 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
             const bool in = cur.m < M;
             const uint32_t mc = in ? cur.m : M - 1u;          // unconditional (clamped) loads: a static number in flight
 #pragma unroll
-            for (int f = 0; f < F; ++f) g_next[f] = ld32<float>(gplanes, (uint32_t)f * plane_bytes + mc * 4u);
+            for (int f = 0; f < F; ++f) g_next[f] = DBG_SKIP(32) ? ld32<float>(gplanes, (uint32_t)f * plane_bytes + mc * 4u) : ld32_stream<float>(gplanes, (uint32_t)f * plane_bytes + mc * 4u);
             load_raw_point(src, mc, in ? cur.ray : last_ray, p_next);
         }
         const bool wave_any = __ballot(any) != 0ull;
+        PHASE(0);
         Cell c;
         uint32_t e[8];
         float w[8];
@@ -321,13 +344,14 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
             unit_point(src, p_cur, x);
             c = cell_of(L, x);
             cell_entries(L, c, e);
-            if constexpr (EARLY_DX) gather_entries<F>(table, e, tv);
+            if constexpr (EARLY_DX) { if (!DBG_SKIP(4)) gather_entries<F>(table, e, tv); }
             cell_weights(c, w);
             // runs = consecutive samples (lanes of one 16-lane row) in the same CELL, not merely the same hashed entry
             if (combine) cell_runs(c, lane, head, run);
         }
+        PHASE(1);
 #pragma unroll
-        for (int pass = 0; pass < (emit ? NPASS : 0); ++pass) {
+        for (int pass = 0; pass < (emit && !DBG_SKIP(16) ? NPASS : 0); ++pass) {
             // ---- A: this thread's records of the batch; rank within the owner's bucket from an LDS histogram
             float rv0[8], rv1[8]; int rrank[8];
 #pragma unroll
@@ -364,7 +388,9 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
                     }
                 }
             }
+            PHASE(2);
             __syncthreads();
+            PHASE(3);
             // ---- B: exclusive scan of the histogram; reserve the slots in the regions
             if (wave == 0) {
                 int running = 0;
@@ -376,7 +402,7 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
                     for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
                     if (o < maxo) {
                         const int have = gcur[o];
-                        const uint64_t p = reinterpret_cast<uint64_t>(sink.regions) + (region0 + o * region_step) * (size_t)sink.cap * 8u + (size_t)have * rec_bytes;
+                        const uint64_t p = reinterpret_cast<uint64_t>(level_regions) + ((size_t)o * bpg + chunk) * (size_t)region_bytes + (size_t)have * rec_bytes;
                         OwnerSlot os;
                         os.ptr_lo = (uint32_t)p; os.ptr_hi = (uint32_t)(p >> 32);
                         os.scan = running + incl - n;
@@ -389,7 +415,9 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
                 }
                 if (lane == 0) s_total = running;
             }
+            PHASE(4);
             __syncthreads();
+            PHASE(5);
             // ---- C: scatter into the staging buffer, grouped by owner
             if (xp) {
                 // x-pair: (float index of the x corner, a0, a1, fx rounded to 28 bits with t in the freed low nibble)
@@ -413,7 +441,9 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
                     else reinterpret_cast<uint2*>(stage)[at] = make_uint2(fi, __float_as_uint(rv0[k]));
                 }
             }
+            PHASE(6);
             __syncthreads();
+            PHASE(7);
             // ---- D: linear copy-out; neighbouring lanes write neighbouring records of the same region
             const int total = s_total;
             if (xp) {
@@ -423,9 +453,10 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
                     const float a0 = __uint_as_float(r4.y), a1 = __uint_as_float(r4.z), fx = __uint_as_float(r4.w & ~0xFu);
                     const OwnerSlot os = oslot[(int)(idx >> sink.shift) - first_owner];
                     const int k = i - os.scan;
+                    if (DBG_SKIP(8)) continue;
                     if (k < os.room) {
-                        LnrXRec* dst = reinterpret_cast<LnrXRec*>((((uint64_t)os.ptr_hi << 32) | os.ptr_lo) + (uint64_t)k * 12u);
-                        *dst = lnr_pack_xpair((idx & ((1u << LNR_SLICE_SHIFT) - 1u)) >> 1, t, a0, a1, fx);
+                        const LnrXRec rec = lnr_pack_xpair((idx & ((1u << LNR_SLICE_SHIFT) - 1u)) >> 1, t, a0, a1, fx);
+                        store_stream_b96((((uint64_t)os.ptr_hi << 32) | os.ptr_lo) + (uint64_t)k * 12u, rec.a, rec.b, rec.c);
                     } else {
                         const uint32_t in_level = idx - level_base;                       // e1 = e0 ^ (2^(t+1) - 1): float index ^ (mask << 1)
                         xpair_overflow(ovf, in_level, in_level ^ (((2u << t) - 1u) << 1), t, a0, a1, fx);
@@ -440,37 +471,40 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
                 const int local = (int)(idx >> sink.shift) - first_owner;
                 const OwnerSlot os = oslot[local];
                 const int k = i - os.scan;
+                if (DBG_SKIP(8)) continue;
                 if (k < os.room) {
                     if (PAIR) r2 = lnr_pack_pair((idx & ((1u << LNR_SLICE_SHIFT) - 1u)) >> 1, v0, v1);
-                    uint2* dst = reinterpret_cast<uint2*>(((uint64_t)os.ptr_hi << 32) | os.ptr_lo) + k;
-                    *dst = r2;
+                    store_stream_b64((((uint64_t)os.ptr_hi << 32) | os.ptr_lo) + (uint64_t)k * 8u, r2);
                 } else if (ovf) {
                     // same 26-bit rounding as a packed record: which records overflow depends on arrival order, the sum must not
                     const float q0 = PAIR ? __uint_as_float(lnr_pack26(v0) << 6) : v0, q1 = PAIR ? __uint_as_float(lnr_pack26(v1) << 6) : 0.0f;
-                    if (q0 != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(ovf + (idx - level_base)), (unsigned long long)__float2ll_rn(q0 * LNR_FIX_SCALE));
-                    if (PAIR && q1 != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(ovf + (idx - level_base) + 1), (unsigned long long)__float2ll_rn(q1 * LNR_FIX_SCALE));
+                    if (q0 != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(ovf + (idx - level_base)), (unsigned long long)lnr_to_fix(q0));
+                    if (PAIR && q1 != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(ovf + (idx - level_base) + 1), (unsigned long long)lnr_to_fix(q1));
                 } else {
                     atomicAdd(sink.grad_table + idx, v0);
                     if (PAIR) atomicAdd(sink.grad_table + idx + 1, v1);
                 }
             }
             // no barrier here: the next histogram only touches cnt[], and its first barrier orders D before the next B/C
+            PHASE(8);
         }
         if constexpr (WANT_DX) {
             float dx[3] = {0.0f, 0.0f, 0.0f};
-            if (any) {
+            if (any && !DBG_SKIP(2)) {
                 if constexpr (EARLY_DX) dx_from_entries<F>(L, c, g, tv, dx);
                 else { float tl[8][F]; gather_entries<F>(table, e, tl); dx_from_entries<F>(L, c, g, tl, dx); }
             }
             if constexpr (DXM == ENC_DX_RAYS) {
-                if (wave_any)                            // wave-uniform; lane 0 holds the wave's first (live) sample
+                if (wave_any && !DBG_SKIP(1))            // wave-uniform; lane 0 holds the wave's first (live) sample
                     ray_accumulate_dx(dxl, (uint32_t)__builtin_amdgcn_readfirstlane((int)ray_cur), p_cur.z, dx, lane);
             } else if (live) {
 #pragma unroll
                 for (int d = 0; d < 3; ++d) st32<float>(dxplanes, (uint32_t)d * plane_bytes + m * 4u, dx[d]);
             }
         }
+        PHASE(9);
     }
+    PHASE_FLUSH(lnr_phase_cycles, xp ? LNR_N_PHASES : 0);
     __syncthreads();
     if (emit)
         for (int i = threadIdx.x; i < maxo; i += ENC_BLOCK)
@@ -531,7 +565,7 @@ encode_backward_dense_kernel(const LnrNetSpec spec, const float* __restrict__ ta
                 for (int f = 0; f < F; ++f) {
                     const float v = row_run_sum(w[k] * g[f], run);
                     if (head && v != 0.0f)
-                        atomicAdd(reinterpret_cast<unsigned long long*>(&dacc[el + f]), (unsigned long long)__float2ll_rn(v * LNR_FIX_SCALE));
+                        atomicAdd(reinterpret_cast<unsigned long long*>(&dacc[el + f]), (unsigned long long)lnr_to_fix(v));
                 }
             }
             if constexpr (WANT_DX) {
@@ -640,8 +674,8 @@ int lnr_encode_forward(const LnrNetSpec* spec, const float* params, const PointS
 }
 
 int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, const float* dfeat,
-                        float* dxl, int64_t m_pad, float* grad_table, void* regions, int* counts, float* dense_slabs, int bpg,
-                        int maxo, int cap, int shift, long long* ovf, float* d_pts, float* d_rays_acc, long long* ray_acc, hipStream_t st) {
+                        float* dxl, int64_t m_pad, float* grad_table, void* regions, const RegionPlan* plan, int* counts, float* dense_slabs, int bpg,
+                        int maxo, int shift, long long* ovf, float* d_pts, float* d_rays_acc, long long* ray_acc, hipStream_t st) {
     const float* table = params + spec->n_mlp_params;
     // d/dx mode: d_rays_acc (rays form, n_samples % 64 == 0, checked by the caller) > d_pts (planes) > none
     const int dxm = d_rays_acc ? ENC_DX_RAYS : (d_pts ? ENC_DX_PLANES : ENC_DX_NONE);
@@ -665,6 +699,10 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
             } else {
                 const int nfl = (int)spec->level_size[l] * spec->n_features;
                 const bool coherent = lnr_level_has_overflow_acc(spec, l);
+#ifdef LNR_ABLATE
+                static const int lmask = getenv("LNR_X_LEVELS") ? (int)strtol(getenv("LNR_X_LEVELS"), nullptr, 0) : -1;
+                if (!((lmask >> l) & 1)) { if (coherent) ovf_total += nfl; continue; }
+#endif
                 rec_levels.lv[rec_levels.n] = l; rec_levels.slab_off[rec_levels.n] = coherent ? ovf_total : -1; rec_levels.n++;
                 if (coherent) ovf_total += nfl;
             }
@@ -695,13 +733,27 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
                 lnr_set_error("lnr_density_backward: hipMemsetAsync failed");
                 return LNR_ERR_LAUNCH;
             }
-            sink.grad_table = grad_table; sink.ovf = ovf; sink.regions = regions; sink.counts = counts; sink.maxo = maxo; sink.cap = cap; sink.shift = shift;
+            sink.grad_table = grad_table; sink.ovf = ovf; sink.regions = regions; sink.plan = *plan; sink.counts = counts; sink.maxo = maxo; sink.shift = shift;
             sink.combine_scale_max = LNR_COMBINE_SCALE_MAX;
+#ifdef LNR_ABLATE
+            sink.dbg = getenv("LNR_X_DBG") ? atoi(getenv("LNR_X_DBG")) : 0;
+#endif
             const dim3 grid((unsigned)(rec_levels.n * bpg));
             LnrProfScope prof("encode_backward", st);
             const int maxo4 = (maxo + 3) & ~3;
             const size_t lds = (size_t)(2 * maxo4 + 4 * maxo) * sizeof(int) + (size_t)ENC_STAGE_RECORDS * (spec->n_features >= 2 ? 16 : 8);
             LNR_LAUNCH_F(encode_backward_kernel, *spec, table, *src, dfeat, dx_out, m_pad, bpg, rec_levels, sink);
+#ifdef LNR_PHASE_TIMING
+            if (getenv("LNR_PHASE_TIMING")) {
+                static const char* names[LNR_N_PHASES] = {"load inputs", "cell/entries/gather/weights", "A rank", "barrier 1", "B scan", "barrier 2",
+                                                          "C stage", "barrier 3", "D copy-out", "dx", "-", "loop"};
+                unsigned long long h[2 * LNR_N_PHASES];
+                if (lnr_phase_fetch(HIP_SYMBOL(lnr_phase_cycles), h, 2 * LNR_N_PHASES, st)) {
+                    lnr_phase_print("encode_backward 8-byte", names, h);
+                    lnr_phase_print("encode_backward x-pair", names, h + LNR_N_PHASES);
+                }
+            }
+#endif
         }
         if (dense_levels.n > 0) {
             const int dbpg = lnr_dense_bpg(bpg);

@@ -28,6 +28,25 @@ __device__ __forceinline__ void st32(void* base, uint32_t byte_off, T v) {
     *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (size_t)byte_off) = v;
 }
 
+// Streaming variants (nt cache policy): data that is written once and read once by a later kernel (gradient records) or read
+// once per launch (the d_feature planes) should not evict the table lines the gathers live on from the 4 MB L2 of an XCD.
+template <typename T>
+__device__ __forceinline__ T ld32_stream(const void* base, uint32_t byte_off) {
+    return __builtin_nontemporal_load(reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (size_t)byte_off));
+}
+template <typename T>
+__device__ __forceinline__ void st32_stream(void* base, uint32_t byte_off, T v) {
+    __builtin_nontemporal_store(v, reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (size_t)byte_off));
+}
+__device__ __forceinline__ void store_stream_b96(uint64_t global_addr, uint32_t a, uint32_t b, uint32_t c) {
+    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+    const u32x3 v = {a, b, c};
+    asm volatile("global_store_dwordx3 %0, %1, off nt" :: "v"(global_addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_stream_b64(uint64_t global_addr, uint2 v) {
+    asm volatile("global_store_dwordx2 %0, %1, off nt" :: "v"(global_addr), "v"(v) : "memory");
+}
+
 // Sample index of a thread that walks m, m+step, m+2*step, ...: the ray index m / n_samples is kept incrementally
 // (one division at the start instead of one per sample).
 struct SampleCursor {
