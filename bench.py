@@ -311,8 +311,8 @@ def main():
     n_local = opt.last_stats["n_valid_rays"] / max(args.steps, 1)          # rays per launch on this rank
     pts = n_local * args.samples
     F = int(spec.n_features)
-    n_rec = sum(1 for l in range(int(spec.n_levels)) if int(spec.level_size[l]) * F > 12288)      # levels of the record kernel
-    rec_table_floats = sum(int(spec.level_size[l]) * F for l in range(int(spec.n_levels)) if int(spec.level_size[l]) * F > 12288)
+    n_rec = int(spec.n_levels)                                      # every level goes through the record kernel
+    rec_table_floats = sum(int(spec.level_size[l]) * F for l in range(int(spec.n_levels)))
     h, ind, nh = spec.n_neurons, spec.in_dim, spec.n_hidden
     mac = h * ind + (nh - 1) * h * h
     # Algorithmic work per launch:

@@ -142,8 +142,14 @@ __device__ __forceinline__ void reduce_regions(long long* acc, const int* __rest
                 const int q = __builtin_ctzll(more);
                 more &= more - 1ull;
                 const int n = __builtin_amdgcn_readlane(my_n, q);
-                for (int off = 64; off < n; off += 64)
-                    if (off + lane < n) reduce_xpair(acc, *reinterpret_cast<const LnrXRec*>(round_regions + (size_t)q * region_bytes + (size_t)(off + lane) * 12));
+                const char* rg = round_regions + (size_t)q * region_bytes;
+                for (int off = 64; off < n; off += 64 * 4) {                                         // four pieces in flight
+                    LnrXRec r[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const int k = off + 64 * u + lane; r[u] = load_xrec_stream(rg + (size_t)(k < n ? k : n - 1) * 12); }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (off + 64 * u + lane < n) reduce_xpair(acc, r[u]);
+                }
             }
             continue;
         }
@@ -175,19 +181,27 @@ __device__ __forceinline__ void reduce_regions(long long* acc, const int* __rest
             more &= more - 1ull;
             const int n = __builtin_amdgcn_readlane(my_n, q);
             const uint2* rg = reinterpret_cast<const uint2*>(round_regions + (size_t)q * region_bytes);
-            for (int off = 128; off < n; off += 64)
-                if (off + lane < n) reduce_one<PAIR>(acc, rg[off + lane], base);
+            for (int off = 128; off < n; off += 128 * 4) {                                           // four pieces (of 128 records) in flight
+                uint4 r[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int k = off + 128 * u + 2 * lane; r[u] = load_rec2_stream(reinterpret_cast<const uint4*>(rg) + (k < n ? k : 0) / 2); }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = off + 128 * u + 2 * lane;
+                    if (k < n) reduce_one<PAIR>(acc, make_uint2(r[u].x, r[u].y), base);
+                    if (k + 1 < n) reduce_one<PAIR>(acc, make_uint2(r[u].z, r[u].w), base);
+                }
+            }
         }
     }
 }
 
 // float range of level l, its record-level bookkeeping (shared by the two reduce kernels)
-struct RedLevel { uint64_t lo, hi; bool dense; };
+struct RedLevel { uint64_t lo, hi; };
 __device__ __forceinline__ RedLevel red_level(const LnrNetSpec& spec, int l) {
     RedLevel r;
     r.lo = (uint64_t)spec.level_offset[l] * spec.n_features;
     r.hi = r.lo + (uint64_t)spec.level_size[l] * spec.n_features;
-    r.dense = r.hi - r.lo <= (uint64_t)LNR_DENSE_LEVEL_FLOATS;
     return r;
 }
 
@@ -207,11 +221,11 @@ table_grad_reduce_split_kernel(const LnrNetSpec spec, const void* __restrict__ r
     RedLevel lv;
     for (;; ++l) {                                                          // the host launched exactly sum(span * split) workgroups
         lv = red_level(spec, l);
-        span = lv.dense ? 0 : (int)(((lv.hi - 1) >> shift) - (lv.lo >> shift)) + 1;
+        span = (int)(((lv.hi - 1) >> shift) - (lv.lo >> shift)) + 1;
         const int n = plan.split[l] > 1 ? span * plan.split[l] : 0;
         if (b < n) break;
         b -= n;
-        if (!lv.dense) my_ovf += (int64_t)(lv.hi - lv.lo);
+        my_ovf += (int64_t)(lv.hi - lv.lo);
     }
     const int parts = plan.split[l], local = b / parts, part = b % parts;
     const uint32_t base = ((uint32_t)(lv.lo >> shift) + (uint32_t)local) << shift;
@@ -257,9 +271,8 @@ table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ region
         const RedLevel lv = red_level(spec, l);
         const uint64_t lo = lv.lo, hi = lv.hi;
         const int64_t my_ovf = ovf_off;
-        if (!lv.dense) ovf_off += (int64_t)(hi - lo);                       // every record level has overflow accumulators
+        ovf_off += (int64_t)(hi - lo);                                      // every level has overflow accumulators
         if (hi <= base || lo >= (uint64_t)base + slice) continue;
-        if (lv.dense) continue;                                             // dense level: arrives through the slabs
         {
             // records that did not fit their region were summed into 64-bit accumulators by the encode kernel (and, on split levels, all
             // records by the split kernel): same fixed point, so region records + overflow add up exactly, whatever the (arrival-order
@@ -315,7 +328,7 @@ struct Layout {
     int64_t m_pad;
     int n_groups, bpg, maxo, shift, nown, n_split;
     RegionPlan plan;
-    size_t off_feat, off_dfeat, off_dxl, off_dpts, off_rayacc, off_slabs, off_dense, off_ovf, off_counts, off_regions, total;
+    size_t off_feat, off_dfeat, off_dxl, off_dpts, off_rayacc, off_slabs, off_ovf, off_counts, off_regions, total;
 };
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -339,7 +352,7 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
     bpg = (bpg + 3) & ~(int64_t)3;       // the wave-private partition runs 4 waves (= 4 chunks) per workgroup
     L.bpg = (int)bpg;
     L.maxo = 1;
-    size_t dense_total = 0, ovf_total = 0;
+    size_t ovf_total = 0;
     uint64_t region_total = 0;
     for (int l = 0; l < LNR_MAX_LEVELS; ++l) { L.plan.off[l] = 0; L.plan.bytes[l] = 0; L.plan.xp[l] = 0; L.plan.split[l] = 1; }
     L.n_split = 0;
@@ -348,9 +361,8 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
         for (int pass = 0; pass < 2; ++pass) {                              // pass 1 only if the plan exceeds the budget: scaled down
             if (pass == 1 && region_total <= LNR_REGION_BUDGET) break;
             const double shrink = pass == 0 ? 1.0 : (double)LNR_REGION_BUDGET / (double)region_total;
-            region_total = 0; dense_total = 0; ovf_total = 0; L.maxo = 1; L.n_split = 0;
+            region_total = 0; ovf_total = 0; L.maxo = 1; L.n_split = 0;
             for (int l = 0; l < spec->n_levels; ++l) {
-                if (lnr_level_is_dense(spec, l)) { dense_total += (size_t)spec->level_size[l] * F; continue; }
                 ovf_total += (size_t)spec->level_size[l] * F;
                 const uint64_t lo = (uint64_t)spec->level_offset[l] * F, hi = lo + (uint64_t)spec->level_size[l] * F;
                 const int span = (int)(((hi - 1) >> L.shift) - (lo >> L.shift)) + 1;
@@ -385,7 +397,6 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
     L.off_dpts = off; off += align256((size_t)3 * L.m_pad * sizeof(float));      // d_pts scratch of the general d_rays route
     L.off_rayacc = off; off += align256((size_t)(L.m_pad / 64) * 6 * sizeof(long long));   // per-ray sums of the d_rays route (n_samples >= 64 there)
     L.off_slabs = off; off += align256((size_t)LNR_BWD_MAX_BLOCKS * spec->n_mlp_params * sizeof(float));
-    L.off_dense = off; off += align256(dense_total * (size_t)lnr_dense_bpg(L.bpg) * sizeof(float));
     L.off_ovf = off; off += align256(ovf_total * sizeof(long long));
     L.off_counts = off; off += align256(hash ? (size_t)blocks * L.maxo * sizeof(int) : 0);
     L.off_regions = off; off += (size_t)region_total;
@@ -394,11 +405,10 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
 }
 
 // LNR_REPORT_REGIONS=1: how full the record regions ran (diagnostic for sizing RegionPlan; synchronises the stream)
-static void report_regions(const LnrNetSpec* spec, const Layout& L, const RegionPlan& plan, const int* counts, hipStream_t st) {
+static void report_regions(const LnrNetSpec* spec, const Layout& L, const RegionPlan& plan, const int* counts, const float* dfeat, int64_t n_points, hipStream_t st) {
     std::vector<int> h((size_t)spec->n_levels * L.maxo * L.bpg);
     if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(h.data(), counts, h.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return;
     for (int l = 0; l < spec->n_levels; ++l) {
-        if (lnr_level_is_dense(spec, l)) continue;
         const int rec = plan.xp[l] ? 12 : 8, cap = (int)(plan.bytes[l] / rec);
         long long sum = 0, over = 0; int mx = 0;
         const uint64_t lo = (uint64_t)spec->level_offset[l] * spec->n_features, hi = lo + (uint64_t)spec->level_size[l] * spec->n_features;
@@ -408,6 +418,14 @@ static void report_regions(const LnrNetSpec* spec, const Layout& L, const Region
                 const int v = h[((size_t)l * L.maxo + o) * L.bpg + c];
                 sum += v; if (v > mx) mx = v; if (v > cap) over += v - cap;
             }
+        if (dfeat != nullptr && n_points > 0) {                 // how many samples carry a gradient into this level at all
+            std::vector<float> plane((size_t)n_points);
+            if (hipMemcpy(plane.data(), dfeat + (size_t)l * spec->n_features * L.m_pad, plane.size() * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess) {
+                long long nz = 0, runs = 0;
+                for (int64_t i = 0; i < n_points; ++i) { nz += plane[i] != 0.0f; runs += (plane[i] != 0.0f) && (i == 0 || plane[i - 1] == 0.0f); }
+                fprintf(stderr, "[lnr regions] level %2d: %lld of %lld samples have d_feature != 0, in %lld runs\n", l, nz, (long long)n_points, runs);
+            }
+        }
         fprintf(stderr, "[lnr regions] level %2d: %d-B records, capacity %d, mean %.1f, max %d, overflowed %lld of %lld\n", l, rec, cap,
                 (double)sum / ((double)span * L.bpg), mx, over, sum);
     }
@@ -613,7 +631,6 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     float* dfeat = (float*)(ws + L.off_dfeat);
     float* dxl = (float*)(ws + L.off_dxl);
     float* slabs = (float*)(ws + L.off_slabs);
-    float* dense_slabs = (float*)(ws + L.off_dense);
     long long* ovf = (long long*)(ws + L.off_ovf);
     int* counts = (int*)(ws + L.off_counts);
     void* regions = (void*)(ws + L.off_regions);
@@ -662,11 +679,16 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
                    (flags & LNR_BWD_TABLE_ATOMICS) ? 0 : L.n_split};
     if (want_dfeat) {
         rc = lnr_encode_backward(spec, params, &src, cap, dfeat, dxl, L.m_pad, grad_table, want_grad ? regions : nullptr, &rplan, counts,
-                                 want_grad ? dense_slabs : nullptr, L.bpg, L.maxo, L.shift,
+                                 L.bpg, L.maxo, L.shift,
                                  ovf, d_pts_eff, ray_accum ? d_rays : nullptr, (long long*)(ws + L.off_rayacc), st);
         if (rc) return rc;
         LNR_CHECK_LAUNCH("lnr_density_backward(encode backward)");
-        if (want_grad && getenv("LNR_REPORT_REGIONS")) report_regions(spec, L, rplan, counts, st);
+        if (want_grad && getenv("LNR_REPORT_REGIONS")) {
+            int64_t live = cap;
+            int32_t nr = 0;
+            if (n_rays_dev && hipStreamSynchronize(st) == hipSuccess && hipMemcpy(&nr, n_rays_dev, sizeof(nr), hipMemcpyDeviceToHost) == hipSuccess) live = (int64_t)nr * n_samples;
+            report_regions(spec, L, rplan, counts, dfeat, live, st);
+        }
     }
     if (d_rays && !ray_accum) {
         rc = lnr_points_grad_to_rays(d_pts_eff, z, n_rays, n_rays_dev, n_samples, d_rays, stream);

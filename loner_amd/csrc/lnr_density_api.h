@@ -25,7 +25,6 @@ struct PointSrc {
 #define LNR_REGION_HEADROOM 2.0     // region capacity = expectation x this + LNR_REGION_SLACK records
 #define LNR_REGION_SLACK 64.0
 #define LNR_REDUCE_SPLIT 32         // reduce workgroups per owner of a dense-indexed record level
-#define LNR_DENSE_LEVEL_FLOATS 12288      /* levels up to this many floats are accumulated densely in LDS (see below) */
 #define LNR_FIX_SCALE 4398046511104.0f /* 2^42: LDS gradient accumulators are 64-bit fixed point */
 #define LNR_XPAIR_SCALE_MIN 3000.0f   /* hashed power-of-two levels at least this fine take x-pair records (below: run-length combined 8-byte records) */
 
@@ -105,7 +104,6 @@ __device__ __forceinline__ void lnr_xpair_fix(float a0, float a1, float fx, long
 static inline bool lnr_level_can_use_xpairs(const LnrNetSpec& s, int l, float scale_min) {
     const uint32_t size = s.level_size[l];
     return s.n_features == 2 && s.level_hashed[l] != 0 && (size & (size - 1u)) == 0u && s.level_scale[l] >= scale_min &&
-           (uint64_t)size * 2u > (uint64_t)LNR_DENSE_LEVEL_FLOATS &&
            ((s.level_offset[l] * 2u) & ((1u << LNR_SLICE_SHIFT) - 1u)) == 0u;      // owner slices aligned with the level: low index bits stay inside a slice
 }
 
@@ -138,14 +136,11 @@ LNR_DECLARE_HT(4)
 LNR_DECLARE_HT(8)
 LNR_DECLARE_HT(16)
 
-// Levels whose whole table is at most this many floats are accumulated densely in LDS by the encode-backward
-// workgroups (64-bit fixed point) and leave as per-workgroup slabs instead of records: on those levels every ray
-// crosses the same few thousand entries, which would make their one or two owner slices the tail of the reduce.
+// the record levels handled by one encode-backward launch
 struct LevelList {
     int n;                          // levels handled by a launch
     int lv[LNR_MAX_LEVELS];
-    int slab_off[LNR_MAX_LEVELS];   // dense levels: float offset inside one workgroup's slab;
-                                    // record levels: offset of the level's 64-bit overflow accumulators, or -1 (see below)
+    int slab_off[LNR_MAX_LEVELS];   // offset of the level's 64-bit overflow accumulators (see below)
 };
 // Every record level has 64-bit fixed-point overflow accumulators in the workspace (one per table float of the level): a
 // record that does not fit its staging bin or its region is added there (integer atomics: exact, order-independent) with
@@ -153,12 +148,6 @@ struct LevelList {
 // table gradient does not depend on which records happened to overflow.  Levels with dense (non-hashed) indexing overflow
 // routinely (they are spatially coherent: an owner slice is a slab of cells and a ray pours into a few of them), hashed
 // levels only by statistical accident.
-static inline bool lnr_level_has_overflow_acc(const LnrNetSpec* s, int l) { (void)s; (void)l; return true; }
-// workgroups per dense level: each pays for zeroing and writing out an LDS copy of the level, so fewer than for the record levels
-static inline int lnr_dense_bpg(int bpg) { return bpg < 512 ? bpg : 512; }
-static inline bool lnr_level_is_dense(const LnrNetSpec* s, int l) {
-    return (uint64_t)s->level_size[l] * (uint64_t)s->n_features <= (uint64_t)LNR_DENSE_LEVEL_FLOATS;
-}
 
 // Record regions, sized per level: [owner of the level][chunk (= encode-backward workgroup)] x bytes[l], back to back from off[l].
 // A region is as large as the level's expected records per (owner, chunk) plus 25 % and a small slack, in that level's record
@@ -167,7 +156,7 @@ static inline bool lnr_level_is_dense(const LnrNetSpec* s, int l) {
 // gaps and the reduce ran at 1.6 TB/s whatever its arithmetic cost).
 struct RegionPlan {
     uint64_t off[LNR_MAX_LEVELS];       // byte offset of the level's regions
-    uint32_t bytes[LNR_MAX_LEVELS];     // bytes per region (multiple of 16); 0: the level emits no records (dense level) or all records overflow
+    uint32_t bytes[LNR_MAX_LEVELS];     // bytes per region (multiple of 16); 0: all records overflow (LNR_BWD_TABLE_ATOMICS)
     uint8_t xp[LNR_MAX_LEVELS];         // 1: the level's records are 12-byte x-pair records, 0: 8-byte records
     uint8_t split[LNR_MAX_LEVELS];      // > 1: the level's owners are reduced by this many workgroups each (table_grad_reduce_split_kernel)
 };
@@ -184,5 +173,5 @@ int lnr_mlp_bwd_f16(const LnrNetSpec* spec, const float* params, const void* fea
                     float* dfeat, float* slabs, int want_dfeat, int* n_slabs, hipStream_t st);
 int lnr_selftest_mfma_f16(float* out, hipStream_t st);
 int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, const float* dfeat,
-                        float* dxl, int64_t m_pad, float* grad_table, void* regions, const RegionPlan* plan, int* counts, float* dense_slabs, int bpg,
+                        float* dxl, int64_t m_pad, float* grad_table, void* regions, const RegionPlan* plan, int* counts, int bpg,
                         int maxo, int shift, long long* ovf, float* d_pts, float* d_rays_acc, long long* ray_acc, hipStream_t st);

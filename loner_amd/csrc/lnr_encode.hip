@@ -122,7 +122,7 @@ freq_forward_kernel(const LnrNetSpec spec, const PointSrc src, float* __restrict
 // table_grad_reduce2_kernel (lnr_density.hip) sums each owner's regions in LDS.
 struct EncSink {
     float* grad_table;      // fallback target for records beyond a region's capacity (float atomics) ...
-    long long* ovf;         // ... unless the level has 64-bit overflow accumulators (LevelList::slab_off >= 0)
+    long long* ovf;         // the levels' 64-bit overflow accumulators (LevelList::slab_off)
     void* regions;          // record regions, laid out by `plan` (lnr_density_api.h)
     RegionPlan plan;
     int* counts;            // [level][maxo][chunk]
@@ -511,102 +511,6 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
             sink.counts[region0 + i * region_step] = gcur[i] < cap_rec ? gcur[i] : cap_rec;
 }
 
-// Dense levels (lnr_density_api.h): the workgroup sums its samples' corner updates in an LDS copy of the level's
-// table (64-bit fixed point: LDS integer atomics are ~16x faster than float ones on CDNA4 and order-independent) and
-// writes it out once as a slab; dense_slab_reduce_kernel adds the slabs of all workgroups to the table gradient.
-template <int F, int DXM>
-__global__ void __launch_bounds__(ENC_BLOCK)
-encode_backward_dense_kernel(const LnrNetSpec spec, const float* __restrict__ table, const PointSrc src, const float* __restrict__ dfeat,
-                             float* __restrict__ dxl, int64_t m_pad, int bpg, const LevelList list, float* __restrict__ slabs,
-                             int dense_total) {
-    constexpr bool WANT_DX = DXM != ENC_DX_NONE;
-    extern __shared__ long long dacc[];
-    const int slot = blockIdx.x / bpg, chunk = blockIdx.x % bpg;
-    const int lv = list.lv[slot];
-    const LevelInfo L = level_info(spec, lv);
-    const int nfl = (int)L.size * F;
-    const uint32_t level_base = L.offset * F;
-    for (int i = threadIdx.x; i < nfl; i += ENC_BLOCK) dacc[i] = 0ll;
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const uint32_t M = (uint32_t)live_points(src);
-    const uint32_t m_round = (M + 63u) / 64u * 64u;           // whole waves: the run logic uses cross-lane reads
-    const float* gplanes = dfeat + (size_t)(lv * F) * m_pad;
-    float* dxplanes = dxl + (size_t)(lv * 3) * m_pad;
-    const uint32_t plane_bytes = (uint32_t)m_pad * 4u;
-    SampleCursor cur;
-    cur.init((uint32_t)chunk * ENC_BLOCK + threadIdx.x, (uint32_t)bpg * ENC_BLOCK, src.pts ? 1u : (uint32_t)src.n_samples);
-    const uint32_t last_ray = src.pts ? 0u : (M > 0u ? (M - 1u) / cur.S : 0u);
-    for (; cur.m < m_round; cur.advance()) {
-        const uint32_t m = cur.m;
-        const bool live = m < M;
-        float g[F];
-        bool any = false;
-#pragma unroll
-        for (int f = 0; f < F; ++f) { g[f] = live ? ld32<float>(gplanes, (uint32_t)f * plane_bytes + m * 4u) : 0.0f; any |= (g[f] != 0.0f); }
-        float dx[3] = {0.0f, 0.0f, 0.0f};
-        const bool wave_any = __ballot(any) != 0ull;
-        RawPoint rp;
-        rp.z = 0.0f;
-        if (wave_any) {                                     // wave-uniform
-            load_raw_point(src, live ? m : M - 1u, live ? cur.ray : last_ray, rp);
-            float x[3];
-            unit_point(src, rp, x);
-            const Cell c = cell_of(L, x);
-            uint32_t e[8]; float w[8];
-            cell_entries(L, c, e);
-            cell_weights(c, w);
-            bool head; RunMask run;
-            cell_runs(c, lane, head, run);
-#pragma unroll
-            for (int k = 0; k < (slabs ? 8 : 0); ++k) {          // slabs == nullptr: parameters frozen, input gradient only
-                const uint32_t el = e[k] * F - level_base;
-#pragma unroll
-                for (int f = 0; f < F; ++f) {
-                    const float v = row_run_sum(w[k] * g[f], run);
-                    if (head && v != 0.0f)
-                        atomicAdd(reinterpret_cast<unsigned long long*>(&dacc[el + f]), (unsigned long long)lnr_to_fix(v));
-                }
-            }
-            if constexpr (WANT_DX) {
-                if (any) { float tv[8][F]; gather_entries<F>(table, e, tv); dx_from_entries<F>(L, c, g, tv, dx); }
-            }
-        }
-        if constexpr (DXM == ENC_DX_RAYS) {
-            if (wave_any) ray_accumulate_dx(dxl, (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.ray), rp.z, dx, lane);
-        } else if constexpr (DXM == ENC_DX_PLANES) {
-            if (live) {
-#pragma unroll
-                for (int d = 0; d < 3; ++d) st32<float>(dxplanes, (uint32_t)d * plane_bytes + m * 4u, dx[d]);
-            }
-        }
-    }
-    __syncthreads();
-    if (slabs == nullptr) return;
-    float* slab = slabs + (size_t)chunk * dense_total + list.slab_off[slot];
-    for (int i = threadIdx.x; i < nfl; i += ENC_BLOCK) slab[i] = (float)((double)dacc[i] * (1.0 / (double)LNR_FIX_SCALE));
-}
-
-__global__ void __launch_bounds__(ENC_BLOCK)
-dense_slab_reduce_kernel(const LnrNetSpec spec, const LevelList list, const float* __restrict__ slabs, int bpg, int dense_total,
-                         float* __restrict__ grad_table) {
-    const int slot = blockIdx.y;
-    const int lv = list.lv[slot];
-    const int nfl = (int)spec.level_size[lv] * spec.n_features;
-    const int i = blockIdx.x * ENC_BLOCK + threadIdx.x;
-    if (i >= nfl) return;
-    const float* p = slabs + list.slab_off[slot] + i;
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    int b = 0;
-    for (; b + 3 < bpg; b += 4) {
-        s0 += p[(size_t)b * dense_total]; s1 += p[(size_t)(b + 1) * dense_total];
-        s2 += p[(size_t)(b + 2) * dense_total]; s3 += p[(size_t)(b + 3) * dense_total];
-    }
-    for (; b < bpg; ++b) s0 += p[(size_t)b * dense_total];
-    const float s = (s0 + s1) + (s2 + s3);
-    if (s != 0.0f) grad_table[(size_t)spec.level_offset[lv] * spec.n_features + i] += s;
-}
-
 // Frequency encoding has no table: backward is only the input gradient, one plane group for all features.
 __global__ void __launch_bounds__(ENC_BLOCK)
 freq_backward_kernel(const LnrNetSpec spec, const PointSrc src, const float* __restrict__ dfeat, float* __restrict__ dxl, int64_t m_pad) {
@@ -674,7 +578,7 @@ int lnr_encode_forward(const LnrNetSpec* spec, const float* params, const PointS
 }
 
 int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, const float* dfeat,
-                        float* dxl, int64_t m_pad, float* grad_table, void* regions, const RegionPlan* plan, int* counts, float* dense_slabs, int bpg,
+                        float* dxl, int64_t m_pad, float* grad_table, void* regions, const RegionPlan* plan, int* counts, int bpg,
                         int maxo, int shift, long long* ovf, float* d_pts, float* d_rays_acc, long long* ray_acc, hipStream_t st) {
     const float* table = params + spec->n_mlp_params;
     // d/dx mode: d_rays_acc (rays form, n_samples % 64 == 0, checked by the caller) > d_pts (planes) > none
@@ -687,25 +591,17 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
     int n_groups = 1;
     if (spec->encoding == LNR_ENC_HASHGRID) {
         n_groups = spec->n_levels;
-        LevelList rec_levels, dense_levels;
-        rec_levels.n = dense_levels.n = 0;
-        int dense_total = 0, dense_max = 0, ovf_total = 0;
+        LevelList rec_levels;
+        rec_levels.n = 0;
+        int ovf_total = 0;
         for (int l = 0; l < spec->n_levels; ++l) {
-            if (lnr_level_is_dense(spec, l)) {
-                const int nfl = (int)spec->level_size[l] * spec->n_features;
-                dense_levels.lv[dense_levels.n] = l; dense_levels.slab_off[dense_levels.n] = dense_total; dense_levels.n++;
-                dense_total += nfl;
-                if (nfl > dense_max) dense_max = nfl;
-            } else {
-                const int nfl = (int)spec->level_size[l] * spec->n_features;
-                const bool coherent = lnr_level_has_overflow_acc(spec, l);
+            const int nfl = (int)spec->level_size[l] * spec->n_features;
 #ifdef LNR_ABLATE
-                static const int lmask = getenv("LNR_X_LEVELS") ? (int)strtol(getenv("LNR_X_LEVELS"), nullptr, 0) : -1;
-                if (!((lmask >> l) & 1)) { if (coherent) ovf_total += nfl; continue; }
+            static const int lmask = getenv("LNR_X_LEVELS") ? (int)strtol(getenv("LNR_X_LEVELS"), nullptr, 0) : -1;
+            if (!((lmask >> l) & 1)) { ovf_total += nfl; continue; }
 #endif
-                rec_levels.lv[rec_levels.n] = l; rec_levels.slab_off[rec_levels.n] = coherent ? ovf_total : -1; rec_levels.n++;
-                if (coherent) ovf_total += nfl;
-            }
+            rec_levels.lv[rec_levels.n] = l; rec_levels.slab_off[rec_levels.n] = ovf_total; rec_levels.n++;
+            ovf_total += nfl;
         }
         const dim3 block(ENC_BLOCK);
 #define LNR_LAUNCH_DXM(KERNEL, F, ...)                                                                                        \
@@ -754,15 +650,6 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
                 }
             }
 #endif
-        }
-        if (dense_levels.n > 0) {
-            const int dbpg = lnr_dense_bpg(bpg);
-            const dim3 grid((unsigned)(dense_levels.n * dbpg));
-            LnrProfScope prof("encode_backward_dense", st);
-            const size_t lds = (size_t)dense_max * sizeof(long long);
-            LNR_LAUNCH_F(encode_backward_dense_kernel, *spec, table, *src, dfeat, dx_out, m_pad, dbpg, dense_levels, dense_slabs, dense_total);
-            if (dense_slabs != nullptr) hipLaunchKernelGGL(dense_slab_reduce_kernel, dim3((unsigned)((dense_max + ENC_BLOCK - 1) / ENC_BLOCK), (unsigned)dense_levels.n), block, 0, st,
-                               *spec, dense_levels, dense_slabs, dbpg, dense_total, grad_table);
         }
 #undef LNR_LAUNCH_F
 #undef LNR_LAUNCH_DXM
