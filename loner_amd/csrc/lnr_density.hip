@@ -116,34 +116,38 @@ __device__ __forceinline__ void reduce_regions(long long* acc, const int* __rest
         const int my_n = lane < nq ? wave_counts[r0 + lane] : 0;
         const char* round_regions = wave_regions + (size_t)r0 * region_bytes;
         if (xp) {
-            // x-pair levels (lnr_density_api.h): 12-byte records, a piece = 64 records = one 12-byte load per lane
-            LnrXRec cur[RED_U], nxt[RED_U];
-            auto loadx = [&](int q0, LnrXRec out[RED_U]) {
+            // x-pair levels (lnr_density_api.h): 12-byte records, a piece = 64 records = one 12-byte load per lane; the first two pieces
+            // of a region go through the pipelined loop (an encode-backward workgroup leaves ~65 records per region)
+            LnrXRec cur[RED_U][2], nxt[RED_U][2];
+            auto loadx = [&](int q0, LnrXRec out[RED_U][2]) {
 #pragma unroll
                 for (int u = 0; u < RED_U; ++u) {
                     const int q = q0 + u < nq ? q0 + u : nq - 1;                                     // clamp: unconditional loads
                     const int n = __builtin_amdgcn_readlane(my_n, q);
-                    out[u] = load_xrec_stream(round_regions + (size_t)q * region_bytes + (lane < n ? lane : 0) * 12);
+                    const char* rg = round_regions + (size_t)q * region_bytes;
+                    out[u][0] = load_xrec_stream(rg + (lane < n ? lane : 0) * 12);
+                    out[u][1] = load_xrec_stream(rg + (lane + 64 < n ? lane + 64 : 0) * 12);
                 }
             };
             loadx(0, nxt);
             for (int q0 = 0; q0 < nq; q0 += RED_U) {
 #pragma unroll
-                for (int u = 0; u < RED_U; ++u) cur[u] = nxt[u];
+                for (int u = 0; u < RED_U; ++u) { cur[u][0] = nxt[u][0]; cur[u][1] = nxt[u][1]; }
                 if (q0 + RED_U < nq) loadx(q0 + RED_U, nxt);
 #pragma unroll
                 for (int u = 0; u < RED_U; ++u) {
                     const int n = q0 + u < nq ? __builtin_amdgcn_readlane(my_n, q0 + u < 64 ? q0 + u : 63) : 0;
-                    if (lane < n) reduce_xpair(acc, cur[u]);
+                    if (lane < n) reduce_xpair(acc, cur[u][0]);
+                    if (lane + 64 < n) reduce_xpair(acc, cur[u][1]);
                 }
             }
-            unsigned long long more = __ballot(my_n > 64);                                           // regions with further pieces: rare
+            unsigned long long more = __ballot(my_n > 128);                                          // regions with further pieces: rare
             while (more) {
                 const int q = __builtin_ctzll(more);
                 more &= more - 1ull;
                 const int n = __builtin_amdgcn_readlane(my_n, q);
                 const char* rg = round_regions + (size_t)q * region_bytes;
-                for (int off = 64; off < n; off += 64 * 4) {                                         // four pieces in flight
+                for (int off = 128; off < n; off += 64 * 4) {                                        // four pieces in flight
                     LnrXRec r[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) { const int k = off + 64 * u + lane; r[u] = load_xrec_stream(rg + (size_t)(k < n ? k : n - 1) * 12); }
@@ -346,7 +350,7 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
     L.shift = LNR_SLICE_SHIFT;
     const int64_t n_table = spec->n_params - spec->n_mlp_params;
     L.nown = (int)((n_table + (1 << L.shift) - 1) >> L.shift);
-    int64_t bpg = (n_points + 256 * 4 - 1) / (256 * 4);        // ~4 batches of 256 samples per encode-backward workgroup
+    int64_t bpg = (n_points + LNR_ENC_BWD_BLOCK * 4 - 1) / (LNR_ENC_BWD_BLOCK * 4);        // ~4 batches per encode-backward workgroup
     if (bpg < 1) bpg = 1;
     if (bpg > LNR_ENC_BWD_MAX_BPG) bpg = LNR_ENC_BWD_MAX_BPG;
     bpg = (bpg + 3) & ~(int64_t)3;       // the wave-private partition runs 4 waves (= 4 chunks) per workgroup
@@ -512,10 +516,12 @@ static int launch_reduce_variant(const ReduceCtx& c, int n_owners, hipStream_t s
         hipFuncSetAttribute(reinterpret_cast<const void*>(table_grad_reduce_split_kernel<PAIR, U, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         lnr_set_error("lnr_density_backward: hipFuncSetAttribute failed"); return LNR_ERR_LAUNCH;
     }
-    LnrProfScope prof("table_grad_reduce", st);
-    if (c.n_split > 0)
+    if (c.n_split > 0) {
+        LnrProfScope prof("table_grad_reduce_split", st);
         hipLaunchKernelGGL((table_grad_reduce_split_kernel<PAIR, U, W>), dim3(c.n_split), dim3(1024), lds, st, *c.spec, c.regions, c.plan, c.counts, c.bpg, c.maxo,
                            const_cast<long long*>(c.ovf));
+    }
+    LnrProfScope prof("table_grad_reduce", st);
     hipLaunchKernelGGL((table_grad_reduce2_kernel<PAIR, U, W>), dim3(n_owners), dim3(1024), lds, st, *c.spec, c.regions, c.plan, c.counts, c.bpg, c.maxo,
                        c.ovf, c.grad_table, c.n_table);
     return LNR_OK;

@@ -24,6 +24,9 @@ struct PointSrc {
 #define LNR_COMBINE_FILL 1.0        // expected records of a run-length combined level, as a fraction of its uncombined count
 #define LNR_REGION_HEADROOM 2.0     // region capacity = expectation x this + LNR_REGION_SLACK records
 #define LNR_REGION_SLACK 64.0
+#ifndef LNR_ENC_BWD_BLOCK
+#define LNR_ENC_BWD_BLOCK 512       // threads of an encode-backward workgroup = samples of one partition batch
+#endif
 #define LNR_REDUCE_SPLIT 32         // reduce workgroups per owner of a dense-indexed record level
 #define LNR_FIX_SCALE 4398046511104.0f /* 2^42: LDS gradient accumulators are 64-bit fixed point */
 #define LNR_XPAIR_SCALE_MIN 3000.0f   /* hashed power-of-two levels at least this fine take x-pair records (below: run-length combined 8-byte records) */

@@ -216,7 +216,8 @@ ray_grad_apply_kernel(const long long* __restrict__ ray_acc, int n_rays, const i
     if (q != 0ll) d_rays[(size_t)(i / 6) * LNR_RAY_STRIDE + (i % 6)] += (float)((double)q * (1.0 / (double)LNR_FIX_SCALE));
 }
 
-#define ENC_STAGE_RECORDS (ENC_BLOCK * 8)
+#define ENC_BWD_BLOCK LNR_ENC_BWD_BLOCK
+#define ENC_STAGE_RECORDS (ENC_BWD_BLOCK * 8)
 
 // what the copy-out phase needs to know about one owner of the current batch: one 16-byte LDS read per record
 struct OwnerSlot {
@@ -251,7 +252,7 @@ __device__ unsigned long long lnr_phase_cycles[2 * LNR_N_PHASES];          // [8
 
 // dynamic LDS: int cnt[maxo4], gcur[maxo4]; OwnerSlot slot[maxo] (16-byte aligned); then the staging buffer
 template <int F, int DXM>
-__global__ void __launch_bounds__(ENC_BLOCK)
+__global__ void __launch_bounds__(ENC_BWD_BLOCK, 4)   // (max threads, min waves per SIMD): 128 VGPRs
 encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, const PointSrc src, const float* __restrict__ dfeat,
                        float* __restrict__ dxl, int64_t m_pad, int bpg, const LevelList list, const EncSink sink) {
     constexpr bool WANT_DX = DXM != ENC_DX_NONE;          // dxl: the d/dx planes (ENC_DX_PLANES) or d_rays [n_rays,13] (ENC_DX_RAYS)
@@ -265,7 +266,7 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
     int* gcur = dyn + maxo4;
     OwnerSlot* oslot = reinterpret_cast<OwnerSlot*>(dyn + 2 * maxo4);
     void* stage = reinterpret_cast<void*>(dyn + 2 * maxo4 + 4 * maxo);
-    for (int i = threadIdx.x; i < maxo; i += ENC_BLOCK) { cnt[i] = 0; gcur[i] = 0; }
+    for (int i = threadIdx.x; i < maxo; i += ENC_BWD_BLOCK) { cnt[i] = 0; gcur[i] = 0; }
     __syncthreads();
     const int lv = list.lv[blockIdx.x / bpg], chunk = blockIdx.x % bpg;
     const LevelInfo L = level_info(spec, lv);
@@ -286,14 +287,14 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
     const uint32_t level_base = L.offset * F;
     const size_t region0 = (size_t)lv * maxo * bpg + chunk;
     const size_t region_step = (size_t)bpg;          // between consecutive owners
-    const uint32_t step = (uint32_t)bpg * ENC_BLOCK;
+    const uint32_t step = (uint32_t)bpg * ENC_BWD_BLOCK;
     const uint32_t n_iter = (M + step - 1u) / step;          // workgroup-uniform trip count (the loop body has barriers)
     const float* gplanes = dfeat + (size_t)(lv * F) * m_pad;
     float* dxplanes = dxl + (size_t)(lv * 3) * m_pad;
     const uint32_t plane_bytes = (uint32_t)m_pad * 4u;
     const bool emit = sink.regions != nullptr;                // false: parameters frozen, only the input gradient is wanted
     if (M == 0u) {                                            // workgroup-uniform
-        if (emit) for (int i = threadIdx.x; i < maxo; i += ENC_BLOCK) sink.counts[region0 + i * region_step] = 0;
+        if (emit) for (int i = threadIdx.x; i < maxo; i += ENC_BWD_BLOCK) sink.counts[region0 + i * region_step] = 0;
         return;
     }
 
@@ -301,7 +302,7 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
     // through its three barriers, and the table gathers of the d/dx term are issued before them and consumed after.
     constexpr bool EARLY_DX = WANT_DX && F <= 2;
     SampleCursor cur;
-    cur.init((uint32_t)chunk * ENC_BLOCK + threadIdx.x, step, src.pts ? 1u : (uint32_t)src.n_samples);
+    cur.init((uint32_t)chunk * ENC_BWD_BLOCK + threadIdx.x, step, src.pts ? 1u : (uint32_t)src.n_samples);
     const uint32_t last_ray = src.pts ? 0u : (M - 1u) / cur.S;
     float g_next[F];
     RawPoint p_next;
@@ -447,7 +448,7 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
             // ---- D: linear copy-out; neighbouring lanes write neighbouring records of the same region
             const int total = s_total;
             if (xp) {
-                for (int i = threadIdx.x; i < total; i += ENC_BLOCK) {
+                for (int i = threadIdx.x; i < total; i += ENC_BWD_BLOCK) {
                     const uint4 r4 = reinterpret_cast<const uint4*>(stage)[i];
                     const uint32_t idx = r4.x, t = r4.w & 0xFu;
                     const float a0 = __uint_as_float(r4.y), a1 = __uint_as_float(r4.z), fx = __uint_as_float(r4.w & ~0xFu);
@@ -463,7 +464,7 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
                     }
                 }
             } else
-            for (int i = threadIdx.x; i < total; i += ENC_BLOCK) {
+            for (int i = threadIdx.x; i < total; i += ENC_BWD_BLOCK) {
                 uint32_t idx; float v0, v1 = 0.0f;
                 uint2 r2;
                 if (PAIR) { const uint4 r4 = reinterpret_cast<const uint4*>(stage)[i]; idx = r4.x; v0 = __uint_as_float(r4.y); v1 = __uint_as_float(r4.z); }
@@ -507,7 +508,7 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
     PHASE_FLUSH(lnr_phase_cycles, xp ? LNR_N_PHASES : 0);
     __syncthreads();
     if (emit)
-        for (int i = threadIdx.x; i < maxo; i += ENC_BLOCK)
+        for (int i = threadIdx.x; i < maxo; i += ENC_BWD_BLOCK)
             sink.counts[region0 + i * region_step] = gcur[i] < cap_rec ? gcur[i] : cap_rec;
 }
 
@@ -603,7 +604,7 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
             rec_levels.lv[rec_levels.n] = l; rec_levels.slab_off[rec_levels.n] = ovf_total; rec_levels.n++;
             ovf_total += nfl;
         }
-        const dim3 block(ENC_BLOCK);
+        const dim3 block(ENC_BWD_BLOCK);
 #define LNR_LAUNCH_DXM(KERNEL, F, ...)                                                                                        \
         do {                                                                                                                  \
             hipError_t e_ = hipSuccess;                                                                                       \
