@@ -31,6 +31,24 @@ __global__ void __launch_bounds__(256) gather_k(const float* __restrict__ tab, u
     if (acc == 12345.678f) out[0] = acc;
 }
 
+// Is a gather priced per wave instruction or per active lane?  Only every HALF-th lane loads (the others sit the kernel out).
+template <int HALF, int U>
+__global__ void __launch_bounds__(256) gather_masked_k(const float* __restrict__ tab, uint32_t n_lines, int iters, uint32_t seed, float* out) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t s = hash32(tid * 2654435761u + seed);
+    float acc = 0.0f;
+    if ((tid % HALF) == 0) {
+        for (int i = 0; i < iters; ++i) {
+            float2 part[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { s = hash32(s + u + 1); part[u] = *reinterpret_cast<const float2*>(tab + (size_t)(s % n_lines) * 16u); }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc += part[u].x + part[u].y;
+        }
+    }
+    if (acc == 12345.678f) out[0] = acc;
+}
+
 // sc1 / nt variants of the 8-byte gather, through the builtins that lower to those policy bits (relaxed agent-scope atomic
 // load = sc1, system scope = sc0 sc1, nontemporal = nt); hand-written asm loads are invisible to the register allocator's
 // view of what is still in flight.
@@ -96,6 +114,7 @@ static float* g_tab; static float* g_out; static uint32_t g_lines;
 #define BLOCKS 4096
 template <int W, int G, int U> void lg(int it) { gather_k<W, G, U><<<BLOCKS, 256>>>(g_tab, g_lines, it, 7u, g_out); }
 template <int P, int U> void lp(int it) { gather8_policy_k<P, U><<<BLOCKS, 256>>>(g_tab, g_lines, it, 7u, g_out); }
+template <int H, int U> void lm(int it) { gather_masked_k<H, U><<<BLOCKS, 256>>>(g_tab, g_lines, it, 7u, g_out); }
 template <int M> void ll(int it) { lds_k<M><<<1024, 1024, 65536>>>(g_out, it, 3u); }
 
 template <int W, int G, int U> void rg(const char* name) {
@@ -104,6 +123,12 @@ template <int W, int G, int U> void rg(const char* name) {
     const double lanes = (double)BLOCKS * 256 * it * U;
     printf("%-64s %7.3f ms %8.1f G lane-gathers/s %8.1f G lines/s  %6.2f lines/clk/CU@2.1GHz\n", name, ms, lanes / ms / 1e6, lanes / G / ms / 1e6,
            lanes / G / ms / 1e6 / (256 * 2.1));
+}
+template <int H, int U> void rm(const char* name) {
+    const int it = 32;
+    const float ms = timeit(lm<H, U>, 2, it);
+    const double instr = (double)BLOCKS * 4 * it * U;
+    printf("%-64s %7.3f ms %8.2f clk per wave instruction and CU @2.1GHz\n", name, ms, ms * 1e-3 * 2.1e9 * 256 / instr);
 }
 template <int P, int U> void rp(const char* name) {
     const int it = 32;
@@ -134,6 +159,9 @@ int main() {
         rg<8, 4, 8>("8 B, 4 lanes/line");
         rg<8, 8, 8>("8 B, 8 lanes/line (full line)");
         rg<4, 16, 8>("4 B, 16 lanes/line (full line)");
+        rm<1, 8>("8 B, all 64 lanes of a wave load");
+        rm<2, 8>("8 B, every 2nd lane loads");
+        rm<4, 8>("8 B, every 4th lane loads");
         rp<0, 8>("8 B plain (u64)");
         rp<1, 8>("8 B sc1 (agent relaxed atomic load)");
         rp<2, 8>("8 B nt");
