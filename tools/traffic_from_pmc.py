@@ -11,7 +11,8 @@ def per_kernel(counter):
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
 ALIAS = {"encode_backward_kernel": "encode_backward", "encode_forward_kernel": "encode_forward", "table_grad_reduce2_kernel": "table_grad_reduce",
-         "mlp_backward_relu32_kernel": "mlp_backward", "mlp_forward_relu32_kernel": "mlp_forward", "encode_backward_dense_kernel": "encode_backward_dense",
+         "table_grad_reduce_split_kernel": "table_grad_reduce_split",
+         "mlp_backward_relu32_kernel": "mlp_backward", "mlp_forward_relu32_kernel": "mlp_forward",
          "sum_dx_planes_kernel": "sum_dx_planes", "adam_kernel": "adam", "los_loss_fused_kernel": "los_loss_fused"}
 fetch, write = per_kernel("FETCH_SIZE"), per_kernel("WRITE_SIZE")
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace), bench.py --steps 6 --warmup 2, 1x MI355X",
