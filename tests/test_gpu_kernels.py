@@ -778,6 +778,39 @@ def test_density_backward_with_frozen_parameters(ops, prec):
         ops.density_backward(spec_h, P, dv(ds), None, rays=R, z=Z)
 
 
+@pytest.mark.parametrize("net", ["default", "hash_f4_2hidden", "hash_f1", "hash_f8", "small_hash"])
+def test_record_partition_equals_global_accumulation(ops, net):
+    """Every route a table-gradient contribution can take - 8-byte pair records, 12-byte x-pair records, run-length combined
+    records, the split reduce of dense-indexed levels, region overflow - ends in the same 64-bit fixed-point sum as the
+    LNR_BWD_TABLE_ATOMICS route (every contribution straight into the overflow accumulators): the gradients are EQUAL, bit for
+    bit, at a size where several reduce workgroups share an owner (76 800 samples), with a ragged live-ray count and samples
+    bunched on few cells (the regions of the coarse levels overflow)."""
+    from loner_amd import hip
+    enc, net_cfg = NETS[net]
+    spec = hip.make_net_spec(enc, net_cfg)
+    gen = torch.Generator().manual_seed(11)
+    params = dv(NW.init_params(NW.NetworkSpec.from_config(enc, net_cfg), 3))
+    params[spec.n_mlp_params:] *= 500
+    N, S, live = 300, 256, 277
+    o = torch.rand(N, 3, generator=gen) * 0.2 - 0.1
+    d = torch.nn.functional.normalize(torch.randn(N, 3, generator=gen), dim=1)
+    rays = torch.zeros(N, 13); rays[:, 0:3] = o; rays[:, 3:6] = d; rays[:, 6:9] = -d; rays[:, 11] = 0.01; rays[:, 12] = 0.8
+    z = torch.sort(torch.rand(N, S, generator=gen) ** 3 * 0.75 + 0.01, dim=1).values          # bunched near the origin
+    d_sigma = torch.randn(N, S, generator=gen) * torch.logspace(-3, 2, N)[:, None]
+    n_dev = torch.tensor([live], dtype=torch.int32, device=DEV)
+    ops.density_forward(spec, params, rays=dv(rays), z=dv(z), n_rays_dev=n_dev)
+    g_rec = torch.zeros(int(spec.n_params), device=DEV); g_acc = torch.zeros_like(g_rec)
+    r_rec = torch.zeros(N, 13, device=DEV); r_acc = torch.zeros_like(r_rec)
+    ops.density_backward(spec, params, dv(d_sigma), g_rec, rays=dv(rays), z=dv(z), n_rays_dev=n_dev, d_rays=r_rec)
+    ops.density_backward(spec, params, dv(d_sigma), g_acc, rays=dv(rays), z=dv(z), n_rays_dev=n_dev, d_rays=r_acc, table_atomics=True)
+    table = slice(int(spec.n_mlp_params), int(spec.n_params))
+    assert float(g_rec[table].abs().max()) > 0
+    print(net, "entries touched", int((g_rec[table] != 0).sum()), "differing", int((g_rec[table] != g_acc[table]).sum()))
+    assert torch.equal(g_rec[table], g_acc[table])
+    assert torch.equal(g_rec[:table.start], g_acc[:table.start]) and torch.equal(r_rec, r_acc)
+    assert float(r_rec[live:].abs().max()) == 0.0                                  # dropped rays receive nothing
+
+
 # ------------------------------------------------------------------------------------------- full-size properties
 def test_full_size_iteration_properties(ops):
     """BASELINE size (4096 rays x 512 samples, default network): size-independent properties of every stage, and the
