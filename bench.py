@@ -180,6 +180,40 @@ class KernelTimer:
         return out
 
 
+def north_star_network_leg(n_rays, n_samples, device):
+    """The network class the north star names besides the default one (sin/cos encoding + a wider ReLU MLP: frequency-12 -> 128 x 2,
+    fp16 mode): forward and backward of lnr_density_* at the bench's sample count, against the dense fp16 MFMA peak.  Not part of the
+    timed region; a secondary roofline entry (this is the one place where MFMA utilisation is the right yardstick)."""
+    from loner_amd import hip, ops
+    spec = hip.make_net_spec(dict(otype="Frequency", n_frequencies=12), dict(activation="ReLU", n_neurons=128, n_hidden_layers=2, precision="fp16"))
+    g = torch.Generator(device="cpu").manual_seed(5)
+    rays = torch.zeros(n_rays, 13); rays[:, 0:3] = torch.rand(n_rays, 3, generator=g) * 0.2 - 0.1
+    rays[:, 3:6] = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=g), dim=1); rays[:, 11] = 0.0117; rays[:, 12] = 0.58
+    z = torch.sort(torch.rand(n_rays, n_samples, generator=g) * 0.57 + 0.0117, dim=1).values
+    rays, z = rays.to(device), z.to(device)
+    ds = torch.randn(n_rays, n_samples, generator=g).to(device); dr = torch.zeros(n_rays, 13, device=device)
+    p = (torch.rand(int(spec.n_params), generator=g) - 0.5).to(device); grad = torch.zeros_like(p)
+
+    def timed(fn, n=5):
+        fn(); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record(); torch.cuda.synchronize()
+        return a.elapsed_time(b) / n
+    fwd = timed(lambda: ops.density_forward(spec, p, rays=rays, z=z))
+    bwd = timed(lambda: ops.density_backward(spec, p, ds, grad, rays=rays, z=z, reuse_features=True, d_rays=dr))
+    mac = spec.n_neurons * spec.in_dim + (spec.n_hidden - 1) * spec.n_neurons ** 2 + spec.n_neurons
+    pts = n_rays * n_samples
+    return {"network": "Frequency(12) -> 128 ReLU x 2 -> 1, fp16 storage / fp32 accumulation (v_mfma_f32_16x16x32_f16)", "samples": pts,
+            "forward_ms": round(fwd, 4), "backward_ms": round(bwd, 4),
+            "forward_TFLOPs": round(pts * 2.0 * mac / fwd / 1e9, 1), "backward_TFLOPs": round(pts * 6.0 * mac / bwd / 1e9, 1),
+            "peak_TFLOPs": 2500.0, "forward_mfma_frac": round(pts * 2.0 * mac / fwd / 1e9 / 2500.0, 4),
+            "backward_mfma_frac": round(pts * 6.0 * mac / bwd / 1e9 / 2500.0, 4),
+            "note": "backward = weight + input gradients incl. the encoding's backward, features reused from the forward (the training loop's route)"}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -306,6 +340,12 @@ def main():
         except Exception as e:
             other = {"error": str(e)}
 
+    ns_net = None
+    if world == 1:
+        try:
+            ns_net = north_star_network_leg(args.keyframes * args.rays, args.samples, "cuda")
+        except Exception as e:
+            ns_net = {"error": str(e)}
     ksum = timer.summary()
     spec = opt._model.nerf_model._model_sigma.spec
     n_local = opt.last_stats["n_valid_rays"] / max(args.steps, 1)          # rays per launch on this rank
@@ -373,6 +413,7 @@ def main():
                    "keyframes": args.keyframes, "rays_per_keyframe": args.rays, "samples_per_ray": args.samples,
                    "parallelism": f"keyframe-sharded x{world}" if world > 1 else "single GPU"},
         "roofline": roofline,
+        "north_star_network": ns_net,
         # whole-path HBM roofline of SURVEY 8d: B_ray = 72 B (ray record, gt depth, per-ray outputs) + dense Adam traffic
         # (28 B per parameter: read p,g,m,v, write p,m,v) amortised over the rays of an iteration
         "path_hbm_roofline": (lambda b: {"algorithmic_bytes_per_ray": b, "rays_per_s_at_8TBps": 8e12 / b * world,
