@@ -63,7 +63,9 @@ void lnr_profile_end(int span, hipStream_t st) {
 extern "C" int lnr_profile_enable(int32_t on) {
     std::lock_guard<std::mutex> lock(g_prof_mutex);
     g_prof_on = on != 0;
-    // events are created here, not inside the timed launches (a few thousand cover ~100 iterations between two reads)
+    // events are created here, not inside the timed launches (a few thousand cover ~100 iterations between two reads); a caller that
+    // toggles profiling per iteration (bench.py samples every 4th) must not pay for event creation each time: refill only when low
+    if (g_prof_on && g_prof_pool.size() >= 256) return LNR_OK;
     while (g_prof_on && g_prof_pool.size() < 4096) {
         hipEvent_t e = nullptr;
         if (hipEventCreate(&e) != hipSuccess) break;

@@ -119,7 +119,15 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
+
+
 def _stream(device=None):
+    """torch's current stream on `device` (default: the current device) as a hipStream_t.  Called once per library call, ~25 times
+    per mapping iteration: torch.cuda.current_stream() builds a Stream object (8 us), the raw query is a plain C call."""
+    if _raw_stream is not None and (device is None or isinstance(device, int)):
+        return C.c_void_p(_raw_stream(_raw_device() if device is None else device))
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
