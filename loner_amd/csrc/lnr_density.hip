@@ -689,7 +689,7 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
                                  ovf, d_pts_eff, ray_accum ? d_rays : nullptr, (long long*)(ws + L.off_rayacc), st);
         if (rc) return rc;
         LNR_CHECK_LAUNCH("lnr_density_backward(encode backward)");
-        if (want_grad && getenv("LNR_REPORT_REGIONS")) {
+        if (hash && want_grad && getenv("LNR_REPORT_REGIONS")) {
             int64_t live = cap;
             int32_t nr = 0;
             if (n_rays_dev && hipStreamSynchronize(st) == hipSuccess && hipMemcpy(&nr, n_rays_dev, sizeof(nr), hipMemcpyDeviceToHost) == hipSuccess) live = (int64_t)nr * n_samples;
