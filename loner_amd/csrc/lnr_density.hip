@@ -332,7 +332,7 @@ struct Layout {
     int64_t m_pad;
     int n_groups, bpg, maxo, shift, nown, n_split;
     RegionPlan plan;
-    size_t off_feat, off_dfeat, off_dxl, off_dpts, off_rayacc, off_active, off_slabs, off_ovf, off_counts, off_regions, total;
+    size_t off_feat, off_dfeat, off_dxl, off_dpts, off_rayacc, off_slabs, off_ovf, off_counts, off_regions, total;
 };
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -400,8 +400,6 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
     L.off_dxl = off; off += align256((size_t)L.n_groups * 3 * L.m_pad * sizeof(float));
     L.off_dpts = off; off += align256((size_t)3 * L.m_pad * sizeof(float));      // d_pts scratch of the general d_rays route
     L.off_rayacc = off; off += align256((size_t)(L.m_pad / 64) * 6 * sizeof(long long));   // per-ray sums of the d_rays route (n_samples >= 64 there)
-    // encode backward's list of active samples: activity words, their prefix (+ total), {sample, ray} entries
-    L.off_active = off; off += align256((size_t)(L.m_pad / 64) * 8 + (size_t)(L.m_pad / 64 + 2) * 4 + (size_t)L.m_pad * 8);
     L.off_slabs = off; off += align256((size_t)LNR_BWD_MAX_BLOCKS * spec->n_mlp_params * sizeof(float));
     L.off_ovf = off; off += align256(ovf_total * sizeof(long long));
     L.off_counts = off; off += align256(hash ? (size_t)blocks * L.maxo * sizeof(int) : 0);
@@ -688,8 +686,7 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     if (want_dfeat) {
         rc = lnr_encode_backward(spec, params, &src, cap, dfeat, dxl, L.m_pad, grad_table, want_grad ? regions : nullptr, &rplan, counts,
                                  L.bpg, L.maxo, L.shift,
-                                 ovf, d_pts_eff, ray_accum ? d_rays : nullptr, (long long*)(ws + L.off_rayacc),
-                                 (unsigned long long*)(ws + L.off_active), st);
+                                 ovf, d_pts_eff, ray_accum ? d_rays : nullptr, (long long*)(ws + L.off_rayacc), st);
         if (rc) return rc;
         LNR_CHECK_LAUNCH("lnr_density_backward(encode backward)");
         if (hash && want_grad && getenv("LNR_REPORT_REGIONS")) {

@@ -193,50 +193,17 @@ __device__ __forceinline__ void dx_from_entries(const LevelInfo& L, const Cell& 
                               // straight into that ray's record gradient (origin += dx/2, direction += z dx/2): six atomics per
                               // wave instead of three plane stores per thread, a 400 MB plane sum and the d_pts round trip
 
-// all lanes active; dx = 0 on lanes without a contribution.  The lanes of a wave are consecutive ACTIVE samples (see the sample list
-// of encode_backward_kernel), so a wave usually lies inside one ray and sometimes straddles two: one pass per distinct ray.
+// all lanes active; dx = 0 on lanes without a contribution
 __device__ __forceinline__ void ray_accumulate_dx(float* __restrict__ ray_acc_f, uint32_t ray, float z, const float dx[3], int lane) {
     long long* ray_acc = reinterpret_cast<long long*>(ray_acc_f);        // [n_rays][6] fixed-point sums (passed through the float* d/dx argument)
-    unsigned long long todo = ~0ull;
-    while (todo) {
-        const uint32_t rf = (uint32_t)__builtin_amdgcn_readlane((int)ray, __builtin_ctzll(todo));
-        const bool mine = ray == rf;
-        todo &= ~__ballot(mine);
-        float t[6];
+    float t[6];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const float v = mine ? dx[d] : 0.0f;
-            t[d] = wave_sum_dpp(v); t[3 + d] = wave_sum_dpp(z * v);
-        }
-        if (lane < 6) {
-            const float v = lane == 0 ? t[0] : lane == 1 ? t[1] : lane == 2 ? t[2] : lane == 3 ? t[3] : lane == 4 ? t[4] : t[5];
-            // 64-bit fixed point: integer atomics add exactly, so the ray gradient does not depend on the order of the waves
-            if (v != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(ray_acc) + (size_t)rf * 6 + lane,
-                                     (unsigned long long)lnr_to_fix(0.5f * v));                                   // x = (xyz + 1) / 2
-        }
-    }
-}
-
-// Which samples carry a gradient at all: bit m of active[] = some d_feature plane is non-zero at sample m.  With the reference's
-// network (ReLU hidden layer, linear density output) a free-space sample ends up with every hidden unit off - exactly zero
-// density AND exactly zero gradient - so about half of the samples of a scan (more once the map has formed) have nothing to
-// scatter, scattered finely among the others (runs of ~2 samples): skipping them lane by lane saves nothing, compacting them does.
-__global__ void __launch_bounds__(ENC_BLOCK)
-sample_activity_kernel(const float* __restrict__ dfeat, int n_planes, int64_t m_pad, const PointSrc src, unsigned long long* __restrict__ active,
-                       int64_t n_words) {
-    const int64_t M = live_points(src);
-    const uint32_t plane_bytes = (uint32_t)m_pad * 4u;
-    for (int64_t w = (int64_t)blockIdx.x * (ENC_BLOCK / 64) + (threadIdx.x >> 6); w < n_words; w += (int64_t)gridDim.x * (ENC_BLOCK / 64)) {
-        const int64_t m = w * 64 + (threadIdx.x & 63);
-        bool nz = false;
-        if (m < M) {
-            uint32_t any = 0u;
-#pragma unroll 8
-            for (int f = 0; f < n_planes; ++f) any |= ld32_stream<uint32_t>(dfeat, (uint32_t)f * plane_bytes + (uint32_t)m * 4u) << 1;   // -0.0 is zero too
-            nz = any != 0u;
-        }
-        const unsigned long long bits = __ballot(nz);
-        if ((threadIdx.x & 63) == 0) active[w] = bits;
+    for (int d = 0; d < 3; ++d) { t[d] = wave_sum_dpp(dx[d]); t[3 + d] = wave_sum_dpp(z * dx[d]); }
+    if (lane < 6) {
+        const float v = lane == 0 ? t[0] : lane == 1 ? t[1] : lane == 2 ? t[2] : lane == 3 ? t[3] : lane == 4 ? t[4] : t[5];
+        // 64-bit fixed point: integer atomics add exactly, so the ray gradient does not depend on the order of the waves
+        if (v != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(ray_acc) + (size_t)ray * 6 + lane,
+                                 (unsigned long long)__float2ll_rn(0.5f * v * LNR_FIX_SCALE));             // x = (xyz + 1) / 2
     }
 }
 
@@ -249,44 +216,8 @@ ray_grad_apply_kernel(const long long* __restrict__ ray_acc, int n_rays, const i
     if (q != 0ll) d_rays[(size_t)(i / 6) * LNR_RAY_STRIDE + (i % 6)] += (float)((double)q * (1.0 / (double)LNR_FIX_SCALE));
 }
 
-// exclusive prefix of the words' popcounts (one workgroup: the array is a few thousand words), total in word_base[n_words]
-__global__ void __launch_bounds__(1024)
-sample_scan_kernel(const unsigned long long* __restrict__ active, int64_t n_words, uint32_t* __restrict__ word_base) {
-    __shared__ uint32_t part[1024];
-    const int64_t per = (n_words + 1023) / 1024, lo = (int64_t)threadIdx.x * per, hi = lo + per < n_words ? lo + per : n_words;
-    uint32_t sum = 0;
-    for (int64_t w = lo; w < hi; ++w) sum += (uint32_t)__builtin_popcountll(active[w]);
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {                       // Hillis-Steele inclusive scan
-        const uint32_t v = threadIdx.x >= (unsigned)d ? part[threadIdx.x - d] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t run = part[threadIdx.x] - sum;
-    for (int64_t w = lo; w < hi; ++w) { word_base[w] = run; run += (uint32_t)__builtin_popcountll(active[w]); }
-    if (threadIdx.x == 1023) word_base[n_words] = part[1023];
-}
-
-// the list of the active samples, in sample order: {sample index, ray index}
-__global__ void __launch_bounds__(ENC_BLOCK)
-sample_compact_kernel(const unsigned long long* __restrict__ active, const uint32_t* __restrict__ word_base, int64_t n_words, uint32_t n_samples,
-                      uint2* __restrict__ list) {
-    const int lane = threadIdx.x & 63;
-    for (int64_t w = (int64_t)blockIdx.x * (ENC_BLOCK / 64) + (threadIdx.x >> 6); w < n_words; w += (int64_t)gridDim.x * (ENC_BLOCK / 64)) {
-        const unsigned long long bits = active[w];
-        if ((bits >> lane) & 1ull) {
-            const uint32_t m = (uint32_t)w * 64u + (uint32_t)lane;
-            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(bits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bits, 0u));
-            list[word_base[w] + before] = make_uint2(m, m / n_samples);
-        }
-    }
-}
-
 #define ENC_BWD_BLOCK LNR_ENC_BWD_BLOCK
 #define ENC_STAGE_RECORDS (ENC_BWD_BLOCK * 8)
-#define ENC_SUB (4u * ENC_BWD_BLOCK)     // list entries per sub-chunk of encode_backward_kernel (4 batches)
 
 // what the copy-out phase needs to know about one owner of the current batch: one 16-byte LDS read per record
 struct OwnerSlot {
@@ -323,8 +254,7 @@ __device__ unsigned long long lnr_phase_cycles[2 * LNR_N_PHASES];          // [8
 template <int F, int DXM>
 __global__ void __launch_bounds__(ENC_BWD_BLOCK, 4)   // (max threads, min waves per SIMD): 128 VGPRs
 encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, const PointSrc src, const float* __restrict__ dfeat,
-                       float* __restrict__ dxl, int64_t m_pad, int bpg, const LevelList list, const EncSink sink,
-                       const uint2* __restrict__ slist, const uint32_t* __restrict__ slist_count) {
+                       float* __restrict__ dxl, int64_t m_pad, int bpg, const LevelList list, const EncSink sink) {
     constexpr bool WANT_DX = DXM != ENC_DX_NONE;          // dxl: the d/dx planes (ENC_DX_PLANES) or d_rays [n_rays,13] (ENC_DX_RAYS)
     extern __shared__ __attribute__((aligned(16))) int dyn[];
     __shared__ int s_total;
@@ -357,6 +287,8 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
     const uint32_t level_base = L.offset * F;
     const size_t region0 = (size_t)lv * maxo * bpg + chunk;
     const size_t region_step = (size_t)bpg;          // between consecutive owners
+    const uint32_t step = (uint32_t)bpg * ENC_BWD_BLOCK;
+    const uint32_t n_iter = (M + step - 1u) / step;          // workgroup-uniform trip count (the loop body has barriers)
     const float* gplanes = dfeat + (size_t)(lv * F) * m_pad;
     float* dxplanes = dxl + (size_t)(lv * 3) * m_pad;
     const uint32_t plane_bytes = (uint32_t)m_pad * 4u;
@@ -366,51 +298,39 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
         return;
     }
 
-    // The samples are taken from the list of the ACTIVE samples (sample_activity_kernel ... sample_compact_kernel), ENC_SUB consecutive
-    // entries per sub-chunk = four full batches: the lanes that would have idled through the hashing, the gathers and the d/dx term of a
-    // dead sample do not exist.  slist == nullptr (the d/dx planes are wanted for every sample): every live sample, in order.
-    const uint32_t S = src.pts ? 1u : (uint32_t)src.n_samples;
-    const uint32_t n_list = slist != nullptr ? *slist_count : M;
-    const uint32_t n_sub = DBG_SKIP(128) ? 0u : (n_list + ENC_SUB - 1u) / ENC_SUB;
     // Software pipeline: the inputs of iteration it+1 (d_feature values, the point) are loaded while iteration it goes
-    // through its three barriers (its list entry one iteration earlier still), and the table gathers of the d/dx term are issued
-    // before them and consumed after.
+    // through its three barriers, and the table gathers of the d/dx term are issued before them and consumed after.
     constexpr bool EARLY_DX = WANT_DX && F <= 2;
-    PHASE_INIT();
-    for (uint32_t sub = (uint32_t)chunk; sub < n_sub; sub += (uint32_t)bpg) {          // workgroup-uniform
-    const uint32_t i0 = sub * ENC_SUB;
-    const uint32_t n_act = n_list - i0 < ENC_SUB ? n_list - i0 : ENC_SUB;
-    const uint32_t n_iter = (n_act + ENC_BWD_BLOCK - 1u) / ENC_BWD_BLOCK;
-    auto entry = [&](uint32_t it) -> uint2 {                             // clamped: unconditional loads, always of a listed sample
-        const uint32_t k = it * ENC_BWD_BLOCK + threadIdx.x;
-        const uint32_t idx = i0 + (k < n_act ? k : n_act - 1u);
-        if (slist != nullptr) return ld32<uint2>(slist, idx * 8u);
-        return make_uint2(idx, idx / S);
-    };
+    SampleCursor cur;
+    cur.init((uint32_t)chunk * ENC_BWD_BLOCK + threadIdx.x, step, src.pts ? 1u : (uint32_t)src.n_samples);
+    const uint32_t last_ray = src.pts ? 0u : (M - 1u) / cur.S;
     float g_next[F];
     RawPoint p_next;
-    uint2 e_next = entry(0u), e_next2 = entry(1u);
     {
+        const bool in = cur.m < M;
+        const uint32_t mc = in ? cur.m : M - 1u;
 #pragma unroll
-        for (int f = 0; f < F; ++f) g_next[f] = ld32_stream<float>(gplanes, (uint32_t)f * plane_bytes + e_next.x * 4u);
-        load_raw_point(src, e_next.x, e_next.y, p_next);
+        for (int f = 0; f < F; ++f) g_next[f] = ld32_stream<float>(gplanes, (uint32_t)f * plane_bytes + mc * 4u);
+        load_raw_point(src, mc, in ? cur.ray : last_ray, p_next);
     }
+    PHASE_INIT();
     for (uint32_t it = 0; it < n_iter; ++it) {
         PHASE(11);
-        const uint32_t m = e_next.x;
-        const bool live = it * ENC_BWD_BLOCK + threadIdx.x < n_act;
+        const uint32_t m = cur.m;
+        const bool live = m < M;
         float g[F];
         bool any = false;
 #pragma unroll
         for (int f = 0; f < F; ++f) { g[f] = live ? g_next[f] : 0.0f; any |= (g[f] != 0.0f); }
         const RawPoint p_cur = p_next;
-        const uint32_t ray_cur = e_next.y;
+        const uint32_t ray_cur = cur.ray;
+        cur.advance();
         {
-            e_next = e_next2;
-            e_next2 = entry(it + 2u);
+            const bool in = cur.m < M;
+            const uint32_t mc = in ? cur.m : M - 1u;          // unconditional (clamped) loads: a static number in flight
 #pragma unroll
-            for (int f = 0; f < F; ++f) g_next[f] = ld32_stream<float>(gplanes, (uint32_t)f * plane_bytes + e_next.x * 4u);
-            load_raw_point(src, e_next.x, e_next.y, p_next);
+            for (int f = 0; f < F; ++f) g_next[f] = DBG_SKIP(32) ? ld32<float>(gplanes, (uint32_t)f * plane_bytes + mc * 4u) : ld32_stream<float>(gplanes, (uint32_t)f * plane_bytes + mc * 4u);
+            load_raw_point(src, mc, in ? cur.ray : last_ray, p_next);
         }
         const bool wave_any = __ballot(any) != 0ull;
         PHASE(0);
@@ -537,18 +457,6 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
                     if (DBG_SKIP(8)) continue;
                     if (k < os.room) {
                         const LnrXRec rec = lnr_pack_xpair((idx & ((1u << LNR_SLICE_SHIFT) - 1u)) >> 1, t, a0, a1, fx);
-                        if (DBG_SKIP(64)) {        // ablation: the same bytes as one contiguous, line-aligned stream per workgroup
-                            const uint64_t a = reinterpret_cast<uint64_t>(sink.regions) + ((uint64_t)(blockIdx.x & 8191u) << 16) + (((uint64_t)it * 4096u + (uint64_t)i) * 12u & 0xFFFCu);
-                            store_stream_b96(a, rec.a, rec.b, rec.c);
-                        } else if (DBG_SKIP(256 | 512 | 1024 | 2048)) {
-                            typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-                            const u32x3 v = {rec.a, rec.b, rec.c};
-                            const uint64_t a = (((uint64_t)os.ptr_hi << 32) | os.ptr_lo) + (uint64_t)k * 12u;
-                            if (DBG_SKIP(256)) asm volatile("global_store_dwordx3 %0, %1, off sc1 nt" :: "v"(a), "v"(v) : "memory");
-                            else if (DBG_SKIP(512)) asm volatile("global_store_dwordx3 %0, %1, off sc0 nt" :: "v"(a), "v"(v) : "memory");
-                            else if (DBG_SKIP(1024)) asm volatile("global_store_dwordx3 %0, %1, off sc0 sc1 nt" :: "v"(a), "v"(v) : "memory");
-                            else asm volatile("global_store_dwordx3 %0, %1, off" :: "v"(a), "v"(v) : "memory");
-                        } else
                         store_stream_b96((((uint64_t)os.ptr_hi << 32) | os.ptr_lo) + (uint64_t)k * 12u, rec.a, rec.b, rec.c);
                     } else {
                         const uint32_t in_level = idx - level_base;                       // e1 = e0 ^ (2^(t+1) - 1): float index ^ (mask << 1)
@@ -567,10 +475,6 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
                 if (DBG_SKIP(8)) continue;
                 if (k < os.room) {
                     if (PAIR) r2 = lnr_pack_pair((idx & ((1u << LNR_SLICE_SHIFT) - 1u)) >> 1, v0, v1);
-                    if (DBG_SKIP(64)) {
-                        const uint64_t a = reinterpret_cast<uint64_t>(sink.regions) + ((uint64_t)(blockIdx.x & 8191u) << 16) + (((uint64_t)it * 4096u + (uint64_t)i) * 8u & 0xFFF8u);
-                        store_stream_b64(a, r2);
-                    } else
                     store_stream_b64((((uint64_t)os.ptr_hi << 32) | os.ptr_lo) + (uint64_t)k * 8u, r2);
                 } else if (ovf) {
                     // same 26-bit rounding as a packed record: which records overflow depends on arrival order, the sum must not
@@ -592,15 +496,14 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
                 else { float tl[8][F]; gather_entries<F>(table, e, tl); dx_from_entries<F>(L, c, g, tl, dx); }
             }
             if constexpr (DXM == ENC_DX_RAYS) {
-                if (wave_any && !DBG_SKIP(1))            // wave-uniform
-                    ray_accumulate_dx(dxl, ray_cur, p_cur.z, dx, lane);
+                if (wave_any && !DBG_SKIP(1))            // wave-uniform; lane 0 holds the wave's first (live) sample
+                    ray_accumulate_dx(dxl, (uint32_t)__builtin_amdgcn_readfirstlane((int)ray_cur), p_cur.z, dx, lane);
             } else if (live) {
 #pragma unroll
                 for (int d = 0; d < 3; ++d) st32<float>(dxplanes, (uint32_t)d * plane_bytes + m * 4u, dx[d]);
             }
         }
         PHASE(9);
-    }
     }
     PHASE_FLUSH(lnr_phase_cycles, xp ? LNR_N_PHASES : 0);
     __syncthreads();
@@ -677,8 +580,7 @@ int lnr_encode_forward(const LnrNetSpec* spec, const float* params, const PointS
 
 int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, const float* dfeat,
                         float* dxl, int64_t m_pad, float* grad_table, void* regions, const RegionPlan* plan, int* counts, int bpg,
-                        int maxo, int shift, long long* ovf, float* d_pts, float* d_rays_acc, long long* ray_acc, unsigned long long* active_words,
-                        hipStream_t st) {
+                        int maxo, int shift, long long* ovf, float* d_pts, float* d_rays_acc, long long* ray_acc, hipStream_t st) {
     const float* table = params + spec->n_mlp_params;
     // d/dx mode: d_rays_acc (rays form, n_samples % 64 == 0, checked by the caller) > d_pts (planes) > none
     const int dxm = d_rays_acc ? ENC_DX_RAYS : (d_pts ? ENC_DX_PLANES : ENC_DX_NONE);
@@ -722,23 +624,6 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
             case 4: LNR_LAUNCH_DXM(KERNEL, 4, __VA_ARGS__); break;                  \
             default: LNR_LAUNCH_DXM(KERNEL, 8, __VA_ARGS__); break;                 \
         }
-        // the list of the active samples (not when the d/dx planes are wanted: they need a value for every sample)
-        const uint2* slist = nullptr;
-        const uint32_t* slist_count = nullptr;
-        if (rec_levels.n > 0 && dxm != ENC_DX_PLANES && active_words != nullptr && cap_points > 0) {
-            const int64_t n_words = (cap_points + 63) / 64;
-            int64_t blocks = (n_words + (ENC_BLOCK / 64) - 1) / (ENC_BLOCK / 64);
-            if (blocks > 8192) blocks = 8192;
-            uint32_t* word_base = reinterpret_cast<uint32_t*>(active_words + n_words);
-            uint2* list = reinterpret_cast<uint2*>(word_base + ((n_words + 1 + 1) & ~(int64_t)1));         // 8-byte aligned
-            LnrProfScope prof("sample_list", st);
-            hipLaunchKernelGGL(sample_activity_kernel, dim3((unsigned)blocks), dim3(ENC_BLOCK), 0, st, dfeat, spec->n_levels * spec->n_features, m_pad, *src,
-                               active_words, n_words);
-            hipLaunchKernelGGL(sample_scan_kernel, dim3(1), dim3(1024), 0, st, active_words, n_words, word_base);
-            hipLaunchKernelGGL(sample_compact_kernel, dim3((unsigned)blocks), dim3(ENC_BLOCK), 0, st, active_words, word_base, n_words,
-                               src->pts ? 1u : (uint32_t)src->n_samples, list);
-            slist = list; slist_count = word_base + n_words;
-        }
         if (rec_levels.n > 0) {
             EncSink sink;
             if (regions != nullptr && ovf_total > 0 && hipMemsetAsync(ovf, 0, (size_t)ovf_total * sizeof(long long), st) != hipSuccess) {
@@ -754,7 +639,7 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
             LnrProfScope prof("encode_backward", st);
             const int maxo4 = (maxo + 3) & ~3;
             const size_t lds = (size_t)(2 * maxo4 + 4 * maxo) * sizeof(int) + (size_t)ENC_STAGE_RECORDS * (spec->n_features >= 2 ? 16 : 8);
-            LNR_LAUNCH_F(encode_backward_kernel, *spec, table, *src, dfeat, dx_out, m_pad, bpg, rec_levels, sink, slist, slist_count);
+            LNR_LAUNCH_F(encode_backward_kernel, *spec, table, *src, dfeat, dx_out, m_pad, bpg, rec_levels, sink);
 #ifdef LNR_PHASE_TIMING
             if (getenv("LNR_PHASE_TIMING")) {
                 static const char* names[LNR_N_PHASES] = {"load inputs", "cell/entries/gather/weights", "A rank", "barrier 1", "B scan", "barrier 2",
