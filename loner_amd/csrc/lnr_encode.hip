@@ -251,7 +251,9 @@ __device__ unsigned long long lnr_phase_cycles[2 * LNR_N_PHASES];          // [8
 #endif
 
 // dynamic LDS: int cnt[maxo4], gcur[maxo4]; OwnerSlot slot[maxo] (16-byte aligned); then the staging buffer
-template <int F, int DXM>
+// XP: the launch's levels take x-pair records (compile-time: the two record formats share little code, and a kernel that carries both
+// spills ~60 SGPRs into VGPR lanes inside the batch loop)
+template <int F, int DXM, bool XP>
 __global__ void __launch_bounds__(ENC_BWD_BLOCK, 4)   // (max threads, min waves per SIMD): 128 VGPRs
 encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, const PointSrc src, const float* __restrict__ dfeat,
                        float* __restrict__ dxl, int64_t m_pad, int bpg, const LevelList list, const EncSink sink) {
@@ -275,7 +277,7 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
     const int first_owner = (int)(((uint64_t)L.offset * F) >> sink.shift);
     // x-pair records (12 bytes for the two x-neighbours of a corner pair) on the hashed power-of-two levels from LNR_XPAIR_SCALE_MIN up;
     // 8-byte records, run-length combined along the rays, on the coarser ones
-    const bool xp = F == 2 && sink.plan.xp[lv] != 0;
+    constexpr bool xp = XP && F == 2;
     const bool combine = !xp && L.scale < sink.combine_scale_max;
     const uint32_t rec_bytes = xp ? 12u : 8u;
     const uint32_t region_bytes = sink.plan.bytes[lv];
@@ -592,8 +594,8 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
     int n_groups = 1;
     if (spec->encoding == LNR_ENC_HASHGRID) {
         n_groups = spec->n_levels;
-        LevelList rec_levels;
-        rec_levels.n = 0;
+        LevelList rec_levels, xp_levels;                                   // 8-byte record levels, x-pair record levels: one launch each
+        rec_levels.n = xp_levels.n = 0;
         int ovf_total = 0;
         for (int l = 0; l < spec->n_levels; ++l) {
             const int nfl = (int)spec->level_size[l] * spec->n_features;
@@ -601,30 +603,31 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
             static const int lmask = getenv("LNR_X_LEVELS") ? (int)strtol(getenv("LNR_X_LEVELS"), nullptr, 0) : -1;
             if (!((lmask >> l) & 1)) { ovf_total += nfl; continue; }
 #endif
-            rec_levels.lv[rec_levels.n] = l; rec_levels.slab_off[rec_levels.n] = ovf_total; rec_levels.n++;
+            LevelList& ll = (spec->n_features == 2 && plan->xp[l] != 0) ? xp_levels : rec_levels;
+            ll.lv[ll.n] = l; ll.slab_off[ll.n] = ovf_total; ll.n++;
             ovf_total += nfl;
         }
         const dim3 block(ENC_BWD_BLOCK);
-#define LNR_LAUNCH_DXM(KERNEL, F, ...)                                                                                        \
+#define LNR_LAUNCH_DXM(KERNEL, F, XP, ...)                                                                                    \
         do {                                                                                                                  \
             hipError_t e_ = hipSuccess;                                                                                       \
-            const void* fn_ = dxm == ENC_DX_RAYS ? reinterpret_cast<const void*>(KERNEL<F, ENC_DX_RAYS>)                      \
-                            : dxm == ENC_DX_PLANES ? reinterpret_cast<const void*>(KERNEL<F, ENC_DX_PLANES>)                  \
-                                                   : reinterpret_cast<const void*>(KERNEL<F, ENC_DX_NONE>);                   \
+            const void* fn_ = dxm == ENC_DX_RAYS ? reinterpret_cast<const void*>(KERNEL<F, ENC_DX_RAYS, XP>)                  \
+                            : dxm == ENC_DX_PLANES ? reinterpret_cast<const void*>(KERNEL<F, ENC_DX_PLANES, XP>)              \
+                                                   : reinterpret_cast<const void*>(KERNEL<F, ENC_DX_NONE, XP>);               \
             e_ = hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
             if (e_ != hipSuccess) { lnr_set_error("lnr_density_backward: hipFuncSetAttribute(%zu) failed", lds); return LNR_ERR_LAUNCH; } \
-            if (dxm == ENC_DX_RAYS) hipLaunchKernelGGL((KERNEL<F, ENC_DX_RAYS>), grid, block, lds, st, __VA_ARGS__);   \
-            else if (dxm == ENC_DX_PLANES) hipLaunchKernelGGL((KERNEL<F, ENC_DX_PLANES>), grid, block, lds, st, __VA_ARGS__); \
-            else hipLaunchKernelGGL((KERNEL<F, ENC_DX_NONE>), grid, block, lds, st, __VA_ARGS__);                      \
+            if (dxm == ENC_DX_RAYS) hipLaunchKernelGGL((KERNEL<F, ENC_DX_RAYS, XP>), grid, block, lds, st, __VA_ARGS__);   \
+            else if (dxm == ENC_DX_PLANES) hipLaunchKernelGGL((KERNEL<F, ENC_DX_PLANES, XP>), grid, block, lds, st, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<F, ENC_DX_NONE, XP>), grid, block, lds, st, __VA_ARGS__);                      \
         } while (0)
 #define LNR_LAUNCH_F(KERNEL, ...)                                                   \
         switch (spec->n_features) {                                                 \
-            case 1: LNR_LAUNCH_DXM(KERNEL, 1, __VA_ARGS__); break;                  \
-            case 2: LNR_LAUNCH_DXM(KERNEL, 2, __VA_ARGS__); break;                  \
-            case 4: LNR_LAUNCH_DXM(KERNEL, 4, __VA_ARGS__); break;                  \
-            default: LNR_LAUNCH_DXM(KERNEL, 8, __VA_ARGS__); break;                 \
+            case 1: LNR_LAUNCH_DXM(KERNEL, 1, false, __VA_ARGS__); break;           \
+            case 2: LNR_LAUNCH_DXM(KERNEL, 2, false, __VA_ARGS__); break;           \
+            case 4: LNR_LAUNCH_DXM(KERNEL, 4, false, __VA_ARGS__); break;           \
+            default: LNR_LAUNCH_DXM(KERNEL, 8, false, __VA_ARGS__); break;          \
         }
-        if (rec_levels.n > 0) {
+        if (rec_levels.n + xp_levels.n > 0) {
             EncSink sink;
             if (regions != nullptr && ovf_total > 0 && hipMemsetAsync(ovf, 0, (size_t)ovf_total * sizeof(long long), st) != hipSuccess) {
                 lnr_set_error("lnr_density_backward: hipMemsetAsync failed");
@@ -635,11 +638,17 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
 #ifdef LNR_ABLATE
             sink.dbg = getenv("LNR_X_DBG") ? atoi(getenv("LNR_X_DBG")) : 0;
 #endif
-            const dim3 grid((unsigned)(rec_levels.n * bpg));
             LnrProfScope prof("encode_backward", st);
             const int maxo4 = (maxo + 3) & ~3;
             const size_t lds = (size_t)(2 * maxo4 + 4 * maxo) * sizeof(int) + (size_t)ENC_STAGE_RECORDS * (spec->n_features >= 2 ? 16 : 8);
-            LNR_LAUNCH_F(encode_backward_kernel, *spec, table, *src, dfeat, dx_out, m_pad, bpg, rec_levels, sink);
+            if (rec_levels.n > 0) {
+                const dim3 grid((unsigned)(rec_levels.n * bpg));
+                LNR_LAUNCH_F(encode_backward_kernel, *spec, table, *src, dfeat, dx_out, m_pad, bpg, rec_levels, sink);
+            }
+            if (xp_levels.n > 0) {                                          // n_features == 2
+                const dim3 grid((unsigned)(xp_levels.n * bpg));
+                LNR_LAUNCH_DXM(encode_backward_kernel, 2, true, *spec, table, *src, dfeat, dx_out, m_pad, bpg, xp_levels, sink);
+            }
 #ifdef LNR_PHASE_TIMING
             if (getenv("LNR_PHASE_TIMING")) {
                 static const char* names[LNR_N_PHASES] = {"load inputs", "cell/entries/gather/weights", "A rank", "barrier 1", "B scan", "barrier 2",
