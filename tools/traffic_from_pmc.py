@@ -10,7 +10,7 @@ def per_kernel(counter):
                 agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
-ALIAS = {"encode_backward_kernel": "encode_backward", "encode_forward_kernel": "encode_forward", "table_grad_reduce2_kernel": "table_grad_reduce",
+ALIAS = {"encode_backward_kernel": "encode_backward", "encode_forward_kernel<2, false>": "encode_forward", "encode_forward_kernel<2, true>": "encode_forward_f16", "table_grad_reduce2_kernel": "table_grad_reduce",
          "table_grad_reduce_split_kernel": "table_grad_reduce_split",
          "mlp_backward_relu32_kernel": "mlp_backward", "mlp_forward_relu32_kernel": "mlp_forward",
          "sum_dx_planes_kernel": "sum_dx_planes", "adam_kernel": "adam", "los_loss_fused_kernel": "los_loss_fused"}
@@ -25,8 +25,10 @@ for k in sorted(set(fetch) | set(write)):
     if short is None:
         continue
     f, w = fetch.get(k, 0.0), write.get(k, 0.0)
-    out["per_launch"][short] = {"kernel": k[:100], "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "bytes_raw": (f + w) * 1024.0,
-                                "bytes_corrected": (2.0 * f + w) * 1024.0}
-    out[short + "_bytes_per_launch"] = (2.0 * f + w) * 1024.0
+    ent = out["per_launch"].setdefault(short, {"kernels": [], "FETCH_SIZE_KiB": 0.0, "WRITE_SIZE_KiB": 0.0, "bytes_raw": 0.0, "bytes_corrected": 0.0})
+    ent["kernels"].append(k[:100])             # an op made of several kernels (encode_backward: one per record format) is their sum
+    ent["FETCH_SIZE_KiB"] += f; ent["WRITE_SIZE_KiB"] += w
+    ent["bytes_raw"] += (f + w) * 1024.0; ent["bytes_corrected"] += (2.0 * f + w) * 1024.0
+    out[short + "_bytes_per_launch"] = ent["bytes_corrected"]
 json.dump(out, open(sys.argv[1] if len(sys.argv) > 1 else "profiles/traffic.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k.endswith("_per_launch") and k != "per_launch"}, indent=1))
