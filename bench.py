@@ -38,7 +38,27 @@ def parse():
                     help="arithmetic of the density network: f32 (default, stricter than the reference) or f16 "
                          "(the reference's storage types: fp16 features and weights on MFMA, fp32 accumulation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only bring the ranks up, check the world size against --gpus, print {n_gpus, ranks} and exit "
+                         "(no GPU work: with LNR_DIST_BACKEND=gloo this runs on a CPU-only box; tests/test_host.py)")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher around it: re-exec this command line under
+    torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1 (the reference fans its processes out itself too,
+    examples/run_loner.py:339-424).  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
 
 
 def build_window(n_kf, device=None):
@@ -227,23 +247,46 @@ def north_star_network_leg(n_rays, n_samples, device):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))                # no launcher around us: become one
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
     # LNR_DIST_BACKEND=gloo lets two ranks share one GPU (RCCL refuses that): used to exercise the sharded code path on a 1-GPU box
     backend = os.environ.get("LNR_DIST_BACKEND", "nccl")
+    import torch.distributed as dist
+    if args.launch_check:
+        # the argument -> ranks path alone (CPU test): every rank joins, rank 0 reports what the process group saw
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend if backend != "nccl" or torch.cuda.is_available() else "gloo")
+        seen = dist.get_world_size() if world > 1 else 1
+        assert seen == args.gpus, (seen, args.gpus)
+        ranks = [None] * seen
+        if world > 1:
+            dist.all_gather_object(ranks, rank)
+            dist.destroy_process_group()
+        else:
+            ranks = [0]
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": seen, "ranks": ranks}), flush=True)
+        return
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
     if backend != "nccl":
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
-    import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+        # n_gpus in the line is what the process group saw, and it must be what --gpus asked for
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+        world = dist.get_world_size()
 
     import __graft_entry__ as ge
     if rank == 0:

@@ -58,6 +58,17 @@ typedef enum LnrPrecision { LNR_PREC_F32 = 0, LNR_PREC_F16 = 1 } LnrPrecision;
  * differ by one fp32 ulp of pos = 1/32 cell on the finest default level. */
 typedef enum LnrPosRounding { LNR_POS_FMA = 0, LNR_POS_MUL_ADD = 1 } LnrPosRounding;
 
+/* Failure guard.  The reference checks, in EVERY iteration, the loss for NaN (inside compute_loss, optimizer.py:590) and - after
+ * backward, before optimizer.step() - every pose gradient and pose tensor for non-finite values (optimizer.py:368-374); an
+ * exception leaves the step of that iteration unreached.  Without a host sync per iteration the same contract is kept on the
+ * device: `poison_dev` (nullable everywhere) is an int32[2] word {code, tag}, zeroed by the caller at the start of a phase.
+ * lnr_los_loss_fused and lnr_pose_backward set it (first event wins; tag = the caller's iteration index) and lnr_adam_step /
+ * lnr_occ_grid_apply do nothing once it is non-zero, so parameters, poses and the occupancy grid stay at the values they had
+ * when the failing iteration began; the host reads the word once per phase and raises the reference's error. */
+#define LNR_POISON_NAN_LOSS 1    /* AssertionError("NaN Loss Encountered") */
+#define LNR_POISON_POSE_GRAD 2   /* RuntimeError("Fatal: Encountered invalid gradient in pose.") */
+#define LNR_POISON_POSE 3        /* RuntimeError("Fatal: Encountered invalid pose tensor.") */
+
 /* lnr_density_backward flags */
 #define LNR_BWD_TABLE_ATOMICS 1   /* test hook: every table-gradient record goes to the 64-bit overflow accumulators (atomics) */
 
@@ -125,6 +136,16 @@ int lnr_net_spec_finalize(LnrNetSpec* spec /*host, in/out*/);
  * Limits: n_points * max(n_features_per_level, 4) < 2^30 per call, encoding table < 2^30 floats (32-bit byte offsets). */
 size_t lnr_density_workspace(const LnrNetSpec* spec /*host*/, int64_t n_points);
 
+/* The first LNR_WORKSPACE_STATUS_BYTES of a workspace are int32 status words the kernels write and the caller may read (with
+ * the device in sync) and reset; lnr_density_workspace_init zeroes them - call it once after allocating a workspace.
+ *   [LNR_STATUS_CLIPPED]  number of density outputs lnr_density_forward clipped since the last reset: non-finite values - and, with
+ *                         LNR_PREC_F16, values beyond +-65504, which the reference's fp16 network returns as +-inf - are replaced
+ *                         by the extremes of the network's dtype, NaN by 0, as DecoupledNeRF.forward does with nan_to_num
+ *                         (nerf_tcnn.py:70-78); the caller prints the reference's "Clipping infinite outputs" warning once. */
+#define LNR_WORKSPACE_STATUS_BYTES 256
+#define LNR_STATUS_CLIPPED 0
+int lnr_density_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
+
 /* sigma = MLP(enc((xyz+1)/2))[0]           replaces tinycudann forward at nerf_tcnn.py:63-72
  * Points are given either explicitly (pts != NULL, [n_points,3] in the world cube [-1,1]) or
  * implicitly as rays [n_rays,13] + z [n_rays,n_samples] (xyz = o + d*z, rendering_tcnn.py:241).
@@ -179,7 +200,7 @@ int lnr_build_window_rays(const float* const* directions, const float* const* di
  * accumulate != 0 adds to d_pose6). */
 int lnr_pose_forward(const float* pose6, int32_t n, float* transforms, void* stream);
 int lnr_pose_backward(const float* pose6, const float* d_transforms, const uint8_t* mask, int32_t n, float* d_pose6,
-                      int32_t accumulate, void* stream);
+                      int32_t accumulate, int32_t* poison_dev, int32_t poison_tag, void* stream);
 
 /* Order-preserving compaction of candidate rays by `keep` (the boolean indexing at
  * ray_utils.py:322 and the vstack at optimizer.py:333-338 for a whole window).
@@ -274,7 +295,7 @@ int lnr_los_loss_fused(const float* sigma, const float* z, const float* rays, co
                        const float* noise, float noise_std, uint64_t seed,
                        float scale, const LnrLossConfig* cfg /*host*/, const int32_t* counts_dev, const float* far0_dev,
                        float* loss_out, float* d_sigma, float* d_rays, float* ray_stats,
-                       float* weights_out, float* block_partials, void* stream);
+                       float* weights_out, float* block_partials, int32_t* poison_dev, int32_t poison_tag, void* stream);
 
 /* ---- optimisers -------------------------------------------------------------------------------------- */
 /* torch.optim.Adam step (optimizer.py:257-269,376-380): betas (b1,b2), eps, no weight decay,
@@ -282,7 +303,7 @@ int lnr_los_loss_fused(const float* sigma, const float* z, const float* rays, co
  * (zero_grad(set_to_none=True), :380).  grad_scale multiplies the gradient first (1.0 normally). */
 int lnr_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t count,
                   float lr, float beta1, float beta2, float eps, int32_t step, float grad_scale,
-                  int32_t zero_grad, void* stream);
+                  int32_t zero_grad, const int32_t* poison_dev, void* stream);
 
 /* Optimizer._step_occupancy_grid (optimizer.py:598-609): pseudo-gradient per sample
  * (losses.py:54-62) scattered trilinearly into the logit grid, SGD step grid -= lr*grad.
@@ -293,7 +314,8 @@ int lnr_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq
 int lnr_occ_grid_step(float* grid, int32_t V, const float* rays, const float* z, const float* depth_gt,
                       int32_t n_rays, const int32_t* n_rays_dev, int32_t n_samples, float scale,
                       float lr, float margin, float l_free, float l_occ, int64_t* grad_acc, void* stream);
-int lnr_occ_grid_apply(float* grid, int64_t* grad_acc, int64_t count, float lr, int32_t zero_grad, void* stream);
+int lnr_occ_grid_apply(float* grid, int64_t* grad_acc, int64_t count, float lr, int32_t zero_grad, const int32_t* poison_dev,
+                       void* stream);
 
 /* ---- self test ------------------------------------------------------------------------------------------ */
 /* Checks the MFMA fragment layouts the density kernels rely on (v_mfma_f32_16x16x4_f32 and v_mfma_f32_16x16x32_f16,

@@ -332,7 +332,7 @@ struct Layout {
     int64_t m_pad;
     int n_groups, bpg, maxo, shift, nown, n_split;
     RegionPlan plan;
-    size_t off_feat, off_dfeat, off_dxl, off_dpts, off_rayacc, off_slabs, off_ovf, off_counts, off_regions, total;
+    size_t off_status, off_feat, off_dfeat, off_dxl, off_dpts, off_rayacc, off_slabs, off_ovf, off_counts, off_regions, total;
 };
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -395,6 +395,7 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
     }
     const int64_t blocks = (int64_t)L.n_groups * L.bpg;
     size_t off = 0;
+    L.off_status = off; off += LNR_WORKSPACE_STATUS_BYTES;          // status words (include/loner_hip.h), same place for every n_points
     L.off_feat = off; off += align256((size_t)spec->enc_dim * L.m_pad * sizeof(float));
     L.off_dfeat = off; off += align256((size_t)spec->enc_dim * L.m_pad * sizeof(float));
     L.off_dxl = off; off += align256((size_t)L.n_groups * 3 * L.m_pad * sizeof(float));
@@ -540,12 +541,12 @@ static int make_src(PointSrc* s, MlpPoints* mp, const float* pts, int64_t n_poin
     if (pts != nullptr) {
         LNR_REQUIRE(n_points >= 0, "%s: negative n_points", who);
         *s = PointSrc{pts, nullptr, nullptr, 1, n_points, 0, nullptr};
-        *mp = MlpPoints{n_points, nullptr, 0, 1};
+        *mp = MlpPoints{n_points, nullptr, 0, 1, nullptr};
     } else {
         LNR_REQUIRE(rays != nullptr && z != nullptr, "%s: need either pts or (rays, z)", who);
         LNR_REQUIRE(n_rays >= 0 && n_samples > 0, "%s: bad n_rays/n_samples", who);
         *s = PointSrc{nullptr, rays, z, n_samples, 0, n_rays, n_rays_dev};
-        *mp = MlpPoints{(int64_t)n_rays * n_samples, n_rays_dev, n_rays, n_samples};
+        *mp = MlpPoints{(int64_t)n_rays * n_samples, n_rays_dev, n_rays, n_samples, nullptr};
     }
     return LNR_OK;
 }
@@ -553,6 +554,15 @@ static int make_src(PointSrc* s, MlpPoints* mp, const float* pts, int64_t n_poin
 extern "C" size_t lnr_density_workspace(const LnrNetSpec* spec, int64_t n_points) {
     if (!spec || n_points < 0) return 0;
     return make_layout(spec, n_points).total;
+}
+
+extern "C" int lnr_density_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
+    LNR_REQUIRE(workspace != nullptr && workspace_bytes >= LNR_WORKSPACE_STATUS_BYTES, "lnr_density_workspace_init: workspace too small");
+    if (hipMemsetAsync(workspace, 0, LNR_WORKSPACE_STATUS_BYTES, (hipStream_t)stream) != hipSuccess) {
+        lnr_set_error("lnr_density_workspace_init: hipMemsetAsync failed");
+        return LNR_ERR_LAUNCH;
+    }
+    return LNR_OK;
 }
 
 extern "C" int lnr_density_forward(const LnrNetSpec* spec, const float* params, const float* pts, int64_t n_points,
@@ -582,6 +592,7 @@ extern "C" int lnr_density_forward(const LnrNetSpec* spec, const float* params, 
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     float* feat = (float*)((char*)workspace + L.off_feat);
+    mp.clip_flag = reinterpret_cast<int32_t*>((char*)workspace + L.off_status) + LNR_STATUS_CLIPPED;
     {
         LnrProfScope prof("encode_forward", st);
         rc = lnr_encode_forward(spec, params, &src, cap, feat, L.m_pad, f16, st);

@@ -18,7 +18,7 @@ struct PointSrc {
 };
 
 #define LNR_BWD_MAX_BLOCKS 512
-#define LNR_SLICE_SHIFT 13            // 8192 floats (32 KB of LDS) per owner
+#define LNR_SLICE_SHIFT 13            // 8192 floats per owner (64 KB of LDS: 64-bit fixed-point accumulators)
 #define LNR_REGION_BUDGET (24ull << 30)
 #define LNR_COMBINE_SCALE_MAX 3000.0f
 #define LNR_COMBINE_FILL 1.0        // expected records of a run-length combined level, as a fraction of its uncombined count
@@ -125,6 +125,7 @@ struct MlpPoints {
     int64_t n_points;            // explicit point count (pts mode)
     const int32_t* n_rays_dev;   // non-null: live ray count on the device (rays mode)
     int32_t n_rays, n_samples;
+    int32_t* clip_flag;          // workspace status word: number of sigma outputs clipped by the forward kernels (nullable)
 };
 
 #define LNR_DECLARE_HT(HT)                                                                                              \

@@ -66,7 +66,7 @@ __device__ __forceinline__ u32x4 load_xb(const uint32_t* __restrict__ featp, uin
 template <int HT>
 __global__ void __launch_bounds__(LNR_DENSITY_BLOCK, 2)
 mlp_forward_f16_kernel(const float* __restrict__ params, const uint32_t* __restrict__ featp, int64_t m_pad, int64_t n_points,
-                       const int32_t* __restrict__ n_rays_dev, int n_rays, int n_samples, float* __restrict__ sigma) {
+                       const int32_t* __restrict__ n_rays_dev, int n_rays, int n_samples, float* __restrict__ sigma, int32_t* __restrict__ clip_flag) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     f16x8 wa[HT]; float wo[HT][4];
@@ -97,7 +97,7 @@ mlp_forward_f16_kernel(const float* __restrict__ params, const uint32_t* __restr
             part += __shfl_xor(part, 16, 64);
             part += __shfl_xor(part, 32, 64);
             const int64_t m = tile * 32 + 16 * t + c;
-            if (g == 0 && m < M) sigma[m] = finite_or_clipped(part);
+            if (g == 0 && m < M) sigma[m] = finite_or_clipped<true>(part, clip_flag);
         }
         cur[0] = nxt[0]; cur[1] = nxt[1];
         tile = nt;
@@ -465,7 +465,7 @@ __device__ __forceinline__ f32x4 layer_z(const f16* Ws, const GenDims& d, int l,
 template <int HT, int ACT>
 __global__ void __launch_bounds__(LNR_DENSITY_BLOCK)
 mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ params, const uint32_t* __restrict__ featp, int64_t m_pad,
-                           int64_t n_points, const int32_t* __restrict__ n_rays_dev, int n_rays, int n_samples, float* __restrict__ sigma) {
+                           int64_t n_points, const int32_t* __restrict__ n_rays_dev, int n_rays, int n_samples, float* __restrict__ sigma, int32_t* __restrict__ clip_flag) {
     extern __shared__ __attribute__((aligned(16))) f16 Ws[];
     const GenDims d = gen_dims(spec);
     fill_weights(Ws, params, d);
@@ -497,7 +497,7 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
             part += __shfl_xor(part, 16, 64);
             part += __shfl_xor(part, 32, 64);
             const int64_t m = tile * 32 + 16 * t + c;
-            if (g == 0 && m < M) sigma[m] = finite_or_clipped(part);
+            if (g == 0 && m < M) sigma[m] = finite_or_clipped<true>(part, clip_flag);
         }
     }
 }
@@ -779,9 +779,9 @@ int lnr_mlp_fwd_f16(const LnrNetSpec* spec, const float* params, const void* fea
     const uint32_t* fp = reinterpret_cast<const uint32_t*>(featp);
     if (f16_fast_class(spec)) {
         switch (spec->n_neurons / 16) {
-            case 1: hipLaunchKernelGGL(mlp_forward_f16_kernel<1>, grid, block, 0, st, params, fp, m_pad, pt->n_points, pt->n_rays_dev, pt->n_rays, pt->n_samples, sigma); break;
-            case 2: hipLaunchKernelGGL(mlp_forward_f16_kernel<2>, grid, block, 0, st, params, fp, m_pad, pt->n_points, pt->n_rays_dev, pt->n_rays, pt->n_samples, sigma); break;
-            default: hipLaunchKernelGGL(mlp_forward_f16_kernel<4>, grid, block, 0, st, params, fp, m_pad, pt->n_points, pt->n_rays_dev, pt->n_rays, pt->n_samples, sigma); break;
+            case 1: hipLaunchKernelGGL(mlp_forward_f16_kernel<1>, grid, block, 0, st, params, fp, m_pad, pt->n_points, pt->n_rays_dev, pt->n_rays, pt->n_samples, sigma, pt->clip_flag); break;
+            case 2: hipLaunchKernelGGL(mlp_forward_f16_kernel<2>, grid, block, 0, st, params, fp, m_pad, pt->n_points, pt->n_rays_dev, pt->n_rays, pt->n_samples, sigma, pt->clip_flag); break;
+            default: hipLaunchKernelGGL(mlp_forward_f16_kernel<4>, grid, block, 0, st, params, fp, m_pad, pt->n_points, pt->n_rays_dev, pt->n_rays, pt->n_samples, sigma, pt->clip_flag); break;
         }
         return LNR_OK;
     }
@@ -792,7 +792,7 @@ int lnr_mlp_fwd_f16(const LnrNetSpec* spec, const float* params, const void* fea
         int rc_ = f16_set_lds(mlp_forward_f16_gen_kernel<HT, ACT>, lds, "lnr_density_forward");                                  \
         if (rc_) return rc_;                                                                                                     \
         hipLaunchKernelGGL((mlp_forward_f16_gen_kernel<HT, ACT>), grid, block, lds, st, *spec, params, fp, m_pad, pt->n_points,   \
-                           pt->n_rays_dev, pt->n_rays, pt->n_samples, sigma);                                                    \
+                           pt->n_rays_dev, pt->n_rays, pt->n_samples, sigma, pt->clip_flag);                                     \
     } while (0)
 #define LNR_F16_GEN_FWD_A(HT) do { if (akind == LNR_ACT_RELU) LNR_F16_GEN_FWD(HT, LNR_ACT_RELU); else if (akind == LNR_ACT_SINE) LNR_F16_GEN_FWD(HT, LNR_ACT_SINE); else LNR_F16_GEN_FWD(HT, -1); } while (0)
     switch (spec->n_neurons / 16) {

@@ -22,7 +22,7 @@ static int set_lds(K kernel, size_t bytes, const char* who) {
         rc = set_lds(mlp_forward_kernel<LNR_HT, WL, ACT>, plan->lds, "lnr_density_forward");                          \
         if (rc) return rc;                                                                                            \
         hipLaunchKernelGGL((mlp_forward_kernel<LNR_HT, WL, ACT>), grid, block, plan->lds, st, *spec, params, feat, m_pad, \
-                           pt->n_points, pt->n_rays_dev, pt->n_rays, pt->n_samples, sigma);                           \
+                           pt->n_points, pt->n_rays_dev, pt->n_rays, pt->n_samples, sigma, pt->clip_flag);            \
     } while (0)
 
 int LNR_CAT(lnr_mlp_fwd_ht, LNR_HT)(const LnrNetSpec* spec, const float* params, const float* feat, int64_t m_pad, const MlpPoints* pt,
@@ -35,7 +35,7 @@ int LNR_CAT(lnr_mlp_fwd_ht, LNR_HT)(const LnrNetSpec* spec, const float* params,
         rc = set_lds(mlp_forward_relu32_kernel<LNR_HT>, plan->lds, "lnr_density_forward");
         if (rc) return rc;
         hipLaunchKernelGGL((mlp_forward_relu32_kernel<LNR_HT>), grid, block, plan->lds, st, *spec, params, feat, m_pad, pt->n_points,
-                           pt->n_rays_dev, pt->n_rays, pt->n_samples, sigma);
+                           pt->n_rays_dev, pt->n_rays, pt->n_samples, sigma, pt->clip_flag);
         return LNR_OK;
     }
 #endif

@@ -51,10 +51,16 @@ __device__ __forceinline__ float act_bwd(float v, int kind) {
     }
 }
 
-// DecoupledNeRF.forward clips non-finite densities (nerf_tcnn.py:74-78: nan_to_num with the dtype's extremes, NaN -> 0)
-__device__ __forceinline__ float finite_or_clipped(float v) {
-    if (__builtin_isfinite(v)) return v;
-    return v != v ? 0.0f : copysignf(3.402823466e+38f, v);
+// DecoupledNeRF.forward clips non-finite densities (nerf_tcnn.py:70-78: nan_to_num with the extremes of the NETWORK's dtype,
+// NaN -> 0, and a warning the first time).  HALF = false: the fp32 network, limits +-FLT_MAX.  HALF = true (LNR_PREC_F16): the
+// reference's network returns fp16, so whatever exceeds 65504 is +-inf there and comes back as +-65504.  `flag` (nullable) counts
+// the clipped outputs; the host prints the reference's warning once when it finds it non-zero.
+template <bool HALF>
+__device__ __forceinline__ float finite_or_clipped(float v, int32_t* __restrict__ flag) {
+    const float lim = HALF ? 65504.0f : 3.402823466e+38f;
+    if (__builtin_expect(__builtin_fabsf(v) <= lim, 1)) return v;          // false for NaN
+    if (flag != nullptr) atomicAdd(flag, 1);
+    return v != v ? 0.0f : copysignf(lim, v);
 }
 
 #define MFMA4(acc, a4, b0, b1, b2, b3)                                      \
@@ -110,7 +116,7 @@ __device__ __forceinline__ void layer1_from_planes(const LnrNetSpec& spec, const
 template <int HT, bool W_LDS, int ACT>
 __global__ void __launch_bounds__(LNR_DENSITY_BLOCK)
 mlp_forward_kernel(const LnrNetSpec spec, const float* __restrict__ params, const float* __restrict__ feat, int64_t m_pad,
-                   int64_t n_points, const int32_t* __restrict__ n_rays_dev, int n_rays, int n_samples, float* __restrict__ sigma) {
+                   int64_t n_points, const int32_t* __restrict__ n_rays_dev, int n_rays, int n_samples, float* __restrict__ sigma, int32_t* __restrict__ clip_flag) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = 16 * HT;
     const int n_mlp = spec.n_mlp_params;
@@ -146,7 +152,7 @@ mlp_forward_kernel(const LnrNetSpec spec, const float* __restrict__ params, cons
         }
         part += __shfl_xor(part, 16, 64);
         part += __shfl_xor(part, 32, 64);
-        if (g == 0 && valid) sigma[m] = finite_or_clipped(part);
+        if (g == 0 && valid) sigma[m] = finite_or_clipped<false>(part, clip_flag);
     }
 }
 
@@ -404,7 +410,7 @@ __device__ __forceinline__ void load_tile32(const float* __restrict__ feat, cons
 template <int HT>
 __global__ void __launch_bounds__(LNR_DENSITY_BLOCK, 2)
 mlp_forward_relu32_kernel(const LnrNetSpec spec, const float* __restrict__ params, const float* __restrict__ feat, int64_t m_pad,
-                          int64_t n_points, const int32_t* __restrict__ n_rays_dev, int n_rays, int n_samples, float* __restrict__ sigma) {
+                          int64_t n_points, const int32_t* __restrict__ n_rays_dev, int n_rays, int n_samples, float* __restrict__ sigma, int32_t* __restrict__ clip_flag) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int H = 16 * HT;
     const int n_mlp = spec.n_mlp_params;
@@ -442,7 +448,7 @@ mlp_forward_relu32_kernel(const LnrNetSpec spec, const float* __restrict__ param
         part += __shfl_xor(part, 16, 64);
         part += __shfl_xor(part, 32, 64);
         const int64_t m = tile * 16 + c;
-        if (g == 0 && m < M) sigma[m] = finite_or_clipped(part);
+        if (g == 0 && m < M) sigma[m] = finite_or_clipped<false>(part, clip_flag);
         cur = nxt;
         tile = nt;
     }

@@ -20,7 +20,10 @@ __device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v,
 
 __global__ void __launch_bounds__(256)
 adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
-            float lr_over_c1, float b1, float b2, float eps, float inv_c2, float grad_scale, int zero_grad) {
+            float lr_over_c1, float b1, float b2, float eps, float inv_c2, float grad_scale, int zero_grad, const int32_t* __restrict__ poison) {
+    // failure guard (see lnr_los_loss_fused / lnr_pose_backward): once the run is marked failed no parameter moves any more,
+    // as in the reference, where the exception leaves optimizer.step() unreached (optimizer.py:368-376)
+    if (poison != nullptr && *poison != 0) return;
     const int64_t n4 = n / 4;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     float4* p4 = reinterpret_cast<float4*>(p);
@@ -46,7 +49,7 @@ adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
 }
 
 extern "C" int lnr_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t count, float lr, float beta1,
-                             float beta2, float eps, int32_t step, float grad_scale, int32_t zero_grad, void* stream) {
+                             float beta2, float eps, int32_t step, float grad_scale, int32_t zero_grad, const int32_t* poison_dev, void* stream) {
     LNR_REQUIRE(params && grads && exp_avg && exp_avg_sq, "lnr_adam_step: null argument");
     LNR_REQUIRE(count >= 0 && step >= 1, "lnr_adam_step: bad count/step");
     LNR_REQUIRE((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15u) == 0, "lnr_adam_step: buffers must be 16-byte aligned");
@@ -57,7 +60,7 @@ extern "C" int lnr_adam_step(float* params, float* grads, float* exp_avg, float*
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, count,
-                       (float)((double)lr / c1), beta1, beta2, eps, (float)(1.0 / c2), grad_scale, zero_grad);
+                       (float)((double)lr / c1), beta1, beta2, eps, (float)(1.0 / c2), grad_scale, zero_grad, poison_dev);
     LNR_CHECK_LAUNCH("lnr_adam_step");
     return LNR_OK;
 }
@@ -125,7 +128,9 @@ occ_grid_step_kernel(float* __restrict__ grid, int V, const float* __restrict__ 
     }
 }
 
-__global__ void occ_grid_apply_kernel(float* __restrict__ grid, long long* __restrict__ grad, int64_t n, float lr, int zero_grad) {
+__global__ void occ_grid_apply_kernel(float* __restrict__ grid, long long* __restrict__ grad, int64_t n, float lr, int zero_grad,
+                                      const int32_t* __restrict__ poison) {
+    if (poison != nullptr && *poison != 0) return;          // failed run: the grid stays as it was (optimizer.py:382-384 is never reached)
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const long long q = grad[i];
@@ -150,12 +155,12 @@ extern "C" int lnr_occ_grid_step(float* grid, int32_t V, const float* rays, cons
     return LNR_OK;
 }
 
-extern "C" int lnr_occ_grid_apply(float* grid, int64_t* grad_acc, int64_t count, float lr, int32_t zero_grad, void* stream) {
+extern "C" int lnr_occ_grid_apply(float* grid, int64_t* grad_acc, int64_t count, float lr, int32_t zero_grad, const int32_t* poison_dev, void* stream) {
     LNR_REQUIRE(grid && grad_acc && count >= 0, "lnr_occ_grid_apply: bad argument");
     if (count == 0) return LNR_OK;
     int64_t blocks = (count + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(occ_grid_apply_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, grid, reinterpret_cast<long long*>(grad_acc), count, lr, zero_grad);
+    hipLaunchKernelGGL(occ_grid_apply_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, grid, reinterpret_cast<long long*>(grad_acc), count, lr, zero_grad, poison_dev);
     LNR_CHECK_LAUNCH("lnr_occ_grid_apply");
     return LNR_OK;
 }

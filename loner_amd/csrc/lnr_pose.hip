@@ -32,9 +32,12 @@ __global__ void pose_forward_kernel(const float* __restrict__ pose6, int n, floa
     T[8] = s2 * (x * z - y * w);        T[9] = s2 * (y * z + x * w);        T[10] = 1.0f - s2 * (x * x + y * y); T[11] = p[2];
 }
 
-// d_pose6[i] = mask[i] * J^T dT12[i]   (mask nullable: 1 = pose is optimised, 0 = fixed / anchored)
+// d_pose6[i] = mask[i] * J^T dT12[i]   (mask nullable: 1 = pose is optimised, 0 = fixed / anchored: gradient exactly 0)
+// poison (nullable, int32[2]): the reference raises "invalid gradient in pose" / "invalid pose tensor" after backward and BEFORE
+// the optimiser step of the same iteration (optimizer.py:368-374); here the first non-finite pose gradient (of an optimised pose)
+// or pose tensor marks the word, and the steps that follow read it and do nothing.
 __global__ void pose_backward_kernel(const float* __restrict__ pose6, const float* __restrict__ dT12, const uint8_t* __restrict__ mask,
-                                     int n, float* __restrict__ d_pose6, int accumulate) {
+                                     int n, float* __restrict__ d_pose6, int accumulate, int32_t* __restrict__ poison, int32_t poison_tag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* p = pose6 + 6 * i;
@@ -64,7 +67,15 @@ __global__ void pose_backward_kernel(const float* __restrict__ pose6, const floa
     out[4] = q.k * dy + d_theta * b * inv_theta;
     out[5] = q.k * dz + d_theta * c * inv_theta;
     float* o = d_pose6 + 6 * i;
-    for (int j = 0; j < 6; ++j) o[j] = (accumulate ? o[j] : 0.0f) + m * out[j];
+    bool bad_grad = false, bad_pose = false;
+    for (int j = 0; j < 6; ++j) {
+        const float v = (accumulate ? o[j] : 0.0f) + (m != 0.0f ? out[j] : 0.0f);
+        o[j] = v;
+        bad_grad |= !isfinite(v);
+        bad_pose |= !isfinite(p[j]);
+    }
+    if (poison != nullptr && (bad_grad || bad_pose) && atomicCAS(poison, 0, bad_grad ? LNR_POISON_POSE_GRAD : LNR_POISON_POSE) == 0)
+        poison[1] = poison_tag;
 }
 
 extern "C" int lnr_pose_forward(const float* pose6, int32_t n, float* transforms, void* stream) {
@@ -76,11 +87,11 @@ extern "C" int lnr_pose_forward(const float* pose6, int32_t n, float* transforms
 }
 
 extern "C" int lnr_pose_backward(const float* pose6, const float* d_transforms, const uint8_t* mask, int32_t n, float* d_pose6,
-                                 int32_t accumulate, void* stream) {
+                                 int32_t accumulate, int32_t* poison_dev, int32_t poison_tag, void* stream) {
     LNR_REQUIRE(pose6 && d_transforms && d_pose6 && n >= 0, "lnr_pose_backward: bad argument");
     if (n == 0) return LNR_OK;
     hipLaunchKernelGGL(pose_backward_kernel, dim3(lnr_div_up(n, 64)), dim3(64), 0, (hipStream_t)stream, pose6, d_transforms, mask, n,
-                       d_pose6, accumulate);
+                       d_pose6, accumulate, poison_dev, poison_tag);
     LNR_CHECK_LAUNCH("lnr_pose_backward");
     return LNR_OK;
 }

@@ -346,7 +346,11 @@ los_loss_fused_kernel(const float* __restrict__ sigma, const float* __restrict__
     }
 }
 
-__global__ void loss_reduce_kernel(const float* __restrict__ block_partials, int n_blocks, float* __restrict__ loss_out) {
+// poison (nullable, int32[2] = {code, tag}): a NaN total marks the run as failed at iteration `tag` (LNR_POISON_NAN_LOSS) - the
+// reference asserts "NaN Loss Encountered" inside compute_loss, before backward and step (optimizer.py:590); here the steps that
+// follow read the word and become no-ops (lnr_adam_step, lnr_occ_grid_apply), and the host raises at the end of the phase.
+__global__ void loss_reduce_kernel(const float* __restrict__ block_partials, int n_blocks, float* __restrict__ loss_out,
+                                   int32_t* __restrict__ poison, int32_t poison_tag) {
     __shared__ float part[4][8];
     const int term = threadIdx.x & 7, slice = threadIdx.x >> 3;          // 256 threads = 32 slices x 8 terms
     float v = 0.0f;
@@ -354,7 +358,11 @@ __global__ void loss_reduce_kernel(const float* __restrict__ block_partials, int
     v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
     if ((threadIdx.x & 63) < 8) part[threadIdx.x >> 6][term] = v;
     __syncthreads();
-    if (threadIdx.x < 5) loss_out[threadIdx.x] += part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    if (threadIdx.x < 5) {
+        const float t = loss_out[threadIdx.x] + (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+        loss_out[threadIdx.x] = t;
+        if (threadIdx.x == 0 && poison != nullptr && t != t && atomicCAS(poison, 0, LNR_POISON_NAN_LOSS) == 0) poison[1] = poison_tag;
+    }
 }
 
 __global__ void count_opaque_kernel(const float* __restrict__ rays, const float* __restrict__ depth_gt, int n_rays,
@@ -494,8 +502,9 @@ extern "C" int lnr_los_loss_fused(const float* sigma, const float* z, const floa
                                   const int32_t* n_rays_dev, int32_t n_samples, const float* noise, float noise_std, uint64_t seed,
                                   float scale, const LnrLossConfig* cfg, const int32_t* counts_dev, const float* far0_dev, float* loss_out,
                                   float* d_sigma, float* d_rays, float* ray_stats, float* weights_out, float* block_partials,
-                                  void* stream) {
+                                  int32_t* poison_dev, int32_t poison_tag, void* stream) {
     LNR_REQUIRE(sigma && z && rays && depth_gt && cfg && counts_dev && loss_out && d_sigma && d_rays, "lnr_los_loss_fused: null argument");
+    LNR_REQUIRE(poison_dev == nullptr || block_partials != nullptr, "lnr_los_loss_fused: the failure guard needs block_partials (the deterministic reduction)");
     LNR_REQUIRE(cfg->selection >= 0 && cfg->selection <= 3, "lnr_los_loss_fused: unknown loss selection %d", cfg->selection);
     LNR_REQUIRE(n_rays >= 0 && n_samples >= 2, "lnr_los_loss_fused: bad sizes");
     if (n_rays == 0) return LNR_OK;
@@ -506,7 +515,7 @@ extern "C" int lnr_los_loss_fused(const float* sigma, const float* z, const floa
                                              ray_stats, weights_out, block_partials, far0_dev));
     LNR_CHECK_LAUNCH("lnr_los_loss_fused");
     if (block_partials) {
-        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, block_partials, (int)grid.x, loss_out);
+        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, block_partials, (int)grid.x, loss_out, poison_dev, poison_tag);
         LNR_CHECK_LAUNCH("lnr_los_loss_fused(reduce)");
     }
     return LNR_OK;

@@ -26,6 +26,8 @@ LOSS_SELECTIONS = {"L1_JS": 0, "L2_JS": 1, "L1_LOS": 2, "L2_LOS": 3}
 PRECISIONS = {"fp32": 0, "float32": 0, "fp16": 1, "half": 1, "float16": 1}
 POS_ROUNDINGS = {"fma": 0, "mul_add": 1}
 BWD_TABLE_ATOMICS = 1        # LNR_BWD_TABLE_ATOMICS
+WORKSPACE_STATUS_BYTES, STATUS_CLIPPED = 256, 0            # LNR_WORKSPACE_STATUS_BYTES, LNR_STATUS_CLIPPED
+POISON_NAN_LOSS, POISON_POSE_GRAD, POISON_POSE = 1, 2, 3      # LNR_POISON_* codes of the failure guard (int32[2] device word)
 
 
 class NetSpec(C.Structure):
@@ -54,6 +56,7 @@ _SIGNATURES = {
     "lnr_profile_read": (C.c_int, [P, C.c_int32, P, P, C.c_int32]),
     "lnr_net_spec_finalize": (C.c_int, [C.POINTER(NetSpec)]),
     "lnr_density_workspace": (C.c_size_t, [C.POINTER(NetSpec), C.c_int64]),
+    "lnr_density_workspace_init": (C.c_int, [P, C.c_size_t, P]),
     "lnr_density_forward": (C.c_int, [C.POINTER(NetSpec), P, P, C.c_int64, P, P, C.c_int32, C.c_int32, P, P, P, C.c_size_t, P]),
     "lnr_density_backward": (C.c_int, [C.POINTER(NetSpec), P, P, C.c_int64, P, P, C.c_int32, C.c_int32, P, P, P, P, P,
                                        C.c_int32, C.c_int32, P, C.c_size_t, P]),
@@ -63,7 +66,7 @@ _SIGNATURES = {
                                         C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, P, P, C.c_uint64, P, C.c_float, C.c_float,
                                         C.c_float, C.POINTER(C.c_float), P, P, P, P]),
     "lnr_pose_forward": (C.c_int, [P, C.c_int32, P, P]),
-    "lnr_pose_backward": (C.c_int, [P, P, P, C.c_int32, P, C.c_int32, P]),
+    "lnr_pose_backward": (C.c_int, [P, P, P, C.c_int32, P, C.c_int32, P, C.c_int32, P]),
     "lnr_compact_rays": (C.c_int, [P, P, P, P, C.c_int32, C.POINTER(C.c_int32), C.c_int32, P, P, P, P, P, P]),
     "lnr_lidar_rays_backward": (C.c_int, [P, P, P, P, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), P,
                                           C.c_float, P, P]),
@@ -78,12 +81,12 @@ _SIGNATURES = {
     "lnr_logits_grad": (C.c_int, [P, P, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, P, P]),
     "lnr_count_opaque": (C.c_int, [P, P, C.c_int32, P, P, P, P]),
     "lnr_los_loss_fused": (C.c_int, [P, P, P, P, C.c_int32, P, C.c_int32, P, C.c_float, C.c_uint64, C.c_float,
-                                     C.POINTER(LossConfig), P, P, P, P, P, P, P, P, P]),
+                                     C.POINTER(LossConfig), P, P, P, P, P, P, P, P, P, C.c_int32, P]),
     "lnr_adam_step": (C.c_int, [P, P, P, P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
-                                C.c_float, C.c_int32, P]),
+                                C.c_float, C.c_int32, P, P]),
     "lnr_occ_grid_step": (C.c_int, [P, C.c_int32, P, P, P, C.c_int32, P, C.c_int32, C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_float, P, P]),
-    "lnr_occ_grid_apply": (C.c_int, [P, P, C.c_int64, C.c_float, C.c_int32, P]),
+    "lnr_occ_grid_apply": (C.c_int, [P, P, C.c_int64, C.c_float, C.c_int32, P, P]),
     "lnr_selftest_mfma": (C.c_int, [P, P]),
 }
 

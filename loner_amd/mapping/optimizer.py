@@ -14,7 +14,9 @@ it drops into the reference's Mapper unchanged.  What differs is where the work 
   (ray_sampling.py, rendering_tcnn.py,            / density bwd kernels chained on one HIP stream
    optimizer.py:437-595) + autograd
   loss.item() and eps.cpu() syncs (:354,:503)     no host sync inside the loop; the NaN / finite
-                                                  checks (:368-374,:590) run once per call
+  per-iteration checks before step (:368-374,     checks are made on the device in every iteration (a
+  :590)                                           "poison" word the step kernels obey) and raised
+                                                  once per phase
   torch.optim.Adam over 7.4 M params              one fused Adam kernel (lnr_adam_step)
 
 Random numbers: by default the kernels' counter-based generator is used (seeded per iteration from
@@ -54,8 +56,9 @@ class HipAdam(torch.optim.Optimizer):
     """torch.optim.Adam semantics (betas 0.9/0.999, eps 1e-8, no weight decay) with the update done by
     lnr_adam_step.  State keys match torch's Adam so that state_dict() round-trips (mapper.py:161-175)."""
 
-    def __init__(self, param_groups):
+    def __init__(self, param_groups, poison=None):
         super().__init__(param_groups, dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8))
+        self.poison = poison          # failure guard of the optimisation phase (int32[2] device word, include/loner_hip.h) or None
 
     @torch.no_grad()
     def step(self, zero_grad=True, groups=None, ranges=None):
@@ -77,7 +80,8 @@ class HipAdam(torch.optim.Optimizer):
                 flat = (p.data.view(-1), p.grad.view(-1), st["exp_avg"].view(-1), st["exp_avg_sq"].view(-1))
                 for lo, hi in (ranges if ranges is not None else [(0, flat[0].numel())]):
                     ops.adam_step(flat[0][lo:hi], flat[1][lo:hi], flat[2][lo:hi], flat[3][lo:hi],
-                                  group["lr"], st["step"], betas=group["betas"], eps=group["eps"], zero_grad=zero_grad)
+                                  group["lr"], st["step"], betas=group["betas"], eps=group["eps"], zero_grad=zero_grad,
+                                  poison=self.poison)
 
 
 class _LidarLossFn(torch.autograd.Function):
@@ -149,6 +153,8 @@ class Optimizer:
         self._results_lidar = None
         self._depth_eps = None
         self._grad_buf = None
+        self._poison = None          # failure guard of the running phase (device int32[2]), None outside a phase
+        self.last_failure = None
         self._pending_density = None  # (all-reduce handle or None, group index, lr): density Adam step deferred by the training loop
         self._defer_density_step = True   # False: step right away (same arithmetic; the tests compare the two)
         self.last_stats = {}
@@ -252,7 +258,11 @@ class Optimizer:
             if any_free:
                 groups.append({'params': [pose_dev], 'lr': self._model_config.train.lrate_pose})
             # always an Adam, like the reference (Mapper.build_ckpt reads its state_dict unconditionally, mapper.py:161-175)
-            self._optimizer = HipAdam(groups if groups else [{'params': []}])
+            # failure guard: {code, iteration} written by the loss / pose-gradient kernels of the iteration that fails; every
+            # step kernel after it does nothing (the reference raises before optimizer.step(), optimizer.py:368-376,590)
+            poison = torch.zeros(2, device=self._device, dtype=torch.int32)
+            self._poison = poison
+            self._optimizer = HipAdam(groups if groups else [{'params': []}], poison=poison)
             gamma = float(self._model_config.train.lrate_gamma)
             base_lrs = [g['lr'] for g in groups]
             # the density step may be deferred (see below) when the density parameters are trained in this phase
@@ -272,11 +282,11 @@ class Optimizer:
                                                self._model.nerf_model._model_sigma.params, it_idx, want_ray_grads=any_free,
                                                want_param_grads=not os_.freeze_sigma_mlp, n_rays_dev=batch["n_dev"],
                                                loss_out=loss_log[it_idx], accumulate_into_param_grad=True, want_stats=False,
-                                               defer_grad_wait=True)
+                                               defer_grad_wait=True, poison=poison)
                 else:
                     out = self._join_without_rays(sigma_params[0] if sigma_params else None, want_param_grads=not os_.freeze_sigma_mlp)
                 if any_free:
-                    self._pose_backward(batch, out["d_rays"], pose_dev, free_rows)
+                    self._pose_backward(batch, out["d_rays"], pose_dev, free_rows, poison=poison, poison_tag=it_idx)
                 if groups:
                     for g, lr0 in zip(self._optimizer.param_groups, base_lrs):
                         g['lr'] = lr0 * (gamma ** it_idx)
@@ -302,8 +312,25 @@ class Optimizer:
                     self._progress_bar.update()
 
             self._flush_density_step()
-            # ---- one host sync per phase: checks the reference does every iteration (:368-374,:590) ----
+            # ---- one host sync per phase.  The checks the reference makes in every iteration (:368-374,:590) were made on the
+            # device, by the kernels of that iteration; the state below is the one the failing iteration started from ----
+            if self._dist is not None:
+                # a failure on any rank is everybody's (the other ranks kept stepping until here - the run is lost either way)
+                self._dist.all_reduce_max(poison)
+            code, failed_it = (int(v) for v in poison.cpu())
+            self._poison = None
+            self._model.nerf_model.warn_if_clipped(self._device)      # nerf_tcnn.py:70-78, once per phase instead of per forward
             loss_host = loss_log[:, 0].cpu()
+            if code != 0:
+                with torch.no_grad():           # hand the poses of the last good iteration back, like every other phase end
+                    for k, p in enumerate(pose_cpu):
+                        p.data.copy_(pose_dev[k].detach().to(p.device))
+                self.last_failure = {"code": code, "iteration": failed_it}
+                if code == hip.POISON_NAN_LOSS:
+                    raise AssertionError("NaN Loss Encountered")
+                if code == hip.POISON_POSE_GRAD:
+                    raise RuntimeError("Fatal: Encountered invalid gradient in pose.")
+                raise RuntimeError("Fatal: Encountered invalid pose tensor.")
             if n_it and torch.isnan(loss_host).any():
                 raise AssertionError("NaN Loss Encountered")
             if any_free and not torch.isfinite(pose_dev.detach()).all():
@@ -397,7 +424,7 @@ class Optimizer:
         rays, depths, src, out_seg, n_dev = ops.compact_rays(rays_c, depths_c, keep, src_c, tab.seg_start_list)
         return dict(rays=rays, depths=depths, src=src, seg_start=out_seg, n_dev=n_dev, T12=T12, tab=tab)
 
-    def _pose_backward(self, batch, d_rays, pose_dev, free_mask_u8):
+    def _pose_backward(self, batch, d_rays, pose_dev, free_mask_u8, poison=None, poison_tag=0):
         """dL/drays -> dL/d[R|t] per segment (HIP) -> dL/dpose6 (HIP, analytic axis-angle Jacobian)."""
         tab = batch["tab"]
         seg_T = batch["T12"] if not tab.has_sky else batch["T12"][tab.seg_kf_dev]
@@ -407,9 +434,9 @@ class Optimizer:
         else:
             dT = dT_seg
         if pose_dev.grad is None:
-            pose_dev.grad = ops.pose_backward(pose_dev, dT, mask=free_mask_u8)
+            pose_dev.grad = ops.pose_backward(pose_dev, dT, mask=free_mask_u8, poison=poison, poison_tag=poison_tag)
         else:
-            ops.pose_backward(pose_dev, dT, mask=free_mask_u8, out=pose_dev.grad, accumulate=True)
+            ops.pose_backward(pose_dev, dT, mask=free_mask_u8, out=pose_dev.grad, accumulate=True, poison=poison, poison_tag=poison_tag)
 
     # -------------------------------------------------------------------------------------------
     def _loss_config(self, iteration_idx) -> hip.LossConfig:
@@ -433,7 +460,8 @@ class Optimizer:
         return cfg
 
     def _loss_and_grads(self, rays, depths, params, iteration_idx, want_ray_grads, want_param_grads, n_rays_dev=None,
-                        loss_out=None, accumulate_into_param_grad=False, draws=None, want_stats=True, defer_grad_wait=False):
+                        loss_out=None, accumulate_into_param_grad=False, draws=None, want_stats=True, defer_grad_wait=False,
+                        poison=None):
         """sample -> density -> fused render+loss(+backward) -> density backward.  rays [N,13], depths [N] on device."""
         draws = draws if draws is not None else self._draws
         render = self._model_config.model.render
@@ -470,11 +498,15 @@ class Optimizer:
             counts_work.wait()
         loss, d_sigma, d_rays, stats, _ = ops.los_loss_fused(sigma, z, rays, depths, self._scale_f, self._loss_config(iteration_idx),
                                                             counts, noise=noise, noise_std=noise_std, seed=seed + 1,
-                                                            n_rays_dev=n_rays_dev, want_stats=want_stats, loss_out=loss_out, far0=far0)
+                                                            n_rays_dev=n_rays_dev, want_stats=want_stats, loss_out=loss_out, far0=far0,
+                                                            poison=poison, poison_tag=iteration_idx)
         grad_params = None
         grad_work = None
         if want_param_grads or want_ray_grads:
-            if accumulate_into_param_grad and want_param_grads:
+            if not want_param_grads:
+                grad_params = None            # frozen parameters (tracking / freeze_sigma phases): input gradient only - no table-
+                                              # gradient records, no reduce, no 30 MB zero buffer (lnr_density_backward, grad_params NULL)
+            elif accumulate_into_param_grad:
                 if params.grad is None:
                     params.grad = torch.zeros_like(params)
                 grad_params = params.grad
@@ -484,7 +516,10 @@ class Optimizer:
             ops.density_backward(spec, p, d_sigma, grad_params, rays=rays, z=z, n_rays_dev=n_rays_dev,
                                  reuse_features=True, d_rays=d_rays if want_ray_grads else None)
             if self._dist is not None and want_param_grads:
-                grad_work = self._dist.exchange_grads(grad_params, int(spec.n_mlp_params), async_op=True)
+                # only the training loop (defer_grad_wait) steps a slice and gathers the parameters; every other caller
+                # (compute_loss -> autograd -> an optimiser of its own) gets the whole sum whatever the exchange form
+                grad_work = self._dist.exchange_grads(grad_params, int(spec.n_mlp_params), async_op=True,
+                                                      force_all_reduce=not defer_grad_wait)
                 if not defer_grad_wait:
                     grad_work.wait()
                     grad_work = None
@@ -573,7 +608,7 @@ class Optimizer:
                               grad_buf=self._grad_buf, n_rays_dev=res["n_rays_dev"])
         if self._dist is not None:
             self._dist.all_reduce_grads(self._grad_buf)
-        ops.occ_grid_apply(grid.data, self._grad_buf, occ.lr, zero_grad=True)
+        ops.occ_grid_apply(grid.data, self._grad_buf, occ.lr, zero_grad=True, poison=self._poison)
         self._occupancy_grid = self._occupancy_grid_model()
         self._ray_sampler.update_occ_grid(self._occupancy_grid.detach())
 

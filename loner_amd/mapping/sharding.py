@@ -80,12 +80,14 @@ class DistContext:
         chunk = n_table // self.world_size
         return n_mlp + self.rank * chunk, n_mlp + (self.rank + 1) * chunk
 
-    def exchange_grads(self, flat: torch.Tensor, n_mlp: int, async_op: bool = True):
+    def exchange_grads(self, flat: torch.Tensor, n_mlp: int, async_op: bool = True, force_all_reduce: bool = False):
         """Sum the flat density gradient [MLP | tables] over the ranks.  After .wait(): form "all_reduce" - `flat` holds the sum
         everywhere; form "reduce_scatter" - flat[:n_mlp] and flat[lo:hi] (table_slice) hold the sums, the rest of the table
-        gradient is zeroed (it belongs to other ranks)."""
+        gradient is zeroed (it belongs to other ranks).  force_all_reduce: the whole sum everywhere whatever the configured
+        form - for callers that hand the gradient to an optimiser of their own (Optimizer.compute_loss through autograd): only
+        the training loop knows how to step a slice and gather the parameters afterwards."""
         bf16 = self.payload == "bf16"
-        sl = self.table_slice(n_mlp, flat.numel())
+        sl = None if force_all_reduce else self.table_slice(n_mlp, flat.numel())
         if sl is None:
             buf = flat.to(torch.bfloat16) if bf16 else flat
             work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -130,10 +132,20 @@ class DistContext:
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         return work if async_op else flat
 
+    def all_reduce_max(self, t: torch.Tensor) -> torch.Tensor:
+        """element-wise maximum over the ranks, in place (the failure guard's {code, iteration} word at the end of a phase)"""
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return t
+
     def broadcast_far0(self, rays, device=None) -> torch.Tensor:
         """The reference's `depth > far[0]` test (optimizer.py:460-461) uses the first ray of the whole batch.  Rank 0 owns the
         first active keyframe, hence that ray: it sends `rays[0, 12]`, everyone gets a device float [1] to hand to
-        lnr_count_opaque / lnr_los_loss_fused.  `rays` may be None on ranks without rays."""
+        lnr_count_opaque / lnr_los_loss_fused.  `rays` may be None on ranks without rays.
+        Limitation (documented): if the cube test drops EVERY candidate ray of the first active keyframe,
+        the single-GPU batch starts with a later keyframe's ray while rank 0 still sends the first row of its own compacted
+        batch (its next keyframe's first ray, or a dead row if it has none left); finding the true first ray would cost a
+        second small collective and several device-side index operations per iteration for a case that needs a whole
+        keyframe of 512 rays to miss the world cube."""
         if self.rank == 0:
             far0 = rays[0:1, 12].clone()
         else:

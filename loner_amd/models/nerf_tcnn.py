@@ -108,9 +108,12 @@ class DecoupledNeRF(nn.Module):
         w, nh = int(net.get("n_neurons", 64)), int(net.get("n_hidden_layers", 4))
         in_dim = -(-(pe.enc_dim + (16 if self._enable_view_dependence else 0)) // 16) * 16
         self._model_intensity = _FrozenParams(w * in_dim + (nh - 1) * w * w + 16 * w, num_colors)
-        self._max_float = torch.finfo(torch.float32).max
-        self._min_float = torch.finfo(torch.float32).min
+        # the clip limits are those of the network's dtype (nerf_tcnn.py:51-52): fp32, or fp16 in the reference's precision
+        half = hip.PRECISIONS[str(dict(cfg["sigma_network"]).get("precision", "fp32"))] == 1
+        self._max_float = torch.finfo(torch.float16 if half else torch.float32).max
+        self._min_float = torch.finfo(torch.float16 if half else torch.float32).min
         self._warn_infinite = True
+        self._clipped_seen = 0
 
     def forward(self, pos, dir=None, sigma_only=False, detach_sigma=True):
         """pos [N,3] in the world cube [-1,1] -> sigma [N,1] (nerf_tcnn.py:59-82).  Only sigma_only=True
@@ -118,4 +121,17 @@ class DecoupledNeRF(nn.Module):
         if not sigma_only:
             raise NotImplementedError("colour rendering (sigma_only=False) is not part of the LiDAR mapping path")
         sigma = self._model_sigma.density(pos)[..., None]
+        self.warn_if_clipped(pos.device)
         return sigma
+
+    def warn_if_clipped(self, device):
+        """The kernels clip non-finite densities themselves (nan_to_num semantics, nerf_tcnn.py:70-78) and count them in a
+        status word of the workspace; this prints the reference's warning the first time the count moves.  Reads one device
+        word (a sync - the reference's `torch.isfinite(sigma).all()` is one too); the training loop calls it once per phase."""
+        if not self._warn_infinite:
+            return
+        n = ops.density_clipped_count(device)
+        if n > self._clipped_seen:
+            print("Warning: Clipping infinite outputs. Will not warn about this again (but it will happen again)")
+            self._warn_infinite = False
+        self._clipped_seen = n

@@ -62,9 +62,22 @@ def _workspace(spec, device, n_points):
     key = str(device)
     ent = _workspaces.get(key)
     if ent is None or ent["buf"].numel() * 4 < need:
-        ent = {"buf": torch.empty((need + 3) // 4, device=device, dtype=torch.float32), "features_of": None}
+        clipped = 0 if ent is None else ent["clipped_before"] + int(ent["buf"][:1].view(torch.int32).item())
+        _workspaces.pop(key, None)
+        ent = None                                  # release the old buffer before the larger one is allocated
+        ent = {"buf": torch.empty((need + 3) // 4, device=device, dtype=torch.float32), "features_of": None, "clipped_before": clipped}
+        check(load().lnr_density_workspace_init(_ptr(ent["buf"]), ent["buf"].numel() * 4, _stream()), "lnr_density_workspace_init")
         _workspaces[key] = ent
     return ent, need
+
+
+def density_clipped_count(device) -> int:
+    """Number of density outputs the forward kernels have clipped on `device` so far (non-finite values, and values beyond
+    +-65504 in the fp16 mode: nerf_tcnn.py:70-78).  Reads a status word of the workspace: synchronises with the device."""
+    ent = _workspaces.get(str(device))
+    if ent is None:
+        return 0
+    return ent["clipped_before"] + int(ent["buf"][hip.STATUS_CLIPPED:hip.STATUS_CLIPPED + 1].view(torch.int32).item())
 
 
 def density_forward(spec, params, pts=None, rays=None, z=None, n_rays_dev=None):
@@ -192,14 +205,15 @@ def pose_forward(pose6):
     return T
 
 
-def pose_backward(pose6, d_transforms, mask=None, out=None, accumulate=False):
-    require_device(pose6, d_transforms, mask, out)
+def pose_backward(pose6, d_transforms, mask=None, out=None, accumulate=False, poison=None, poison_tag=0):
+    """poison (int32[2] device word, optional): failure guard, see include/loner_hip.h."""
+    require_device(pose6, d_transforms, mask, out, poison)
     p = _f32c(pose6.detach()).reshape(-1, 6)
     if out is None:
         out = torch.empty_like(p)
         accumulate = False
-    check(load().lnr_pose_backward(_ptr(p), _ptr(_f32c(d_transforms)), _ptr(mask), p.shape[0], _ptr(out), int(accumulate), _stream()),
-          "lnr_pose_backward")
+    check(load().lnr_pose_backward(_ptr(p), _ptr(_f32c(d_transforms)), _ptr(mask), p.shape[0], _ptr(out), int(accumulate),
+                                   _ptr(poison), int(poison_tag), _stream()), "lnr_pose_backward")
     return out
 
 
@@ -354,8 +368,8 @@ def count_opaque(rays, depth_gt, n_rays_dev=None, far0=None):
 
 
 def los_loss_fused(sigma, z, rays, depth_gt, scale, cfg: hip.LossConfig, counts, noise=None, noise_std=0.0, seed=0,
-                   n_rays_dev=None, want_stats=False, want_weights=False, loss_out=None, far0=None):
-    require_device(sigma, z, rays, depth_gt, counts, noise, far0)
+                   n_rays_dev=None, want_stats=False, want_weights=False, loss_out=None, far0=None, poison=None, poison_tag=0):
+    require_device(sigma, z, rays, depth_gt, counts, noise, far0, poison)
     sigma, z, rays, depth_gt = _f32c(sigma), _f32c(z), _f32c(rays), _f32c(depth_gt)
     n, s = z.shape
     dev = z.device
@@ -368,17 +382,18 @@ def los_loss_fused(sigma, z, rays, depth_gt, scale, cfg: hip.LossConfig, counts,
     partials = torch.empty(((n + hip.LOSS_RAYS_PER_BLOCK - 1) // hip.LOSS_RAYS_PER_BLOCK) * 8, device=dev)
     check(load().lnr_los_loss_fused(_ptr(sigma), _ptr(z), _ptr(rays), _ptr(depth_gt), n, _ptr(n_rays_dev), s,
                                     _ptr(_f32c(noise)), float(noise_std), int(seed), float(scale), C.byref(cfg), _ptr(counts),
-                                    _ptr(far0), _ptr(loss_out), _ptr(d_sigma), _ptr(d_rays), _ptr(stats), _ptr(w), _ptr(partials), _stream()),
+                                    _ptr(far0), _ptr(loss_out), _ptr(d_sigma), _ptr(d_rays), _ptr(stats), _ptr(w), _ptr(partials),
+                                    _ptr(poison), int(poison_tag), _stream()),
           "lnr_los_loss_fused")
     return loss_out, d_sigma, d_rays, stats, w
 
 
 # ---------------------------------------------------------------- optimisers
-def adam_step(params, grads, exp_avg, exp_avg_sq, lr, step, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, zero_grad=True):
-    require_device(params, grads, exp_avg, exp_avg_sq)
+def adam_step(params, grads, exp_avg, exp_avg_sq, lr, step, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, zero_grad=True, poison=None):
+    require_device(params, grads, exp_avg, exp_avg_sq, poison)
     check(load().lnr_adam_step(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), params.numel(), float(lr),
                                float(betas[0]), float(betas[1]), float(eps), int(step), float(grad_scale), int(zero_grad),
-                               _stream()), "lnr_adam_step")
+                               _ptr(poison), _stream()), "lnr_adam_step")
 
 
 def occ_grid_step(grid, rays, z, depth_gt, scale, lr, margin=2.0, l_free=0.25, l_occ=2.5, grad_buf=None, n_rays_dev=None):
@@ -392,10 +407,10 @@ def occ_grid_step(grid, rays, z, depth_gt, scale, lr, margin=2.0, l_free=0.25, l
                                    _stream()), "lnr_occ_grid_step")
 
 
-def occ_grid_apply(grid, grad_buf, lr, zero_grad=True):
-    require_device(grid, grad_buf)
+def occ_grid_apply(grid, grad_buf, lr, zero_grad=True, poison=None):
+    require_device(grid, grad_buf, poison)
     assert grad_buf.dtype == torch.int64 and grad_buf.is_contiguous()
-    check(load().lnr_occ_grid_apply(_ptr(grid), _ptr(grad_buf), grid.numel(), float(lr), int(zero_grad), _stream()),
+    check(load().lnr_occ_grid_apply(_ptr(grid), _ptr(grad_buf), grid.numel(), float(lr), int(zero_grad), _ptr(poison), _stream()),
           "lnr_occ_grid_apply")
 
 

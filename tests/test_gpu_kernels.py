@@ -882,3 +882,51 @@ def test_full_size_iteration_properties(ops):
     out_rays2 = d_rays.clone(); g5 = torch.zeros_like(g1)
     ops.density_backward(spec, params, d_sigma, g5, rays=rays, z=z, d_rays=out_rays2)
     assert torch.equal(out_rays2, out_rays) and torch.equal(g5, g4)          # fixed-point ray sums: reproducible as well
+
+
+# ------------------------------------------------------------------------------------------- failure guard (poison word)
+def test_failure_guard_kernels(ops, golden):
+    """include/loner_hip.h "Failure guard": the loss reduce marks a NaN total, pose_backward a non-finite pose gradient / pose,
+    first event wins with the caller's tag; lnr_adam_step and lnr_occ_grid_apply do nothing once the word is set."""
+    from loner_amd import hip
+    g, spec_o, spec_h = _g8_setup(golden)
+    rays, z, depths, params = dv(g["rays"]), dv(g["z"]), dv(g["depths"]), dv(g["params"])
+    cfg = hip.LossConfig(selection=0, min_js=1.0, max_js=10.0, js_alpha=1.0, los_lambda=1000.0, depth_lambda=0.005, min_eps=0.5, fixed_eps=3.0)
+    counts = ops.count_opaque(rays, depths)
+    sigma = ops.density_forward(spec_h, params, rays=rays, z=z)
+    poison = torch.zeros(2, device=DEV, dtype=torch.int32)
+    loss = ops.los_loss_fused(sigma, z, rays, depths, float(g["scale"]), cfg, counts, noise_std=0.0, poison=poison, poison_tag=7)[0]
+    assert np.isfinite(float(loss[0])) and poison.cpu().tolist() == [0, 0]
+    bad = sigma.clone(); bad[3, 5] = float("nan")
+    loss = ops.los_loss_fused(bad, z, rays, depths, float(g["scale"]), cfg, counts, noise_std=0.0, poison=poison, poison_tag=7)[0]
+    assert np.isnan(float(loss[0])) and poison.cpu().tolist() == [hip.POISON_NAN_LOSS, 7]
+    # first event wins
+    p6 = torch.tensor([[0.1, 0.2, 0.3, 0.01, -0.02, 0.03], [0.0, 0.0, 0.0, 0.3, 0.1, -0.2]], device=DEV)
+    dT = torch.randn(2, 12, device=DEV); dT[1, 4] = float("inf")
+    ops.pose_backward(p6, dT, poison=poison, poison_tag=9)
+    assert poison.cpu().tolist() == [hip.POISON_NAN_LOSS, 7]
+    # pose gradient / pose checks on a fresh word; a fixed pose's gradient is exactly zero even if its cotangent is not finite
+    poison.zero_()
+    mask = torch.tensor([1, 0], device=DEV, dtype=torch.uint8)
+    d = ops.pose_backward(p6, dT, mask=mask, poison=poison, poison_tag=2)
+    assert poison.cpu().tolist() == [0, 0] and float(d[1].abs().max()) == 0.0 and torch.isfinite(d).all()
+    ops.pose_backward(p6, dT, poison=poison, poison_tag=3)
+    assert poison.cpu().tolist() == [hip.POISON_POSE_GRAD, 3]
+    poison.zero_()
+    p_bad = p6.clone(); p_bad[0, 1] = float("nan")
+    ops.pose_backward(p_bad, torch.zeros(2, 12, device=DEV), mask=torch.tensor([0, 1], device=DEV, dtype=torch.uint8), poison=poison, poison_tag=4)
+    assert poison.cpu().tolist() == [hip.POISON_POSE, 4]
+    # the step kernels obey the word
+    n = 1003
+    p, gr, m, v = torch.randn(n, device=DEV), torch.randn(n, device=DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    p0, g0 = p.clone(), gr.clone()
+    ops.adam_step(p, gr, m, v, 0.01, 1, zero_grad=True, poison=poison)
+    assert torch.equal(p, p0) and torch.equal(gr, g0) and float(m.abs().max()) == 0.0
+    grid, buf = torch.randn(8, 8, 8, device=DEV), torch.randint(-1000, 1000, (512,), device=DEV, dtype=torch.int64) << 30
+    grid0, buf0 = grid.clone(), buf.clone()
+    ops.occ_grid_apply(grid, buf, 1e-2, poison=poison)
+    assert torch.equal(grid, grid0) and torch.equal(buf, buf0)
+    poison.zero_()
+    ops.adam_step(p, gr, m, v, 0.01, 1, zero_grad=True, poison=poison)
+    ops.occ_grid_apply(grid, buf, 1e-2, poison=poison)
+    assert not torch.equal(p, p0) and not torch.equal(grid, grid0)

@@ -587,3 +587,116 @@ def test_cfg1_loop_matches_oracle_with_default_network():
     print("touched params", int(touched.sum()), "of", touched.numel(), " mean diff over touched", float(diff[touched].mean()))
     assert moved > 1e-3 and float(torch.quantile(diff[touched][:2000000], 0.9)) < 2e-2 * moved
     assert rel(opt._occupancy_grid_model.occupancy_grid[0, 0], oracle.grid[0, 0]) < 1e-3
+
+
+def _guarded_run(inject, n_it=8, at=4, precision="fp32"):
+    """A joint map + pose phase of n_it iterations on the small network; `inject(opt, pose_dev)` runs inside the loop right before
+    the density forward of iteration `at` (no host sync).  -> (opt, keyframes, snapshot taken at that moment, raised exception)"""
+    from loner_amd import ops
+    from loner_amd.mapping.optimizer import OptimizationSettings, Optimizer
+    from loner_amd.utils import synthetic as SY
+    s = small_settings(96, 64)
+    s["model_config"]["model"]["nerf_config"]["sigma_network"]["precision"] = precision
+    torch.manual_seed(0)
+    opt = Optimizer(s, None, world_cube(), 0, False, True, False)
+    base = SY.trajectory_pose6(2)
+    kfs = make_keyframes([base[0], base[1] + torch.tensor([0.02, -0.01, 0.0, 0.0, 0.0, 0.0])])
+    kfs[0].is_anchored = True
+    snap, calls = {}, [0]
+    orig_fwd, orig_pose_fwd = ops.density_forward, ops.pose_forward
+    pose_seen = []
+
+    def pose_fwd(p):
+        pose_seen.append(p)
+        return orig_pose_fwd(p)
+
+    def fwd(spec, params, **kw):
+        if calls[0] == at:
+            # the deferred density step of iteration at-1 has landed (it is flushed right before this call): this is the state
+            # the failing iteration starts from
+            snap["params"] = params.detach().clone()
+            snap["poses"] = pose_seen[-1].detach().clone()
+            snap["grid"] = opt._occupancy_grid_model.occupancy_grid.detach().clone()
+            inject(opt, pose_seen[-1], params)
+        calls[0] += 1
+        return orig_fwd(spec, params, **kw)
+    ops.density_forward, ops.pose_forward = fwd, pose_fwd
+    err = None
+    try:
+        torch.manual_seed(3)
+        opt._do_iterate_optimizer(kfs, [None], optimizer_settings=OptimizationSettings(n_it, False, False, False, True))
+    except (RuntimeError, AssertionError) as e:
+        err = e
+    finally:
+        ops.density_forward, ops.pose_forward = orig_fwd, orig_pose_fwd
+    return opt, kfs, snap, err
+
+
+def test_failure_in_iteration_k_stops_every_update_at_iteration_k():
+    """The reference checks loss / pose gradient / pose in EVERY iteration and raises before optimizer.step()
+    (optimizer.py:368-374,590).  Here the kernels of the failing iteration mark a device word and every later step kernel obeys
+    it: parameters, poses and the occupancy grid keep the values they had when iteration k began, and the reference's error is
+    raised at the end of the phase - without a host sync per iteration."""
+    from loner_amd import hip
+
+    # (a) an infinite MLP weight: sigma is clipped (finite loss, like the reference's nan_to_num), but the gradient that flows back
+    # through that weight is not finite -> "invalid gradient in pose"
+    def inf_weight(opt, pose_dev, params):
+        params.view(-1)[5] = float("inf")
+    opt, kfs, snap, err = _guarded_run(inf_weight)
+    assert isinstance(err, RuntimeError) and str(err) == "Fatal: Encountered invalid gradient in pose."
+    assert opt.last_failure == {"code": hip.POISON_POSE_GRAD, "iteration": 4}
+    p = opt._model.nerf_model._model_sigma.params.detach()
+    keep = torch.ones_like(p, dtype=torch.bool); keep[5] = False
+    assert torch.equal(p[keep], snap["params"][keep]), "density parameters moved after the failing iteration"
+    assert torch.equal(opt._occupancy_grid_model.occupancy_grid.detach(), snap["grid"])
+    got = torch.stack([kf.get_lidar_pose().get_pose_tensor().detach().cpu() for kf in kfs])
+    assert torch.equal(got, snap["poses"].cpu()), "poses moved after the failing iteration"
+    assert torch.isfinite(got).all()
+
+    # (b) a pose that turns NaN in the middle of iteration 4 (after its rays were built): the loss of that iteration is still
+    # finite, its pose check is not -> one of the two pose errors, at iteration 4, and nothing moves from there on
+    def nan_translation(opt, pose_dev, params):
+        pose_dev.data[1, 0] = float("nan")
+    opt, kfs, snap, err = _guarded_run(nan_translation)
+    assert isinstance(err, RuntimeError) and str(err) in ("Fatal: Encountered invalid gradient in pose.", "Fatal: Encountered invalid pose tensor.")
+    assert opt.last_failure["iteration"] == 4 and opt.last_failure["code"] in (hip.POISON_POSE, hip.POISON_POSE_GRAD)
+    p = opt._model.nerf_model._model_sigma.params.detach()
+    assert torch.equal(p, snap["params"]) and torch.isfinite(p).all(), "a step was applied after the failing iteration"
+    assert torch.equal(opt._occupancy_grid_model.occupancy_grid.detach(), snap["grid"])
+
+    # (c) a healthy run raises nothing and leaves the word at zero
+    opt, kfs, snap, err = _guarded_run(lambda *a: None)
+    assert err is None and opt.last_failure is None
+
+
+def test_fp16_mode_clips_sigma_at_the_half_extremes_and_warns_once(capsys):
+    """nerf_tcnn.py:51-52,70-78: non-finite densities are replaced by the extremes of the NETWORK's dtype (fp16 in the reference:
+    +-65504; whatever exceeds that is +-inf in an fp16 output) and NaN by 0, with one warning."""
+    from loner_amd import hip, ops
+    from loner_amd.models.nerf_tcnn import DecoupledNeRF
+    from loner_amd.common.settings import default_nerf_config
+    for prec, lim in (("fp16", 65504.0), ("fp32", float(torch.finfo(torch.float32).max))):
+        nc = default_nerf_config()
+        nc["sigma_network"]["precision"] = prec
+        torch.manual_seed(1)
+        net = DecoupledNeRF(nc).to(DEV)
+        sig = net._model_sigma
+        n_mlp = int(sig.spec.n_mlp_params)
+        pts = (torch.rand(4096, 3, device=DEV) * 1.6 - 0.8)
+        with torch.no_grad():
+            sig.params[n_mlp:] *= 1e4                       # features of order one
+            out_row = sig.params[sig.spec.n_neurons * sig.spec.in_dim: sig.spec.n_neurons * sig.spec.in_dim + sig.spec.n_neurons]
+            out_row.fill_(3e4 if prec == "fp16" else 1e38)  # sum of 64 relu(z) * 3e4 exceeds 65504 for many points, never inf in fp32 ...
+            if prec == "fp32":
+                out_row[0] = float("inf")                   # ... so the fp32 case gets a genuine inf
+        before = ops.density_clipped_count(pts.device)
+        capsys.readouterr()
+        s = net(pts, sigma_only=True)
+        text = capsys.readouterr().out
+        assert torch.isfinite(s).all() and float(s.abs().max()) == lim
+        assert ops.density_clipped_count(pts.device) > before
+        assert text.count("Clipping infinite outputs") == 1 and net._warn_infinite is False
+        net(pts, sigma_only=True)
+        assert "Clipping" not in capsys.readouterr().out    # once only
+        assert (net._max_float, net._min_float) == (lim, -lim)

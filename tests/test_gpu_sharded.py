@@ -224,3 +224,21 @@ def test_rccl_world_size_one_is_bit_identical_to_non_distributed():
     assert np.array_equal(r["loss"], single["loss"])
     for a, b in zip(r["poses"], single["poses"]):
         assert np.array_equal(a, b)
+
+
+def test_bench_entry_point_spawns_its_ranks_and_reports_what_the_group_saw():
+    """`python bench.py --gpus 2` (no launcher around it) on the one GPU of the box, ranks over gloo: the line's n_gpus is the
+    process group's world size and the sharded window trains (the driver's SCALE runs use this entry point with RCCL)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LNR_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--keyframes", "4",
+                        "--rays", "128", "--samples", "128", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["parallelism"] == "keyframe-sharded x2"

@@ -183,3 +183,23 @@ def test_synthetic_scene_is_exact_and_has_transparent_rays():
     assert float(r.min()) > 1.0 and int((r > 50).sum()) > 100          # window rays exceed the 50 m range
     scale, shift = SY.world_cube()
     assert abs(scale - 85.7614) < 1e-3 and np.allclose(shift, [7.5, 5.0, 0.0])
+
+
+def test_bench_gpus_argument_spawns_that_many_ranks():
+    """`python bench.py --gpus N` with no launcher around it must become N ranks (--gpus was parsed and ignored).
+    --launch-check runs the argument -> torch.distributed.run -> process group path alone, over gloo on the CPU."""
+    import json
+    env = dict(os.environ, LNR_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and sorted(line["ranks"]) == [0, 1]
+    # a launcher that started a different number of ranks than --gpus is an error, not a silently wrong n_gpus
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--launch-check"],
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "--gpus 4" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--launch-check"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
