@@ -100,6 +100,17 @@ def window_poses(n_kf):
     return base, init
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
 def oracle_leg(args, device, budget_s, max_iters, min_iters=2):
     """A baseline leg: the oracle (oracle/mapping_step.py - the reference's mapping iteration restated op for op in torch, with
     the reference's own sampler op sequence, oracle/torch_sampling.py) on the SAME workload as the HIP path: the whole
@@ -159,6 +170,8 @@ def oracle_leg(args, device, budget_s, max_iters, min_iters=2):
            "ms_per_iter": 1e3 * dt / iters, "iterations": iters, "l1_depth_m_after": l1}
     if dev.type == "cpu":
         out["cores"] = threads
+        out["host_cores"] = os.cpu_count()
+        out["cpu_model"] = cpu_model()
     else:
         out["device"] = torch.cuda.get_device_name(0)
         out["kind"] = "port (the oracle's torch ops through PyTorch-ROCm on the same MI355X: a restatement - the reference's density net is tinycudann, CUDA-only)"

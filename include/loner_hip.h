@@ -71,6 +71,7 @@ typedef enum LnrPosRounding { LNR_POS_FMA = 0, LNR_POS_MUL_ADD = 1 } LnrPosRound
 
 /* lnr_density_backward flags */
 #define LNR_BWD_TABLE_ATOMICS 1   /* test hook: every table-gradient record goes to the 64-bit overflow accumulators (atomics) */
+#define LNR_BWD_REPORT_REGIONS 2  /* diagnostic: print to stderr how full the record regions ran (synchronises the stream) */
 
 typedef enum LnrActivation {
     LNR_ACT_NONE = 0, LNR_ACT_RELU = 1, LNR_ACT_SINE = 2, LNR_ACT_LEAKY_RELU = 3,
@@ -135,6 +136,9 @@ int lnr_net_spec_finalize(LnrNetSpec* spec /*host, in/out*/);
  * table-gradient partition.  The content between calls only matters for `reuse_features` below.
  * Limits: n_points * max(n_features_per_level, 4) < 2^30 per call, encoding table < 2^30 floats (32-bit byte offsets). */
 size_t lnr_density_workspace(const LnrNetSpec* spec /*host*/, int64_t n_points);
+/* The part of it lnr_density_forward alone needs (status words + feature planes): rendering / inference callers
+ * (Model.forward(testing=True), analysis/compute_l1_depth.py:42-64) never pay for the backward's record regions. */
+size_t lnr_density_workspace_forward(const LnrNetSpec* spec /*host*/, int64_t n_points);
 
 /* The first LNR_WORKSPACE_STATUS_BYTES of a workspace are int32 status words the kernels write and the caller may read (with
  * the device in sync) and reset; lnr_density_workspace_init zeroes them - call it once after allocating a workspace.

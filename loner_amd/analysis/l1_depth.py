@@ -27,8 +27,7 @@ def compute_l1_depth(lidar_pose, ray_directions: LidarRayDirections, model, ray_
         rays, depths = ray_directions.build_lidar_rays(chunk, ray_range, world_cube, T)
         if rays.shape[0] == 0:
             continue
-        out = model(rays.detach(), ray_sampler, scale, testing=True, return_variance=True, camera=False)
-        rendered = out["depth_fine"] * float(scale)
+        rendered = model.render_depth(rays, ray_sampler, scale, testing=True) * float(scale)   # = forward(testing=True)["depth_fine"]
         gt = depths * float(scale)
         good = (gt > float(ray_range[0])) & (gt < float(ray_range[1]) - 0.25)
         err_sum += float((rendered[good] - gt[good]).abs().sum())

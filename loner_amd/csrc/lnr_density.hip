@@ -409,7 +409,7 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
     return L;
 }
 
-// LNR_REPORT_REGIONS=1: how full the record regions ran (diagnostic for sizing RegionPlan; synchronises the stream)
+// flag LNR_BWD_REPORT_REGIONS: how full the record regions ran (diagnostic for sizing RegionPlan; synchronises the stream)
 static void report_regions(const LnrNetSpec* spec, const Layout& L, const RegionPlan& plan, const int* counts, const float* dfeat, int64_t n_points, hipStream_t st) {
     std::vector<int> h((size_t)spec->n_levels * L.maxo * L.bpg);
     if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(h.data(), counts, h.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return;
@@ -556,6 +556,11 @@ extern "C" size_t lnr_density_workspace(const LnrNetSpec* spec, int64_t n_points
     return make_layout(spec, n_points).total;
 }
 
+extern "C" size_t lnr_density_workspace_forward(const LnrNetSpec* spec, int64_t n_points) {
+    if (!spec || n_points < 0) return 0;
+    return make_layout(spec, n_points).off_dfeat;          // status words + feature planes: all the forward touches
+}
+
 extern "C" int lnr_density_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
     LNR_REQUIRE(workspace != nullptr && workspace_bytes >= LNR_WORKSPACE_STATUS_BYTES, "lnr_density_workspace_init: workspace too small");
     if (hipMemsetAsync(workspace, 0, LNR_WORKSPACE_STATUS_BYTES, (hipStream_t)stream) != hipSuccess) {
@@ -580,8 +585,8 @@ extern "C" int lnr_density_forward(const LnrNetSpec* spec, const float* params, 
     LNR_REQUIRE(cap * (spec->n_features > 4 ? spec->n_features : 4) < (1ll << 30),
                 "lnr_density_forward: too many points per call for 32-bit plane offsets (n_points * max(n_features, 4) must be < 2^30)");
     const Layout L = make_layout(spec, cap);
-    if (workspace_bytes < L.total) {
-        lnr_set_error("lnr_density_forward: workspace %zu < %zu (lnr_density_workspace)", workspace_bytes, L.total);
+    if (workspace_bytes < L.off_dfeat) {
+        lnr_set_error("lnr_density_forward: workspace %zu < %zu (lnr_density_workspace_forward)", workspace_bytes, L.off_dfeat);
         return LNR_ERR_WORKSPACE;
     }
     const bool f16 = spec->precision == LNR_PREC_F16;
@@ -700,7 +705,7 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
                                  ovf, d_pts_eff, ray_accum ? d_rays : nullptr, (long long*)(ws + L.off_rayacc), st);
         if (rc) return rc;
         LNR_CHECK_LAUNCH("lnr_density_backward(encode backward)");
-        if (hash && want_grad && getenv("LNR_REPORT_REGIONS")) {
+        if (hash && want_grad && (flags & LNR_BWD_REPORT_REGIONS)) {           // diagnostic, call-time flag: synchronises the stream
             int64_t live = cap;
             int32_t nr = 0;
             if (n_rays_dev && hipStreamSynchronize(st) == hipSuccess && hipMemcpy(&nr, n_rays_dev, sizeof(nr), hipMemcpyDeviceToHost) == hipSuccess) live = (int64_t)nr * n_samples;

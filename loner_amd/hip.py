@@ -26,6 +26,7 @@ LOSS_SELECTIONS = {"L1_JS": 0, "L2_JS": 1, "L1_LOS": 2, "L2_LOS": 3}
 PRECISIONS = {"fp32": 0, "float32": 0, "fp16": 1, "half": 1, "float16": 1}
 POS_ROUNDINGS = {"fma": 0, "mul_add": 1}
 BWD_TABLE_ATOMICS = 1        # LNR_BWD_TABLE_ATOMICS
+BWD_REPORT_REGIONS = 2       # LNR_BWD_REPORT_REGIONS
 WORKSPACE_STATUS_BYTES, STATUS_CLIPPED = 256, 0            # LNR_WORKSPACE_STATUS_BYTES, LNR_STATUS_CLIPPED
 POISON_NAN_LOSS, POISON_POSE_GRAD, POISON_POSE = 1, 2, 3      # LNR_POISON_* codes of the failure guard (int32[2] device word)
 
@@ -56,6 +57,7 @@ _SIGNATURES = {
     "lnr_profile_read": (C.c_int, [P, C.c_int32, P, P, C.c_int32]),
     "lnr_net_spec_finalize": (C.c_int, [C.POINTER(NetSpec)]),
     "lnr_density_workspace": (C.c_size_t, [C.POINTER(NetSpec), C.c_int64]),
+    "lnr_density_workspace_forward": (C.c_size_t, [C.POINTER(NetSpec), C.c_int64]),
     "lnr_density_workspace_init": (C.c_int, [P, C.c_size_t, P]),
     "lnr_density_forward": (C.c_int, [C.POINTER(NetSpec), P, P, C.c_int64, P, P, C.c_int32, C.c_int32, P, P, P, C.c_size_t, P]),
     "lnr_density_backward": (C.c_int, [C.POINTER(NetSpec), P, P, C.c_int64, P, P, C.c_int32, C.c_int32, P, P, P, P, P,

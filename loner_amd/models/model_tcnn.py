@@ -1,6 +1,4 @@
 """Model / OccupancyGridModel with the reference's interface (src/models/model_tcnn.py), on HIP."""
-from collections import defaultdict
-
 import torch
 import torch.nn as nn
 
@@ -48,24 +46,94 @@ class Model(nn.Module):
     def inference_points(self, xyz_, dir_, sigma_only):
         return inference(self.nerf_model, xyz_, dir_, netchunk=0, sigma_only=sigma_only, meshing=True)
 
+    # rays per launch of the no-grad route: up to 2^24 samples per launch (8192 rays at 2048 samples: 2 GB of feature planes)
+    _POINTS_PER_LAUNCH = 1 << 24
+
+    def _sample_counts(self, testing):
+        r = self.cfg.render
+        return (r.N_samples_test, 0.) if testing else (r.N_samples_train, r.perturb)
+
+    def _render_no_grad(self, rays, ray_sampler, n_samples, perturb, want_weights, want_variance):
+        """Rendering without autograd (Model.forward under no_grad / for inputs that need no gradient, render_depth): the whole
+        batch goes through sampler -> density forward -> compositing in launches of _POINTS_PER_LAUNCH samples, whatever
+        cfg.render.chunk says (the reference's chunk loop, model_tcnn.py:81-101, bounds ITS memory; results do not depend on
+        it).  Nothing is kept for a backward pass: forward-only workspace, no [N,S] weights unless asked for.
+        Parity hook: a `draws` object on the sampler is consumed chunk by chunk in the reference's order (per chunk: sampler
+        draws, then the density noise), so recorded reference draws replay bit for bit."""
+        rays = rays.detach().float().contiguous()
+        net = self.nerf_model._model_sigma
+        noise_std = float(self.cfg.render.raw_noise_std)
+        n = rays.shape[0]
+        draws = getattr(ray_sampler, "_draws", None)
+        occ = hasattr(ray_sampler, "update_occ_grid")
+        pre = None
+        if draws is not None:
+            u1, u2, nz = [], [], []
+            for lo in range(0, n, self.cfg.render.chunk):
+                m = min(self.cfg.render.chunk, n - lo)
+                if perturb > 0:
+                    u1.append(draws.jitter(m, n_samples // 2 if occ else n_samples))
+                if occ:
+                    u2.append(draws.pdf(m, n_samples // 2))
+                if noise_std > 0:
+                    nz.append(draws.noise(m, n_samples) * noise_std)
+            cat = lambda xs: torch.cat(xs).to(rays.device) if xs else None
+            pre = (cat(u1), cat(u2), cat(nz))
+        step = max(64, self._POINTS_PER_LAUNCH // int(n_samples))
+        out = {"depth": [], "opacity": [], "variance": [], "weights": [], "z": []}
+        for lo in range(0, n, step):
+            r = rays[lo:lo + step]
+            kw = {}
+            noise = None
+            if pre is not None:
+                if pre[0] is not None:
+                    kw["u_jitter"] = pre[0][lo:lo + step]
+                if pre[1] is not None:
+                    kw["u_pdf"] = pre[1][lo:lo + step]
+                noise = pre[2][lo:lo + step] if pre[2] is not None else None
+            z = ray_sampler.get_samples(r, n_samples, perturb, **kw)
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (noise is None and noise_std > 0) else 0
+            sigma = ops.density_forward(net.spec, net.params.detach(), rays=r, z=z, forward_only=True)
+            depth, weights, opacity, variance = ops.render_forward(sigma, z, r, noise=noise, noise_std=noise_std, seed=seed,
+                                                                   want_weights=want_weights)
+            for k, v in (("depth", depth), ("opacity", opacity), ("variance", variance), ("weights", weights), ("z", z)):
+                if v is not None and (k != "z" or self.cfg.render.retraw):
+                    out[k].append(v)
+        self.nerf_model.warn_if_clipped(rays.device)
+        return {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in out.items() if v}
+
+    @torch.no_grad()
+    def render_depth(self, rays, ray_sampler, scale_factor=None, testing=True):
+        """Rendered depth per ray and nothing else (what compute_l1_depth, renderer_lidar and the meshing consumers read from the
+        result dictionary: analysis/compute_l1_depth.py:56-58): the lean form of forward(testing=True, camera=False)."""
+        n_samples, perturb = self._sample_counts(testing)
+        return self._render_no_grad(rays, ray_sampler, n_samples, perturb, want_weights=False, want_variance=False)["depth"]
+
     def forward(self, rays, ray_sampler, scale_factor, testing=False, camera=True, detach_sigma=True, return_variance=False):
-        """Batched rendering in chunks of cfg.render.chunk rays (model_tcnn.py:70-105)."""
-        if testing:
-            n_samples, perturb = self.cfg.render.N_samples_test, 0.
-        else:
-            n_samples, perturb = self.cfg.render.N_samples_train, self.cfg.render.perturb
-        results = defaultdict(list)
-        for i in range(0, rays.shape[0], self.cfg.render.chunk):
-            chunk = render_rays(rays[i:i + self.cfg.render.chunk, :], ray_sampler, self.nerf_model, self.cfg.ray_range,
-                                scale_factor, N_samples=n_samples, retraw=self.cfg.render.retraw, perturb=perturb,
-                                white_bkgd=self.cfg.render.white_bkgd, raw_noise_std=self.cfg.render.raw_noise_std,
-                                netchunk=self.cfg.render.netchunk, num_colors=self.cfg.num_colors, sigma_only=(not camera),
-                                detach_sigma=detach_sigma, return_variance=return_variance)
-            for k, v in chunk.items():
-                results[k] += [v]
-        for k, v in results.items():
-            results[k] = torch.cat(v, 0)
-        return results
+        """Batched rendering with the reference's signature and result dictionary (model_tcnn.py:70-105).  When a gradient can
+        flow (grad mode on and the rays or the density parameters require one) each cfg.render.chunk of rays goes through the
+        differentiable render_rays; otherwise the batch takes the forward-only route in a few large launches."""
+        if camera:
+            raise NotImplementedError("Model.forward: colour rendering (camera=True) is not part of the LiDAR mapping path")
+        n_samples, perturb = self._sample_counts(testing)
+        sig = self.nerf_model._model_sigma.params
+        if not (torch.is_grad_enabled() and (rays.requires_grad or sig.requires_grad)):
+            r = self._render_no_grad(rays, ray_sampler, n_samples, perturb, want_weights=True, want_variance=return_variance)
+            results = {'rgb_fine': torch.tensor([-1.]).repeat(-(-rays.shape[0] // self.cfg.render.chunk)), 'depth_fine': r["depth"],
+                       'weights_fine': r["weights"], 'opacity_fine': r["opacity"]}
+            if return_variance:
+                results["variance"] = r["variance"]
+            if self.cfg.render.retraw:
+                results['samples_fine'] = r["z"]
+                results['points_fine'] = rays[:, None, 0:3] + rays[:, None, 3:6] * r["z"][:, :, None]
+            return results
+        parts = [render_rays(rays[i:i + self.cfg.render.chunk, :], ray_sampler, self.nerf_model, self.cfg.ray_range,
+                             scale_factor, N_samples=n_samples, retraw=self.cfg.render.retraw, perturb=perturb,
+                             white_bkgd=self.cfg.render.white_bkgd, raw_noise_std=self.cfg.render.raw_noise_std,
+                             netchunk=self.cfg.render.netchunk, num_colors=self.cfg.num_colors, sigma_only=True,
+                             detach_sigma=detach_sigma, return_variance=return_variance)
+                 for i in range(0, rays.shape[0], self.cfg.render.chunk)]
+        return {k: torch.cat([p[k] for p in parts], 0) for k in parts[0]}
 
 
 class OccupancyGridModel(nn.Module):

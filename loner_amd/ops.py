@@ -56,9 +56,11 @@ def profile_read():
 _workspaces = {}
 
 
-def _workspace(spec, device, n_points):
-    """One scratch buffer per device, grown on demand (feature planes, gradient records, ... - see the header)."""
-    need = load().lnr_density_workspace(C.byref(spec), int(n_points))
+def _workspace(spec, device, n_points, forward_only=False):
+    """One scratch buffer per device, grown on demand (feature planes, gradient records, ... - see the header).
+    forward_only: sized for lnr_density_forward alone (no backward will follow on these points)."""
+    lib = load()
+    need = (lib.lnr_density_workspace_forward if forward_only else lib.lnr_density_workspace)(C.byref(spec), int(n_points))
     key = str(device)
     ent = _workspaces.get(key)
     if ent is None or ent["buf"].numel() * 4 < need:
@@ -80,30 +82,32 @@ def density_clipped_count(device) -> int:
     return ent["clipped_before"] + int(ent["buf"][hip.STATUS_CLIPPED:hip.STATUS_CLIPPED + 1].view(torch.int32).item())
 
 
-def density_forward(spec, params, pts=None, rays=None, z=None, n_rays_dev=None):
+def density_forward(spec, params, pts=None, rays=None, z=None, n_rays_dev=None, forward_only=False):
+    """forward_only: the caller will not call density_backward(reuse_features=True) on these points - the workspace is sized
+    for the forward alone (rendering / inference: no record regions)."""
     require_device(params, pts, rays, z)
     params = _f32c(params)
     if pts is not None:
         pts = _f32c(pts).reshape(-1, 3)
         n = pts.shape[0]
-        ent, need = _workspace(spec, params.device, n)
+        ent, need = _workspace(spec, params.device, n, forward_only)
         sigma = torch.empty(n, device=params.device, dtype=torch.float32)
         check(load().lnr_density_forward(C.byref(spec), _ptr(params), _ptr(pts), n, None, None, 0, 0, None,
                                          _ptr(sigma), _ptr(ent["buf"]), need, _stream()), "lnr_density_forward")
-        ent["features_of"] = (params.data_ptr(), pts.data_ptr(), 0, n)
+        ent["features_of"] = None if forward_only else (params.data_ptr(), pts.data_ptr(), 0, n)
         return sigma
     rays, z = _f32c(rays), _f32c(z)
     n, s = z.shape
-    ent, need = _workspace(spec, params.device, n * s)
+    ent, need = _workspace(spec, params.device, n * s, forward_only)
     sigma = torch.empty(n, s, device=params.device, dtype=torch.float32)      # rows >= *n_rays_dev are never read
     check(load().lnr_density_forward(C.byref(spec), _ptr(params), None, 0, _ptr(rays), _ptr(z), n, s,
                                      _ptr(n_rays_dev), _ptr(sigma), _ptr(ent["buf"]), need, _stream()), "lnr_density_forward")
-    ent["features_of"] = (params.data_ptr(), rays.data_ptr(), z.data_ptr(), n * s)
+    ent["features_of"] = None if forward_only else (params.data_ptr(), rays.data_ptr(), z.data_ptr(), n * s)
     return sigma
 
 
 def density_backward(spec, params, d_sigma, grad_params, pts=None, rays=None, z=None, n_rays_dev=None,
-                     want_d_pts=False, reuse_features=False, d_rays=None, table_atomics=False):
+                     want_d_pts=False, reuse_features=False, d_rays=None, table_atomics=False, report_regions=False):
     """Accumulates into grad_params [n_params] (None: parameters frozen, only the input gradient is computed);
     returns d_pts ([...,3]) or None.  table_atomics: test hook (LNR_BWD_TABLE_ATOMICS).
     reuse_features: the caller asserts that the last density_forward on this device ran on the same params and
@@ -113,7 +117,7 @@ def density_backward(spec, params, d_sigma, grad_params, pts=None, rays=None, z=
     require_device(params, d_sigma, grad_params, pts, rays, z)
     params, d_sigma = _f32c(params), _f32c(d_sigma)
     assert grad_params is None or (grad_params.dtype == torch.float32 and grad_params.is_contiguous())
-    flags = hip.BWD_TABLE_ATOMICS if table_atomics else 0
+    flags = (hip.BWD_TABLE_ATOMICS if table_atomics else 0) | (hip.BWD_REPORT_REGIONS if report_regions else 0)
     n_points = (pts.numel() // 3) if pts is not None else z.numel()
     ent, need = _workspace(spec, params.device, n_points)
     if pts is not None:
@@ -296,13 +300,14 @@ def sample_rays_uniform(rays, n_samples, perturb, u_jitter=None, seed=0, n_rays_
 
 
 # ---------------------------------------------------------------- rendering
-def render_forward(sigma, z, rays, noise=None, noise_std=0.0, seed=0, n_rays_dev=None):
+def render_forward(sigma, z, rays, noise=None, noise_std=0.0, seed=0, n_rays_dev=None, want_weights=True):
+    """-> (depth, weights, opacity, variance); want_weights=False leaves the [n, S] weights unwritten (returns None for them)."""
     require_device(sigma, z, rays, noise)
     sigma, z, rays = _f32c(sigma), _f32c(z), _f32c(rays)
     n, s = z.shape
     dev = z.device
     depth = torch.zeros(n, device=dev); opacity = torch.zeros(n, device=dev); variance = torch.zeros(n, device=dev)
-    weights = torch.zeros(n, s, device=dev)
+    weights = torch.zeros(n, s, device=dev) if want_weights else None
     check(load().lnr_render_forward(_ptr(sigma), _ptr(z), _ptr(rays), n, _ptr(n_rays_dev), s, _ptr(_f32c(noise)),
                                     float(noise_std), int(seed), _ptr(depth), _ptr(weights), _ptr(opacity), _ptr(variance),
                                     _stream()), "lnr_render_forward")
