@@ -358,7 +358,7 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
     L.maxo = 1;
     size_t ovf_total = 0;
     uint64_t region_total = 0;
-    for (int l = 0; l < LNR_MAX_LEVELS; ++l) { L.plan.off[l] = 0; L.plan.bytes[l] = 0; L.plan.xp[l] = 0; L.plan.split[l] = 1; }
+    for (int l = 0; l < LNR_MAX_LEVELS; ++l) { L.plan.off[l] = 0; L.plan.bytes[l] = 0; L.plan.xp[l] = 0; L.plan.split[l] = 1; L.plan.binned[l] = 0; }
     L.n_split = 0;
     if (hash) {
         const int F = spec->n_features;
@@ -381,6 +381,13 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
                 // so the capacity is generous (sweep in DESIGN.md; the reduce does not care how full a region is)
                 const double recs = (r * LNR_REGION_HEADROOM + LNR_REGION_SLACK) * shrink;
                 uint64_t bytes = (uint64_t)(recs * (xp ? 12.0 : 8.0));
+                // Binned partition (lnr_encode.hip): hashed levels, whose records spread evenly over the owners - a batch (one sample per
+                // thread) must be expected to fill at most half a bin, worst case (nothing dead, nothing combined)
+                const double bin_fill = (double)LNR_ENC_BWD_BLOCK * 8.0 * (xp ? 0.5 * 12.0 : 8.0) / (double)span;
+                const bool binned = F >= 2 && spec->level_hashed[l] != 0 && span <= LNR_BIN_MAX_OWNERS && bin_fill <= 0.5 * LNR_BIN_BYTES + 8.0 &&
+                                    LNR_ENC_BWD_BLOCK == 512 && shrink == 1.0;
+                L.plan.binned[l] = binned ? 1 : 0;
+                if (binned) bytes += LNR_BIN_BYTES + 128;
                 bytes = (bytes + 255u) & ~(uint64_t)255u;
                 // spatially coherent (dense-indexed) levels: several reduce workgroups per owner (table_grad_reduce_split_kernel)
                 int parts = spec->level_hashed[l] == 0 ? LNR_REDUCE_SPLIT : 1;
@@ -400,7 +407,7 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
     L.off_dfeat = off; off += align256((size_t)spec->enc_dim * L.m_pad * sizeof(float));
     L.off_dxl = off; off += align256((size_t)L.n_groups * 3 * L.m_pad * sizeof(float));
     L.off_dpts = off; off += align256((size_t)3 * L.m_pad * sizeof(float));      // d_pts scratch of the general d_rays route
-    L.off_rayacc = off; off += align256((size_t)(L.m_pad / 64) * 6 * sizeof(long long));   // per-ray sums of the d_rays route (n_samples >= 64 there)
+    L.off_rayacc = off; off += align256(((size_t)(L.m_pad / 64) * 6 + 1) * sizeof(long long));   // per-ray sums of the d_rays route (n_samples >= 64 there) + its non-finite word
     L.off_slabs = off; off += align256((size_t)LNR_BWD_MAX_BLOCKS * spec->n_mlp_params * sizeof(float));
     L.off_ovf = off; off += align256(ovf_total * sizeof(long long));
     L.off_counts = off; off += align256(hash ? (size_t)blocks * L.maxo * sizeof(int) : 0);
@@ -662,6 +669,8 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     RegionPlan rplan = L.plan;
     if (flags & LNR_BWD_TABLE_ATOMICS)                       // no room anywhere: every record takes the overflow path
         for (int l = 0; l < LNR_MAX_LEVELS; ++l) rplan.bytes[l] = 0;
+    if (flags & LNR_BWD_NO_BINS)
+        for (int l = 0; l < LNR_MAX_LEVELS; ++l) rplan.binned[l] = 0;
     const bool f16 = spec->precision == LNR_PREC_F16;
     rc = check_f16(spec, "lnr_density_backward");
     if (rc) return rc;

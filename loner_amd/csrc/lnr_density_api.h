@@ -29,6 +29,8 @@ struct PointSrc {
 #endif
 #define LNR_REDUCE_SPLIT 32         // reduce workgroups per owner of a dense-indexed record level
 #define LNR_FIX_SCALE 4398046511104.0f /* 2^42: LDS gradient accumulators are 64-bit fixed point */
+#define LNR_BIN_BYTES 1024            /* LDS bin of one owner in the binned partition (lnr_encode.hip) */
+#define LNR_BIN_MAX_OWNERS 64         /* 64 bins = 64 KB of LDS: two workgroups per CU */
 #define LNR_XPAIR_SCALE_MIN 3000.0f   /* hashed power-of-two levels at least this fine take x-pair records (below: run-length combined 8-byte records) */
 
 // rn(v * 2^42) as a 64-bit integer.  There is no f32 -> i64 convert instruction (the compiler's expansion is ~20 VALU
@@ -154,15 +156,16 @@ struct LevelList {
 // levels only by statistical accident.
 
 // Record regions, sized per level: [owner of the level][chunk (= encode-backward workgroup)] x bytes[l], back to back from off[l].
-// A region is as large as the level's expected records per (owner, chunk) plus 25 % and a small slack, in that level's record
-// format (8-byte pair records, 12-byte x-pair records) - the reduce streams an owner's chunks back to back, so every unused byte
-// of a region is a gap in its HBM stream (with one global capacity, sized for the busiest level, two thirds of the stream were
-// gaps and the reduce ran at 1.6 TB/s whatever its arithmetic cost).
+// A region holds twice the level's expected records per (owner, chunk) plus 64 (LNR_REGION_HEADROOM / _SLACK; binned levels: plus
+// one bin and a line, the room a region must have left to stay open), in that level's record format (8-byte pair records, 12-byte
+// x-pair records), in 256-byte units.  The reduce reads only the records a region holds (its count), so capacity costs memory -
+// several GB at the bench shape, lnr_density_workspace reports it - not bandwidth.
 struct RegionPlan {
     uint64_t off[LNR_MAX_LEVELS];       // byte offset of the level's regions
     uint32_t bytes[LNR_MAX_LEVELS];     // bytes per region (multiple of 16); 0: all records overflow (LNR_BWD_TABLE_ATOMICS)
     uint8_t xp[LNR_MAX_LEVELS];         // 1: the level's records are 12-byte x-pair records, 0: 8-byte records
     uint8_t split[LNR_MAX_LEVELS];      // > 1: the level's owners are reduced by this many workgroups each (table_grad_reduce_split_kernel)
+    uint8_t binned[LNR_MAX_LEVELS];     // 1: partitioned by encode_backward_binned_kernel (fixed LDS bin per owner, whole-line appends)
 };
 
 // level-major encoding (lnr_encode.hip)

@@ -194,7 +194,7 @@ __device__ __forceinline__ void dx_from_entries(const LevelInfo& L, const Cell& 
                               // wave instead of three plane stores per thread, a 400 MB plane sum and the d_pts round trip
 
 // all lanes active; dx = 0 on lanes without a contribution
-__device__ __forceinline__ void ray_accumulate_dx(float* __restrict__ ray_acc_f, uint32_t ray, float z, const float dx[3], int lane) {
+__device__ __forceinline__ void ray_accumulate_dx(float* __restrict__ ray_acc_f, uint32_t ray, float z, const float dx[3], int lane, int n_rays_cap) {
     long long* ray_acc = reinterpret_cast<long long*>(ray_acc_f);        // [n_rays][6] fixed-point sums (passed through the float* d/dx argument)
     float t[6];
 #pragma unroll
@@ -202,18 +202,32 @@ __device__ __forceinline__ void ray_accumulate_dx(float* __restrict__ ray_acc_f,
     if (lane < 6) {
         const float v = lane == 0 ? t[0] : lane == 1 ? t[1] : lane == 2 ? t[2] : lane == 3 ? t[3] : lane == 4 ? t[4] : t[5];
         // 64-bit fixed point: integer atomics add exactly, so the ray gradient does not depend on the order of the waves
-        if (v != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(ray_acc) + (size_t)ray * 6 + lane,
-                                 (unsigned long long)__float2ll_rn(0.5f * v * LNR_FIX_SCALE));             // x = (xyz + 1) / 2
+        if (__builtin_expect(__builtin_isfinite(v), 1)) {
+            if (v != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(ray_acc) + (size_t)ray * 6 + lane,
+                                     (unsigned long long)__float2ll_rn(0.5f * v * LNR_FIX_SCALE));         // x = (xyz + 1) / 2
+        } else {
+            // an integer sum cannot carry inf / NaN: the word behind the sums says that one occurred, and ray_grad_apply_kernel turns
+            // the ray gradient into NaN - what a float sum would have produced, and what the pose check of the reference looks for
+            // (optimizer.py:368-370)
+            ray_acc[(size_t)n_rays_cap * 6] = 1ll;
+        }
     }
 }
 
-// d_rays[ray, 0:6] += the per-ray sums of ray_accumulate_dx
+// d_rays[ray, 0:6] += the per-ray sums of ray_accumulate_dx (ray_acc[n_rays * 6] != 0: a non-finite term occurred -> NaN)
 __global__ void __launch_bounds__(ENC_BLOCK)
 ray_grad_apply_kernel(const long long* __restrict__ ray_acc, int n_rays, const int32_t* __restrict__ n_rays_dev, float* __restrict__ d_rays) {
     const int i = blockIdx.x * ENC_BLOCK + threadIdx.x;
     if (i >= lnr_live_rays(n_rays, n_rays_dev) * 6) return;
     const long long q = ray_acc[i];
-    if (q != 0ll) d_rays[(size_t)(i / 6) * LNR_RAY_STRIDE + (i % 6)] += (float)((double)q * (1.0 / (double)LNR_FIX_SCALE));
+    if (__builtin_expect(ray_acc[(size_t)n_rays * 6] != 0ll, 0)) d_rays[(size_t)(i / 6) * LNR_RAY_STRIDE + (i % 6)] = __builtin_nanf("");
+    else if (q != 0ll) d_rays[(size_t)(i / 6) * LNR_RAY_STRIDE + (i % 6)] += (float)((double)q * (1.0 / (double)LNR_FIX_SCALE));
+}
+
+__device__ __forceinline__ void store_stream_b128(uint64_t global_addr, uint4 v) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 q = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(global_addr), "v"(q) : "memory");
 }
 
 #define ENC_BWD_BLOCK LNR_ENC_BWD_BLOCK
@@ -499,7 +513,7 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
             }
             if constexpr (DXM == ENC_DX_RAYS) {
                 if (wave_any && !DBG_SKIP(1))            // wave-uniform; lane 0 holds the wave's first (live) sample
-                    ray_accumulate_dx(dxl, (uint32_t)__builtin_amdgcn_readfirstlane((int)ray_cur), p_cur.z, dx, lane);
+                    ray_accumulate_dx(dxl, (uint32_t)__builtin_amdgcn_readfirstlane((int)ray_cur), p_cur.z, dx, lane, src.n_rays);
             } else if (live) {
 #pragma unroll
                 for (int d = 0; d < 3; ++d) st32<float>(dxplanes, (uint32_t)d * plane_bytes + m * 4u, dx[d]);
@@ -512,6 +526,251 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
     if (emit)
         for (int i = threadIdx.x; i < maxo; i += ENC_BWD_BLOCK)
             sink.counts[region0 + i * region_step] = gcur[i] < cap_rec ? gcur[i] : cap_rec;
+}
+
+// ------------------------------------------------------------------------------------------------ binned partition
+// The same partition for HASHED levels, where the records of a batch spread evenly over the owners: every owner has a fixed BIN
+// of LDS, a record takes its place with one returning atomic on the bin's fill (no histogram pass, no scan, no OwnerSlot lookups:
+// two barriers per batch instead of three and no single-wave phase), and the bin IS the staging buffer - packed records, appended
+// in arrival order.  What leaves the workgroup is whole 128-byte lines: after the barrier wave w copies the full lines of its
+// eight owners' bins out (one ds_read_b128 + one global_store_dwordx4 per owner, region address and line count on the scalar
+// unit) and moves the unfinished line - the tail, < 128 bytes - to the front of the bin, where the next batch appends.  A region is
+// therefore a dense byte stream of records written line by line; only the last line of a region, flushed when the kernel ends, is
+// partial (round 2 measured the partial-line appends of the per-batch copy-out at 0.25-0.38 of 0.94 ms against 0.12 ms for the
+// same bytes as whole lines, and the per-owner bookkeeping of a first whole-line attempt as costlier than that gain: here the
+// bookkeeping is a lane-resident {position, tail} pair per owner and nothing is looked up per record).
+// A record that finds its bin full (BIN_BYTES covers > 5 sigma of a batch's records per owner plus the tail), or whose region is
+// closed (no room left for another worst-case batch), takes the overflow path with the rounding of a packed record, as before.
+#define ENC_BIN_BYTES LNR_BIN_BYTES
+#define ENC_BIN_CLOSED 0x40000000
+static_assert(LNR_BIN_BYTES == 64 * 16, "a wave copies a whole bin with one 16-byte load per lane");
+
+template <int F, int DXM, bool XP>
+__global__ void __launch_bounds__(ENC_BWD_BLOCK, 4)
+encode_backward_binned_kernel(const LnrNetSpec spec, const float* __restrict__ table, const PointSrc src, const float* __restrict__ dfeat,
+                              float* __restrict__ dxl, int64_t m_pad, int bpg, const LevelList list, const EncSink sink) {
+    constexpr bool WANT_DX = DXM != ENC_DX_NONE;
+    static_assert(F >= 2, "binned records are pair records");
+    static_assert(ENC_BWD_BLOCK == 512, "wave w serves owners 8w .. 8w+7: 8 waves x 8 owners");
+    extern __shared__ __attribute__((aligned(16))) int dyn[];
+    constexpr int NPASS = F / 2;
+    constexpr bool xp = XP && F == 2;
+    constexpr uint32_t REC = xp ? 12u : 8u;
+    int* fill = dyn;                                             // [64] bytes in the owner's bin (tail + this batch's records)
+    char* stage = reinterpret_cast<char*>(dyn + 64);             // [64][ENC_BIN_BYTES]
+    const int maxo = sink.maxo;                                  // <= 64 (host)
+    const int lv = list.lv[blockIdx.x / bpg], chunk = blockIdx.x % bpg;
+    const LevelInfo L = level_info(spec, lv);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t M = (uint32_t)live_points(src);
+    const int first_owner = (int)(((uint64_t)L.offset * F) >> sink.shift);
+    const bool combine = !xp && L.scale < sink.combine_scale_max;
+    const uint32_t region_bytes = sink.plan.bytes[lv];
+    char* level_regions = reinterpret_cast<char*>(sink.regions) + sink.plan.off[lv];
+    const int ovf_off = list.slab_off[blockIdx.x / bpg];
+    long long* ovf = sink.ovf + ovf_off;
+    const uint32_t level_base = L.offset * F;
+    const size_t region0 = (size_t)lv * maxo * bpg + chunk;
+    const size_t region_step = (size_t)bpg;
+    const uint32_t step = (uint32_t)bpg * ENC_BWD_BLOCK;
+    const uint32_t n_iter = (M + step - 1u) / step;
+    const float* gplanes = dfeat + (size_t)(lv * F) * m_pad;
+    float* dxplanes = dxl + (size_t)(lv * 3) * m_pad;
+    const uint32_t plane_bytes = (uint32_t)m_pad * 4u;
+    const bool emit = sink.regions != nullptr;
+    // owner bookkeeping: lanes 8k..8k+7 of wave w all hold the state of owner 8w+k (k = lane >> 3)
+    const int my_owner = wave * 8 + (lane >> 3);
+    const bool own = my_owner < maxo;
+    uint32_t gpos = 0u;                                           // bytes of the owner's region already written (multiple of 128)
+    uint32_t tail = 0u;                                           // bytes of the unfinished line at the front of the bin
+    // a region too small for one worst-case batch never opens (LNR_BWD_TABLE_ATOMICS: region_bytes == 0)
+    bool closed = !own || region_bytes < (uint32_t)(ENC_BIN_BYTES + 128);
+    if (threadIdx.x < 64) fill[threadIdx.x] = 0;
+    __syncthreads();
+    if ((lane & 7) == 0 && own && closed) fill[my_owner] = ENC_BIN_CLOSED;
+    __syncthreads();
+    if (M == 0u) {
+        if (emit) for (int i = threadIdx.x; i < maxo; i += ENC_BWD_BLOCK) sink.counts[region0 + i * region_step] = 0;
+        return;
+    }
+    constexpr bool EARLY_DX = WANT_DX && F <= 2;
+    SampleCursor cur;
+    cur.init((uint32_t)chunk * ENC_BWD_BLOCK + threadIdx.x, step, src.pts ? 1u : (uint32_t)src.n_samples);
+    const uint32_t last_ray = src.pts ? 0u : (M - 1u) / cur.S;
+    float g_next[F];
+    RawPoint p_next;
+    {
+        const bool in = cur.m < M;
+        const uint32_t mc = in ? cur.m : M - 1u;
+#pragma unroll
+        for (int f = 0; f < F; ++f) g_next[f] = ld32_stream<float>(gplanes, (uint32_t)f * plane_bytes + mc * 4u);
+        load_raw_point(src, mc, in ? cur.ray : last_ray, p_next);
+    }
+    for (uint32_t it = 0; it < n_iter; ++it) {
+        const uint32_t m = cur.m;
+        const bool live = m < M;
+        float g[F];
+        bool any = false;
+#pragma unroll
+        for (int f = 0; f < F; ++f) { g[f] = live ? g_next[f] : 0.0f; any |= (g[f] != 0.0f); }
+        const RawPoint p_cur = p_next;
+        const uint32_t ray_cur = cur.ray;
+        cur.advance();
+        {
+            const bool in = cur.m < M;
+            const uint32_t mc = in ? cur.m : M - 1u;
+#pragma unroll
+            for (int f = 0; f < F; ++f) g_next[f] = ld32_stream<float>(gplanes, (uint32_t)f * plane_bytes + mc * 4u);
+            load_raw_point(src, mc, in ? cur.ray : last_ray, p_next);
+        }
+        const bool wave_any = __ballot(any) != 0ull;
+        Cell c;
+        uint32_t e[8];
+        float w[8];
+        bool head = true;
+        RunMask run = {false, false, false, false};
+        float tv[EARLY_DX ? 8 : 1][F];
+        if (wave_any) {
+            float x[3];
+            unit_point(src, p_cur, x);
+            c = cell_of(L, x);
+            cell_entries(L, c, e);
+            if constexpr (EARLY_DX) gather_entries<F>(table, e, tv);
+            cell_weights(c, w);
+            if (combine) cell_runs(c, lane, head, run);
+        }
+#pragma unroll
+        for (int pass = 0; pass < (emit ? NPASS : 0); ++pass) {
+            // ---- A: every record is packed and put into its owner's bin at the offset a returning atomic hands out
+            if (wave_any && xp) {
+                const uint32_t xt = (uint32_t)__builtin_ctz(~c.b[0]);
+                const float wy[2] = {1.0f - c.frac[1], c.frac[1]}, wz[2] = {1.0f - c.frac[2], c.frac[2]};
+#pragma unroll
+                for (int k2 = 0; k2 < 4; ++k2) {
+                    const float wyz = wy[k2 & 1] * wz[k2 >> 1];
+                    const float a0 = wyz * g[0], a1 = wyz * g[1];
+                    if ((a0 != 0.0f) | (a1 != 0.0f)) {
+                        const uint32_t fi = e[2 * k2] * F;
+                        bool placed = false;
+                        if (xt < 12u) {
+                            const int o = (int)(fi >> sink.shift) - first_owner;
+                            const uint32_t at = (uint32_t)atomicAdd(&fill[o], (int)REC);
+                            if (at + REC <= (uint32_t)ENC_BIN_BYTES) {
+                                const LnrXRec rec = lnr_pack_xpair((fi & ((1u << LNR_SLICE_SHIFT) - 1u)) >> 1, xt, a0, a1, c.frac[0]);
+                                uint32_t* dst = reinterpret_cast<uint32_t*>(stage + (uint32_t)o * ENC_BIN_BYTES + at);
+                                dst[0] = rec.a; dst[1] = rec.b; dst[2] = rec.c;
+                                placed = true;
+                            }
+                        }
+                        // (bin full, region closed, or the two corners straddle owner slices; same rounding as a packed record)
+                        if (!placed) xpair_overflow(ovf, fi - level_base, e[2 * k2 + 1] * F - level_base, xt, a0, a1, c.frac[0]);
+                    }
+                }
+            } else if (wave_any) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float v0 = w[k] * g[2 * pass], v1 = w[k] * g[2 * pass + 1];
+                    if (combine) { v0 = row_run_sum(v0, run); v1 = row_run_sum(v1, run); }
+                    if (head & ((v0 != 0.0f) | (v1 != 0.0f))) {
+                        const uint32_t fi = e[k] * F + 2 * pass;
+                        const int o = (int)(fi >> sink.shift) - first_owner;
+                        const uint32_t at = (uint32_t)atomicAdd(&fill[o], (int)REC);
+                        if (at + REC <= (uint32_t)ENC_BIN_BYTES) {
+                            *reinterpret_cast<uint2*>(stage + (uint32_t)o * ENC_BIN_BYTES + at) = lnr_pack_pair((fi & ((1u << LNR_SLICE_SHIFT) - 1u)) >> 1, v0, v1);
+                        } else {
+                            const float q0 = __uint_as_float(lnr_pack26(v0) << 6), q1 = __uint_as_float(lnr_pack26(v1) << 6);
+                            if (q0 != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(ovf + (fi - level_base)), (unsigned long long)lnr_to_fix(q0));
+                            if (q1 != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(ovf + (fi - level_base) + 1), (unsigned long long)lnr_to_fix(q1));
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- B: whole lines out, tail to the front
+            {
+                const uint32_t f_raw = own ? (uint32_t)fill[my_owner] : 0u;
+                uint32_t valid = 0u;
+                if (!closed) {
+                    const uint32_t n_new = (f_raw - tail) / REC, n_room = ((uint32_t)ENC_BIN_BYTES - tail) / REC;
+                    valid = tail + (n_new < n_room ? n_new : n_room) * REC;
+                }
+                const uint32_t nlines = valid >> 7, rem = valid & 127u;
+                const char* bins = stage + (uint32_t)(wave * 8) * ENC_BIN_BYTES;
+                // tail: lanes 8k..8k+7 move the (< 128) bytes behind the last whole line of owner k to the front of its bin
+                // (LDS operations of a wave execute in order: the line reads below come first, this read next, its write last)
+                const uint32_t sub = (uint32_t)(lane & 7) * 16u;
+                const bool mv = nlines > 0u && sub < rem;
+                char* my_bin = stage + (uint32_t)my_owner * ENC_BIN_BYTES;
+#pragma unroll
+                for (int k0 = 0; k0 < 8; k0 += 4) {
+                    uint4 v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t n16 = (uint32_t)__builtin_amdgcn_readlane((int)nlines, 8 * (k0 + k)) * 8u;
+                        if ((uint32_t)lane < n16) v[k] = *reinterpret_cast<const uint4*>(bins + (k0 + k) * ENC_BIN_BYTES + lane * 16);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t n16 = (uint32_t)__builtin_amdgcn_readlane((int)nlines, 8 * (k0 + k)) * 8u;
+                        if (n16 != 0u) {                                                                   // wave-uniform
+                            const uint32_t gp = (uint32_t)__builtin_amdgcn_readlane((int)gpos, 8 * (k0 + k));
+                            char* dst = level_regions + ((size_t)(wave * 8 + k0 + k) * bpg + chunk) * (size_t)region_bytes + gp;
+                            if ((uint32_t)lane < n16) store_stream_b128(reinterpret_cast<uint64_t>(dst) + (uint32_t)lane * 16u, v[k]);
+                        }
+                    }
+                }
+                if (mv) {
+                    const uint4 t4 = *reinterpret_cast<const uint4*>(my_bin + (nlines << 7) + sub);
+                    *reinterpret_cast<uint4*>(my_bin + sub) = t4;
+                }
+                gpos += nlines << 7;
+                tail = rem;
+                if (!closed && gpos + (uint32_t)(ENC_BIN_BYTES + 128) > region_bytes) {
+                    // no room for another worst-case batch: the tail - now at the front of the bin - goes out as the region's last
+                    // (partial) line and the owner closes; whatever is addressed to it from here on takes the overflow path
+                    char* dst = level_regions + ((size_t)my_owner * bpg + chunk) * (size_t)region_bytes + gpos;
+                    const uint32_t dw = (uint32_t)(lane & 7) * 16u;                                         // 8 lanes x 4 dwords
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t off = dw + 4u * q;
+                        if (off < rem) *reinterpret_cast<uint32_t*>(dst + off) = *reinterpret_cast<const uint32_t*>(my_bin + off);
+                    }
+                    gpos += rem;
+                    tail = 0u;
+                    closed = true;
+                }
+                if ((lane & 7) == 0 && own) fill[my_owner] = closed ? ENC_BIN_CLOSED : (int)tail;
+            }
+            __syncthreads();
+        }
+        if constexpr (WANT_DX) {
+            float dx[3] = {0.0f, 0.0f, 0.0f};
+            if (any) {
+                if constexpr (EARLY_DX) dx_from_entries<F>(L, c, g, tv, dx);
+                else { float tl[8][F]; gather_entries<F>(table, e, tl); dx_from_entries<F>(L, c, g, tl, dx); }
+            }
+            if constexpr (DXM == ENC_DX_RAYS) {
+                if (wave_any) ray_accumulate_dx(dxl, (uint32_t)__builtin_amdgcn_readfirstlane((int)ray_cur), p_cur.z, dx, lane, src.n_rays);
+            } else if (live) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) st32<float>(dxplanes, (uint32_t)d * plane_bytes + m * 4u, dx[d]);
+            }
+        }
+    }
+    if (emit && own) {
+        // the unfinished line of every open owner: the only partial-line write of a region
+        if (!closed && tail > 0u) {
+            const char* my_bin = stage + (uint32_t)my_owner * ENC_BIN_BYTES;
+            char* dst = level_regions + ((size_t)my_owner * bpg + chunk) * (size_t)region_bytes + gpos;
+            const uint32_t dw = (uint32_t)(lane & 7) * 16u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t off = dw + 4u * q;
+                if (off < tail) *reinterpret_cast<uint32_t*>(dst + off) = *reinterpret_cast<const uint32_t*>(my_bin + off);
+            }
+        }
+        if ((lane & 7) == 0) sink.counts[region0 + (size_t)my_owner * region_step] = (int)((gpos + (closed ? 0u : tail)) / REC);
+    }
 }
 
 // Frequency encoding has no table: backward is only the input gradient, one plane group for all features.
@@ -587,15 +846,16 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
     // d/dx mode: d_rays_acc (rays form, n_samples % 64 == 0, checked by the caller) > d_pts (planes) > none
     const int dxm = d_rays_acc ? ENC_DX_RAYS : (d_pts ? ENC_DX_PLANES : ENC_DX_NONE);
     float* dx_out = d_rays_acc ? reinterpret_cast<float*>(ray_acc) : dxl;
-    if (d_rays_acc && hipMemsetAsync(ray_acc, 0, (size_t)src->n_rays * 6 * sizeof(long long), st) != hipSuccess) {
+    if (d_rays_acc && hipMemsetAsync(ray_acc, 0, ((size_t)src->n_rays * 6 + 1) * sizeof(long long), st) != hipSuccess) {   // sums + the non-finite word
         lnr_set_error("lnr_density_backward: hipMemsetAsync failed");
         return LNR_ERR_LAUNCH;
     }
     int n_groups = 1;
     if (spec->encoding == LNR_ENC_HASHGRID) {
         n_groups = spec->n_levels;
-        LevelList rec_levels, xp_levels;                                   // 8-byte record levels, x-pair record levels: one launch each
-        rec_levels.n = xp_levels.n = 0;
+        LevelList rec_levels, xp_levels, brec_levels, bxp_levels;          // 8-byte record levels, x-pair record levels, and their binned forms: one launch each
+        rec_levels.n = xp_levels.n = brec_levels.n = bxp_levels.n = 0;
+        const bool allow_binned = regions != nullptr && maxo <= LNR_BIN_MAX_OWNERS;
         int ovf_total = 0;
         for (int l = 0; l < spec->n_levels; ++l) {
             const int nfl = (int)spec->level_size[l] * spec->n_features;
@@ -603,7 +863,9 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
             static const int lmask = getenv("LNR_X_LEVELS") ? (int)strtol(getenv("LNR_X_LEVELS"), nullptr, 0) : -1;
             if (!((lmask >> l) & 1)) { ovf_total += nfl; continue; }
 #endif
-            LevelList& ll = (spec->n_features == 2 && plan->xp[l] != 0) ? xp_levels : rec_levels;
+            const bool is_xp = spec->n_features == 2 && plan->xp[l] != 0;
+            const bool is_binned = allow_binned && plan->binned[l] != 0 && plan->bytes[l] != 0;
+            LevelList& ll = is_xp ? (is_binned ? bxp_levels : xp_levels) : (is_binned ? brec_levels : rec_levels);
             ll.lv[ll.n] = l; ll.slab_off[ll.n] = ovf_total; ll.n++;
             ovf_total += nfl;
         }
@@ -627,7 +889,7 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
             case 4: LNR_LAUNCH_DXM(KERNEL, 4, false, __VA_ARGS__); break;           \
             default: LNR_LAUNCH_DXM(KERNEL, 8, false, __VA_ARGS__); break;          \
         }
-        if (rec_levels.n + xp_levels.n > 0) {
+        if (rec_levels.n + xp_levels.n + brec_levels.n + bxp_levels.n > 0) {
             EncSink sink;
             if (regions != nullptr && ovf_total > 0 && hipMemsetAsync(ovf, 0, (size_t)ovf_total * sizeof(long long), st) != hipSuccess) {
                 lnr_set_error("lnr_density_backward: hipMemsetAsync failed");
@@ -648,6 +910,23 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
             if (xp_levels.n > 0) {                                          // n_features == 2
                 const dim3 grid((unsigned)(xp_levels.n * bpg));
                 LNR_LAUNCH_DXM(encode_backward_kernel, 2, true, *spec, table, *src, dfeat, dx_out, m_pad, bpg, xp_levels, sink);
+            }
+            {
+                const size_t lds_scan = lds;
+                const size_t lds = 64 * sizeof(int) + (size_t)LNR_BIN_MAX_OWNERS * LNR_BIN_BYTES;       // shadows: the launch macros read `lds`
+                (void)lds_scan;
+                if (brec_levels.n > 0) {
+                    const dim3 grid((unsigned)(brec_levels.n * bpg));
+                    switch (spec->n_features) {
+                        case 2: LNR_LAUNCH_DXM(encode_backward_binned_kernel, 2, false, *spec, table, *src, dfeat, dx_out, m_pad, bpg, brec_levels, sink); break;
+                        case 4: LNR_LAUNCH_DXM(encode_backward_binned_kernel, 4, false, *spec, table, *src, dfeat, dx_out, m_pad, bpg, brec_levels, sink); break;
+                        default: LNR_LAUNCH_DXM(encode_backward_binned_kernel, 8, false, *spec, table, *src, dfeat, dx_out, m_pad, bpg, brec_levels, sink); break;
+                    }
+                }
+                if (bxp_levels.n > 0) {
+                    const dim3 grid((unsigned)(bxp_levels.n * bpg));
+                    LNR_LAUNCH_DXM(encode_backward_binned_kernel, 2, true, *spec, table, *src, dfeat, dx_out, m_pad, bpg, bxp_levels, sink);
+                }
             }
 #ifdef LNR_PHASE_TIMING
             if (getenv("LNR_PHASE_TIMING")) {

@@ -22,6 +22,46 @@ def small_settings(n_rays, n_samples, voxel=32, n_test=None):
     return s
 
 
+# G13 (tests/golden/make_golden3.py): the reduced window of the matched-L1 fixture
+G13 = dict(n_rays=256, n_samples=128, n_test=256, n_l1_rays=512, pose_noise_seed=41, init_seed=1234)
+
+
+class SeededReplay:
+    """The random draws of a recorded reference run, regenerated from its seed: every draw of the reference came from torch's
+    global CPU generator in a fixed order, so a private generator with the same seed issuing the same calls yields the same values
+    (make_golden3.py verified that for the recorded run).  Interface of the `draws` hook (Optimizer.set_draws / sampler.set_draws);
+    `kinds` / `args` are the recorded call signatures, checked call by call; `checksum` accumulates the values handed out."""
+
+    def __init__(self, seed, kinds, args):
+        self.gen = torch.Generator().manual_seed(int(seed))
+        self.kinds, self.args, self.i, self.checksum = [int(k) for k in kinds], [tuple(int(v) for v in a) for a in args], 0, 0.0
+
+    def _next(self, kind, a):
+        assert self.i < len(self.kinds), "more draws than the reference made"
+        assert (self.kinds[self.i], self.args[self.i]) == (kind, a), (self.i, self.kinds[self.i], self.args[self.i], kind, a)
+        self.i += 1
+
+    def _out(self, t):
+        self.checksum += float(t.double().sum())
+        return t
+
+    def ray_index(self, n_points, count):
+        self._next(0, (int(n_points), int(count), 0))
+        return self._out(torch.randint(0, int(n_points), (int(count),), generator=self.gen))
+
+    sky_index = ray_index
+
+    def jitter(self, n, h):
+        self._next(1, (0, int(n), int(h)))
+        return self._out(torch.rand(int(n), int(h), generator=self.gen))
+
+    pdf = jitter
+
+    def noise(self, n, s):
+        self._next(2, (0, int(n), int(s)))
+        return self._out(torch.randn(int(n), int(s), generator=self.gen))
+
+
 def sky_directions(n=40, seed=3):
     """unit vectors pointing up and outwards, sensor frame [3,n] (what the sky segmentation hands to LidarScan.sky_rays)"""
     gen = torch.Generator().manual_seed(seed)

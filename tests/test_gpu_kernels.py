@@ -809,6 +809,44 @@ def test_record_partition_equals_global_accumulation(ops, net):
     assert torch.equal(g_rec[table], g_acc[table])
     assert torch.equal(g_rec[:table.start], g_acc[:table.start]) and torch.equal(r_rec, r_acc)
     assert float(r_rec[live:].abs().max()) == 0.0                                  # dropped rays receive nothing
+    # the scan partition of round 2 (LNR_BWD_NO_BINS) and the binned partition of the hashed levels are the same function too
+    g_scan = torch.zeros_like(g_rec); r_scan = torch.zeros_like(r_rec)
+    ops.density_backward(spec, params, dv(d_sigma), g_scan, rays=dv(rays), z=dv(z), n_rays_dev=n_dev, d_rays=r_scan, no_bins=True)
+    assert torch.equal(g_scan, g_rec) and torch.equal(r_scan, r_rec)
+
+
+@pytest.mark.parametrize("net", ["default", "hash_f4_2hidden"])
+def test_binned_partition_overflow_and_region_close(ops, net):
+    """The binned partition under the worst skew: every sample of the batch sits in the same few cells, so a handful of owners
+    receive everything - their LDS bins overflow in every batch and their regions fill up and close - while the rest stay empty.
+    Whatever route a record takes (bin -> line -> region, bin tail at the kernel's end, bin-full overflow, closed-region overflow),
+    the gradient equals the all-atomics accumulation bit for bit."""
+    from loner_amd import hip
+    enc, net_cfg = NETS[net]
+    spec = hip.make_net_spec(enc, net_cfg)
+    gen = torch.Generator().manual_seed(12)
+    params = dv(NW.init_params(NW.NetworkSpec.from_config(enc, net_cfg), 4))
+    params[spec.n_mlp_params:] *= 500
+    N, S = 256, 128
+    rays = torch.zeros(N, 13)
+    rays[:, 0:3] = torch.tensor([0.05, -0.02, 0.01]); rays[:, 3:6] = torch.tensor([0.6, 0.0, 0.8]); rays[:, 6:9] = -rays[:, 3:6]
+    rays[:, 11] = 0.01; rays[:, 12] = 0.8
+    # three clusters of samples 1e-6 apart (same cells on every level), a few stragglers elsewhere
+    z = torch.full((N, S), 0.2) + torch.rand(N, S, generator=gen) * 1e-6
+    z[:, 40:80] += 0.1; z[:, 80:] += 0.25
+    z[::17, ::9] = torch.rand(len(range(0, N, 17)), len(range(0, S, 9)), generator=gen) * 0.7 + 0.02
+    z = torch.sort(z, dim=1).values
+    d_sigma = torch.randn(N, S, generator=gen)
+    for n_live in (N, 3):                                                          # also a batch with three live rays (one partial batch)
+        n_dev = torch.tensor([n_live], dtype=torch.int32, device=DEV)
+        ops.density_forward(spec, params, rays=dv(rays), z=dv(z), n_rays_dev=n_dev)
+        g_bin = torch.zeros(int(spec.n_params), device=DEV); g_acc = torch.zeros_like(g_bin); g_scan = torch.zeros_like(g_bin)
+        ops.density_backward(spec, params, dv(d_sigma), g_bin, rays=dv(rays), z=dv(z), n_rays_dev=n_dev)
+        ops.density_backward(spec, params, dv(d_sigma), g_acc, rays=dv(rays), z=dv(z), n_rays_dev=n_dev, table_atomics=True)
+        ops.density_backward(spec, params, dv(d_sigma), g_scan, rays=dv(rays), z=dv(z), n_rays_dev=n_dev, no_bins=True)
+        assert float(g_bin.abs().max()) > 0
+        assert torch.equal(g_bin, g_acc), int((g_bin != g_acc).sum())
+        assert torch.equal(g_bin, g_scan)
 
 
 # ------------------------------------------------------------------------------------------- full-size properties
@@ -897,8 +935,9 @@ def test_failure_guard_kernels(ops, golden):
     poison = torch.zeros(2, device=DEV, dtype=torch.int32)
     loss = ops.los_loss_fused(sigma, z, rays, depths, float(g["scale"]), cfg, counts, noise_std=0.0, poison=poison, poison_tag=7)[0]
     assert np.isfinite(float(loss[0])) and poison.cpu().tolist() == [0, 0]
-    bad = sigma.clone(); bad[3, 5] = float("nan")
-    loss = ops.los_loss_fused(bad, z, rays, depths, float(g["scale"]), cfg, counts, noise_std=0.0, poison=poison, poison_tag=7)[0]
+    # (a NaN density is harmless: relu(sigma + noise) maps it to 0, in the reference's F.relu on the GPU as here; a NaN sample depth is not)
+    bad = z.clone(); bad[3, 5] = float("nan")
+    loss = ops.los_loss_fused(sigma, bad, rays, depths, float(g["scale"]), cfg, counts, noise_std=0.0, poison=poison, poison_tag=7)[0]
     assert np.isnan(float(loss[0])) and poison.cpu().tolist() == [hip.POISON_NAN_LOSS, 7]
     # first event wins
     p6 = torch.tensor([[0.1, 0.2, 0.3, 0.01, -0.02, 0.03], [0.0, 0.0, 0.0, 0.3, 0.1, -0.2]], device=DEV)
