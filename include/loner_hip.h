@@ -71,7 +71,8 @@ typedef enum LnrPosRounding { LNR_POS_FMA = 0, LNR_POS_MUL_ADD = 1 } LnrPosRound
 
 /* lnr_density_backward flags */
 #define LNR_BWD_TABLE_ATOMICS 1   /* test hook: every table-gradient record goes to the 64-bit overflow accumulators (atomics) */
-#define LNR_BWD_NO_BINS 4         /* test / A-B hook: hashed levels take the scan partition (round 2) instead of the binned one */
+#define LNR_BWD_BINS 4            /* hashed levels take the binned partition (whole-line appends; same sums, measured ~3 % slower than the scan partition: DESIGN.md section 8) */
+#define LNR_BWD_BINS_W8 8         /* A-B hook: the binned partition with 512-thread workgroups / 1 KB bins instead of 256 / 512 bytes */
 #define LNR_BWD_REPORT_REGIONS 2  /* diagnostic: print to stderr how full the record regions ran (synchronises the stream) */
 
 typedef enum LnrActivation {

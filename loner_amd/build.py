@@ -14,9 +14,11 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-BUILD = os.path.join(HERE, "_build")
+# LNR_BUILD_TAG=<name>: a development build beside the product's (objects in _build_<name>, library _lib/libloner_hip_<name>.so)
+_TAG = os.environ.get("LNR_BUILD_TAG", "")
+BUILD = os.path.join(HERE, "_build" + ("_" + _TAG if _TAG else ""))
 LIBDIR = os.path.join(HERE, "_lib")
-LIB = os.path.join(LIBDIR, "libloner_hip.so")
+LIB = os.path.join(LIBDIR, "libloner_hip" + ("_" + _TAG if _TAG else "") + ".so")
 MANIFEST = os.path.join(BUILD, "manifest.json")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 

@@ -669,7 +669,7 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     RegionPlan rplan = L.plan;
     if (flags & LNR_BWD_TABLE_ATOMICS)                       // no room anywhere: every record takes the overflow path
         for (int l = 0; l < LNR_MAX_LEVELS; ++l) rplan.bytes[l] = 0;
-    if (flags & LNR_BWD_NO_BINS)
+    if (!(flags & LNR_BWD_BINS))
         for (int l = 0; l < LNR_MAX_LEVELS; ++l) rplan.binned[l] = 0;
     const bool f16 = spec->precision == LNR_PREC_F16;
     rc = check_f16(spec, "lnr_density_backward");
@@ -711,7 +711,7 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     if (want_dfeat) {
         rc = lnr_encode_backward(spec, params, &src, cap, dfeat, dxl, L.m_pad, grad_table, want_grad ? regions : nullptr, &rplan, counts,
                                  L.bpg, L.maxo, L.shift,
-                                 ovf, d_pts_eff, ray_accum ? d_rays : nullptr, (long long*)(ws + L.off_rayacc), st);
+                                 ovf, d_pts_eff, ray_accum ? d_rays : nullptr, (long long*)(ws + L.off_rayacc), (flags & LNR_BWD_BINS_W8) != 0, st);
         if (rc) return rc;
         LNR_CHECK_LAUNCH("lnr_density_backward(encode backward)");
         if (hash && want_grad && (flags & LNR_BWD_REPORT_REGIONS)) {           // diagnostic, call-time flag: synchronises the stream

@@ -181,4 +181,4 @@ int lnr_mlp_bwd_f16(const LnrNetSpec* spec, const float* params, const void* fea
 int lnr_selftest_mfma_f16(float* out, hipStream_t st);
 int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, const float* dfeat,
                         float* dxl, int64_t m_pad, float* grad_table, void* regions, const RegionPlan* plan, int* counts, int bpg,
-                        int maxo, int shift, long long* ovf, float* d_pts, float* d_rays_acc, long long* ray_acc, hipStream_t st);
+                        int maxo, int shift, long long* ovf, float* d_pts, float* d_rays_acc, long long* ray_acc, bool bins_w8, hipStream_t st);

@@ -147,6 +147,26 @@ __device__ __forceinline__ float row_run_sum(float v, const RunMask& k) {
     return v;
 }
 
+// The same for N values at once, step by step: one fused multiply-add per value and step (v += neighbour * {1, 0}: the DPP read folds
+// into v_fmac_f32_dpp; fma(t, 1, v) rounds like t + v, fma(t, 0, v) = v), and consecutive instructions belong to different
+// values, so that the DPP read-after-write wait states are filled with work.  The select form cost an add, a v_cndmask and two idle
+// states per value and step.
+struct RunMul { float m1, m2, m4, m8; };
+__device__ __forceinline__ RunMul run_multipliers(const RunMask& k) {
+    return RunMul{k.take1 ? 1.0f : 0.0f, k.take2 ? 1.0f : 0.0f, k.take4 ? 1.0f : 0.0f, k.take8 ? 1.0f : 0.0f};
+}
+template <int N>
+__device__ __forceinline__ void row_run_sum_n(float (&v)[N], const RunMul& m) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = __builtin_fmaf(row_down_f<1>(v[i]), m.m1, v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = __builtin_fmaf(row_down_f<2>(v[i]), m.m2, v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = __builtin_fmaf(row_down_f<4>(v[i]), m.m4, v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = __builtin_fmaf(row_down_f<8>(v[i]), m.m8, v[i]);
+}
+
 // run masks of one 16-lane row: which lanes share the cell of their left neighbour
 __device__ __forceinline__ void cell_runs(const Cell& c, int lane, bool& head, RunMask& run) {
     const int c16 = lane & 15;
@@ -193,14 +213,38 @@ __device__ __forceinline__ void dx_from_entries(const LevelInfo& L, const Cell& 
                               // straight into that ray's record gradient (origin += dx/2, direction += z dx/2): six atomics per
                               // wave instead of three plane stores per thread, a 400 MB plane sum and the d_pts round trip
 
-// all lanes active; dx = 0 on lanes without a contribution
+// all lanes active; dx = 0 on lanes without a contribution.
+// Six wave sums at once: every value is first summed over its 16-lane row with four DPP butterfly steps (all lanes of a row end
+// up with the row's sum), lane k < 6 of every row then keeps value k, and the four rows are added with the two cross-row
+// swaps of CDNA4 (v_permlane16_swap / v_permlane32_swap): 24 + 5 + 6 VALU instructions instead of six independent
+// reductions with four v_readlane each (71).  Fixed association, the same in every launch.
+__device__ __forceinline__ float row_sum_all(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
+}
+__device__ __forceinline__ float rows_sum_all(float v) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const unsigned a = __float_as_uint(v);
+    const u2 r = __builtin_amdgcn_permlane16_swap(a, a, false, false);          // rows (0,1) and (2,3) meet
+    const float s = __uint_as_float(r.x) + __uint_as_float(r.y);
+    const unsigned b = __float_as_uint(s);
+    const u2 q = __builtin_amdgcn_permlane32_swap(b, b, false, false);          // the two halves meet
+    return __uint_as_float(q.x) + __uint_as_float(q.y);
+}
 __device__ __forceinline__ void ray_accumulate_dx(float* __restrict__ ray_acc_f, uint32_t ray, float z, const float dx[3], int lane, int n_rays_cap) {
     long long* ray_acc = reinterpret_cast<long long*>(ray_acc_f);        // [n_rays][6] fixed-point sums (passed through the float* d/dx argument)
-    float t[6];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { t[d] = wave_sum_dpp(dx[d]); t[3 + d] = wave_sum_dpp(z * dx[d]); }
+    const int c16 = lane & 15;
+    float v = row_sum_all(dx[0]);
+    { const float t = row_sum_all(dx[1]); if (c16 == 1) v = t; }
+    { const float t = row_sum_all(dx[2]); if (c16 == 2) v = t; }
+    { const float t = row_sum_all(z * dx[0]); if (c16 == 3) v = t; }
+    { const float t = row_sum_all(z * dx[1]); if (c16 == 4) v = t; }
+    { const float t = row_sum_all(z * dx[2]); if (c16 == 5) v = t; }
+    v = rows_sum_all(v);
     if (lane < 6) {
-        const float v = lane == 0 ? t[0] : lane == 1 ? t[1] : lane == 2 ? t[2] : lane == 3 ? t[3] : lane == 4 ? t[4] : t[5];
         // 64-bit fixed point: integer atomics add exactly, so the ray gradient does not depend on the order of the waves
         if (__builtin_expect(__builtin_isfinite(v), 1)) {
             if (v != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(ray_acc) + (size_t)ray * 6 + lane,
@@ -361,7 +405,9 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
             unit_point(src, p_cur, x);
             c = cell_of(L, x);
             cell_entries(L, c, e);
-            if constexpr (EARLY_DX) { if (!DBG_SKIP(4)) gather_entries<F>(table, e, tv); }
+            // (a gather costs per ACTIVE lane and line - tools/gather_bench.hip - and on the fine levels no two lanes share a line:
+            // the 48 % of the samples without a gradient must not gather)
+            if constexpr (EARLY_DX) { if (any && !DBG_SKIP(4)) gather_entries<F>(table, e, tv); }
             cell_weights(c, w);
             // runs = consecutive samples (lanes of one 16-lane row) in the same CELL, not merely the same hashed entry
             if (combine) cell_runs(c, lane, head, run);
@@ -545,19 +591,28 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
 #define ENC_BIN_CLOSED 0x40000000
 static_assert(LNR_BIN_BYTES == 64 * 16, "a wave copies a whole bin with one 16-byte load per lane");
 
-template <int F, int DXM, bool XP>
-__global__ void __launch_bounds__(ENC_BWD_BLOCK, 4)
+// NW = waves per workgroup (8: 512 threads, 1 KB bins; 4: 256 threads, 512-byte bins - twice as many independent barrier domains per CU
+// at the same LDS and wave count; a region only ever receives whole lines, so the batch size does not change what reaches HBM)
+template <int F, int DXM, bool XP, int NW>
+__global__ void __launch_bounds__(64 * NW, 4)
 encode_backward_binned_kernel(const LnrNetSpec spec, const float* __restrict__ table, const PointSrc src, const float* __restrict__ dfeat,
                               float* __restrict__ dxl, int64_t m_pad, int bpg, const LevelList list, const EncSink sink) {
     constexpr bool WANT_DX = DXM != ENC_DX_NONE;
     static_assert(F >= 2, "binned records are pair records");
-    static_assert(ENC_BWD_BLOCK == 512, "wave w serves owners 8w .. 8w+7: 8 waves x 8 owners");
+    static_assert(NW == 8 || NW == 4, "8 waves x 8 owners or 4 waves x 16 owners");
+    constexpr int BLK = 64 * NW;                                  // threads = samples of a batch
+    constexpr int BIN = 128 * NW;                                 // bytes of an owner's bin: tail (< 128) + a batch's records with > 5 sigma to spare
+    constexpr int OPW = 64 / NW;                                  // owners served by a wave
+    constexpr int G = NW;                                         // lanes that hold the state of one owner (G x 128 / G bytes move its tail)
+    constexpr int LPB = BIN / 16;                                 // lanes that copy one bin (16 bytes each)
+    constexpr int BPI = 64 / LPB;                                 // bins per copy instruction
+    constexpr int TQ = 128 / G / 16;                              // 16-byte pieces of the tail per lane
     extern __shared__ __attribute__((aligned(16))) int dyn[];
     constexpr int NPASS = F / 2;
     constexpr bool xp = XP && F == 2;
     constexpr uint32_t REC = xp ? 12u : 8u;
     int* fill = dyn;                                             // [64] bytes in the owner's bin (tail + this batch's records)
-    char* stage = reinterpret_cast<char*>(dyn + 64);             // [64][ENC_BIN_BYTES]
+    char* stage = reinterpret_cast<char*>(dyn + 64);             // [64][BIN]
     const int maxo = sink.maxo;                                  // <= 64 (host)
     const int lv = list.lv[blockIdx.x / bpg], chunk = blockIdx.x % bpg;
     const LevelInfo L = level_info(spec, lv);
@@ -572,30 +627,30 @@ encode_backward_binned_kernel(const LnrNetSpec spec, const float* __restrict__ t
     const uint32_t level_base = L.offset * F;
     const size_t region0 = (size_t)lv * maxo * bpg + chunk;
     const size_t region_step = (size_t)bpg;
-    const uint32_t step = (uint32_t)bpg * ENC_BWD_BLOCK;
+    const uint32_t step = (uint32_t)bpg * BLK;
     const uint32_t n_iter = (M + step - 1u) / step;
     const float* gplanes = dfeat + (size_t)(lv * F) * m_pad;
     float* dxplanes = dxl + (size_t)(lv * 3) * m_pad;
     const uint32_t plane_bytes = (uint32_t)m_pad * 4u;
     const bool emit = sink.regions != nullptr;
-    // owner bookkeeping: lanes 8k..8k+7 of wave w all hold the state of owner 8w+k (k = lane >> 3)
-    const int my_owner = wave * 8 + (lane >> 3);
+    // owner bookkeeping: lanes G k .. G k + G - 1 of wave w all hold the state of owner OPW w + k
+    const int my_owner = wave * OPW + lane / G;
     const bool own = my_owner < maxo;
     uint32_t gpos = 0u;                                           // bytes of the owner's region already written (multiple of 128)
     uint32_t tail = 0u;                                           // bytes of the unfinished line at the front of the bin
     // a region too small for one worst-case batch never opens (LNR_BWD_TABLE_ATOMICS: region_bytes == 0)
-    bool closed = !own || region_bytes < (uint32_t)(ENC_BIN_BYTES + 128);
+    bool closed = !own || region_bytes < (uint32_t)(BIN + 128);
     if (threadIdx.x < 64) fill[threadIdx.x] = 0;
     __syncthreads();
-    if ((lane & 7) == 0 && own && closed) fill[my_owner] = ENC_BIN_CLOSED;
+    if (lane % G == 0 && own && closed) fill[my_owner] = ENC_BIN_CLOSED;
     __syncthreads();
     if (M == 0u) {
-        if (emit) for (int i = threadIdx.x; i < maxo; i += ENC_BWD_BLOCK) sink.counts[region0 + i * region_step] = 0;
+        if (emit) for (int i = threadIdx.x; i < maxo; i += BLK) sink.counts[region0 + i * region_step] = 0;
         return;
     }
     constexpr bool EARLY_DX = WANT_DX && F <= 2;
     SampleCursor cur;
-    cur.init((uint32_t)chunk * ENC_BWD_BLOCK + threadIdx.x, step, src.pts ? 1u : (uint32_t)src.n_samples);
+    cur.init((uint32_t)chunk * BLK + threadIdx.x, step, src.pts ? 1u : (uint32_t)src.n_samples);
     const uint32_t last_ray = src.pts ? 0u : (M - 1u) / cur.S;
     float g_next[F];
     RawPoint p_next;
@@ -635,122 +690,156 @@ encode_backward_binned_kernel(const LnrNetSpec spec, const float* __restrict__ t
             unit_point(src, p_cur, x);
             c = cell_of(L, x);
             cell_entries(L, c, e);
-            if constexpr (EARLY_DX) gather_entries<F>(table, e, tv);
+            if constexpr (EARLY_DX) { if (any && !DBG_SKIP(4)) gather_entries<F>(table, e, tv); }
             cell_weights(c, w);
             if (combine) cell_runs(c, lane, head, run);
         }
 #pragma unroll
-        for (int pass = 0; pass < (emit ? NPASS : 0); ++pass) {
-            // ---- A: every record is packed and put into its owner's bin at the offset a returning atomic hands out
+        for (int pass = 0; pass < (emit && !DBG_SKIP(16) ? NPASS : 0); ++pass) {
+            // ---- A: every record is packed and put into its owner's bin at the offset a returning atomic hands out.  All of a
+            // thread's atomics are issued before the first offset is used: one LDS round trip per batch instead of one per record
+            // (measured: the rank atomics cost 0.11 of the x-pair levels' 0.54 ms when each was waited for in turn).
+            constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
             if (wave_any && xp) {
                 const uint32_t xt = (uint32_t)__builtin_ctz(~c.b[0]);
                 const float wy[2] = {1.0f - c.frac[1], c.frac[1]}, wz[2] = {1.0f - c.frac[2], c.frac[2]};
+                float a0[4], a1[4];
+                uint32_t at[4];
 #pragma unroll
                 for (int k2 = 0; k2 < 4; ++k2) {
                     const float wyz = wy[k2 & 1] * wz[k2 >> 1];
-                    const float a0 = wyz * g[0], a1 = wyz * g[1];
-                    if ((a0 != 0.0f) | (a1 != 0.0f)) {
+                    a0[k2] = wyz * g[0]; a1[k2] = wyz * g[1];
+                    at[k2] = NO_SLOT;
+                    if (((a0[k2] != 0.0f) | (a1[k2] != 0.0f)) & (xt < 12u)) {
+                        const int o = (int)((e[2 * k2] * F) >> LNR_SLICE_SHIFT) - first_owner;
+                        at[k2] = DBG_SKIP(64) ? (uint32_t)((threadIdx.x * 4 + k2) & 31) * REC : (uint32_t)atomicAdd(&fill[o], (int)REC);
+                    }
+                }
+#pragma unroll
+                for (int k2 = 0; k2 < 4; ++k2) {
+                    if ((a0[k2] != 0.0f) | (a1[k2] != 0.0f)) {
                         const uint32_t fi = e[2 * k2] * F;
-                        bool placed = false;
-                        if (xt < 12u) {
-                            const int o = (int)(fi >> sink.shift) - first_owner;
-                            const uint32_t at = (uint32_t)atomicAdd(&fill[o], (int)REC);
-                            if (at + REC <= (uint32_t)ENC_BIN_BYTES) {
-                                const LnrXRec rec = lnr_pack_xpair((fi & ((1u << LNR_SLICE_SHIFT) - 1u)) >> 1, xt, a0, a1, c.frac[0]);
-                                uint32_t* dst = reinterpret_cast<uint32_t*>(stage + (uint32_t)o * ENC_BIN_BYTES + at);
+                        if (at[k2] <= (uint32_t)BIN - REC) {
+                            if (!DBG_SKIP(128)) {
+                                const int o = (int)(fi >> LNR_SLICE_SHIFT) - first_owner;
+                                const LnrXRec rec = lnr_pack_xpair((fi & ((1u << LNR_SLICE_SHIFT) - 1u)) >> 1, xt, a0[k2], a1[k2], c.frac[0]);
+                                uint32_t* dst = reinterpret_cast<uint32_t*>(stage + (uint32_t)o * BIN + at[k2]);
                                 dst[0] = rec.a; dst[1] = rec.b; dst[2] = rec.c;
-                                placed = true;
                             }
+                        } else {
+                            // bin full, region closed, or the two corners straddle owner slices: same rounding as a packed record
+                            xpair_overflow(ovf, fi - level_base, e[2 * k2 + 1] * F - level_base, xt, a0[k2], a1[k2], c.frac[0]);
                         }
-                        // (bin full, region closed, or the two corners straddle owner slices; same rounding as a packed record)
-                        if (!placed) xpair_overflow(ovf, fi - level_base, e[2 * k2 + 1] * F - level_base, xt, a0, a1, c.frac[0]);
                     }
                 }
             } else if (wave_any) {
+                float v0[8], v1[8];
+                uint32_t at[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { v0[k] = w[k] * g[2 * pass]; v1[k] = w[k] * g[2 * pass + 1]; }
+                if (combine) {
+                    const RunMul rm = run_multipliers(run);
+                    row_run_sum_n<8>(v0, rm);
+                    row_run_sum_n<8>(v1, rm);
+                }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    float v0 = w[k] * g[2 * pass], v1 = w[k] * g[2 * pass + 1];
-                    if (combine) { v0 = row_run_sum(v0, run); v1 = row_run_sum(v1, run); }
-                    if (head & ((v0 != 0.0f) | (v1 != 0.0f))) {
+                    at[k] = NO_SLOT;
+                    if (head & ((v0[k] != 0.0f) | (v1[k] != 0.0f))) {
+                        const int o = (int)((e[k] * F + 2 * pass) >> LNR_SLICE_SHIFT) - first_owner;
+                        at[k] = (uint32_t)atomicAdd(&fill[o], (int)REC);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (at[k] != NO_SLOT) {
                         const uint32_t fi = e[k] * F + 2 * pass;
-                        const int o = (int)(fi >> sink.shift) - first_owner;
-                        const uint32_t at = (uint32_t)atomicAdd(&fill[o], (int)REC);
-                        if (at + REC <= (uint32_t)ENC_BIN_BYTES) {
-                            *reinterpret_cast<uint2*>(stage + (uint32_t)o * ENC_BIN_BYTES + at) = lnr_pack_pair((fi & ((1u << LNR_SLICE_SHIFT) - 1u)) >> 1, v0, v1);
+                        if (at[k] <= (uint32_t)BIN - REC) {
+                            const int o = (int)(fi >> LNR_SLICE_SHIFT) - first_owner;
+                            *reinterpret_cast<uint2*>(stage + (uint32_t)o * BIN + at[k]) = lnr_pack_pair((fi & ((1u << LNR_SLICE_SHIFT) - 1u)) >> 1, v0[k], v1[k]);
                         } else {
-                            const float q0 = __uint_as_float(lnr_pack26(v0) << 6), q1 = __uint_as_float(lnr_pack26(v1) << 6);
+                            const float q0 = __uint_as_float(lnr_pack26(v0[k]) << 6), q1 = __uint_as_float(lnr_pack26(v1[k]) << 6);
                             if (q0 != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(ovf + (fi - level_base)), (unsigned long long)lnr_to_fix(q0));
                             if (q1 != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(ovf + (fi - level_base) + 1), (unsigned long long)lnr_to_fix(q1));
                         }
                     }
                 }
             }
-            __syncthreads();
+            if (!DBG_SKIP(256)) __syncthreads();
             // ---- B: whole lines out, tail to the front
-            {
+            if (!DBG_SKIP(32)) {
                 const uint32_t f_raw = own ? (uint32_t)fill[my_owner] : 0u;
                 uint32_t valid = 0u;
                 if (!closed) {
-                    const uint32_t n_new = (f_raw - tail) / REC, n_room = ((uint32_t)ENC_BIN_BYTES - tail) / REC;
+                    const uint32_t n_new = (f_raw - tail) / REC, n_room = ((uint32_t)BIN - tail) / REC;
                     valid = tail + (n_new < n_room ? n_new : n_room) * REC;
                 }
                 const uint32_t nlines = valid >> 7, rem = valid & 127u;
-                const char* bins = stage + (uint32_t)(wave * 8) * ENC_BIN_BYTES;
-                // tail: lanes 8k..8k+7 move the (< 128) bytes behind the last whole line of owner k to the front of its bin
-                // (LDS operations of a wave execute in order: the line reads below come first, this read next, its write last)
-                const uint32_t sub = (uint32_t)(lane & 7) * 16u;
+                const char* bins = stage + (uint32_t)(wave * OPW) * BIN;
+                // tail: the G lanes of an owner move the (< 128) bytes behind its last whole line to the front of its bin
+                // (LDS operations of a wave execute in order: the line reads below come first, the tail's read next, its write last)
+                const uint32_t sub = (uint32_t)(lane % G) * (128u / G);
                 const bool mv = nlines > 0u && sub < rem;
-                char* my_bin = stage + (uint32_t)my_owner * ENC_BIN_BYTES;
+                char* my_bin = stage + (uint32_t)my_owner * BIN;
+                const int half = lane / LPB, piece = lane % LPB;                                            // which bin of a copy instruction, which 16 bytes of it
 #pragma unroll
-                for (int k0 = 0; k0 < 8; k0 += 4) {
+                for (int j0 = 0; j0 < OPW / BPI; j0 += 4) {
                     uint4 v[4];
+                    uint32_t n16[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const uint32_t n16 = (uint32_t)__builtin_amdgcn_readlane((int)nlines, 8 * (k0 + k)) * 8u;
-                        if ((uint32_t)lane < n16) v[k] = *reinterpret_cast<const uint4*>(bins + (k0 + k) * ENC_BIN_BYTES + lane * 16);
+                    for (int j = 0; j < 4; ++j) {
+                        // line count of the bin this lane copies from: wave-uniform per bin, selected per lane when an instruction covers two bins
+                        n16[j] = (uint32_t)__builtin_amdgcn_readlane((int)nlines, ((j0 + j) * BPI) * G) * 8u;
+                        if constexpr (BPI == 2) { const uint32_t n1 = (uint32_t)__builtin_amdgcn_readlane((int)nlines, ((j0 + j) * BPI + 1) * G) * 8u; if (half) n16[j] = n1; }
+                        if ((uint32_t)piece < n16[j]) v[j] = *reinterpret_cast<const uint4*>(bins + (j0 + j) * (BPI * BIN) + lane * 16);
                     }
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const uint32_t n16 = (uint32_t)__builtin_amdgcn_readlane((int)nlines, 8 * (k0 + k)) * 8u;
-                        if (n16 != 0u) {                                                                   // wave-uniform
-                            const uint32_t gp = (uint32_t)__builtin_amdgcn_readlane((int)gpos, 8 * (k0 + k));
-                            char* dst = level_regions + ((size_t)(wave * 8 + k0 + k) * bpg + chunk) * (size_t)region_bytes + gp;
-                            if ((uint32_t)lane < n16) store_stream_b128(reinterpret_cast<uint64_t>(dst) + (uint32_t)lane * 16u, v[k]);
+                    for (int j = 0; j < 4; ++j) {
+                        const int o0 = wave * OPW + (j0 + j) * BPI;
+                        uint64_t dst = reinterpret_cast<uint64_t>(level_regions) + ((size_t)o0 * bpg + chunk) * (size_t)region_bytes +
+                                       (uint32_t)__builtin_amdgcn_readlane((int)gpos, ((j0 + j) * BPI) * G);
+                        if constexpr (BPI == 2) {
+                            const uint64_t d1 = reinterpret_cast<uint64_t>(level_regions) + ((size_t)(o0 + 1) * bpg + chunk) * (size_t)region_bytes +
+                                                (uint32_t)__builtin_amdgcn_readlane((int)gpos, ((j0 + j) * BPI + 1) * G);
+                            if (half) dst = d1;
                         }
+                        if ((uint32_t)piece < n16[j] && !DBG_SKIP(8)) store_stream_b128(dst + (uint32_t)piece * 16u, v[j]);
                     }
                 }
                 if (mv) {
-                    const uint4 t4 = *reinterpret_cast<const uint4*>(my_bin + (nlines << 7) + sub);
-                    *reinterpret_cast<uint4*>(my_bin + sub) = t4;
+                    uint4 t4[TQ];
+#pragma unroll
+                    for (int q = 0; q < TQ; ++q) if (sub + 16u * q < rem) t4[q] = *reinterpret_cast<const uint4*>(my_bin + (nlines << 7) + sub + 16u * q);
+#pragma unroll
+                    for (int q = 0; q < TQ; ++q) if (sub + 16u * q < rem) *reinterpret_cast<uint4*>(my_bin + sub + 16u * q) = t4[q];
                 }
                 gpos += nlines << 7;
                 tail = rem;
-                if (!closed && gpos + (uint32_t)(ENC_BIN_BYTES + 128) > region_bytes) {
+                if (!closed && gpos + (uint32_t)(BIN + 128) > region_bytes) {
                     // no room for another worst-case batch: the tail - now at the front of the bin - goes out as the region's last
                     // (partial) line and the owner closes; whatever is addressed to it from here on takes the overflow path
                     char* dst = level_regions + ((size_t)my_owner * bpg + chunk) * (size_t)region_bytes + gpos;
-                    const uint32_t dw = (uint32_t)(lane & 7) * 16u;                                         // 8 lanes x 4 dwords
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const uint32_t off = dw + 4u * q;
+                    for (int q = 0; q < 32 / G; ++q) {
+                        const uint32_t off = sub + 4u * q;
                         if (off < rem) *reinterpret_cast<uint32_t*>(dst + off) = *reinterpret_cast<const uint32_t*>(my_bin + off);
                     }
                     gpos += rem;
                     tail = 0u;
                     closed = true;
                 }
-                if ((lane & 7) == 0 && own) fill[my_owner] = closed ? ENC_BIN_CLOSED : (int)tail;
+                if (lane % G == 0 && own) fill[my_owner] = closed ? ENC_BIN_CLOSED : (int)tail;
             }
             __syncthreads();
         }
         if constexpr (WANT_DX) {
             float dx[3] = {0.0f, 0.0f, 0.0f};
-            if (any) {
+            if (any && !DBG_SKIP(2)) {
                 if constexpr (EARLY_DX) dx_from_entries<F>(L, c, g, tv, dx);
                 else { float tl[8][F]; gather_entries<F>(table, e, tl); dx_from_entries<F>(L, c, g, tl, dx); }
             }
             if constexpr (DXM == ENC_DX_RAYS) {
-                if (wave_any) ray_accumulate_dx(dxl, (uint32_t)__builtin_amdgcn_readfirstlane((int)ray_cur), p_cur.z, dx, lane, src.n_rays);
+                if (wave_any && !DBG_SKIP(1)) ray_accumulate_dx(dxl, (uint32_t)__builtin_amdgcn_readfirstlane((int)ray_cur), p_cur.z, dx, lane, src.n_rays);
             } else if (live) {
 #pragma unroll
                 for (int d = 0; d < 3; ++d) st32<float>(dxplanes, (uint32_t)d * plane_bytes + m * 4u, dx[d]);
@@ -760,16 +849,16 @@ encode_backward_binned_kernel(const LnrNetSpec spec, const float* __restrict__ t
     if (emit && own) {
         // the unfinished line of every open owner: the only partial-line write of a region
         if (!closed && tail > 0u) {
-            const char* my_bin = stage + (uint32_t)my_owner * ENC_BIN_BYTES;
+            const char* my_bin = stage + (uint32_t)my_owner * BIN;
             char* dst = level_regions + ((size_t)my_owner * bpg + chunk) * (size_t)region_bytes + gpos;
-            const uint32_t dw = (uint32_t)(lane & 7) * 16u;
+            const uint32_t sub = (uint32_t)(lane % G) * (128u / G);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t off = dw + 4u * q;
+            for (int q = 0; q < 32 / G; ++q) {
+                const uint32_t off = sub + 4u * q;
                 if (off < tail) *reinterpret_cast<uint32_t*>(dst + off) = *reinterpret_cast<const uint32_t*>(my_bin + off);
             }
         }
-        if ((lane & 7) == 0) sink.counts[region0 + (size_t)my_owner * region_step] = (int)((gpos + (closed ? 0u : tail)) / REC);
+        if (lane % G == 0) sink.counts[region0 + (size_t)my_owner * region_step] = (int)((gpos + (closed ? 0u : tail)) / REC);
     }
 }
 
@@ -841,7 +930,7 @@ int lnr_encode_forward(const LnrNetSpec* spec, const float* params, const PointS
 
 int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, const float* dfeat,
                         float* dxl, int64_t m_pad, float* grad_table, void* regions, const RegionPlan* plan, int* counts, int bpg,
-                        int maxo, int shift, long long* ovf, float* d_pts, float* d_rays_acc, long long* ray_acc, hipStream_t st) {
+                        int maxo, int shift, long long* ovf, float* d_pts, float* d_rays_acc, long long* ray_acc, bool bins_w8, hipStream_t st) {
     const float* table = params + spec->n_mlp_params;
     // d/dx mode: d_rays_acc (rays form, n_samples % 64 == 0, checked by the caller) > d_pts (planes) > none
     const int dxm = d_rays_acc ? ENC_DX_RAYS : (d_pts ? ENC_DX_PLANES : ENC_DX_NONE);
@@ -912,21 +1001,37 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
                 LNR_LAUNCH_DXM(encode_backward_kernel, 2, true, *spec, table, *src, dfeat, dx_out, m_pad, bpg, xp_levels, sink);
             }
             {
-                const size_t lds_scan = lds;
-                const size_t lds = 64 * sizeof(int) + (size_t)LNR_BIN_MAX_OWNERS * LNR_BIN_BYTES;       // shadows: the launch macros read `lds`
-                (void)lds_scan;
+                // binned partition: NW = 4 (256-thread workgroups, 512-byte bins) or 8 (512 threads, 1 KB bins)
+                const int nw = bins_w8 ? 8 : 4;
+                const size_t lds_b = 64 * sizeof(int) + (size_t)LNR_BIN_MAX_OWNERS * (size_t)(128 * nw);
+                const dim3 block_b(64 * nw);
+#define LNR_LAUNCH_BINNED(F, XP, LIST)                                                                                              \
+                do {                                                                                                                \
+                    const dim3 grid_b((unsigned)((LIST).n * bpg));                                                                  \
+                    const void* fn_ = nullptr;                                                                                      \
+                    if (nw == 8) fn_ = dxm == ENC_DX_RAYS ? (const void*)encode_backward_binned_kernel<F, ENC_DX_RAYS, XP, 8>       \
+                                     : dxm == ENC_DX_PLANES ? (const void*)encode_backward_binned_kernel<F, ENC_DX_PLANES, XP, 8>   \
+                                                            : (const void*)encode_backward_binned_kernel<F, ENC_DX_NONE, XP, 8>;    \
+                    else fn_ = dxm == ENC_DX_RAYS ? (const void*)encode_backward_binned_kernel<F, ENC_DX_RAYS, XP, 4>               \
+                             : dxm == ENC_DX_PLANES ? (const void*)encode_backward_binned_kernel<F, ENC_DX_PLANES, XP, 4>           \
+                                                    : (const void*)encode_backward_binned_kernel<F, ENC_DX_NONE, XP, 4>;            \
+                    if (hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b) != hipSuccess) {           \
+                        lnr_set_error("lnr_density_backward: hipFuncSetAttribute(%zu) failed", lds_b); return LNR_ERR_LAUNCH;       \
+                    }                                                                                                               \
+                    void* args_[] = {(void*)spec, (void*)&table, (void*)src, (void*)&dfeat, (void*)&dx_out, (void*)&m_pad, (void*)&bpg, (void*)&(LIST), (void*)&sink}; \
+                    if (hipLaunchKernel(fn_, grid_b, block_b, args_, lds_b, st) != hipSuccess) {                                    \
+                        lnr_set_error("lnr_density_backward: launch of the binned partition failed"); return LNR_ERR_LAUNCH;         \
+                    }                                                                                                               \
+                } while (0)
                 if (brec_levels.n > 0) {
-                    const dim3 grid((unsigned)(brec_levels.n * bpg));
                     switch (spec->n_features) {
-                        case 2: LNR_LAUNCH_DXM(encode_backward_binned_kernel, 2, false, *spec, table, *src, dfeat, dx_out, m_pad, bpg, brec_levels, sink); break;
-                        case 4: LNR_LAUNCH_DXM(encode_backward_binned_kernel, 4, false, *spec, table, *src, dfeat, dx_out, m_pad, bpg, brec_levels, sink); break;
-                        default: LNR_LAUNCH_DXM(encode_backward_binned_kernel, 8, false, *spec, table, *src, dfeat, dx_out, m_pad, bpg, brec_levels, sink); break;
+                        case 2: LNR_LAUNCH_BINNED(2, false, brec_levels); break;
+                        case 4: LNR_LAUNCH_BINNED(4, false, brec_levels); break;
+                        default: LNR_LAUNCH_BINNED(8, false, brec_levels); break;
                     }
                 }
-                if (bxp_levels.n > 0) {
-                    const dim3 grid((unsigned)(bxp_levels.n * bpg));
-                    LNR_LAUNCH_DXM(encode_backward_binned_kernel, 2, true, *spec, table, *src, dfeat, dx_out, m_pad, bpg, bxp_levels, sink);
-                }
+                if (bxp_levels.n > 0) LNR_LAUNCH_BINNED(2, true, bxp_levels);
+#undef LNR_LAUNCH_BINNED
             }
 #ifdef LNR_PHASE_TIMING
             if (getenv("LNR_PHASE_TIMING")) {

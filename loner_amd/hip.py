@@ -13,7 +13,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libloner_hip.so")
+# (LNR_LIB_PATH: the experiment scripts under tools/ point this at development builds, e.g. -DLNR_ABLATE)
+LIB_PATH = os.environ.get("LNR_LIB_PATH") or os.path.join(_HERE, "_lib", "libloner_hip.so")
 
 MAX_LEVELS = 32
 RAY_STRIDE = 13
@@ -27,7 +28,8 @@ PRECISIONS = {"fp32": 0, "float32": 0, "fp16": 1, "half": 1, "float16": 1}
 POS_ROUNDINGS = {"fma": 0, "mul_add": 1}
 BWD_TABLE_ATOMICS = 1        # LNR_BWD_TABLE_ATOMICS
 BWD_REPORT_REGIONS = 2       # LNR_BWD_REPORT_REGIONS
-BWD_NO_BINS = 4              # LNR_BWD_NO_BINS
+BWD_BINS = 4                 # LNR_BWD_BINS
+BWD_BINS_W8 = 8              # LNR_BWD_BINS_W8
 WORKSPACE_STATUS_BYTES, STATUS_CLIPPED = 256, 0            # LNR_WORKSPACE_STATUS_BYTES, LNR_STATUS_CLIPPED
 POISON_NAN_LOSS, POISON_POSE_GRAD, POISON_POSE = 1, 2, 3      # LNR_POISON_* codes of the failure guard (int32[2] device word)
 

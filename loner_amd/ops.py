@@ -55,7 +55,8 @@ def profile_read():
 
 # ---------------------------------------------------------------- density network
 _workspaces = {}
-_NO_BINS = bool(os.environ.get("LNR_NO_BINS"))      # A/B switch of the experiment scripts (tools/): the scan partition everywhere
+_BINS_W8 = bool(os.environ.get("LNR_BINS_W8"))
+_BINS = bool(os.environ.get("LNR_BINS"))            # A/B switch of the experiment scripts (tools/): the binned partition on hashed levels
 
 
 def _workspace(spec, device, n_points, forward_only=False):
@@ -109,7 +110,7 @@ def density_forward(spec, params, pts=None, rays=None, z=None, n_rays_dev=None, 
 
 
 def density_backward(spec, params, d_sigma, grad_params, pts=None, rays=None, z=None, n_rays_dev=None,
-                     want_d_pts=False, reuse_features=False, d_rays=None, table_atomics=False, report_regions=False, no_bins=False):
+                     want_d_pts=False, reuse_features=False, d_rays=None, table_atomics=False, report_regions=False, bins=False, bins_w8=False):
     """Accumulates into grad_params [n_params] (None: parameters frozen, only the input gradient is computed);
     returns d_pts ([...,3]) or None.  table_atomics: test hook (LNR_BWD_TABLE_ATOMICS).
     reuse_features: the caller asserts that the last density_forward on this device ran on the same params and
@@ -120,7 +121,7 @@ def density_backward(spec, params, d_sigma, grad_params, pts=None, rays=None, z=
     params, d_sigma = _f32c(params), _f32c(d_sigma)
     assert grad_params is None or (grad_params.dtype == torch.float32 and grad_params.is_contiguous())
     flags = (hip.BWD_TABLE_ATOMICS if table_atomics else 0) | (hip.BWD_REPORT_REGIONS if report_regions else 0) | \
-        (hip.BWD_NO_BINS if (no_bins or _NO_BINS) else 0)
+        (hip.BWD_BINS if (bins or _BINS) else 0) | (hip.BWD_BINS_W8 if (bins_w8 or _BINS_W8) else 0)
     n_points = (pts.numel() // 3) if pts is not None else z.numel()
     ent, need = _workspace(spec, params.device, n_points)
     if pts is not None:

@@ -809,10 +809,11 @@ def test_record_partition_equals_global_accumulation(ops, net):
     assert torch.equal(g_rec[table], g_acc[table])
     assert torch.equal(g_rec[:table.start], g_acc[:table.start]) and torch.equal(r_rec, r_acc)
     assert float(r_rec[live:].abs().max()) == 0.0                                  # dropped rays receive nothing
-    # the scan partition of round 2 (LNR_BWD_NO_BINS) and the binned partition of the hashed levels are the same function too
-    g_scan = torch.zeros_like(g_rec); r_scan = torch.zeros_like(r_rec)
-    ops.density_backward(spec, params, dv(d_sigma), g_scan, rays=dv(rays), z=dv(z), n_rays_dev=n_dev, d_rays=r_scan, no_bins=True)
-    assert torch.equal(g_scan, g_rec) and torch.equal(r_scan, r_rec)
+    # the binned partition of the hashed levels (LNR_BWD_BINS, both workgroup sizes) is the same function too
+    for w8 in (False, True):
+        g_bin = torch.zeros_like(g_rec); r_bin = torch.zeros_like(r_rec)
+        ops.density_backward(spec, params, dv(d_sigma), g_bin, rays=dv(rays), z=dv(z), n_rays_dev=n_dev, d_rays=r_bin, bins=True, bins_w8=w8)
+        assert torch.equal(g_bin, g_rec) and torch.equal(r_bin, r_rec)
 
 
 @pytest.mark.parametrize("net", ["default", "hash_f4_2hidden"])
@@ -841,12 +842,15 @@ def test_binned_partition_overflow_and_region_close(ops, net):
         n_dev = torch.tensor([n_live], dtype=torch.int32, device=DEV)
         ops.density_forward(spec, params, rays=dv(rays), z=dv(z), n_rays_dev=n_dev)
         g_bin = torch.zeros(int(spec.n_params), device=DEV); g_acc = torch.zeros_like(g_bin); g_scan = torch.zeros_like(g_bin)
-        ops.density_backward(spec, params, dv(d_sigma), g_bin, rays=dv(rays), z=dv(z), n_rays_dev=n_dev)
+        ops.density_backward(spec, params, dv(d_sigma), g_bin, rays=dv(rays), z=dv(z), n_rays_dev=n_dev, bins=True)
         ops.density_backward(spec, params, dv(d_sigma), g_acc, rays=dv(rays), z=dv(z), n_rays_dev=n_dev, table_atomics=True)
-        ops.density_backward(spec, params, dv(d_sigma), g_scan, rays=dv(rays), z=dv(z), n_rays_dev=n_dev, no_bins=True)
+        ops.density_backward(spec, params, dv(d_sigma), g_scan, rays=dv(rays), z=dv(z), n_rays_dev=n_dev)
         assert float(g_bin.abs().max()) > 0
         assert torch.equal(g_bin, g_acc), int((g_bin != g_acc).sum())
         assert torch.equal(g_bin, g_scan)
+        g_w8 = torch.zeros_like(g_bin)
+        ops.density_backward(spec, params, dv(d_sigma), g_w8, rays=dv(rays), z=dv(z), n_rays_dev=n_dev, bins=True, bins_w8=True)
+        assert torch.equal(g_bin, g_w8)
 
 
 # ------------------------------------------------------------------------------------------- full-size properties
