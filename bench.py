@@ -38,6 +38,9 @@ def parse():
                     help="arithmetic of the density network: f32 (default, stricter than the reference) or f16 "
                          "(the reference's storage types: fp16 features and weights on MFMA, fp32 accumulation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["train", "render"], default="train",
+                    help="train (default): the mapping iteration, with the inference leg as a `render` block in the line; "
+                         "render: only the inference leg (Model.forward(testing=True) over a whole scan), for profiling")
     ap.add_argument("--launch-check", action="store_true",
                     help="only bring the ranks up, check the world size against --gpus, print {n_gpus, ranks} and exit "
                          "(no GPU work: with LNR_DIST_BACKEND=gloo this runs on a CPU-only box; tests/test_host.py)")
@@ -224,6 +227,74 @@ class KernelTimer:
         return out
 
 
+def render_leg(opt, kf, scans=3, dtype="f32"):
+    """The inference path that defines the metric's quality half (analysis/compute_l1_depth.py:42-64,262-265; renderer_lidar.py:71-93):
+    every ray of a 64 x 1024 scan through Model.forward(testing=True) - N_samples_test = 2048 samples per ray, occupancy-guided
+    sampling without jitter, density network forward, compositing - here through Model.render_depth, the depth-only form of it (no
+    [N,S] weights, forward-only workspace, launches of 2^24 samples), and through Model.forward for comparison.  A "step" = one scan."""
+    from loner_amd import ops
+    from loner_amd.common.ray_utils import LidarRayDirections
+    model, sampler = opt._model, opt._ray_sampler
+    scan = kf.get_lidar_scan()
+    lrd = LidarRayDirections(scan, chunk_size=len(scan))
+    T = kf.get_lidar_pose().get_transformation_matrix().detach()
+    with torch.no_grad():
+        rays, depths = lrd.build_lidar_rays(torch.arange(len(scan)), opt._ray_range, opt._world_cube, T)
+    n, S = rays.shape[0], int(model.cfg.render.N_samples_test)
+
+    def timed(fn, reps):
+        fn(); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            out = fn()
+        b.record(); torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps, out
+    ms_depth, depth = timed(lambda: model.render_depth(rays, sampler, opt._scale_f, testing=True), scans)
+    with torch.no_grad():
+        ms_full, _ = timed(lambda: model(rays, sampler, opt._scale_f, testing=True, camera=False, return_variance=True), 1)
+    # per-kernel times of one scan: the library's own events inside lnr_density_forward, torch events around the other two ops
+    ops.profile_read()
+    ops.profile_enable(True)
+    spans = {"sample_rays_occ": [], "render_forward": []}
+    orig = {k: getattr(ops, k) for k in spans}
+
+    def wrap(name):
+        def inner(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); r = orig[name](*a, **k); e1.record()
+            spans[name].append((e0, e1))
+            return r
+        return inner
+    for k in spans:
+        setattr(ops, k, wrap(k))
+    try:
+        model.render_depth(rays, sampler, opt._scale_f, testing=True)
+        torch.cuda.synchronize()
+    finally:
+        for k, f in orig.items():
+            setattr(ops, k, f)
+        ops.profile_enable(False)
+    kern = {k: round(v["total_ms"], 4) for k, v in ops.profile_read().items()}
+    kern.update({k: round(sum(a.elapsed_time(b) for a, b in v), 4) for k, v in spans.items()})
+    spec = model.nerf_model._model_sigma.spec
+    pts = float(n) * S
+    half = dtype == "f16"
+    enc_bytes = pts * (4.0 + spec.enc_dim * (2.0 if half else 4.0)) + n * 24.0 + (float(spec.n_params) - spec.n_mlp_params) * 4.0
+    t_enc = kern.get("encode_forward", 0.0) * 1e-3
+    gt = depths * opt._scale_f
+    good = (gt > float(opt._ray_range[0])) & (gt < float(opt._ray_range[1]) - 0.25)
+    l1 = float(((depth * opt._scale_f)[good] - gt[good]).abs().mean()) if bool(good.any()) else None
+    return {"metric": "inference rays/sec (Model.forward(testing=True) depth, every ray of a 64x1024 scan)", "value": n / (ms_depth * 1e-3), "unit": "rays/s",
+            "rays": n, "samples_per_ray": S, "ms_per_scan": round(ms_depth, 3), "ms_per_scan_full_result_dictionary": round(ms_full, 3),
+            "dtype": dtype, "kernels_ms_per_scan": kern, "l1_depth_m_of_this_scan": l1,
+            "roofline": {"kernel": "encode_forward", "bound": "hbm", "achieved": enc_bytes / t_enc / 1e9 if t_enc > 0 else None, "peak": 8000.0,
+                         "unit": "GB/s", "frac": enc_bytes / t_enc / 8e12 if t_enc > 0 else None, "algorithmic_bytes_per_scan": enc_bytes,
+                         "traffic": None,
+                         "note": "the dominant kernel of a scan: 8 table gathers per sample and level from the level's L2-resident table, bound by "
+                                 "the L1/L2 line rate of the gathers (tools/gather_bench.hip), not by HBM bytes; feature planes are its HBM traffic"}}
+
+
 def north_star_network_leg(n_rays, n_samples, device):
     """The network class the north star names besides the default one (sin/cos encoding + a wider ReLU MLP: frequency-12 -> 128 x 2,
     fp16 mode): forward and backward of lnr_density_* at the bench's sample count, against the dense fp16 MFMA peak.  Not part of the
@@ -338,6 +409,19 @@ def main():
     my_window = window
     phase = lambda n: OptimizationSettings(n, False, False, False, True)
 
+    if args.mode == "render":
+        if args.warmup > 0:
+            opt._do_iterate_optimizer(my_window, [None], optimizer_settings=phase(args.warmup))
+        r = render_leg(opt, my_window[0], scans=max(args.steps, 1), dtype=args.dtype)
+        r.update({"n_gpus": world, "steps": max(args.steps, 1), "warmup": args.warmup, "ms_per_step": r["ms_per_scan"], "higher_is_better": True,
+                  "scaling": "weak", "vs_baseline": None, "data": "synthetic",
+                  "config": {"workload": "inference: one 64x1024 synthetic scan (65536 rays) x 2048 samples through the default network after "
+                                         f"{args.warmup} training iterations", "parallelism": "single GPU"}})
+        if rank == 0:
+            print(json.dumps(r), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     timer = KernelTimer(ops, ["density_backward", "density_forward", "los_loss_fused", "sample_rays_occ", "adam_step",
                               "occ_grid_step", "compact_rays", "lidar_rays_backward", "points_grad_to_rays"])
     # ---- warm-up (untimed) ----
@@ -413,6 +497,12 @@ def main():
             ns_net = north_star_network_leg(args.keyframes * args.rays, args.samples, "cuda")
         except Exception as e:
             ns_net = {"error": str(e)}
+    render = None
+    if world == 1:
+        try:
+            render = render_leg(opt, my_window[0], scans=2, dtype=args.dtype)
+        except Exception as e:
+            render = {"error": str(e)}
     ksum = timer.summary()
     spec = opt._model.nerf_model._model_sigma.spec
     n_local = opt.last_stats["n_valid_rays"] / max(args.steps, 1)          # rays per launch on this rank
@@ -481,6 +571,7 @@ def main():
                    "parallelism": f"keyframe-sharded x{world}" if world > 1 else "single GPU"},
         "roofline": roofline,
         "north_star_network": ns_net,
+        "render": render,
         # whole-path HBM roofline of SURVEY 8d: B_ray = 72 B (ray record, gt depth, per-ray outputs) + dense Adam traffic
         # (28 B per parameter: read p,g,m,v, write p,m,v) amortised over the rays of an iteration
         "path_hbm_roofline": (lambda b: {"algorithmic_bytes_per_ray": b, "rays_per_s_at_8TBps": 8e12 / b * world,

@@ -457,8 +457,9 @@ static int check_spec(const LnrNetSpec* spec, const char* who) {
 // LNR_PREC_F16 is implemented for the reference's sigma network shape class; anything else must say so, not fall back
 static int check_f16(const LnrNetSpec* spec, const char* who) {
     if (spec->precision != LNR_PREC_F16 || lnr_f16_supported(spec)) return LNR_OK;
-    lnr_set_error("%s: precision fp16 covers networks with an even number of encoded features per level, 16/32/64/128 neurons, at most 3 "
-                  "hidden layers and at most 128 (padded) inputs whose weights fit the LDS; use precision fp32 for this network", who);
+    lnr_set_error("%s: precision fp16 covers networks with an even number of encoded features per level, 16/32/64/128 neurons (256 with one "
+                  "hidden layer), at most 3 hidden layers and at most 128 (padded) inputs whose weights fit the LDS; use precision fp32 for "
+                  "this network", who);
     return LNR_ERR_UNSUPPORTED;
 }
 

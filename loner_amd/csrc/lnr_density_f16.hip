@@ -405,19 +405,68 @@ __device__ __forceinline__ void pack_acts(const f32x4 A, int jt, u32x4 Bn[F16_KB
     Bn[jt >> 1][2 * (jt & 1) + 1] = pack_h2(A[2], A[3]);
 }
 
+// The A fragments (weights, from LDS) of one 16-neuron row of a layer: first layer `kt1` K blocks (run-time count, zero beyond the
+// inputs), hidden layers KBH blocks.  PIPE: the fragments of row jt + 1 are requested before the MFMAs of row jt are issued, so that an
+// LDS round trip (~100 cycles against 16 per MFMA) is not waited for in front of every product; costs 2 x KBH x 4 registers.
+template <int HT>
+__device__ __forceinline__ void load_row_frags(const f16* Ws, const GenDims& d, int l, int jt, int c, int g, f16x8 a[F16_KB_MAX]) {
+    constexpr int H = 16 * HT, KBH = (HT + 1) / 2;
+    if (l == 0) {
+#pragma unroll
+        for (int kb = 0; kb < F16_KB_MAX; ++kb) a[kb] = kb < d.kt1 ? frag_first(Ws, d, 16 * jt + c, kb, g) : frag_from_dwords(0u, 0u, 0u, 0u);
+    } else if constexpr (KBH <= F16_KB_MAX) {                        // (256 neurons: one hidden layer only, there is no hidden matrix)
+        const f16* Wl = Ws + d.off_h + (l - 1) * H * d.sh;
+#pragma unroll
+        for (int kb = 0; kb < F16_KB_MAX; ++kb) a[kb] = kb < KBH ? frag_hidden<HT>(Wl, d.sh, 16 * jt + c, kb, g) : frag_from_dwords(0u, 0u, 0u, 0u);
+    }
+}
+// Z (both column tiles) of row jt from its fragments
+template <int HT>
+__device__ __forceinline__ void row_products(const GenDims& d, int l, const f16x8 a[F16_KB_MAX], const u32x4 Bin[F16_KB_MAX][2], f32x4 Z[2]) {
+    constexpr int KBH = (HT + 1) / 2;
+    Z[0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; Z[1] = Z[0];
+#pragma unroll
+    for (int kb = 0; kb < F16_KB_MAX; ++kb) {
+        if (l == 0 ? kb < d.kt1 : kb < KBH) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) Z[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kb], __builtin_bit_cast(f16x8, Bin[kb][t]), Z[t], 0, 0, 0);
+        }
+    }
+}
+
 // inputs of layer L (as B operands, both column tiles) from the features: a chain of L layers
-template <int HT, int ACT>
+template <int HT, int ACT, bool PIPE = false>
 __device__ __forceinline__ void forward_chain(const f16* Ws, const GenDims& d, int L, int c, int g, const u32x4 xb[F16_KB_MAX][2],
                                               u32x4 Bout[F16_KB_MAX][2]) {
     constexpr int H = 16 * HT, KBH = (HT + 1) / 2;
 #pragma unroll
     for (int kb = 0; kb < F16_KB_MAX; ++kb) { Bout[kb][0] = xb[kb][0]; Bout[kb][1] = xb[kb][1]; }
     for (int l = 0; l < L; ++l) {
-        u32x4 Bn[2][F16_KB_MAX];
+        if constexpr (KBH > F16_KB_MAX) return;                           // 256 neurons: never called with L > 0 (one hidden layer)
+        u32x4 Bn[2][KBH > F16_KB_MAX ? KBH : F16_KB_MAX];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int kb = 0; kb < F16_KB_MAX; ++kb) Bn[t][kb] = u32x4{0u, 0u, 0u, 0u};
+        if constexpr (PIPE) {
+            f16x8 a_cur[F16_KB_MAX], a_nxt[F16_KB_MAX];
+            load_row_frags<HT>(Ws, d, l, 0, c, g, a_cur);
+#pragma unroll
+            for (int jt = 0; jt < HT; ++jt) {
+                if (jt + 1 < HT) load_row_frags<HT>(Ws, d, l, jt + 1, c, g, a_nxt);
+                f32x4 Z[2];
+                row_products<HT>(d, l, a_cur, Bout, Z);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x4 A;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) A[r] = gact<ACT>(Z[t][r], d.act);
+                    pack_acts<HT>(A, jt, Bn[t]);
+                }
+#pragma unroll
+                for (int kb = 0; kb < F16_KB_MAX; ++kb) a_cur[kb] = a_nxt[kb];
+            }
+        } else {
 #pragma unroll
         for (int jt = 0; jt < HT; ++jt) {
 #pragma unroll
@@ -427,7 +476,7 @@ __device__ __forceinline__ void forward_chain(const f16* Ws, const GenDims& d, i
 #pragma unroll
                     for (int kb = 0; kb < F16_KB_MAX; ++kb)
                         if (kb < d.kt1) Z = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag_first(Ws, d, 16 * jt + c, kb, g), __builtin_bit_cast(f16x8, Bout[kb][t]), Z, 0, 0, 0);
-                } else {
+                } else if constexpr (KBH <= F16_KB_MAX) {
                     const f16* Wl = Ws + d.off_h + (l - 1) * H * d.sh;
 #pragma unroll
                     for (int kb = 0; kb < KBH; ++kb)
@@ -438,6 +487,7 @@ __device__ __forceinline__ void forward_chain(const f16* Ws, const GenDims& d, i
                 for (int r = 0; r < 4; ++r) A[r] = gact<ACT>(Z[r], d.act);
                 pack_acts<HT>(A, jt, Bn[t]);
             }
+        }
         }
 #pragma unroll
         for (int kb = 0; kb < F16_KB_MAX; ++kb) { Bout[kb][0] = Bn[0][kb]; Bout[kb][1] = Bn[1][kb]; }
@@ -453,7 +503,7 @@ __device__ __forceinline__ f32x4 layer_z(const f16* Ws, const GenDims& d, int l,
 #pragma unroll
         for (int kb = 0; kb < F16_KB_MAX; ++kb)
             if (kb < d.kt1) Z = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag_first(Ws, d, 16 * jt + c, kb, g), __builtin_bit_cast(f16x8, Bin[kb][t]), Z, 0, 0, 0);
-    } else {
+    } else if constexpr (KBH <= F16_KB_MAX) {
         const f16* Wl = Ws + d.off_h + (l - 1) * H * d.sh;
 #pragma unroll
         for (int kb = 0; kb < KBH; ++kb)
@@ -463,7 +513,7 @@ __device__ __forceinline__ f32x4 layer_z(const f16* Ws, const GenDims& d, int l,
 }
 
 template <int HT, int ACT>
-__global__ void __launch_bounds__(LNR_DENSITY_BLOCK)
+__global__ void __launch_bounds__(LNR_DENSITY_BLOCK, 2)          // two waves per SIMD: <= 256 registers (two workgroups share a CU's LDS)
 mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ params, const uint32_t* __restrict__ featp, int64_t m_pad,
                            int64_t n_points, const int32_t* __restrict__ n_rays_dev, int n_rays, int n_samples, float* __restrict__ sigma, int32_t* __restrict__ clip_flag) {
     extern __shared__ __attribute__((aligned(16))) f16 Ws[];
@@ -475,30 +525,59 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
     const int64_t M = live_samples(n_points, n_rays_dev, n_rays, n_samples);
     const int64_t n_tiles = M > 0 ? (M + 31) / 32 : 0;
     const uint32_t plane_bytes = (uint32_t)m_pad * 4u;
-    for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < n_tiles; tile += (int64_t)gridDim.x * nw) {
-        u32x4 xb[F16_KB_MAX][2], Bl[F16_KB_MAX][2];
+    // the features of the NEXT tile are in flight while this one goes through the layers (72 dword loads per tile for the 36-pair
+    // frequency encoding: un-prefetched, every tile paid a full HBM round trip before its first MFMA)
+    auto load_tile = [&](int64_t tile, u32x4 (&x)[F16_KB_MAX][2]) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int64_t m = tile * 32 + 16 * t + c;
             const uint32_t mc = (uint32_t)(m < M ? m : M - 1);
 #pragma unroll
-            for (int kb = 0; kb < F16_KB_MAX; ++kb) xb[kb][t] = kb < d.kt1 ? load_xb_gen(featp, plane_bytes, mc, g, kb, d) : u32x4{0u, 0u, 0u, 0u};
+            for (int kb = 0; kb < F16_KB_MAX; ++kb) x[kb][t] = kb < d.kt1 ? load_xb_gen(featp, plane_bytes, mc, g, kb, d) : u32x4{0u, 0u, 0u, 0u};
         }
-        forward_chain<HT, ACT>(Ws, d, d.NH - 1, c, g, xb, Bl);            // inputs of the last hidden layer
+    };
+    float wo[HT][4];                                                     // the lane's entries of the output row
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            float part = 0.0f;
+    for (int jt = 0; jt < HT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wo[jt][r] = (float)Ws[d.off_o + 16 * jt + 4 * g + r];
+    const int64_t stride = (int64_t)gridDim.x * nw;
+    int64_t tile = (int64_t)blockIdx.x * nw + wave;
+    u32x4 xb[F16_KB_MAX][2], xn[F16_KB_MAX][2];
+    if (tile < n_tiles) load_tile(tile, xb);
+    for (; tile < n_tiles; tile += stride) {
+        const int64_t nt = tile + stride;
+        load_tile(nt < n_tiles ? nt : tile, xn);                          // unconditional (clamped): a static number of loads in flight
+        u32x4 Bl[F16_KB_MAX][2];
+        forward_chain<HT, ACT, true>(Ws, d, d.NH - 1, c, g, xb, Bl);      // inputs of the last hidden layer
+        float part[2] = {0.0f, 0.0f};
+        {
+            const int l = d.NH - 1;
+            f16x8 a_cur[F16_KB_MAX], a_nxt[F16_KB_MAX];
+            load_row_frags<HT>(Ws, d, l, 0, c, g, a_cur);
 #pragma unroll
             for (int jt = 0; jt < HT; ++jt) {
-                const f32x4 Z = layer_z<HT>(Ws, d, d.NH - 1, jt, t, c, g, Bl);
+                if (jt + 1 < HT) load_row_frags<HT>(Ws, d, l, jt + 1, c, g, a_nxt);
+                f32x4 Z[2];
+                row_products<HT>(d, l, a_cur, Bl, Z);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) part += (float)Ws[d.off_o + 16 * jt + 4 * g + r] * gact<ACT>(Z[r], d.act);
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) part[t] += wo[jt][r] * gact<ACT>(Z[t][r], d.act);
+#pragma unroll
+                for (int kb = 0; kb < F16_KB_MAX; ++kb) a_cur[kb] = a_nxt[kb];
             }
-            part += __shfl_xor(part, 16, 64);
-            part += __shfl_xor(part, 32, 64);
-            const int64_t m = tile * 32 + 16 * t + c;
-            if (g == 0 && m < M) sigma[m] = finite_or_clipped<true>(part, clip_flag);
         }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float v = part[t];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int64_t m = tile * 32 + 16 * t + c;
+            if (g == 0 && m < M) sigma[m] = finite_or_clipped<true>(v, clip_flag);
+        }
+#pragma unroll
+        for (int kb = 0; kb < F16_KB_MAX; ++kb) { xb[kb][0] = xn[kb][0]; xb[kb][1] = xn[kb][1]; }
     }
 }
 
@@ -515,12 +594,13 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
     extern __shared__ __attribute__((aligned(16))) f16 Ws[];
     constexpr int H = 16 * HT, KBH = (HT + 1) / 2;
     constexpr int NO = HT >= 4 ? HT / 4 : 1;                 // neuron tiles of dW a wave owns: jt = wave + 4 i
-    constexpr int NCOL = 2 * F16_KB_MAX > HT ? 2 * F16_KB_MAX : HT;          // 16-column tiles of the widest layer input
+    constexpr bool WIDE = KBH > F16_KB_MAX;                   // 256 neurons: one hidden layer, dW is H x in_dim only
+    constexpr int NCOL = (WIDE || 2 * F16_KB_MAX > HT) ? 2 * F16_KB_MAX : HT;   // 16-column tiles of the widest layer input
     const GenDims d = gen_dims(spec);
     fill_weights(Ws, params, d);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
-    const int kmax = 32 * d.kt1 > H ? 32 * d.kt1 : H;
+    const int kmax = (d.NH > 1 && 32 * d.kt1 <= H) ? H : 32 * d.kt1;        // rows of the widest layer INPUT (one hidden layer: the features)
     f16* scratch = Ws + ((d.n_w + 7) & ~7);
     const int per_wave = (kmax + H) * F16_TS;
     f16* AT_all = scratch;                                   // wave w: AT_all + w * per_wave, Tdz behind it
@@ -646,11 +726,11 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
                 __syncthreads();                                           // AT / Tdz are rewritten by the next step
             }
             // dA_{l-1} = W_l^T dZ_l (scaled domain); at the first layer: the feature gradient, un-scaled, to the d_feature planes
-            if (l > l_stop) {
+            if (!WIDE && l > l_stop) {
                 const f16* Wl = Ws + d.off_h + (l - 1) * H * d.sh;
-                f32x4 dAn[HT][2];
+                f32x4 dAn[WIDE ? 1 : HT][2];
 #pragma unroll
-                for (int it = 0; it < HT; ++it)
+                for (int it = 0; it < (WIDE ? 0 : HT); ++it)
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         f32x4 D = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -664,7 +744,7 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
                         dAn[it][t] = D;
                     }
 #pragma unroll
-                for (int it = 0; it < HT; ++it) { dA[it][0] = dAn[it][0]; dA[it][1] = dAn[it][1]; }
+                for (int it = 0; it < (WIDE ? 0 : HT); ++it) { dA[it][0] = dAn[it][0]; dA[it][1] = dAn[it][1]; }
             } else if (first && want_dfeat) {
                 for (int it = 0; it < d.in_dim / 16; ++it) {
 #pragma unroll
@@ -734,7 +814,7 @@ static bool f16_fast_class(const LnrNetSpec* spec) {
 static size_t f16_gen_bwd_lds(const LnrNetSpec* spec) {
     const int H = spec->n_neurons, kt1 = (spec->in_dim + 31) / 32;
     const size_t n_w = (size_t)gen_dims(*spec).n_w;
-    const size_t kmax = (size_t)(32 * kt1 > H ? 32 * kt1 : H);
+    const size_t kmax = (size_t)((spec->n_hidden > 1 && 32 * kt1 <= H) ? H : 32 * kt1);
     return ((n_w + 7) & ~(size_t)7) * sizeof(f16) + 4 * (kmax + H) * F16_TS * sizeof(f16) + 4 * sizeof(float) + 4 * (size_t)H * sizeof(float);
 }
 static size_t f16_gen_fwd_lds(const LnrNetSpec* spec) {
@@ -749,7 +829,9 @@ bool lnr_f16_supported(const LnrNetSpec* spec) {
     if (spec->encoding == LNR_ENC_HASHGRID && (spec->n_features & 1)) return false;
     if (spec->enc_dim & 1) return false;
     const int H = spec->n_neurons;
-    if (!(H == 16 || H == 32 || H == 64 || H == 128)) return false;
+    // 256 neurons: with ONE hidden layer (H x in_dim + the output row: the weight gradient is 128 registers per wave); a 256 x 256
+    // hidden matrix neither fits the LDS beside the exchange buffers nor the registers as a gradient
+    if (!(H == 16 || H == 32 || H == 64 || H == 128 || (H == 256 && spec->n_hidden == 1))) return false;
     if (spec->n_hidden < 1 || spec->n_hidden > F16_NH_MAX || spec->in_dim > 32 * F16_KB_MAX) return false;
     return f16_gen_bwd_lds(spec) <= (size_t)LNR_LDS_LIMIT;
 }
@@ -787,11 +869,15 @@ int lnr_mlp_fwd_f16(const LnrNetSpec* spec, const float* params, const void* fea
     }
     const size_t lds = f16_gen_fwd_lds(spec);
     const int akind = spec->activation;
+    // persistent: every workgroup converts the weights into its LDS once, so no more workgroups than the chip holds at a time
+    const size_t fit = (size_t)LNR_LDS_LIMIT / (lds > 0 ? lds : 1);
+    const int64_t resident = 256 * (int64_t)(fit >= 2 ? 2 : 1);
+    const dim3 grid_gen((unsigned)(blocks < resident ? blocks : resident));
 #define LNR_F16_GEN_FWD(HT, ACT)                                                                                                  \
     do {                                                                                                                         \
         int rc_ = f16_set_lds(mlp_forward_f16_gen_kernel<HT, ACT>, lds, "lnr_density_forward");                                  \
         if (rc_) return rc_;                                                                                                     \
-        hipLaunchKernelGGL((mlp_forward_f16_gen_kernel<HT, ACT>), grid, block, lds, st, *spec, params, fp, m_pad, pt->n_points,   \
+        hipLaunchKernelGGL((mlp_forward_f16_gen_kernel<HT, ACT>), grid_gen, block, lds, st, *spec, params, fp, m_pad, pt->n_points,   \
                            pt->n_rays_dev, pt->n_rays, pt->n_samples, sigma, pt->clip_flag);                                     \
     } while (0)
 #define LNR_F16_GEN_FWD_A(HT) do { if (akind == LNR_ACT_RELU) LNR_F16_GEN_FWD(HT, LNR_ACT_RELU); else if (akind == LNR_ACT_SINE) LNR_F16_GEN_FWD(HT, LNR_ACT_SINE); else LNR_F16_GEN_FWD(HT, -1); } while (0)
@@ -799,7 +885,8 @@ int lnr_mlp_fwd_f16(const LnrNetSpec* spec, const float* params, const void* fea
         case 1: LNR_F16_GEN_FWD_A(1); break;
         case 2: LNR_F16_GEN_FWD_A(2); break;
         case 4: LNR_F16_GEN_FWD_A(4); break;
-        default: LNR_F16_GEN_FWD_A(8); break;
+        case 8: LNR_F16_GEN_FWD_A(8); break;
+        default: LNR_F16_GEN_FWD_A(16); break;
     }
 #undef LNR_F16_GEN_FWD_A
 #undef LNR_F16_GEN_FWD
@@ -852,7 +939,8 @@ int lnr_mlp_bwd_f16(const LnrNetSpec* spec, const float* params, const void* fea
         case 1: LNR_F16_GEN_BWD_A(1); break;
         case 2: LNR_F16_GEN_BWD_A(2); break;
         case 4: LNR_F16_GEN_BWD_A(4); break;
-        default: LNR_F16_GEN_BWD_A(8); break;
+        case 8: LNR_F16_GEN_BWD_A(8); break;
+        default: LNR_F16_GEN_BWD_A(16); break;
     }
 #undef LNR_F16_GEN_BWD_A
 #undef LNR_F16_GEN_BWD

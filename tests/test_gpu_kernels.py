@@ -705,7 +705,7 @@ def test_fp16_mode_config5_4096x256(ops):
     assert float(d_rays16[tiny][:, :6].abs().max()) > 0.0
 
 
-@pytest.mark.parametrize("name", ["hash_f4_2hidden", "hash_f8", "freq_siren", "freq_relu128", "small_hash"])
+@pytest.mark.parametrize("name", ["hash_f4_2hidden", "hash_f8", "freq_siren", "freq_relu128", "small_hash", "freq_wide256"])
 def test_fp16_mode_general_networks(ops, name):
     """precision fp16 beyond the reference's default shape: frequency encoding + SIREN / wide ReLU MLPs, several hidden layers,
     4 or 8 features per level - forward and every gradient against the oracle with the same storage rounding (fp16 features,
@@ -747,8 +747,8 @@ def test_fp16_mode_general_networks(ops, name):
 
 def test_fp16_mode_refuses_what_it_does_not_cover(ops):
     from loner_amd import hip
-    for name in ("hash_f1", "freq_wide256"):                      # odd feature count per level; 256 neurons
-        enc, net = NETS[name]
+    wide2 = (NETS["freq_wide256"][0], dict(NETS["freq_wide256"][1], n_hidden_layers=2))
+    for enc, net in (NETS["hash_f1"], wide2):                     # odd feature count per level; a 256 x 256 hidden matrix
         bad = hip.make_net_spec(enc, dict(net, precision="fp16"))
         with pytest.raises(RuntimeError, match="fp16"):
             ops.density_forward(bad, torch.zeros(int(bad.n_params), device=DEV), pts=torch.zeros(64, 3, device=DEV))
