@@ -114,6 +114,19 @@ def cpu_model():
     return platform.processor() or "unknown"
 
 
+class _Shape:
+    def __init__(self, keyframes, rays, samples):
+        self.keyframes, self.rays, self.samples = keyframes, rays, samples
+
+
+# The reduced configuration on which "matched L1 depth" is established: the one of the G13 fixture (tests/golden/make_golden3.py),
+# where the REFERENCE's own optimiser was recorded: 30.0 m before training, 14.55 m after 50 iterations.
+QUALITY_SHAPE = _Shape(keyframes=2, rays=256, samples=128)
+QUALITY_ITERS = 100
+QUALITY_REFERENCE = {"l1_initial_m": 30.02, "l1_after_50_iterations_m": 14.55, "l1_after_100_iterations_m": 10.86,
+                     "source": "tests/golden/g13_l1_curve.npz: the reference's Optimizer + compute_l1_depth on this configuration (512 held-out rays, 256 samples)"}
+
+
 def oracle_leg(args, device, budget_s, max_iters, min_iters=2):
     """A baseline leg: the oracle (oracle/mapping_step.py - the reference's mapping iteration restated op for op in torch, with
     the reference's own sampler op sequence, oracle/torch_sampling.py) on the SAME workload as the HIP path: the whole
@@ -153,6 +166,14 @@ def oracle_leg(args, device, budget_s, max_iters, min_iters=2):
     if dev.type == "cuda":                           # one untimed iteration: kernel selection, allocator warm-up
         m, kfs = make(); torch.manual_seed(0); m.iterate(kfs, 1); sync()
     m, kfs = make()
+
+    def probe():
+        idx = torch.linspace(0, dirs.shape[1] - 1, L1_RAYS).long()
+        torch.manual_seed(123)
+        return OA.l1_depth(spec, m.params, m.grid[0, 0], dirs[:, idx].to(dev), dist0[idx].to(dev), kfs[0].pose6.detach(), m.scale, m.shift,
+                           torch.tensor([1.0, 50.0], device=dev), 256, torch.rand(L1_RAYS, 128).to(dev), (torch.randn(L1_RAYS, 256) * 1.0).to(dev),
+                           sampler="torch")[0]
+    l1_before = probe()
     torch.manual_seed(0)
     t0 = time.time()
     n_valid, iters = 0, 0
@@ -161,13 +182,9 @@ def oracle_leg(args, device, budget_s, max_iters, min_iters=2):
         sync()
         iters += 1
     dt = time.time() - t0
-    # matched-quality probe (outside the timed region): L1 depth of L1_RAYS held-out rays of keyframe 0, as compute_l1_depth does
-    idx = torch.linspace(0, dirs.shape[1] - 1, L1_RAYS).long()
-    torch.manual_seed(123)
-    l1, _ = OA.l1_depth(spec, m.params, m.grid[0, 0], dirs[:, idx].to(dev), dist0[idx].to(dev), kfs[0].pose6.detach(), m.scale, m.shift,
-                        torch.tensor([1.0, 50.0], device=dev), 2048, torch.rand(L1_RAYS, 1024).to(dev), (torch.randn(L1_RAYS, 2048) * 1.0).to(dev),
-                        sampler="torch")
-    out = {"value": n_valid / dt, "unit": "rays/s", "kind": "port",
+    # quality probe (outside the timed region): L1 depth of L1_RAYS held-out rays of keyframe 0, as compute_l1_depth does (256 samples)
+    l1 = probe()
+    out = {"value": n_valid / dt, "unit": "rays/s", "kind": "port", "l1_depth_m_before": l1_before,
            "sample": f"{iters} mapping iterations of the SAME workload ({args.keyframes} keyframes x {args.rays} rays x {args.samples} samples, joint map + "
                      f"pose optimisation, default network, occupancy step at global step 0), oracle torch ops in fp32, {dt:.1f} s wall",
            "ms_per_iter": 1e3 * dt / iters, "iterations": iters, "l1_depth_m_after": l1}
@@ -600,22 +617,59 @@ def main():
             rocm = {"error": str(e)}
         line["cpu_baseline"] = cpu
         line["torch_rocm_baseline"] = rocm
-        n_match = cpu["iterations"]
-        o3, w3 = make_optimizer("f32"), build_window(args.keyframes)
-        o3._do_iterate_optimizer(w3, [None], optimizer_settings=phase(n_match))
-        hip_l1 = l1_of(o3, w3[0], L1_RAYS)
-        legs = {"hip_f32": hip_l1, "cpu_oracle": cpu["l1_depth_m_after"], "torch_rocm_oracle": rocm.get("l1_depth_m_after")}
-        vals = [v for v in legs.values() if isinstance(v, float)]
+        line["speedup_vs_cpu_oracle_same_workload"] = line["value"] / cpu["value"] if args.dtype == "f32" else None
+        if isinstance(rocm.get("value"), float):
+            line["speedup_vs_torch_rocm_oracle_same_workload"] = line["value"] / rocm["value"]
+        # "at matched L1 depth": every leg trains the REDUCED configuration of the G13 fixture from the same initial parameters for the
+        # same number of iterations - long enough to leave the plateau (the reference: 30.0 -> 14.55 m after 50, 10.86 m after 100
+        # iterations) - and is scored the same way; the speed-ups are quoted as "at matched quality" only if the legs end within 15 % of
+        # each other (every leg draws its own random numbers: measured spread of the 256-ray estimate ~10 %) AND below half of where
+        # they started.  (The full workload cannot be taken that far on the CPU within a benchmark run.)
+        q = _Shape(QUALITY_SHAPE.keyframes, QUALITY_SHAPE.rays, QUALITY_SHAPE.samples)
+        legs = {}
+        try:
+            legs["cpu_oracle"] = oracle_leg(q, "cpu", budget_s=0.0, max_iters=QUALITY_ITERS, min_iters=QUALITY_ITERS)
+        except Exception as e:
+            legs["cpu_oracle"] = {"error": str(e)}
+        try:
+            legs["torch_rocm_oracle"] = oracle_leg(q, "cuda", budget_s=0.0, max_iters=QUALITY_ITERS, min_iters=QUALITY_ITERS)
+        except Exception as e:
+            legs["torch_rocm_oracle"] = {"error": str(e)}
+        try:
+            from oracle import network as NW
+            from loner_amd.common.settings import default_nerf_config
+            nc = default_nerf_config()
+            p0 = NW.init_params(NW.NetworkSpec.from_config(nc["pos_encoding_sigma"], nc["sigma_network"]), 0)     # the legs' initial parameters
+            keep = (args.rays, args.samples)
+            args.rays, args.samples = q.rays, q.samples
+            o3, w3 = make_optimizer("f32", params0=p0), build_window(q.keyframes)
+            args.rays, args.samples = keep
+            o3._model.cfg["render"]["N_samples_test"] = 256
+            l1_0 = l1_of(o3, w3[0], L1_RAYS)
+            torch.cuda.synchronize(); t3 = time.perf_counter()
+            o3._do_iterate_optimizer(w3, [None], optimizer_settings=phase(QUALITY_ITERS))
+            torch.cuda.synchronize(); dt3 = time.perf_counter() - t3
+            legs["hip_f32"] = {"value": o3.last_stats["n_valid_rays"] / dt3, "unit": "rays/s", "ms_per_iter": 1e3 * dt3 / QUALITY_ITERS,
+                               "l1_depth_m_before": l1_0, "l1_depth_m_after": l1_of(o3, w3[0], L1_RAYS)}
+        except Exception as e:
+            legs["hip_f32"] = {"error": str(e)}
+        after = {k: v.get("l1_depth_m_after") for k, v in legs.items()}
+        before = {k: v.get("l1_depth_m_before") for k, v in legs.items()}
+        vals = [v for v in after.values() if isinstance(v, float)]
+        off_plateau = all(isinstance(after[k], float) and isinstance(before[k], float) and after[k] < 0.5 * before[k] for k in after)
+        agree = len(vals) == len(after) and (max(vals) - min(vals)) <= 0.15 * max(vals)
         line["matched_quality"] = {
-            "iterations": n_match, "l1_depth_m": legs, "rays": L1_RAYS,
-            "agree_within_5pct": bool(len(vals) >= 2 and (max(vals) - min(vals)) <= 0.05 * max(vals)),
-            "note": "L1 depth (analysis/compute_l1_depth.py semantics, Model.forward(testing=True), 2048 samples) of the same held-out rays "
-                    "after the SAME number of iterations from the same initial parameters on every leg (different random draws); the "
-                    "speed-ups below are only quoted when the legs agree within 5 %"}
-        if line["matched_quality"]["agree_within_5pct"]:
-            line["speedup_vs_cpu_oracle"] = line["value"] / cpu["value"] if args.dtype == "f32" else None
-            if isinstance(rocm.get("value"), float):
-                line["speedup_vs_torch_rocm_oracle"] = line["value"] / rocm["value"]
+            "config": f"{q.keyframes} keyframes x {q.rays} rays x {q.samples} samples, default network, joint map + pose optimisation, {QUALITY_ITERS} iterations",
+            "reference": QUALITY_REFERENCE, "l1_depth_m_before": before, "l1_depth_m_after": after, "rays": L1_RAYS,
+            "rays_per_s": {k: v.get("value") for k, v in legs.items()}, "ms_per_iter": {k: v.get("ms_per_iter") for k, v in legs.items()},
+            "all_below_half_of_initial": bool(off_plateau), "agree_within_15pct": bool(agree), "matched": bool(off_plateau and agree),
+            "note": "L1 depth with analysis/compute_l1_depth.py semantics (Model.forward(testing=True), 256 samples, the same held-out rays "
+                    "of keyframe 0) before and after the SAME number of iterations from the same initial parameters on every leg (each leg "
+                    "draws its own random numbers); tests/test_gpu_mapping.py::test_l1_depth_curve_matches_the_reference_on_its_own_draws "
+                    "ties the HIP path to the reference's own curve on this configuration"}
+        if line["matched_quality"]["matched"]:
+            hv, cv, rv = (legs[k].get("value") for k in ("hip_f32", "cpu_oracle", "torch_rocm_oracle"))
+            line["matched_quality"]["speedup_at_matched_quality"] = {"vs_cpu_oracle": hv / cv, "vs_torch_rocm_oracle": hv / rv}
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
