@@ -177,7 +177,11 @@ int lnr_density_backward(const LnrNetSpec* spec /*host*/, const float* params,
                          const float* rays, const float* z, int32_t n_rays, int32_t n_samples,
                          const int32_t* n_rays_dev,
                          const float* d_sigma, float* grad_params, float* d_pts, float* d_rays,
-                         int32_t reuse_features, int32_t flags, void* workspace, size_t workspace_bytes, void* stream);
+                         int32_t reuse_features, int32_t flags, void* workspace, size_t workspace_bytes,
+                         void* input_grad_event /* hipEvent_t, nullable: recorded on `stream` as soon as d_pts / d_rays are complete,
+                                                   before the table-gradient reduce - the pose tail and the next batch's ray build and
+                                                   sampling can then run on another stream beside the rest of this call */,
+                         void* stream);
 
 /* ---- rays ------------------------------------------------------------------------------------- */
 /* LidarRayDirections.build_lidar_rays (ray_utils.py:269-322) + get_far_val (:31-60) for one

@@ -634,7 +634,8 @@ extern "C" int lnr_density_forward(const LnrNetSpec* spec, const float* params, 
 extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params, const float* pts, int64_t n_points,
                                     const float* rays, const float* z, int32_t n_rays, int32_t n_samples,
                                     const int32_t* n_rays_dev, const float* d_sigma, float* grad_params, float* d_pts, float* d_rays,
-                                    int32_t reuse_features, int32_t flags, void* workspace, size_t workspace_bytes, void* stream) {
+                                    int32_t reuse_features, int32_t flags, void* workspace, size_t workspace_bytes, void* input_grad_event,
+                                    void* stream) {
     int rc = check_spec(spec, "lnr_density_backward");
     if (rc) return rc;
     if (n_points == 0 && (pts != nullptr || n_rays == 0)) return LNR_OK;          // empty batch: nothing to do, nothing to check
@@ -725,6 +726,13 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     if (d_rays && !ray_accum) {
         rc = lnr_points_grad_to_rays(d_pts_eff, z, n_rays, n_rays_dev, n_samples, d_rays, stream);
         if (rc) return rc;
+    }
+    // the input gradient (d_pts / d_rays) is complete here; what follows only finishes grad_params.  A caller that continues with
+    // the input gradient on another stream (pose gradient, pose step, the next batch's rays and samples) waits for this event
+    // instead of for the whole call
+    if (input_grad_event != nullptr && hipEventRecord((hipEvent_t)input_grad_event, st) != hipSuccess) {
+        lnr_set_error("lnr_density_backward: hipEventRecord failed");
+        return LNR_ERR_LAUNCH;
     }
     if (!want_grad) return LNR_OK;       // frozen parameters: no table reduce, no weight-gradient fold
     if (hash && L.nown > 0) {          // also with cap_rec == 0 (all-atomic test path): it folds in the overflow accumulators

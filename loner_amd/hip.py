@@ -64,7 +64,7 @@ _SIGNATURES = {
     "lnr_density_workspace_init": (C.c_int, [P, C.c_size_t, P]),
     "lnr_density_forward": (C.c_int, [C.POINTER(NetSpec), P, P, C.c_int64, P, P, C.c_int32, C.c_int32, P, P, P, C.c_size_t, P]),
     "lnr_density_backward": (C.c_int, [C.POINTER(NetSpec), P, P, C.c_int64, P, P, C.c_int32, C.c_int32, P, P, P, P, P,
-                                       C.c_int32, C.c_int32, P, C.c_size_t, P]),
+                                       C.c_int32, C.c_int32, P, C.c_size_t, P, P]),
     "lnr_build_lidar_rays": (C.c_int, [P, P, C.c_int64, P, C.c_int32, P, C.c_float, C.c_float, C.c_float,
                                        C.POINTER(C.c_float), P, P, P, P]),
     "lnr_build_window_rays": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_float), C.POINTER(C.c_int64),

@@ -109,8 +109,18 @@ def density_forward(spec, params, pts=None, rays=None, z=None, n_rays_dev=None, 
     return sigma
 
 
+def _event(ev):
+    """raw hipEvent_t of a torch.cuda.Event that has been recorded at least once (torch creates the handle lazily), or NULL"""
+    if ev is None:
+        return None
+    h = ev.cuda_event
+    if not h:
+        raise RuntimeError("loner_amd: the torch event has no handle yet - record it once before handing it to the library")
+    return C.c_void_p(h)
+
+
 def density_backward(spec, params, d_sigma, grad_params, pts=None, rays=None, z=None, n_rays_dev=None,
-                     want_d_pts=False, reuse_features=False, d_rays=None, table_atomics=False, report_regions=False, bins=False, bins_w8=False):
+                     want_d_pts=False, reuse_features=False, d_rays=None, table_atomics=False, report_regions=False, bins=False, bins_w8=False, input_grad_event=None):
     """Accumulates into grad_params [n_params] (None: parameters frozen, only the input gradient is computed);
     returns d_pts ([...,3]) or None.  table_atomics: test hook (LNR_BWD_TABLE_ATOMICS).
     reuse_features: the caller asserts that the last density_forward on this device ran on the same params and
@@ -133,7 +143,7 @@ def density_backward(spec, params, d_sigma, grad_params, pts=None, rays=None, z=
         d_pts = torch.empty(n, 3, device=params.device, dtype=torch.float32) if want_d_pts else None
         check(load().lnr_density_backward(C.byref(spec), _ptr(params), _ptr(pts), n, None, None, 0, 0, None,
                                           _ptr(d_sigma), _ptr(grad_params), _ptr(d_pts), None, reuse, flags, _ptr(ent["buf"]), need,
-                                          _stream()), "lnr_density_backward")
+                                          _event(input_grad_event), _stream()), "lnr_density_backward")
         return d_pts
     rays, z = _f32c(rays), _f32c(z)
     n, s = z.shape
@@ -143,7 +153,7 @@ def density_backward(spec, params, d_sigma, grad_params, pts=None, rays=None, z=
     d_pts = torch.empty(n, s, 3, device=params.device, dtype=torch.float32) if want_d_pts else None
     check(load().lnr_density_backward(C.byref(spec), _ptr(params), None, 0, _ptr(rays), _ptr(z), n, s,
                                       _ptr(n_rays_dev), _ptr(d_sigma), _ptr(grad_params), _ptr(d_pts), _ptr(d_rays), reuse, flags,
-                                      _ptr(ent["buf"]), need, _stream()), "lnr_density_backward")
+                                      _ptr(ent["buf"]), need, _event(input_grad_event), _stream()), "lnr_density_backward")
     return d_pts
 
 

@@ -766,3 +766,37 @@ def test_l1_depth_curve_matches_the_reference_on_its_own_draws(golden):
         band = 0.05 if done[ph] <= 100 else 0.15
         assert abs(l1[ph + 1] - float(ref[ph])) < band * float(ref[ph]) + 0.05, (ph, l1[ph + 1], float(ref[ph]))
     assert l1[-1] < 0.5 * l1[0] and float(ref[-1]) < 0.5 * float(g["l1_init"])             # both off the plateau
+
+
+def test_pipelined_loop_equals_the_single_stream_loop():
+    """The training loop runs the pose tail, the occupancy step and the next iteration's front end (ray build, compaction, loss
+    normalisers, sampler) on a second stream beside the table-gradient reduce (lnr_density_backward's input_grad_event).  Same
+    kernels, same arguments, same order of the random draws: parameters, Adam state, poses, occupancy grid and the loss trace are
+    bit-identical to the single-stream loop - with the in-kernel generator (joint phase incl. two occupancy steps, then a tracking
+    phase with frozen parameters) and with the reference's recorded draws (G9)."""
+    from loner_amd.mapping import optimizer as OM
+    from loner_amd.utils import synthetic as SY
+
+    def run(pipeline):
+        s = small_settings(128, 64)
+        torch.manual_seed(0)
+        opt = OM.Optimizer(s, None, world_cube(), 0, False, True, False)
+        opt._pipeline = pipeline
+        base = SY.trajectory_pose6(3)
+        kfs = make_keyframes([base[0], base[1] + torch.tensor([0.02, 0.0, -0.01, 0.0, 0.002, 0.0]), base[2] + torch.tensor([0.0, 0.01, 0.0, 0.001, 0.0, 0.0])])
+        kfs[0].is_anchored = True
+        torch.manual_seed(5)
+        opt._do_iterate_optimizer(kfs, [None], optimizer_settings=OM.OptimizationSettings(23, False, False, False, True))
+        traces = [opt.last_stats["loss_terms"].clone()]
+        opt._do_iterate_optimizer(kfs, [None], optimizer_settings=OM.OptimizationSettings(7, False, True, True, True))     # tracking
+        traces.append(opt.last_stats["loss_terms"].clone())
+        p = opt._model.nerf_model._model_sigma.params
+        used_side = opt._side_stream is not None
+        return (p.detach().clone(), opt._occupancy_grid_model.occupancy_grid.detach().clone(),
+                torch.stack([kf.get_lidar_pose().get_pose_tensor().detach().cpu() for kf in kfs]), traces[0], traces[1]), used_side
+
+    (a, side_a), (b, side_b) = run(True), run(False)
+    assert side_a and not side_b
+    for n, x, y in zip(["params", "occupancy grid", "poses", "loss trace (joint)", "loss trace (tracking)"], a, b):
+        assert torch.equal(x, y), f"{n} differ between the pipelined and the single-stream loop"
+    assert float((a[2][1:] - a[2][0]).abs().max()) > 0
