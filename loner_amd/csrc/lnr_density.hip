@@ -350,7 +350,7 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
     L.shift = LNR_SLICE_SHIFT;
     const int64_t n_table = spec->n_params - spec->n_mlp_params;
     L.nown = (int)((n_table + (1 << L.shift) - 1) >> L.shift);
-    int64_t bpg = (n_points + LNR_ENC_BWD_BLOCK * 4 - 1) / (LNR_ENC_BWD_BLOCK * 4);        // ~4 batches per encode-backward workgroup
+    int64_t bpg = (n_points + LNR_ENC_BWD_BLOCK * LNR_BATCHES_PER_WG - 1) / (LNR_ENC_BWD_BLOCK * LNR_BATCHES_PER_WG);   // batches per encode-backward workgroup
     if (bpg < 1) bpg = 1;
     if (bpg > LNR_ENC_BWD_MAX_BPG) bpg = LNR_ENC_BWD_MAX_BPG;
     bpg = (bpg + 3) & ~(int64_t)3;       // the wave-private partition runs 4 waves (= 4 chunks) per workgroup

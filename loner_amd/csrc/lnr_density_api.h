@@ -27,6 +27,9 @@ struct PointSrc {
 #ifndef LNR_ENC_BWD_BLOCK
 #define LNR_ENC_BWD_BLOCK 512       // threads of an encode-backward workgroup = samples of one partition batch
 #endif
+#ifndef LNR_BATCHES_PER_WG
+#define LNR_BATCHES_PER_WG 4        // partition batches per encode-backward workgroup: a region collects the records of this many batches
+#endif
 #define LNR_REDUCE_SPLIT 32         // reduce workgroups per owner of a dense-indexed record level
 #define LNR_FIX_SCALE 4398046511104.0f /* 2^42: LDS gradient accumulators are 64-bit fixed point */
 #define LNR_BIN_BYTES 1024            /* LDS bin of one owner in the binned partition (lnr_encode.hip) */
