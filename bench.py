@@ -572,10 +572,10 @@ def main():
                                       "(tools/pmc.sh), NOT measured by this run; FETCH_SIZE doubled as the microarchitecture guide prescribes for gfx950",
                     "note": "dominant kernel by total time over the timed region, timed with HIP events recorded by the library on the "
                             "launch stream (lnr_profile_*).  It moves few algorithmic bytes and is not HBM-bound: the SQ counters "
-                            "(profiles/r02b_pmc_sq_summary.csv) show the VALU issuing 62 % of the kernel's cycles (353 M wave instructions per launch: "
-                            "hashing, interpolation weights, the in-LDS radix partition of the gradient records); the rest is the drain of the "
-                            "records' partial-line stores (ablation: 0.25 ms) and the L1 line rate of the table gathers of the d/dx term (2 clk per "
-                            "active lane and line, tools/gather_bench.hip) - DESIGN.md 4.3",
+                            "(profiles/r03_pmc_sq_instmix_scan.txt) show a latency-bound kernel - 296 M VALU wave instructions per backward, the VALU "
+                            "pipe ~45 % busy, 56 % of a wave's cycles parked in s_waitcnt / barriers, scalar unit 15 % - whose parts add up when "
+                            "switched off one by one (profiles/r03_ablate_binned_partition.txt): hashing and weights, the table gathers of the d/dx term "
+                            "(2 clk per active lane and line, tools/gather_bench.hip), the in-LDS radix partition of the gradient records - DESIGN.md 4.3",
                     "secondary": {k: v for k, v in kernels.items() if k != dom and k in ("encode_backward", "mlp_backward", "mlp_forward", "encode_forward", "table_grad_reduce")}}
     line = {
         "metric": "training rays/sec", "value": total_rays / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
