@@ -260,7 +260,11 @@ __global__ void __launch_bounds__(1024, MINW)   // HIP: (max threads, min waves 
 table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ regions_v, const RegionPlan plan, const int* __restrict__ counts, int bpg,
                           int maxo, const long long* __restrict__ ovf, float* __restrict__ grad_table, int64_t n_table_floats) {
     extern __shared__ long long acc[];
-    const int o = blockIdx.x;
+    // Owners in DESCENDING table order: the hardware starts workgroups in blockIdx order, the chip holds 512 of the ~900 at a time, and
+    // the owners of the fine (x-pair) levels - the heaviest, and with the default network exactly 512 of them - sit at the END of the
+    // table: started last they were the kernel's tail behind a half-empty chip; started first they fill it, and the lighter owners of
+    // the coarse levels follow.
+    const int o = (int)gridDim.x - 1 - (int)blockIdx.x;
     constexpr int slice = RED_SLICE, shift = LNR_SLICE_SHIFT;
     const uint32_t base = (uint32_t)o << shift;
     PHASE_INIT();
