@@ -34,7 +34,9 @@ struct PointSrc {
 #define LNR_FIX_SCALE 4398046511104.0f /* 2^42: LDS gradient accumulators are 64-bit fixed point */
 #define LNR_BIN_BYTES 1024            /* LDS bin of one owner in the binned partition (lnr_encode.hip) */
 #define LNR_BIN_MAX_OWNERS 64         /* 64 bins = 64 KB of LDS: two workgroups per CU */
+#ifndef LNR_XPAIR_SCALE_MIN
 #define LNR_XPAIR_SCALE_MIN 3000.0f   /* hashed power-of-two levels at least this fine take x-pair records (below: run-length combined 8-byte records) */
+#endif
 
 // rn(v * 2^42) as a 64-bit integer.  There is no f32 -> i64 convert instruction (the compiler's expansion is ~20 VALU
 // instructions, and these kernels are VALU-issue bound): for |v| < 2^8 the sum (double)v * 2^42 + 1.5 * 2^52 is exact up to
