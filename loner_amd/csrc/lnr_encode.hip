@@ -935,7 +935,8 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
     // d/dx mode: d_rays_acc (rays form, n_samples % 64 == 0, checked by the caller) > d_pts (planes) > none
     const int dxm = d_rays_acc ? ENC_DX_RAYS : (d_pts ? ENC_DX_PLANES : ENC_DX_NONE);
     float* dx_out = d_rays_acc ? reinterpret_cast<float*>(ray_acc) : dxl;
-    if (d_rays_acc && hipMemsetAsync(ray_acc, 0, ((size_t)src->n_rays * 6 + 1) * sizeof(long long), st) != hipSuccess) {   // sums + the non-finite word
+    // sums + the non-finite word, rounded up to 16 bytes (one fill kernel instead of an aligned part and a tail; the workspace has the room)
+    if (d_rays_acc && hipMemsetAsync(ray_acc, 0, ((((size_t)src->n_rays * 6 + 1) * sizeof(long long)) + 15) & ~(size_t)15, st) != hipSuccess) {
         lnr_set_error("lnr_density_backward: hipMemsetAsync failed");
         return LNR_ERR_LAUNCH;
     }

@@ -298,8 +298,9 @@ class Optimizer:
                     b["front"] = self._sample_front(b["rays"], b["depths"], b["n_dev"])
                     return b
                 batch = front_end() if n_it > 0 else None
+                if n_it > 0:
+                    valid_log[0:1] = batch["n_dev"]
                 for it_idx in range(n_it):
-                    valid_log[it_idx:it_idx + 1] = batch["n_dev"]
                     out = self._loss_and_grads(batch["rays"], batch["depths"], sp, it_idx, want_ray_grads=any_free,
                                                want_param_grads=not os_.freeze_sigma_mlp, n_rays_dev=batch["n_dev"],
                                                loss_out=loss_log[it_idx], accumulate_into_param_grad=True, want_stats=False,
@@ -321,6 +322,7 @@ class Optimizer:
                             self._step_occupancy_grid()
                         if it_idx + 1 < n_it:
                             batch = front_end()
+                            valid_log[it_idx + 1:it_idx + 2] = batch["n_dev"]
                     if groups and dg is not None:
                         if density_group is None:
                             self._step_density(out["grad_work"], dg)      # not deferred: right behind the reduce, on the main stream
