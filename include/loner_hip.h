@@ -73,6 +73,9 @@ typedef enum LnrPosRounding { LNR_POS_FMA = 0, LNR_POS_MUL_ADD = 1 } LnrPosRound
 #define LNR_BWD_TABLE_ATOMICS 1   /* test hook: every table-gradient record goes to the 64-bit overflow accumulators (atomics) */
 #define LNR_BWD_BINS 4            /* hashed levels take the binned partition (whole-line appends; same sums, measured ~3 % slower than the scan partition: DESIGN.md section 8) */
 #define LNR_BWD_BINS_W8 8         /* A-B hook: the binned partition with 512-thread workgroups / 1 KB bins instead of 256 / 512 bytes */
+#define LNR_BWD_DEFER_WEIGHT_FOLD 16 /* leave the per-workgroup weight-gradient slabs in the workspace: the caller adds them to grad_params
+                                       with lnr_density_fold_weight_grads (same points capacity) - e.g. on another stream, beside the
+                                       table-gradient reduce, instead of behind it */
 #define LNR_BWD_REPORT_REGIONS 2  /* diagnostic: print to stderr how full the record regions ran (synchronises the stream) */
 
 typedef enum LnrActivation {
@@ -182,6 +185,11 @@ int lnr_density_backward(const LnrNetSpec* spec /*host*/, const float* params,
                                                    before the table-gradient reduce - the pose tail and the next batch's ray build and
                                                    sampling can then run on another stream beside the rest of this call */,
                          void* stream);
+
+/* grad_params[0 : n_mlp_params] += the weight-gradient slabs a lnr_density_backward call with LNR_BWD_DEFER_WEIGHT_FOLD left in
+ * `workspace` (n_points: the n_points / n_rays * n_samples of that call).  Fixed summation order: reproducible. */
+int lnr_density_fold_weight_grads(const LnrNetSpec* spec /*host*/, int64_t n_points, float* grad_params,
+                                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- rays ------------------------------------------------------------------------------------- */
 /* LidarRayDirections.build_lidar_rays (ray_utils.py:269-322) + get_far_val (:31-60) for one

@@ -751,12 +751,36 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
         }
 #endif
     }
-    // (folding the slabs right after the MLP backward instead was measured: +15 us in front of the encode backward, nothing gained
-    // at the end, where the fold runs beside the next batch's sampler and ends with it)
+    // (folding the slabs right after the MLP backward instead was measured: +15 us in front of the encode backward, nothing gained)
+    if (flags & LNR_BWD_DEFER_WEIGHT_FOLD) return LNR_OK;            // the caller folds them with lnr_density_fold_weight_grads
     const int n_mlp = spec->n_mlp_params;
     LnrProfScope prof_slabs("reduce_slabs", st);
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(lnr_div_up(n_mlp, 64)), dim3(64 * LNR_SLAB_GROUPS), 0, st, slabs, n_slabs, n_mlp, grad_params);
     LNR_CHECK_LAUNCH("lnr_density_backward(reduce)");
+    return LNR_OK;
+}
+
+extern "C" int lnr_density_fold_weight_grads(const LnrNetSpec* spec, int64_t n_points, float* grad_params, void* workspace,
+                                             size_t workspace_bytes, void* stream) {
+    int rc = check_spec(spec, "lnr_density_fold_weight_grads");
+    if (rc) return rc;
+    LNR_REQUIRE(grad_params && workspace && n_points > 0, "lnr_density_fold_weight_grads: bad argument");
+    const Layout L = make_layout(spec, n_points);
+    LNR_REQUIRE(workspace_bytes >= L.total, "lnr_density_fold_weight_grads: workspace too small");
+    int n_slabs;
+    if (spec->precision == LNR_PREC_F16) n_slabs = lnr_f16_bwd_slabs(spec, n_points);
+    else {
+        DensityPlan plan;
+        rc = plan_launch(spec, n_points, true, &plan, "lnr_density_fold_weight_grads");
+        if (rc) return rc;
+        n_slabs = plan.grid;
+    }
+    const int n_mlp = spec->n_mlp_params;
+    hipStream_t st = (hipStream_t)stream;
+    LnrProfScope prof_slabs("reduce_slabs", st);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(lnr_div_up(n_mlp, 64)), dim3(64 * LNR_SLAB_GROUPS), 0, st,
+                       (const float*)((const char*)workspace + L.off_slabs), n_slabs, n_mlp, grad_params);
+    LNR_CHECK_LAUNCH("lnr_density_fold_weight_grads");
     return LNR_OK;
 }
 

@@ -183,6 +183,7 @@ int lnr_mlp_fwd_f16(const LnrNetSpec* spec, const float* params, const void* fea
                     hipStream_t st);
 int lnr_mlp_bwd_f16(const LnrNetSpec* spec, const float* params, const void* featp, int64_t m_pad, const MlpPoints* pt, const float* d_sigma,
                     float* dfeat, float* slabs, int want_dfeat, int* n_slabs, hipStream_t st);
+int lnr_f16_bwd_slabs(const LnrNetSpec* spec, int64_t n_points);
 int lnr_selftest_mfma_f16(float* out, hipStream_t st);
 int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, const float* dfeat,
                         float* dxl, int64_t m_pad, float* grad_table, void* regions, const RegionPlan* plan, int* counts, int bpg,

@@ -893,6 +893,16 @@ int lnr_mlp_fwd_f16(const LnrNetSpec* spec, const float* params, const void* fea
     return LNR_OK;
 }
 
+// weight-gradient slabs lnr_mlp_bwd_f16 writes for up to n_points points (one per workgroup)
+int lnr_f16_bwd_slabs(const LnrNetSpec* spec, int64_t n_points) {
+    const int64_t tiles = (n_points + 31) / 32;
+    int64_t blocks = (tiles + 3) / 4;
+    if (blocks > LNR_BWD_MAX_BLOCKS) blocks = LNR_BWD_MAX_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    if (!f16_fast_class(spec) && blocks > 256) blocks = 256;
+    return (int)blocks;
+}
+
 int lnr_mlp_bwd_f16(const LnrNetSpec* spec, const float* params, const void* featp, int64_t m_pad, const MlpPoints* pt, const float* d_sigma,
                     float* dfeat, float* slabs, int want_dfeat, int* n_slabs, hipStream_t st) {
     const int64_t tiles = (pt->n_points + 31) / 32;

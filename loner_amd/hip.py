@@ -28,6 +28,7 @@ PRECISIONS = {"fp32": 0, "float32": 0, "fp16": 1, "half": 1, "float16": 1}
 POS_ROUNDINGS = {"fma": 0, "mul_add": 1}
 BWD_TABLE_ATOMICS = 1        # LNR_BWD_TABLE_ATOMICS
 BWD_REPORT_REGIONS = 2       # LNR_BWD_REPORT_REGIONS
+BWD_DEFER_WEIGHT_FOLD = 16   # LNR_BWD_DEFER_WEIGHT_FOLD
 BWD_BINS = 4                 # LNR_BWD_BINS
 BWD_BINS_W8 = 8              # LNR_BWD_BINS_W8
 WORKSPACE_STATUS_BYTES, STATUS_CLIPPED = 256, 0            # LNR_WORKSPACE_STATUS_BYTES, LNR_STATUS_CLIPPED
@@ -65,6 +66,7 @@ _SIGNATURES = {
     "lnr_density_forward": (C.c_int, [C.POINTER(NetSpec), P, P, C.c_int64, P, P, C.c_int32, C.c_int32, P, P, P, C.c_size_t, P]),
     "lnr_density_backward": (C.c_int, [C.POINTER(NetSpec), P, P, C.c_int64, P, P, C.c_int32, C.c_int32, P, P, P, P, P,
                                        C.c_int32, C.c_int32, P, C.c_size_t, P, P]),
+    "lnr_density_fold_weight_grads": (C.c_int, [C.POINTER(NetSpec), C.c_int64, P, P, C.c_size_t, P]),
     "lnr_build_lidar_rays": (C.c_int, [P, P, C.c_int64, P, C.c_int32, P, C.c_float, C.c_float, C.c_float,
                                        C.POINTER(C.c_float), P, P, P, P]),
     "lnr_build_window_rays": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_float), C.POINTER(C.c_int64),

@@ -304,9 +304,14 @@ class Optimizer:
                     out = self._loss_and_grads(batch["rays"], batch["depths"], sp, it_idx, want_ray_grads=any_free,
                                                want_param_grads=not os_.freeze_sigma_mlp, n_rays_dev=batch["n_dev"],
                                                loss_out=loss_log[it_idx], accumulate_into_param_grad=True, want_stats=False,
-                                               defer_grad_wait=True, poison=poison, front=batch["front"], input_grad_event=ev)
+                                               defer_grad_wait=True, poison=poison, front=batch["front"], input_grad_event=ev,
+                                               defer_weight_fold=True)
                     side.wait_event(ev)
                     with torch.cuda.stream(side):
+                        if out["grad_params"] is not None:
+                            # the weight-gradient slabs of the MLP backward, folded here instead of behind the table-gradient reduce
+                            ops.density_fold_weight_grads(self._model.nerf_model._model_sigma.spec, out["grad_params"],
+                                                          batch["rays"].shape[0] * batch["front"]["z"].shape[1])
                         if any_free:
                             self._pose_backward(batch, out["d_rays"], pose_dev, free_rows, poison=poison, poison_tag=it_idx)
                         if groups:
@@ -554,7 +559,7 @@ class Optimizer:
 
     def _loss_and_grads(self, rays, depths, params, iteration_idx, want_ray_grads, want_param_grads, n_rays_dev=None,
                         loss_out=None, accumulate_into_param_grad=False, draws=None, want_stats=True, defer_grad_wait=False,
-                        poison=None, front=None, input_grad_event=None):
+                        poison=None, front=None, input_grad_event=None, defer_weight_fold=False):
         """sample -> density -> fused render+loss(+backward) -> density backward.  rays [N,13], depths [N] on device.
         front: the result of _sample_front for these rays when the caller already ran it (the pipelined training loop);
         input_grad_event: recorded by the density backward as soon as d_rays is complete (ops.density_backward)."""
@@ -593,7 +598,8 @@ class Optimizer:
                 grad_params = torch.zeros_like(p)
             # the point gradient is reduced per ray inside the backward and added to d_rays (no [N,S,3] tensor)
             ops.density_backward(spec, p, d_sigma, grad_params, rays=rays, z=z, n_rays_dev=n_rays_dev,
-                                 reuse_features=True, d_rays=d_rays if want_ray_grads else None, input_grad_event=input_grad_event)
+                                 reuse_features=True, d_rays=d_rays if want_ray_grads else None, input_grad_event=input_grad_event,
+                                 defer_weight_fold=defer_weight_fold and grad_params is not None)
             if self._dist is not None and want_param_grads:
                 # only the training loop (defer_grad_wait) steps a slice and gathers the parameters; every other caller
                 # (compute_loss -> autograd -> an optimiser of its own) gets the whole sum whatever the exchange form

@@ -120,7 +120,8 @@ def _event(ev):
 
 
 def density_backward(spec, params, d_sigma, grad_params, pts=None, rays=None, z=None, n_rays_dev=None,
-                     want_d_pts=False, reuse_features=False, d_rays=None, table_atomics=False, report_regions=False, bins=False, bins_w8=False, input_grad_event=None):
+                     want_d_pts=False, reuse_features=False, d_rays=None, table_atomics=False, report_regions=False, bins=False, bins_w8=False, input_grad_event=None,
+                     defer_weight_fold=False):
     """Accumulates into grad_params [n_params] (None: parameters frozen, only the input gradient is computed);
     returns d_pts ([...,3]) or None.  table_atomics: test hook (LNR_BWD_TABLE_ATOMICS).
     reuse_features: the caller asserts that the last density_forward on this device ran on the same params and
@@ -131,7 +132,8 @@ def density_backward(spec, params, d_sigma, grad_params, pts=None, rays=None, z=
     params, d_sigma = _f32c(params), _f32c(d_sigma)
     assert grad_params is None or (grad_params.dtype == torch.float32 and grad_params.is_contiguous())
     flags = (hip.BWD_TABLE_ATOMICS if table_atomics else 0) | (hip.BWD_REPORT_REGIONS if report_regions else 0) | \
-        (hip.BWD_BINS if (bins or _BINS) else 0) | (hip.BWD_BINS_W8 if (bins_w8 or _BINS_W8) else 0)
+        (hip.BWD_BINS if (bins or _BINS) else 0) | (hip.BWD_BINS_W8 if (bins_w8 or _BINS_W8) else 0) | \
+        (hip.BWD_DEFER_WEIGHT_FOLD if defer_weight_fold else 0)
     n_points = (pts.numel() // 3) if pts is not None else z.numel()
     ent, need = _workspace(spec, params.device, n_points)
     if pts is not None:
@@ -155,6 +157,15 @@ def density_backward(spec, params, d_sigma, grad_params, pts=None, rays=None, z=
                                       _ptr(n_rays_dev), _ptr(d_sigma), _ptr(grad_params), _ptr(d_pts), _ptr(d_rays), reuse, flags,
                                       _ptr(ent["buf"]), need, _event(input_grad_event), _stream()), "lnr_density_backward")
     return d_pts
+
+
+def density_fold_weight_grads(spec, grad_params, n_points):
+    """Adds the weight-gradient slabs a density_backward(defer_weight_fold=True) call left in the workspace to grad_params
+    (on the current stream: the training loop does it on its side stream, beside the table-gradient reduce)."""
+    require_device(grad_params)
+    ent, need = _workspace(spec, grad_params.device, n_points)
+    check(load().lnr_density_fold_weight_grads(C.byref(spec), int(n_points), _ptr(grad_params), _ptr(ent["buf"]), need, _stream()),
+          "lnr_density_fold_weight_grads")
 
 
 # ---------------------------------------------------------------- rays
@@ -245,8 +256,9 @@ def compact_rays(rays, depths, keep, src_index, seg_start):
     rays_out = torch.empty_like(rays)
     depths_out = torch.empty_like(depths)
     src_out = torch.empty_like(src_index) if src_index is not None else None
-    out_seg = torch.zeros(n_seg + 1, device=dev, dtype=torch.int32)
-    n_out = torch.zeros(1, device=dev, dtype=torch.int32)
+    # (both are written in full by the kernel: no fill launches - the front end of an iteration is a chain of small kernels)
+    out_seg = torch.empty(n_seg + 1, device=dev, dtype=torch.int32)
+    n_out = torch.empty(1, device=dev, dtype=torch.int32)
     seg = (C.c_int32 * (n_seg + 1))(*[int(v) for v in seg_start])
     check(load().lnr_compact_rays(_ptr(rays), _ptr(depths), _ptr(keep), _ptr(src_index), n_in, seg, n_seg,
                                   _ptr(rays_out), _ptr(depths_out), _ptr(src_out), _ptr(out_seg), _ptr(n_out), _stream()),
@@ -259,7 +271,7 @@ def lidar_rays_backward(d_rays, rays, src_index, seg_start_dev, directions_list,
     require_device(d_rays, rays, src_index, seg_start_dev, transforms)
     n_seg = len(directions_list)
     dev = rays.device
-    out = torch.zeros(n_seg, 12, device=dev, dtype=torch.float32)
+    out = torch.empty(n_seg, 12, device=dev, dtype=torch.float32) if rays.shape[0] > 0 else torch.zeros(n_seg, 12, device=dev)
     ptrs = (C.c_void_p * n_seg)(*[d.data_ptr() for d in directions_list])
     npts = (C.c_int64 * n_seg)(*[int(d.shape[1]) for d in directions_list])
     check(load().lnr_lidar_rays_backward(_ptr(_f32c(d_rays)), _ptr(rays), _ptr(src_index), _ptr(seg_start_dev), n_seg, ptrs,
@@ -380,7 +392,7 @@ def count_opaque(rays, depth_gt, n_rays_dev=None, far0=None):
     """-> int32 [2] = {#rays, #opaque rays}.  far0 (device float [1], optional): the `far` every depth is compared with
     (the reference's far[0] quirk) when `rays` is only a shard of the batch."""
     require_device(rays, depth_gt, far0)
-    counts = torch.zeros(2, device=rays.device, dtype=torch.int32)
+    counts = torch.empty(2, device=rays.device, dtype=torch.int32)       # overwritten, also for an empty batch
     check(load().lnr_count_opaque(_ptr(_f32c(rays)), _ptr(_f32c(depth_gt)), rays.shape[0], _ptr(n_rays_dev), _ptr(far0),
                                   _ptr(counts), _stream()), "lnr_count_opaque")
     return counts
