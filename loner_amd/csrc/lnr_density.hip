@@ -541,9 +541,15 @@ static int launch_reduce_variant(const ReduceCtx& c, int n_owners, hipStream_t s
 }
 // 2 regions in flight per wave at 8 waves per SIMD (two workgroups per CU) measured best: 0.35 ms against 0.37 (4 in flight, 8 waves),
 // 0.40 (4, 4 waves) and 0.43 (8, 4 waves) on the bench workload
+#ifndef LNR_RED_U
+#define LNR_RED_U 2
+#endif
+#ifndef LNR_RED_W
+#define LNR_RED_W 8
+#endif
 int launch_table_reduce(const ReduceCtx& c, int n_owners, hipStream_t st) {
-    if (c.spec->n_features < 2) return launch_reduce_variant<0, 2, 8>(c, n_owners, st);
-    return launch_reduce_variant<1, 2, 8>(c, n_owners, st);
+    if (c.spec->n_features < 2) return launch_reduce_variant<0, LNR_RED_U, LNR_RED_W>(c, n_owners, st);
+    return launch_reduce_variant<1, LNR_RED_U, LNR_RED_W>(c, n_owners, st);
 }
 
 }  // namespace
