@@ -305,10 +305,12 @@ class Optimizer:
                                                want_param_grads=not os_.freeze_sigma_mlp, n_rays_dev=batch["n_dev"],
                                                loss_out=loss_log[it_idx], accumulate_into_param_grad=True, want_stats=False,
                                                defer_grad_wait=True, poison=poison, front=batch["front"], input_grad_event=ev,
-                                               defer_weight_fold=True)
+                                               defer_weight_fold=density_group is not None)
                     side.wait_event(ev)
                     with torch.cuda.stream(side):
-                        if out["grad_params"] is not None:
+                        # (only when the density step is deferred: it then waits for this stream; a step taken right away on the main
+                        # stream must find the folded gradient there)
+                        if out["grad_params"] is not None and density_group is not None:
                             # the weight-gradient slabs of the MLP backward, folded here instead of behind the table-gradient reduce
                             ops.density_fold_weight_grads(self._model.nerf_model._model_sigma.spec, out["grad_params"],
                                                           batch["rays"].shape[0] * batch["front"]["z"].shape[1])
@@ -330,7 +332,8 @@ class Optimizer:
                             valid_log[it_idx + 1:it_idx + 2] = batch["n_dev"]
                     if groups and dg is not None:
                         if density_group is None:
-                            self._step_density(out["grad_work"], dg)      # not deferred: right behind the reduce, on the main stream
+                            main.wait_stream(side)                        # (the pose check of this iteration may still mark the failure word)
+                            self._step_density(out["grad_work"], dg)      # not deferred: behind the reduce, on the main stream
                         else:
                             self._pending_density = (out["grad_work"], density_group, self._optimizer.param_groups[density_group]['lr'])
                     main.wait_stream(side)
