@@ -19,27 +19,9 @@
 //   C/D: column c, rows 4g..4g+3  (checked on the device by lnr_selftest_mfma).
 // As in the fp32 kernels the C layout of one product is made the B layout of the next by permuting K: K slot 8g+i of a
 // 32-neuron block stands for neuron 4g+i of its first 16-neuron tile (i < 4) or 4g+i-4 of its second (i >= 4).
-#include "lnr_density_impl.h"
-#include "lnr_encoding.h"
-
-typedef _Float16 f16;
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#include "lnr_f16_common.h"
 
 #define F16_TS 40            // halves per neuron row of the dZ transpose buffer (32 samples + pad: 80-byte rows)
-
-__device__ __forceinline__ f16x8 frag_from_dwords(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
-    return __builtin_bit_cast(f16x8, u32x4{a, b, c, d});
-}
-__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    return __builtin_bit_cast(uint32_t, h2{(f16)lo, (f16)hi});
-}
-__device__ __forceinline__ float round_f16(float v) { return (float)(f16)v; }
-
-__device__ __forceinline__ int64_t live_samples(int64_t n_points, const int32_t* n_rays_dev, int n_rays, int n_samples) {
-    return n_rays_dev ? (int64_t)lnr_live_rays(n_rays, n_rays_dev) * n_samples : n_points;
-}
 
 // layer-1 A fragments (W1 [H][32] row-major fp32 in `params`, rounded to fp16) and the output row, for the lane's neurons
 template <int HT>
@@ -322,9 +304,6 @@ mlp_backward_f16_kernel(const float* __restrict__ params, int n_mlp, const uint3
 //   * dA_{l-1} = W_l^T dZ_l reads W^T fragments with strided 2-byte LDS loads (no transposed weight copy: LDS holds the
 //     weights once plus 4 x (inputs^T + dZ^T) = 140 KB for 96 -> 128 -> 128 -> 1; a transposed copy parked in the scratch of the
 //     feature-gradient launch was measured slower, 4.7 vs 4.1 ms for the whole 128 x 2 backward).
-#define F16_KB_MAX 4                 // 32-wide K blocks of a layer's input: in_dim <= 128, H <= 128
-#define F16_NH_MAX 3
-
 #define F16_WPAD 8                   // halves of padding per weight row in LDS: a 256-byte row stride (H = 128) would put the 16 rows
                                      // of an A fragment on the same banks (16-way conflict, measured 25x off the MFMA rate)
 struct GenDims {
@@ -349,17 +328,6 @@ __device__ __forceinline__ void fill_weights(f16* Ws, const float* __restrict__ 
     for (int l = 0; l < d.NH - 1; ++l)
         for (int i = threadIdx.x; i < nh; i += blockDim.x) Ws[d.off_h + l * d.H * d.sh + (i / d.H) * d.sh + i % d.H] = (f16)params[n0 + l * nh + i];
     for (int i = threadIdx.x; i < d.H; i += blockDim.x) Ws[d.off_o + i] = (f16)params[n0 + (d.NH - 1) * nh + i];
-}
-
-// activations; ACT >= 0 fixes the kind at compile time.  Sine (SIREN) uses the hardware sine/cosine (v_sin_f32 / v_cos_f32, ~1e-6
-// absolute): its result is rounded to fp16 (5e-4) right after, and the range-reduced libm sinf was what bounded these kernels.
-template <int ACT> __device__ __forceinline__ float gact(float v, int kind) {
-    if (ACT == LNR_ACT_SINE) return __sinf(v);
-    return ACT >= 0 ? act_fwd(v, ACT) : act_fwd(v, kind);
-}
-template <int ACT> __device__ __forceinline__ float gact_d(float v, int kind) {
-    if (ACT == LNR_ACT_SINE) return __cosf(v);
-    return ACT >= 0 ? act_bwd(v, ACT) : act_bwd(v, kind);
 }
 
 // B operand of layer 1, K block kb: features 32kb + 8g .. +7 of sample m = half2 pairs 16kb + 4g .. +3
@@ -510,75 +478,6 @@ __device__ __forceinline__ f32x4 layer_z(const f16* Ws, const GenDims& d, int l,
             Z = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag_hidden<HT>(Wl, d.sh, 16 * jt + c, kb, g), __builtin_bit_cast(f16x8, Bin[kb][t]), Z, 0, 0, 0);
     }
     return Z;
-}
-
-template <int HT, int ACT>
-__global__ void __launch_bounds__(LNR_DENSITY_BLOCK, 2)          // two waves per SIMD: <= 256 registers (two workgroups share a CU's LDS)
-mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ params, const uint32_t* __restrict__ featp, int64_t m_pad,
-                           int64_t n_points, const int32_t* __restrict__ n_rays_dev, int n_rays, int n_samples, float* __restrict__ sigma, int32_t* __restrict__ clip_flag) {
-    extern __shared__ __attribute__((aligned(16))) f16 Ws[];
-    const GenDims d = gen_dims(spec);
-    fill_weights(Ws, params, d);
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int c = lane & 15, g = lane >> 4;
-    const int64_t M = live_samples(n_points, n_rays_dev, n_rays, n_samples);
-    const int64_t n_tiles = M > 0 ? (M + 31) / 32 : 0;
-    const uint32_t plane_bytes = (uint32_t)m_pad * 4u;
-    // the features of the NEXT tile are in flight while this one goes through the layers (72 dword loads per tile for the 36-pair
-    // frequency encoding: un-prefetched, every tile paid a full HBM round trip before its first MFMA)
-    auto load_tile = [&](int64_t tile, u32x4 (&x)[F16_KB_MAX][2]) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int64_t m = tile * 32 + 16 * t + c;
-            const uint32_t mc = (uint32_t)(m < M ? m : M - 1);
-#pragma unroll
-            for (int kb = 0; kb < F16_KB_MAX; ++kb) x[kb][t] = kb < d.kt1 ? load_xb_gen(featp, plane_bytes, mc, g, kb, d) : u32x4{0u, 0u, 0u, 0u};
-        }
-    };
-    float wo[HT][4];                                                     // the lane's entries of the output row
-#pragma unroll
-    for (int jt = 0; jt < HT; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) wo[jt][r] = (float)Ws[d.off_o + 16 * jt + 4 * g + r];
-    const int64_t stride = (int64_t)gridDim.x * nw;
-    int64_t tile = (int64_t)blockIdx.x * nw + wave;
-    u32x4 xb[F16_KB_MAX][2], xn[F16_KB_MAX][2];
-    if (tile < n_tiles) load_tile(tile, xb);
-    for (; tile < n_tiles; tile += stride) {
-        const int64_t nt = tile + stride;
-        load_tile(nt < n_tiles ? nt : tile, xn);                          // unconditional (clamped): a static number of loads in flight
-        u32x4 Bl[F16_KB_MAX][2];
-        forward_chain<HT, ACT, true>(Ws, d, d.NH - 1, c, g, xb, Bl);      // inputs of the last hidden layer
-        float part[2] = {0.0f, 0.0f};
-        {
-            const int l = d.NH - 1;
-            f16x8 a_cur[F16_KB_MAX], a_nxt[F16_KB_MAX];
-            load_row_frags<HT>(Ws, d, l, 0, c, g, a_cur);
-#pragma unroll
-            for (int jt = 0; jt < HT; ++jt) {
-                if (jt + 1 < HT) load_row_frags<HT>(Ws, d, l, jt + 1, c, g, a_nxt);
-                f32x4 Z[2];
-                row_products<HT>(d, l, a_cur, Bl, Z);
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) part[t] += wo[jt][r] * gact<ACT>(Z[t][r], d.act);
-#pragma unroll
-                for (int kb = 0; kb < F16_KB_MAX; ++kb) a_cur[kb] = a_nxt[kb];
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            float v = part[t];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            const int64_t m = tile * 32 + 16 * t + c;
-            if (g == 0 && m < M) sigma[m] = finite_or_clipped<true>(v, clip_flag);
-        }
-#pragma unroll
-        for (int kb = 0; kb < F16_KB_MAX; ++kb) { xb[kb][0] = xn[kb][0]; xb[kb][1] = xn[kb][1]; }
-    }
 }
 
 // One launch per hidden layer: target = l accumulates dW of layer l and stops the backward chain there; the launch of layer 0 walks
@@ -817,11 +716,6 @@ static size_t f16_gen_bwd_lds(const LnrNetSpec* spec) {
     const size_t kmax = (size_t)((spec->n_hidden > 1 && 32 * kt1 <= H) ? H : 32 * kt1);
     return ((n_w + 7) & ~(size_t)7) * sizeof(f16) + 4 * (kmax + H) * F16_TS * sizeof(f16) + 4 * sizeof(float) + 4 * (size_t)H * sizeof(float);
 }
-static size_t f16_gen_fwd_lds(const LnrNetSpec* spec) {
-    const size_t n_w = (size_t)gen_dims(*spec).n_w;
-    return ((n_w + 7) & ~(size_t)7) * sizeof(f16);
-}
-
 // what LNR_PREC_F16 covers: half2 pair planes need an even number of features per level; the general kernels hold dW in registers
 // (<= 128 neurons, <= 3 hidden layers) and the weights plus the transposes of four waves in LDS
 bool lnr_f16_supported(const LnrNetSpec* spec) {
@@ -842,15 +736,6 @@ static size_t f16_bwd_lds(const LnrNetSpec* spec) {
            (size_t)2 * kb * 64 * 16;
 }
 
-template <typename K>
-static int f16_set_lds(K kernel, size_t lds, const char* who) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-        lnr_set_error("%s: hipFuncSetAttribute(%zu) failed", who, lds);
-        return LNR_ERR_LAUNCH;
-    }
-    return LNR_OK;
-}
-
 int lnr_mlp_fwd_f16(const LnrNetSpec* spec, const float* params, const void* featp, int64_t m_pad, const MlpPoints* pt, float* sigma,
                     hipStream_t st) {
     const int64_t tiles = (pt->n_points + 31) / 32;
@@ -867,30 +752,7 @@ int lnr_mlp_fwd_f16(const LnrNetSpec* spec, const float* params, const void* fea
         }
         return LNR_OK;
     }
-    const size_t lds = f16_gen_fwd_lds(spec);
-    const int akind = spec->activation;
-    // persistent: every workgroup converts the weights into its LDS once, so no more workgroups than the chip holds at a time
-    const size_t fit = (size_t)LNR_LDS_LIMIT / (lds > 0 ? lds : 1);
-    const int64_t resident = 256 * (int64_t)(fit >= 2 ? 2 : 1);
-    const dim3 grid_gen((unsigned)(blocks < resident ? blocks : resident));
-#define LNR_F16_GEN_FWD(HT, ACT)                                                                                                  \
-    do {                                                                                                                         \
-        int rc_ = f16_set_lds(mlp_forward_f16_gen_kernel<HT, ACT>, lds, "lnr_density_forward");                                  \
-        if (rc_) return rc_;                                                                                                     \
-        hipLaunchKernelGGL((mlp_forward_f16_gen_kernel<HT, ACT>), grid_gen, block, lds, st, *spec, params, fp, m_pad, pt->n_points,   \
-                           pt->n_rays_dev, pt->n_rays, pt->n_samples, sigma, pt->clip_flag);                                     \
-    } while (0)
-#define LNR_F16_GEN_FWD_A(HT) do { if (akind == LNR_ACT_RELU) LNR_F16_GEN_FWD(HT, LNR_ACT_RELU); else if (akind == LNR_ACT_SINE) LNR_F16_GEN_FWD(HT, LNR_ACT_SINE); else LNR_F16_GEN_FWD(HT, -1); } while (0)
-    switch (spec->n_neurons / 16) {
-        case 1: LNR_F16_GEN_FWD_A(1); break;
-        case 2: LNR_F16_GEN_FWD_A(2); break;
-        case 4: LNR_F16_GEN_FWD_A(4); break;
-        case 8: LNR_F16_GEN_FWD_A(8); break;
-        default: LNR_F16_GEN_FWD_A(16); break;
-    }
-#undef LNR_F16_GEN_FWD_A
-#undef LNR_F16_GEN_FWD
-    return LNR_OK;
+    return lnr_mlp_fwd_f16_gen(spec, params, fp, m_pad, pt, sigma, blocks, st);
 }
 
 // weight-gradient slabs lnr_mlp_bwd_f16 writes for up to n_points points (one per workgroup)

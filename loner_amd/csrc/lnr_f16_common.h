@@ -1,0 +1,51 @@
+// Pieces shared by the fp16-mode density kernels (lnr_density_f16.hip: the reference network's class and the general backward;
+// lnr_density_f16_fwd.hip: the general forward).  Lane / fragment conventions: see the head of lnr_density_f16.hip.
+#pragma once
+#include "lnr_density_impl.h"
+#include "lnr_encoding.h"
+
+typedef _Float16 f16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+
+#define F16_KB_MAX 4                 // 32-wide K blocks of a layer's input: in_dim <= 128, H <= 128
+#define F16_NH_MAX 3
+
+__device__ __forceinline__ f16x8 frag_from_dwords(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    return __builtin_bit_cast(f16x8, u32x4{a, b, c, d});
+}
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, h2{(f16)lo, (f16)hi});
+}
+__device__ __forceinline__ float round_f16(float v) { return (float)(f16)v; }
+
+__device__ __forceinline__ int64_t live_samples(int64_t n_points, const int32_t* n_rays_dev, int n_rays, int n_samples) {
+    return n_rays_dev ? (int64_t)lnr_live_rays(n_rays, n_rays_dev) * n_samples : n_points;
+}
+
+// activations; ACT >= 0 fixes the kind at compile time.  Sine (SIREN) uses the hardware sine/cosine (v_sin_f32 / v_cos_f32, ~1e-6
+// absolute): its result is rounded to fp16 (5e-4) right after, and the range-reduced libm sinf was what bounded these kernels.
+template <int ACT> __device__ __forceinline__ float gact(float v, int kind) {
+    if (ACT == LNR_ACT_SINE) return __sinf(v);
+    return ACT >= 0 ? act_fwd(v, ACT) : act_fwd(v, kind);
+}
+template <int ACT> __device__ __forceinline__ float gact_d(float v, int kind) {
+    if (ACT == LNR_ACT_SINE) return __cosf(v);
+    return ACT >= 0 ? act_bwd(v, ACT) : act_bwd(v, kind);
+}
+
+template <typename K>
+static inline int f16_set_lds(K kernel, size_t lds, const char* who) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        lnr_set_error("%s: hipFuncSetAttribute(%zu) failed", who, lds);
+        return LNR_ERR_LAUNCH;
+    }
+    return LNR_OK;
+}
+
+
+// the general forward (any supported width / depth / activation), lnr_density_f16_fwd.hip
+int lnr_mlp_fwd_f16_gen(const LnrNetSpec* spec, const float* params, const uint32_t* featp, int64_t m_pad, const MlpPoints* pt, float* sigma,
+                        int64_t blocks, hipStream_t st);

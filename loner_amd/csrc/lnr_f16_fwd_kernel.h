@@ -1,0 +1,237 @@
+// General fp16-mode forward of the density MLP (any supported width / depth / activation): the kernel and its LDS layout.
+// Host dispatch: lnr_density_f16_fwd.hip.  Semantics = oracle/network.py with precision="fp16" (reference: tinycudann FullyFusedMLP
+// behind src/models/nerf_tcnn.py:35-38).
+//
+// Everything that shapes the instruction stream is a template parameter - HT (16-neuron row tiles), NH (hidden layers), KT (32-wide
+// K blocks of the first layer, the inputs' blocks rounded up to 2 or 4), CT (16-sample column tiles a wave carries) - because the
+// round-3 counters showed what run-time shapes cost here: as a run-time layer loop with run-time first-layer block counts the kernel
+// issued 1030 v_mov per 32-sample tile (activations COPIED from one layer's registers to the next, accumulators copied between the
+// arms of `kb < kt1` branches) beside 112 MFMAs, and waves sat in s_waitcnt 45 % of their cycles because every row of every layer
+// exposed an LDS round trip in front of its MFMAs.
+//   * layers are unrolled at compile time: a layer's outputs ARE the next layer's B operands (register renaming, no copies);
+//   * the first layer's rows are zero-padded in LDS to KT blocks: every fragment load and MFMA is unconditional;
+//   * hidden rows are stored K-PERMUTED (slot 8g+i of a 32-neuron block = neuron 4g+i / 16+4g+i-4: the permutation that makes one
+//     product's C layout the next one's B layout), so a hidden fragment is ONE ds_read_b128 like a first-layer one (it was two
+//     ds_read_b64 at a 2-way bank conflict each: SQ_LDS_BANK_CONFLICT was 45 % of the LDS cycles);
+//   * rows whose length is a multiple of 256 bytes are XOR-swizzled by 16-byte chunk (chunk ^ (row & 15)) instead of padded: the
+//     ds_read_b128 lane groups of an A fragment (16 rows, g differing by at most one inside a group) then hit 64 distinct banks;
+//   * the constant-one padding of the network input (tinycudann pads the encoding to a multiple of 16 with ones) is a per-neuron
+//     bias: the sum of its first-layer weights, kept as fp32 in LDS, is the C operand the first product of a row starts from, and
+//     the padded weight columns are stored as zeros;
+//   * features come through buffer loads, one descriptor per K block whose num_records ends at the last encoded plane: planes
+//     beyond the encoding read as zero in hardware, and a step costs 4 address additions per column tile instead of a 64-bit
+//     multiply-add, two compares and two selects per loaded dword;
+//   * the fragments of row jt + 1 are requested, and pinned there by a scheduling barrier, BEFORE the MFMAs of row jt; the
+//     activations of row jt - 1 are applied after them, in the shadow of the matrix pipe.
+#pragma once
+#include "lnr_f16_common.h"
+
+template <int HT, int NH, int KT>
+struct FwdLds {
+    static constexpr int H = 16 * HT, KBH = (HT + 1) / 2;
+    static constexpr int K0 = 32 * KT, KH = 32 * KBH;                       // halves per stored row: first layer / hidden layers
+    static constexpr bool SWZ0 = K0 % 128 == 0, SWZH = KH % 128 == 0;       // 256-byte multiples: swizzled, else padded by 16 bytes
+    static constexpr int S0 = SWZ0 ? K0 : K0 + 8, SH = SWZH ? KH : KH + 8;  // row strides (halves)
+    static constexpr int OFF_H = H * S0, OFF_O = OFF_H + (NH - 1) * H * SH, N_W = (OFF_O + H + 7) & ~7;
+    static constexpr size_t BYTES = (size_t)N_W * sizeof(f16) + (size_t)H * sizeof(float);   // + the first layer's bias (fp32)
+};
+
+// stored position (halves, within its row) of K slot `col` of row `row`
+template <bool SWZ> __device__ __forceinline__ int fwd_slot(int col, int row) {
+    return SWZ ? ((((col >> 3) ^ (row & 15)) << 3) | (col & 7)) : col;
+}
+
+// fp32 parameters (tinycudann layout: W1 [H][in_dim], hidden [H][H] each, output row [H]) -> the fp16 LDS copy described above.
+// Trip counts are compile-time and the loops unrolled by 8: as `for (i = tid; i < n; i += blockDim.x)` every element was one exposed
+// L2 round trip (128 in a row for the 128 x 2 network: ~20 us in front of the first MFMA of every workgroup).
+template <int HT, int NH, int KT>
+__device__ __forceinline__ void fwd_fill_weights(f16* Ws, const float* __restrict__ params, int in_dim, int enc_dim) {
+    using L = FwdLds<HT, NH, KT>;
+    constexpr int NT = LNR_DENSITY_BLOCK;
+    const int n0 = L::H * in_dim, tid = threadIdx.x;
+    static_assert((L::H * L::K0) % NT == 0 && (L::H * L::KH) % NT == 0, "whole trips");
+#pragma unroll 8
+    for (int it = 0; it < L::H * L::K0 / NT; ++it) {
+        const int i = it * NT + tid, row = i / L::K0, col = i % L::K0;
+        const float w = params[row * in_dim + (col < enc_dim ? col : 0)];
+        Ws[row * L::S0 + fwd_slot<L::SWZ0>(col, row)] = col < enc_dim ? (f16)w : (f16)0.0f;
+    }
+    if constexpr (NH > 1) {
+        for (int l = 0; l < NH - 1; ++l) {
+#pragma unroll 8
+            for (int it = 0; it < L::H * L::KH / NT; ++it) {
+                const int i = it * NT + tid, row = i / L::KH, p = i % L::KH;
+                const int g = (p >> 3) & 3, ii = p & 7;
+                const int n = (p & ~31) + (ii < 4 ? 4 * g + ii : 16 + 4 * g + ii - 4);       // the neuron K slot p stands for
+                const float w = params[n0 + (l * L::H + row) * L::H + (n < L::H ? n : 0)];
+                Ws[L::OFF_H + (l * L::H + row) * L::SH + fwd_slot<L::SWZH>(p, row)] = n < L::H ? (f16)w : (f16)0.0f;
+            }
+        }
+    }
+    float* bias = reinterpret_cast<float*>(Ws + L::N_W);
+    for (int i = tid; i < L::H; i += NT) {
+        Ws[L::OFF_O + i] = (f16)params[n0 + (NH - 1) * L::H * L::H + i];
+        float b = 0.0f;
+        for (int k = enc_dim; k < in_dim; ++k) b += (float)(f16)params[i * in_dim + k];
+        bias[i] = b;
+    }
+}
+
+// per-lane LDS offsets (halves) of the A fragments of row tile 0: K block kb of row c, K slots 8g..8g+7
+template <int KB, int S, bool SWZ>
+__device__ __forceinline__ void fwd_frag_offsets(int c, int g, int (&koff)[F16_KB_MAX]) {
+#pragma unroll
+    for (int kb = 0; kb < F16_KB_MAX; ++kb) koff[kb] = kb < KB ? c * S + fwd_slot<SWZ>(32 * kb + 8 * g, c) : 0;
+}
+
+// Buffer descriptor over the feature planes of K block kb (half2 pairs 16kb .. 16kb+15, planes [pair][sample] of plane_bytes each),
+// ending at the last ENCODED plane: anything beyond reads as zero (raw buffer range check; an empty block has zero records).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t fwd_block_rsrc(const uint32_t* featp, uint32_t plane_bytes, int kb, int enc_pairs) {
+    const int planes = enc_pairs - 16 * kb;
+    const uint32_t n = planes <= 0 ? 0u : (uint32_t)(planes < 16 ? planes : 16) * plane_bytes;
+    const char* base = reinterpret_cast<const char*>(featp) + (planes <= 0 ? 0 : (size_t)(16 * kb) * plane_bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, (int)n, 0x00020000);
+}
+
+// ReLU as one v_max_i32 on the bit pattern (negative floats, -0 included, are negative integers; fmaxf costs two instructions here:
+// a canonicalising v_max of the MFMA result in front of the real one).  A NaN with a clear sign bit stays NaN (numpy's maximum does
+// the same) and reaches the output's finite_or_clipped guard.
+template <int ACT> __device__ __forceinline__ float fwd_act(float v, int kind) {
+    if constexpr (ACT == LNR_ACT_RELU) {
+        const int b = __builtin_bit_cast(int, v);
+        return __builtin_bit_cast(float, b > 0 ? b : 0);
+    } else {
+        return gact<ACT>(v, kind);
+    }
+}
+
+// One layer: B operands Bin (KB K blocks x CT column tiles) against the matrix at Wl (row stride S halves, lane offsets koff).
+// LAST = false: the activations become Bout, the next layer's B operands.  LAST = true: they are reduced against the output row
+// (wo: the lane's entries, rows 16jt + 4g + r) into part[t].
+// BIAS: the products of row tile jt start from bias[16jt + 4g .. +3] (bias_lane = the lane's bias + 4g) instead of zero.
+template <int HT, int ACT, int KB, int S, int CT, bool LAST, bool BIAS>
+__device__ __forceinline__ void fwd_layer(const f16* Wl, const int (&koff)[F16_KB_MAX], const float* bias_lane, int act, const u32x4 (&Bin)[F16_KB_MAX][CT],
+                                          u32x4 (&Bout)[F16_KB_MAX][CT], const float (&wo)[HT][4], float (&part)[CT]) {
+    f16x8 a[2][KB];
+    f32x4 Z[2][CT], z0[2];
+    auto frags = [&](int jt, f16x8 (&dst)[KB], f32x4& zb) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) dst[kb] = *reinterpret_cast<const f16x8*>(Wl + 16 * jt * S + koff[kb]);
+        zb = BIAS ? *reinterpret_cast<const f32x4*>(bias_lane + 16 * jt) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    };
+    auto finish = [&](int jt, const f32x4 (&z)[CT]) {                    // activations of row tile jt
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            if constexpr (LAST) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[t] = __builtin_fmaf(wo[jt][r], fwd_act<ACT>(z[t][r], act), part[t]);
+            } else {
+                Bout[jt >> 1][t][2 * (jt & 1)] = pack_h2(fwd_act<ACT>(z[t][0], act), fwd_act<ACT>(z[t][1], act));
+                Bout[jt >> 1][t][2 * (jt & 1) + 1] = pack_h2(fwd_act<ACT>(z[t][2], act), fwd_act<ACT>(z[t][3], act));
+            }
+        }
+    };
+    if constexpr (!LAST && (HT & 1)) {                                    // odd tile count (16 neurons): the upper half of the last block
+#pragma unroll
+        for (int t = 0; t < CT; ++t) { Bout[HT >> 1][t][2] = 0u; Bout[HT >> 1][t][3] = 0u; }
+    }
+    frags(0, a[0], z0[0]);
+#pragma unroll
+    for (int jt = 0; jt < HT; ++jt) {
+        if (jt + 1 < HT) frags(jt + 1, a[(jt + 1) & 1], z0[(jt + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);                                // the loads stay in front of this row's MFMAs
+#pragma unroll
+        for (int t = 0; t < CT; ++t) Z[jt & 1][t] = z0[jt & 1];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int t = 0; t < CT; ++t)
+                Z[jt & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[jt & 1][kb], __builtin_bit_cast(f16x8, Bin[kb][t]), Z[jt & 1][t], 0, 0, 0);
+        if (jt > 0) finish(jt - 1, Z[(jt - 1) & 1]);
+    }
+    finish(HT - 1, Z[(HT - 1) & 1]);
+}
+
+template <int HT, int ACT, int NH, int KT, int CT>
+__global__ void __launch_bounds__(LNR_DENSITY_BLOCK, 2)          // two waves per SIMD: <= 256 registers (two workgroups share a CU's LDS)
+mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ params, const uint32_t* __restrict__ featp, int64_t m_pad,
+                           int64_t n_points, const int32_t* __restrict__ n_rays_dev, int n_rays, int n_samples, float* __restrict__ sigma, int32_t* __restrict__ clip_flag) {
+    extern __shared__ __attribute__((aligned(16))) f16 Ws[];
+    using L = FwdLds<HT, NH, KT>;
+    static_assert(NH >= 1 && NH <= F16_NH_MAX && KT >= 1 && KT <= F16_KB_MAX, "shape");
+    static_assert(L::KBH <= F16_KB_MAX || NH == 1, "256 neurons: one hidden layer");
+    constexpr int TS = 16 * CT;                                           // samples per wave step
+    fwd_fill_weights<HT, NH, KT>(Ws, params, spec.in_dim, spec.enc_dim);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int act = spec.activation, enc_pairs = spec.enc_dim / 2;
+    const int64_t M = live_samples(n_points, n_rays_dev, n_rays, n_samples);
+    const int64_t n_tiles = M > 0 ? (M + TS - 1) / TS : 0;
+    const uint32_t plane_bytes = (uint32_t)m_pad * 4u;
+    const float* bias_lane = reinterpret_cast<const float*>(Ws + L::N_W) + 4 * g;
+    __amdgpu_buffer_rsrc_t rsrc[KT];
+#pragma unroll
+    for (int kb = 0; kb < KT; ++kb) rsrc[kb] = fwd_block_rsrc(featp, plane_bytes, kb, enc_pairs);
+    uint32_t qoff[4];                                                     // byte offsets of the lane's four planes inside a K block, + its column
+#pragma unroll
+    for (int q = 0; q < 4; ++q) qoff[q] = (uint32_t)(4 * g + q) * plane_bytes + (uint32_t)c * 4u;
+    int koff0[F16_KB_MAX], koffh[F16_KB_MAX];
+    fwd_frag_offsets<KT, L::S0, L::SWZ0>(c, g, koff0);
+    fwd_frag_offsets<(NH > 1 ? L::KBH : 0), L::SH, L::SWZH>(c, g, koffh);
+    float wo[HT][4];                                                      // the lane's entries of the output row
+#pragma unroll
+    for (int jt = 0; jt < HT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wo[jt][r] = (float)Ws[L::OFF_O + 16 * jt + 4 * g + r];
+    // the features of the NEXT step are in flight while this one goes through the layers
+    // (samples past M: their planes are padded to m_pad, whatever they hold only reaches columns that are never stored)
+    auto load_tile = [&](int64_t tile, u32x4 (&x)[F16_KB_MAX][CT]) {
+        const uint32_t m0 = (uint32_t)(tile * TS) * 4u;
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+#pragma unroll
+            for (int kb = 0; kb < F16_KB_MAX; ++kb) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    x[kb][t][q] = kb < KT ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc[kb < KT ? kb : 0], (int)(qoff[q] + m0) + 64 * t, 0, 0) : 0u;
+            }
+        }
+    };
+    auto run_tile = [&](int64_t tile, const u32x4 (&x)[F16_KB_MAX][CT]) {
+        float part[CT];
+#pragma unroll
+        for (int t = 0; t < CT; ++t) part[t] = 0.0f;
+        u32x4 B1[F16_KB_MAX][CT], B2[F16_KB_MAX][CT];
+        if constexpr (NH == 1) {
+            fwd_layer<HT, ACT, KT, L::S0, CT, true, true>(Ws, koff0, bias_lane, act, x, B1, wo, part);
+        } else if constexpr (NH == 2) {
+            fwd_layer<HT, ACT, KT, L::S0, CT, false, true>(Ws, koff0, bias_lane, act, x, B1, wo, part);
+            fwd_layer<HT, ACT, L::KBH, L::SH, CT, true, false>(Ws + L::OFF_H, koffh, bias_lane, act, B1, B2, wo, part);
+        } else {
+            fwd_layer<HT, ACT, KT, L::S0, CT, false, true>(Ws, koff0, bias_lane, act, x, B1, wo, part);
+            fwd_layer<HT, ACT, L::KBH, L::SH, CT, false, false>(Ws + L::OFF_H, koffh, bias_lane, act, B1, B2, wo, part);
+            fwd_layer<HT, ACT, L::KBH, L::SH, CT, true, false>(Ws + L::OFF_H + L::H * L::SH, koffh, bias_lane, act, B2, B1, wo, part);
+        }
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            float v = part[t];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int64_t m = tile * TS + 16 * t + c;
+            if (g == 0 && m < M) sigma[m] = finite_or_clipped<true>(v, clip_flag);
+        }
+    };
+    const int64_t stride = (int64_t)gridDim.x * nw;
+    int64_t tile = (int64_t)blockIdx.x * nw + wave;
+    u32x4 xa[F16_KB_MAX][CT], xb[F16_KB_MAX][CT];
+    if (tile < n_tiles) load_tile(tile, xa);
+    for (; tile < n_tiles; tile += 2 * stride) {                          // two steps per trip: the feature buffers alternate
+        const int64_t t1 = tile + stride, t2 = tile + 2 * stride;
+        load_tile(t1 < n_tiles ? t1 : tile, xb);                          // unconditional (clamped): a static number of loads in flight
+        run_tile(tile, xa);
+        if (t1 >= n_tiles) break;
+        load_tile(t2 < n_tiles ? t2 : t1, xa);
+        run_tile(t1, xb);
+    }
+}
