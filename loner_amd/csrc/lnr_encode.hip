@@ -84,12 +84,12 @@ encode_forward_kernel(const LnrNetSpec spec, const float* __restrict__ table, co
     }
 }
 
-template <bool H16>
+// fp32 feature planes of the frequency encoding: four features per thread (the fp16 mode's pair planes: freq_forward_h16_kernel)
 __global__ void __launch_bounds__(ENC_BLOCK)
 freq_forward_kernel(const LnrNetSpec spec, const PointSrc src, float* __restrict__ feat, int64_t m_pad, int bpg) {
     const int group = blockIdx.x / bpg, chunk = blockIdx.x % bpg;       // 4 features per group
     const int64_t M = live_points(src);
-    const int64_t M16 = H16 ? (M + 31) / 32 * 32 : (M + 15) / 16 * 16;
+    const int64_t M16 = (M + 15) / 16 * 16;
     for (int64_t m = (int64_t)chunk * ENC_BLOCK + threadIdx.x; m < M16; m += (int64_t)bpg * ENC_BLOCK) {
         float out[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (m < M) {
@@ -97,17 +97,66 @@ freq_forward_kernel(const LnrNetSpec spec, const PointSrc src, float* __restrict
             load_unit_point(src, m, x);
             freq_features4(spec, x, 4 * group, out);
         }
-        if constexpr (H16) {                    // half2 pair planes: (sin, cos) of one (dimension, frequency) per dword
-            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-            uint32_t* pairs = reinterpret_cast<uint32_t*>(feat);
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
-                if (4 * group + 2 * q < spec.enc_dim)
-                    pairs[(size_t)(2 * group + q) * m_pad + m] = __builtin_bit_cast(uint32_t, h2{(_Float16)out[2 * q], (_Float16)out[2 * q + 1]});
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (4 * group + r < spec.enc_dim) feat[(size_t)(4 * group + r) * m_pad + m] = out[r];
+        for (int r = 0; r < 4; ++r)
+            if (4 * group + r < spec.enc_dim) feat[(size_t)(4 * group + r) * m_pad + m] = out[r];
+    }
+}
+
+// Half2 pair planes of the frequency encoding (fp16 mode): one thread per (sample, dimension), every frequency's (sin, cos) pair
+// from ONE range reduction.  The reference's features are sin(ph) and sin(rn(ph + pi/2)) with ph = rn(rn(x 2^f) pi)
+// (oracle/encoding.py, tinycudann frequency.h); as two libm sinf calls per pair, four features per thread and the point re-derived by
+// each of the 18 feature groups, this kernel took longer than the 128 x 2 MLP it feeds (165 vs 133 us at 2.1 M samples).  Here
+//   k = rint(ph 2/pi), r = ph - k pi/2 (three-term Cody-Waite with fma), minimax sin / cos of r on [-pi/4, pi/4], quadrant from k & 3
+// gives sin(ph), cos(ph) to ~1e-7, and the second feature is cos(ph + d) = cos(ph) - d sin(ph), d = (fl(pi/2) - pi/2) - e, where e is
+// the rounding error of the fp32 addition ph + fl(pi/2) recovered exactly (TwoSum): 1.2e-7 from sin of the rounded sum (numpy check
+// in DESIGN 4.6), i.e. the same fp16 value except within 1e-7 of a rounding boundary (0.004 % of the features).
+__device__ __forceinline__ void sincos_f32(float ph, float* s_out, float* c_out) {
+    const float k = __builtin_rintf(ph * 0.636619772367581343f);
+    float r = __builtin_fmaf(-k, 1.57079637050628662109375f, ph);
+    r = __builtin_fmaf(-k, -4.37113900018624283e-8f, r);
+    r = __builtin_fmaf(-k, -1.7151245100059e-15f, r);
+    const float z = r * r;
+    float sp = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    sp = __builtin_fmaf(z, sp, -1.6666654611e-1f);
+    const float s = __builtin_fmaf(z * r, sp, r);
+    float cp = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    cp = __builtin_fmaf(z, cp, 4.166664568298827e-2f);
+    const float c = __builtin_fmaf(z * z, cp, __builtin_fmaf(z, -0.5f, 1.0f));
+    const int q = (int)k;
+    const float a = (q & 1) ? c : s, b = (q & 1) ? s : c;                 // q = 0: (s, c)  1: (c, -s)  2: (-s, -c)  3: (-c, s)
+    *s_out = (q & 2) ? -a : a;
+    *c_out = ((q + 1) & 2) ? -b : b;
+}
+
+__global__ void __launch_bounds__(ENC_BLOCK)
+freq_forward_h16_kernel(const LnrNetSpec spec, const PointSrc src, uint32_t* __restrict__ pairs, int64_t m_pad, int bpg) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const int dim = blockIdx.x / bpg, chunk = blockIdx.x % bpg;
+    const int nf = spec.n_frequencies;
+    const int64_t M = live_points(src);
+    const int64_t M32 = (M + 31) / 32 * 32;
+    const uint32_t plane_bytes = (uint32_t)m_pad * 4u;
+    for (int64_t m = (int64_t)chunk * ENC_BLOCK + threadIdx.x; m < M32; m += (int64_t)bpg * ENC_BLOCK) {
+        float xv = 0.0f;
+        const bool live = m < M;
+        if (live) {
+            float x[3];
+            load_unit_point(src, m, x);
+            xv = dim == 0 ? x[0] : (dim == 1 ? x[1] : x[2]);
+        }
+        for (int f = 0; f < nf; ++f) {
+            const float mult = __uint_as_float((uint32_t)(127 + f) << 23);          // 2^f
+            const float ph = lnr_mul_rn(lnr_mul_rn(xv, mult), LNR_PI_F);
+            float s, c;
+            sincos_f32(ph, &s, &c);
+            const float h = lnr_add_rn(ph, LNR_PI_2_F);                              // the reference's second phase; e = its rounding error
+            const float bb = lnr_add_rn(h, -ph);
+            const float e = lnr_add_rn(lnr_add_rn(ph, -lnr_add_rn(h, -bb)), lnr_add_rn(LNR_PI_2_F, -bb));
+            const float d = 4.371139000186243e-8f - e;
+            const float c2 = __builtin_fmaf(-d, s, c);
+            const uint32_t v = live ? __builtin_bit_cast(uint32_t, h2{(_Float16)s, (_Float16)c2}) : 0u;
+            st32<uint32_t>(pairs, (uint32_t)(dim * nf + f) * plane_bytes + (uint32_t)m * 4u, v);
         }
     }
 }
@@ -906,8 +955,14 @@ int lnr_encode_forward(const LnrNetSpec* spec, const float* params, const PointS
     if (bpg > 2048) bpg = 2048;
     const dim3 grid((unsigned)(n_groups * bpg)), block(ENC_BLOCK);
     if (!hash) {
-        if (half_planes) hipLaunchKernelGGL(freq_forward_kernel<true>, grid, block, 0, st, *spec, *src, feat, m_pad, (int)bpg);
-        else hipLaunchKernelGGL(freq_forward_kernel<false>, grid, block, 0, st, *spec, *src, feat, m_pad, (int)bpg);
+        if (half_planes) {
+            int64_t b1 = (cap_points + ENC_BLOCK - 1) / ENC_BLOCK;         // one sample per thread, one block row per dimension
+            if (b1 < 1) b1 = 1;
+            if (b1 > 16384) b1 = 16384;
+            hipLaunchKernelGGL(freq_forward_h16_kernel, dim3((unsigned)(3 * b1)), block, 0, st, *spec, *src, reinterpret_cast<uint32_t*>(feat), m_pad, (int)b1);
+        } else {
+            hipLaunchKernelGGL(freq_forward_kernel, grid, block, 0, st, *spec, *src, feat, m_pad, (int)bpg);
+        }
         return LNR_OK;
     }
     if (half_planes) {
