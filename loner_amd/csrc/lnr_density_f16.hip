@@ -287,435 +287,15 @@ mlp_backward_f16_kernel(const float* __restrict__ params, int n_mlp, const uint3
 }
 
 // ================================================================================================
-// General fp16 kernels: any encoding (half2 pair planes: pair p = features 2p, 2p+1; padding inputs are synthesised - the
-// constant 1 up to in_dim as tiny-cuda-nn pads, 0 beyond), 16..128 neurons, 1..3 hidden layers, any activation.
-// The shape the north star names besides the default one: frequency encoding + <= 128-wide SIREN / ReLU MLP.
-//
-// Weights live in LDS as fp16 ([H][in_dim], (NH-1) x [H][H], output row).  A wave owns 32 samples per step, as above.
-// Backward:
-//   * nothing is kept from the forward pass.  The backward of layer l recomputes its inputs from the features (a chain of l
-//     fp16 MFMA layers - at 16x the fp32 MFMA rate recomputation is cheaper than parking activations in LDS or registers)
-//     and its pre-activations Z_l, forms dZ_l = dA_l * act'(Z_l) in a per-step power-of-two scaled domain (see above);
-//   * weight gradients contract over samples.  dZ_l^T and the layer's inputs^T go through LDS ([row][32 samples] fp16), and the
-//     FOUR waves of the workgroup share the product: wave w owns the neuron tiles jt = w (mod 4) of dW_l and multiplies them
-//     over the four waves' 32-sample blocks (one K = 32 MFMA each), so that all of dW stays in registers for the whole kernel
-//     (a 128 x 128 layer is 64 accumulator registers per wave) - no LDS atomics, no per-tile traffic.  Two workgroup barriers
-//     per layer and step; one wave per SIMD (the register budget is 512 then);
-//   * dA_{l-1} = W_l^T dZ_l reads W^T fragments with strided 2-byte LDS loads (no transposed weight copy: LDS holds the
-//     weights once plus 4 x (inputs^T + dZ^T) = 140 KB for 96 -> 128 -> 128 -> 1; a transposed copy parked in the scratch of the
-//     feature-gradient launch was measured slower, 4.7 vs 4.1 ms for the whole 128 x 2 backward).
-#define F16_WPAD 8                   // halves of padding per weight row in LDS: a 256-byte row stride (H = 128) would put the 16 rows
-                                     // of an A fragment on the same banks (16-way conflict, measured 25x off the MFMA rate)
-struct GenDims {
-    int H, NH, in_dim, enc_pairs, in_pairs, kt1, act;
-    int s0, sh;                      // LDS row strides (halves) of the first / the hidden matrices
-    int off_h, off_o, n_w;           // half offsets of the hidden matrices / the output row in the LDS copy; halves in total
-};
-
-__host__ __device__ __forceinline__ GenDims gen_dims(const LnrNetSpec& spec) {
-    GenDims d;
-    d.H = spec.n_neurons; d.NH = spec.n_hidden; d.in_dim = spec.in_dim; d.act = spec.activation;
-    d.enc_pairs = spec.enc_dim / 2; d.in_pairs = spec.in_dim / 2; d.kt1 = (spec.in_dim + 31) / 32;
-    d.s0 = d.in_dim + F16_WPAD; d.sh = d.H + F16_WPAD;
-    d.off_h = d.H * d.s0; d.off_o = d.off_h + (d.NH - 1) * d.H * d.sh; d.n_w = d.off_o + d.H;
-    return d;
-}
-
-// fp32 parameters (tinycudann layout) -> the padded fp16 copy in LDS
-__device__ __forceinline__ void fill_weights(f16* Ws, const float* __restrict__ params, const GenDims& d) {
-    const int n0 = d.H * d.in_dim, nh = d.H * d.H;
-    for (int i = threadIdx.x; i < n0; i += blockDim.x) Ws[(i / d.in_dim) * d.s0 + i % d.in_dim] = (f16)params[i];
-    for (int l = 0; l < d.NH - 1; ++l)
-        for (int i = threadIdx.x; i < nh; i += blockDim.x) Ws[d.off_h + l * d.H * d.sh + (i / d.H) * d.sh + i % d.H] = (f16)params[n0 + l * nh + i];
-    for (int i = threadIdx.x; i < d.H; i += blockDim.x) Ws[d.off_o + i] = (f16)params[n0 + (d.NH - 1) * nh + i];
-}
-
-// B operand of layer 1, K block kb: features 32kb + 8g .. +7 of sample m = half2 pairs 16kb + 4g .. +3
-__device__ __forceinline__ u32x4 load_xb_gen(const uint32_t* __restrict__ featp, uint32_t plane_bytes, uint32_t m, int g, int kb, const GenDims& d) {
-    u32x4 v;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int pair = 16 * kb + 4 * g + q;
-        v[q] = pair < d.enc_pairs ? ld32<uint32_t>(featp, (uint32_t)pair * plane_bytes + m * 4u) : (pair < d.in_pairs ? 0x3C003C00u : 0u);
-    }
-    return v;
-}
-// A fragments.  Layer 1: natural K order (row `row`, inputs 32kb + 8g .. +7; zero beyond in_dim).
-__device__ __forceinline__ f16x8 frag_first(const f16* W0, const GenDims& d, int row, int kb, int g) {
-    const int k0 = 32 * kb + 8 * g;
-    if (k0 + 8 <= d.in_dim) return *reinterpret_cast<const f16x8*>(W0 + row * d.s0 + k0);
-    return frag_from_dwords(0u, 0u, 0u, 0u);
-}
-// Hidden layers: K slot 8g+i = neuron 32kb + (i < 4 ? 4g+i : 16 + 4g+i-4) - the permutation that makes a C layout a B layout.
-template <int HT>
-__device__ __forceinline__ f16x8 frag_hidden(const f16* Wl, int stride, int row, int kb, int g) {
-    const uint2 lo = *reinterpret_cast<const uint2*>(Wl + row * stride + 32 * kb + 4 * g);
-    uint2 hi = make_uint2(0u, 0u);
-    if (2 * kb + 1 < HT) hi = *reinterpret_cast<const uint2*>(Wl + row * stride + 32 * kb + 16 + 4 * g);
-    return frag_from_dwords(lo.x, lo.y, hi.x, hi.y);
-}
-// W^T fragment for dA_in = W^T dZ: row = input index `col` of W, K slots = neurons of block kb in the permuted order
-template <int HT>
-__device__ __forceinline__ f16x8 frag_transposed(const f16* Wl, int stride, int col, int kb, int g) {
-    constexpr int H = 16 * HT;
-    f16x8 v;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int n = 32 * kb + (i < 4 ? 4 * g + i : 16 + 4 * g + (i - 4));
-        v[i] = n < H ? Wl[n * stride + col] : (f16)0.0f;
-    }
-    return v;
-}
-// activations of a layer (C layout, tile jt, column tile t) -> their slots in the next layer's B operands
-template <int HT>
-__device__ __forceinline__ void pack_acts(const f32x4 A, int jt, u32x4 Bn[F16_KB_MAX]) {
-    Bn[jt >> 1][2 * (jt & 1)] = pack_h2(A[0], A[1]);
-    Bn[jt >> 1][2 * (jt & 1) + 1] = pack_h2(A[2], A[3]);
-}
-
-// The A fragments (weights, from LDS) of one 16-neuron row of a layer: first layer `kt1` K blocks (run-time count, zero beyond the
-// inputs), hidden layers KBH blocks.  PIPE: the fragments of row jt + 1 are requested before the MFMAs of row jt are issued, so that an
-// LDS round trip (~100 cycles against 16 per MFMA) is not waited for in front of every product; costs 2 x KBH x 4 registers.
-template <int HT>
-__device__ __forceinline__ void load_row_frags(const f16* Ws, const GenDims& d, int l, int jt, int c, int g, f16x8 a[F16_KB_MAX]) {
-    constexpr int H = 16 * HT, KBH = (HT + 1) / 2;
-    if (l == 0) {
-#pragma unroll
-        for (int kb = 0; kb < F16_KB_MAX; ++kb) a[kb] = kb < d.kt1 ? frag_first(Ws, d, 16 * jt + c, kb, g) : frag_from_dwords(0u, 0u, 0u, 0u);
-    } else if constexpr (KBH <= F16_KB_MAX) {                        // (256 neurons: one hidden layer only, there is no hidden matrix)
-        const f16* Wl = Ws + d.off_h + (l - 1) * H * d.sh;
-#pragma unroll
-        for (int kb = 0; kb < F16_KB_MAX; ++kb) a[kb] = kb < KBH ? frag_hidden<HT>(Wl, d.sh, 16 * jt + c, kb, g) : frag_from_dwords(0u, 0u, 0u, 0u);
-    }
-}
-// Z (both column tiles) of row jt from its fragments
-template <int HT>
-__device__ __forceinline__ void row_products(const GenDims& d, int l, const f16x8 a[F16_KB_MAX], const u32x4 Bin[F16_KB_MAX][2], f32x4 Z[2]) {
-    constexpr int KBH = (HT + 1) / 2;
-    Z[0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; Z[1] = Z[0];
-#pragma unroll
-    for (int kb = 0; kb < F16_KB_MAX; ++kb) {
-        if (l == 0 ? kb < d.kt1 : kb < KBH) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) Z[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kb], __builtin_bit_cast(f16x8, Bin[kb][t]), Z[t], 0, 0, 0);
-        }
-    }
-}
-
-// inputs of layer L (as B operands, both column tiles) from the features: a chain of L layers
-template <int HT, int ACT, bool PIPE = false>
-__device__ __forceinline__ void forward_chain(const f16* Ws, const GenDims& d, int L, int c, int g, const u32x4 xb[F16_KB_MAX][2],
-                                              u32x4 Bout[F16_KB_MAX][2]) {
-    constexpr int H = 16 * HT, KBH = (HT + 1) / 2;
-#pragma unroll
-    for (int kb = 0; kb < F16_KB_MAX; ++kb) { Bout[kb][0] = xb[kb][0]; Bout[kb][1] = xb[kb][1]; }
-    for (int l = 0; l < L; ++l) {
-        if constexpr (KBH > F16_KB_MAX) return;                           // 256 neurons: never called with L > 0 (one hidden layer)
-        u32x4 Bn[2][KBH > F16_KB_MAX ? KBH : F16_KB_MAX];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int kb = 0; kb < F16_KB_MAX; ++kb) Bn[t][kb] = u32x4{0u, 0u, 0u, 0u};
-        if constexpr (PIPE) {
-            f16x8 a_cur[F16_KB_MAX], a_nxt[F16_KB_MAX];
-            load_row_frags<HT>(Ws, d, l, 0, c, g, a_cur);
-#pragma unroll
-            for (int jt = 0; jt < HT; ++jt) {
-                if (jt + 1 < HT) load_row_frags<HT>(Ws, d, l, jt + 1, c, g, a_nxt);
-                f32x4 Z[2];
-                row_products<HT>(d, l, a_cur, Bout, Z);
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    f32x4 A;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) A[r] = gact<ACT>(Z[t][r], d.act);
-                    pack_acts<HT>(A, jt, Bn[t]);
-                }
-#pragma unroll
-                for (int kb = 0; kb < F16_KB_MAX; ++kb) a_cur[kb] = a_nxt[kb];
-            }
-        } else {
-#pragma unroll
-        for (int jt = 0; jt < HT; ++jt) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                f32x4 Z = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                if (l == 0) {
-#pragma unroll
-                    for (int kb = 0; kb < F16_KB_MAX; ++kb)
-                        if (kb < d.kt1) Z = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag_first(Ws, d, 16 * jt + c, kb, g), __builtin_bit_cast(f16x8, Bout[kb][t]), Z, 0, 0, 0);
-                } else if constexpr (KBH <= F16_KB_MAX) {
-                    const f16* Wl = Ws + d.off_h + (l - 1) * H * d.sh;
-#pragma unroll
-                    for (int kb = 0; kb < KBH; ++kb)
-                        Z = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag_hidden<HT>(Wl, d.sh, 16 * jt + c, kb, g), __builtin_bit_cast(f16x8, Bout[kb][t]), Z, 0, 0, 0);
-                }
-                f32x4 A;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) A[r] = gact<ACT>(Z[r], d.act);
-                pack_acts<HT>(A, jt, Bn[t]);
-            }
-        }
-        }
-#pragma unroll
-        for (int kb = 0; kb < F16_KB_MAX; ++kb) { Bout[kb][0] = Bn[0][kb]; Bout[kb][1] = Bn[1][kb]; }
-    }
-}
-
-// pre-activations of layer l for neuron tile jt, column tile t, from that layer's inputs Bin
-template <int HT>
-__device__ __forceinline__ f32x4 layer_z(const f16* Ws, const GenDims& d, int l, int jt, int t, int c, int g, const u32x4 Bin[F16_KB_MAX][2]) {
-    constexpr int H = 16 * HT, KBH = (HT + 1) / 2;
-    f32x4 Z = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    if (l == 0) {
-#pragma unroll
-        for (int kb = 0; kb < F16_KB_MAX; ++kb)
-            if (kb < d.kt1) Z = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag_first(Ws, d, 16 * jt + c, kb, g), __builtin_bit_cast(f16x8, Bin[kb][t]), Z, 0, 0, 0);
-    } else if constexpr (KBH <= F16_KB_MAX) {
-        const f16* Wl = Ws + d.off_h + (l - 1) * H * d.sh;
-#pragma unroll
-        for (int kb = 0; kb < KBH; ++kb)
-            Z = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag_hidden<HT>(Wl, d.sh, 16 * jt + c, kb, g), __builtin_bit_cast(f16x8, Bin[kb][t]), Z, 0, 0, 0);
-    }
-    return Z;
-}
-
-// One launch per hidden layer: target = l accumulates dW of layer l and stops the backward chain there; the launch of layer 0 walks
-// the whole chain anyway and also writes the feature gradient (d_feature planes) and the output row's gradient (a separate launch
-// for those - target = -1, still accepted - cost 1.3 of 4.1 ms on the 128 x 2 network).  Holding the accumulators of ONE layer keeps
-// a wave inside its register budget (all layers at once needed > 700 registers).
-// LDS: [Ws n_w halves (padded to 8)][per wave: AT kmax x F16_TS | Tdz H x F16_TS halves][sc_up 4 floats][dWo partials 4 x H floats]
-template <int HT, int ACT>
-__global__ void __launch_bounds__(LNR_DENSITY_BLOCK, 1)
-mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ params, const uint32_t* __restrict__ featp, int64_t m_pad,
-                            int64_t n_points, const int32_t* __restrict__ n_rays_dev, int n_rays, int n_samples,
-                            const float* __restrict__ d_sigma, float* __restrict__ dfeat, float* __restrict__ slabs, int want_dfeat, int target) {
-    extern __shared__ __attribute__((aligned(16))) f16 Ws[];
-    constexpr int H = 16 * HT, KBH = (HT + 1) / 2;
-    constexpr int NO = HT >= 4 ? HT / 4 : 1;                 // neuron tiles of dW a wave owns: jt = wave + 4 i
-    constexpr bool WIDE = KBH > F16_KB_MAX;                   // 256 neurons: one hidden layer, dW is H x in_dim only
-    constexpr int NCOL = (WIDE || 2 * F16_KB_MAX > HT) ? 2 * F16_KB_MAX : HT;   // 16-column tiles of the widest layer input
-    const GenDims d = gen_dims(spec);
-    fill_weights(Ws, params, d);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = lane & 15, g = lane >> 4;
-    const int kmax = (d.NH > 1 && 32 * d.kt1 <= H) ? H : 32 * d.kt1;        // rows of the widest layer INPUT (one hidden layer: the features)
-    f16* scratch = Ws + ((d.n_w + 7) & ~7);
-    const int per_wave = (kmax + H) * F16_TS;
-    f16* AT_all = scratch;                                   // wave w: AT_all + w * per_wave, Tdz behind it
-    float* sc_s = reinterpret_cast<float*>(scratch + 4 * per_wave);
-    float* dwo_s = sc_s + 4;
-    f16* AT = AT_all + wave * per_wave;
-    f16* Tdz = AT + kmax * F16_TS;
-    __syncthreads();
-
-    f32x4 acc[NO][NCOL];                                     // dW of the target layer: owned neuron tiles x 16-column tiles of its inputs
-    float dwo[HT][4];
-#pragma unroll
-    for (int i = 0; i < NO; ++i)
-#pragma unroll
-        for (int k = 0; k < NCOL; ++k) acc[i][k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int jt = 0; jt < HT; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dwo[jt][r] = 0.0f;
-
-    const int64_t M = live_samples(n_points, n_rays_dev, n_rays, n_samples);
-    const int64_t n_tiles = M > 0 ? (M + 31) / 32 : 0;
-    const int64_t per_step = (int64_t)gridDim.x * 4;
-    const int64_t n_steps = (n_tiles + per_step - 1) / per_step;             // workgroup-uniform: the loop body has barriers
-    const uint32_t plane_bytes = (uint32_t)m_pad * 4u;
-    const int l_stop = target < 0 ? 0 : target;
-    const bool first = target <= 0;                          // this launch also produces the feature gradient and the output row's gradient
-    for (int64_t step = 0; step < n_steps; ++step) {
-        const int64_t tile = step * per_step + (int64_t)blockIdx.x * 4 + wave;
-        const bool have_tile = tile < n_tiles;
-        u32x4 xb[F16_KB_MAX][2];
-        float ds[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int64_t m = tile * 32 + 16 * t + c;
-            const bool ok = have_tile && m < M;
-            const uint32_t mc = (uint32_t)(ok ? m : (M > 0 ? M - 1 : 0));
-#pragma unroll
-            for (int kb = 0; kb < F16_KB_MAX; ++kb) xb[kb][t] = kb < d.kt1 ? load_xb_gen(featp, plane_bytes, mc, g, kb, d) : u32x4{0u, 0u, 0u, 0u};
-            const float v = d_sigma[mc];
-            ds[t] = ok ? v : 0.0f;
-        }
-        // per-step power-of-two scale: the largest |d_sigma| of the 32 samples lands in [1, 2)
-        const float mx = wave_max(fmaxf(fabsf(ds[0]), fabsf(ds[1])));
-        uint32_t be = (__float_as_uint(mx) >> 23) & 0xFFu;
-        be = be < 1u ? 127u : (be > 253u ? 253u : be);
-        const float sc_dn = __uint_as_float((254u - be) << 23), sc_up = __uint_as_float(be << 23);
-        if (target >= 0 && lane == 0) sc_s[wave] = mx > 0.0f ? sc_up : 0.0f;
-        f32x4 dA[HT][2];                                     // gradient w.r.t. the current layer's activations, scaled domain
-#pragma unroll
-        for (int jt = 0; jt < HT; ++jt)
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dA[jt][t][r] = (ds[t] * sc_dn) * (float)Ws[d.off_o + 16 * jt + 4 * g + r];
-
-        for (int l = d.NH - 1; l >= l_stop; --l) {
-            u32x4 Bin[F16_KB_MAX][2];
-            forward_chain<HT, ACT>(Ws, d, l, c, g, xb, Bin);                 // the inputs of layer l
-            const int kbn = l == 0 ? d.kt1 : KBH;
-            const bool here = l == target;                                  // this launch's dW layer
-            uint32_t dzp[HT][2][2];
-#pragma unroll
-            for (int jt = 0; jt < HT; ++jt) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const f32x4 Z = layer_z<HT>(Ws, d, l, jt, t, c, g, Bin);
-                    float dz[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (first && l == d.NH - 1) dwo[jt][r] += ds[t] * gact<ACT>(Z[r], d.act);
-                        dz[r] = dA[jt][t][r] * gact_d<ACT>(Z[r], d.act);
-                        if (here) Tdz[(16 * jt + 4 * g + r) * F16_TS + 16 * t + c] = (f16)dz[r];
-                    }
-                    dzp[jt][t][0] = pack_h2(dz[0], dz[1]);
-                    dzp[jt][t][1] = pack_h2(dz[2], dz[3]);
-                }
-            }
-            if (here) {
-                // the layer's inputs, transposed: AT[input k][sample]
-#pragma unroll
-                for (int kb = 0; kb < F16_KB_MAX; ++kb) {
-                    if (kb < kbn) {
-#pragma unroll
-                        for (int t = 0; t < 2; ++t)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const uint32_t w2 = Bin[kb][t][q];
-#pragma unroll
-                                for (int h = 0; h < 2; ++h) {
-                                    const int i = 2 * q + h;
-                                    const int k = l == 0 ? 32 * kb + 8 * g + i : 32 * kb + (i < 4 ? 4 * g + i : 16 + 4 * g + (i - 4));
-                                    reinterpret_cast<uint16_t*>(AT)[k * F16_TS + 16 * t + c] = (uint16_t)(h ? (w2 >> 16) : (w2 & 0xFFFFu));
-                                }
-                            }
-                    }
-                }
-                __syncthreads();
-                // dW_l += 2^e * dZ_l^T (own neuron tiles) x inputs^T, over the four waves' sample blocks
-                const int ncol = l == 0 ? 2 * d.kt1 : HT;
-                for (int w2 = 0; w2 < 4; ++w2) {
-                    const float s = sc_s[w2];
-                    if (s == 0.0f) continue;                               // workgroup-uniform per w2
-                    const f16* ATw = AT_all + w2 * per_wave;
-                    const f16* Tw = ATw + kmax * F16_TS;
-#pragma unroll
-                    for (int i = 0; i < NO; ++i) {
-                        const int jt = wave + 4 * i;
-                        if (jt < HT) {
-                            const f16x8 a = *reinterpret_cast<const f16x8*>(Tw + (16 * jt + c) * F16_TS + 8 * g);
-#pragma unroll
-                            for (int kt = 0; kt < NCOL; ++kt) {
-                                if (kt < ncol) {
-                                    const f16x8 b = *reinterpret_cast<const f16x8*>(ATw + (16 * kt + c) * F16_TS + 8 * g);
-                                    const f32x4 D = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, f32x4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
-#pragma unroll
-                                    for (int r = 0; r < 4; ++r) acc[i][kt][r] += s * D[r];
-                                }
-                            }
-                        }
-                    }
-                }
-                __syncthreads();                                           // AT / Tdz are rewritten by the next step
-            }
-            // dA_{l-1} = W_l^T dZ_l (scaled domain); at the first layer: the feature gradient, un-scaled, to the d_feature planes
-            if (!WIDE && l > l_stop) {
-                const f16* Wl = Ws + d.off_h + (l - 1) * H * d.sh;
-                f32x4 dAn[WIDE ? 1 : HT][2];
-#pragma unroll
-                for (int it = 0; it < (WIDE ? 0 : HT); ++it)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        f32x4 D = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                        for (int kb = 0; kb < KBH; ++kb) {
-                            const bool second = 2 * kb + 1 < HT;
-                            const int j1 = second ? 2 * kb + 1 : 2 * kb;
-                            const f16x8 b = frag_from_dwords(dzp[2 * kb][t][0], dzp[2 * kb][t][1], second ? dzp[j1][t][0] : 0u, second ? dzp[j1][t][1] : 0u);
-                            D = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag_transposed<HT>(Wl, d.sh, 16 * it + c, kb, g), b, D, 0, 0, 0);
-                        }
-                        dAn[it][t] = D;
-                    }
-#pragma unroll
-                for (int it = 0; it < (WIDE ? 0 : HT); ++it) { dA[it][0] = dAn[it][0]; dA[it][1] = dAn[it][1]; }
-            } else if (first && want_dfeat) {
-                for (int it = 0; it < d.in_dim / 16; ++it) {
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        f32x4 D = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                        for (int kb = 0; kb < KBH; ++kb) {
-                            const bool second = 2 * kb + 1 < HT;
-                            const int j1 = second ? 2 * kb + 1 : 2 * kb;
-                            const f16x8 b = frag_from_dwords(dzp[2 * kb][t][0], dzp[2 * kb][t][1], second ? dzp[j1][t][0] : 0u, second ? dzp[j1][t][1] : 0u);
-                            D = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag_transposed<HT>(Ws, d.s0, 16 * it + c, kb, g), b, D, 0, 0, 0);
-                        }
-                        const int64_t m = tile * 32 + 16 * t + c;
-                        if (have_tile && m < M) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int k = 16 * it + 4 * g + r;
-                                if (k < 2 * d.enc_pairs) st32<float>(dfeat, (uint32_t)k * plane_bytes + (uint32_t)m * 4u, sc_up * D[r]);
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-    // ---- this launch's part of the workgroup's slab
-    const int n_mlp = spec.n_mlp_params;
-    float* slab = slabs + (size_t)blockIdx.x * n_mlp;
-    if (target >= 0) {                                                     // every neuron tile is owned by exactly one wave
-        const int K = target == 0 ? d.in_dim : H;
-        float* mat = slab + (target == 0 ? 0 : H * d.in_dim + (target - 1) * H * H);              // (the slab has the parameter layout, unpadded)
-#pragma unroll
-        for (int i = 0; i < NO; ++i) {
-            const int jt = wave + 4 * i;
-            if (jt < HT) {
-#pragma unroll
-                for (int kt = 0; kt < NCOL; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int col = 16 * kt + c;
-                        if (col < K) mat[(16 * jt + 4 * g + r) * K + col] = acc[i][kt][r];
-                    }
-            }
-        }
-    }
-    if (!first) return;
-    // output row: every wave has a partial over its own samples; summed in a fixed order.  Rows 1..15 of the padded output matrix: 0.
-#pragma unroll
-    for (int jt = 0; jt < HT; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = dwo[jt][r];
-            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-            if (c == 0) dwo_s[wave * H + 16 * jt + 4 * g + r] = v;
-        }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 16 * H; i += blockDim.x)
-        slab[H * d.in_dim + (d.NH - 1) * H * H + i] = i < H ? ((dwo_s[i] + dwo_s[H + i]) + (dwo_s[2 * H + i] + dwo_s[3 * H + i])) : 0.0f;
-}
-
+// Every other supported shape (any encoding on half2 pair planes, 16..256 neurons, 1..3 hidden layers, any activation; the shape
+// class the north star names besides the default one: frequency encoding + <= 128-wide SIREN / ReLU MLP) runs the general kernels:
+// forward lnr_f16_fwd_kernel.h / lnr_density_f16_fwd.hip, backward lnr_f16_bwd_kernel.h / lnr_density_f16_bwd.hip.
 // ------------------------------------------------------------------------------------------------ host side
 static bool f16_fast_class(const LnrNetSpec* spec) {
     return spec->encoding == LNR_ENC_HASHGRID && spec->n_features == 2 && spec->enc_dim == 32 && spec->in_dim == 32 &&
            spec->n_hidden == 1 && spec->activation == LNR_ACT_RELU && spec->n_neurons <= 64;
 }
 
-static size_t f16_gen_bwd_lds(const LnrNetSpec* spec) {
-    const int H = spec->n_neurons, kt1 = (spec->in_dim + 31) / 32;
-    const size_t n_w = (size_t)gen_dims(*spec).n_w;
-    const size_t kmax = (size_t)((spec->n_hidden > 1 && 32 * kt1 <= H) ? H : 32 * kt1);
-    return ((n_w + 7) & ~(size_t)7) * sizeof(f16) + 4 * (kmax + H) * F16_TS * sizeof(f16) + 4 * sizeof(float) + 4 * (size_t)H * sizeof(float);
-}
 // what LNR_PREC_F16 covers: half2 pair planes need an even number of features per level; the general kernels hold dW in registers
 // (<= 128 neurons, <= 3 hidden layers) and the weights plus the transposes of four waves in LDS
 bool lnr_f16_supported(const LnrNetSpec* spec) {
@@ -727,7 +307,8 @@ bool lnr_f16_supported(const LnrNetSpec* spec) {
     // hidden matrix neither fits the LDS beside the exchange buffers nor the registers as a gradient
     if (!(H == 16 || H == 32 || H == 64 || H == 128 || (H == 256 && spec->n_hidden == 1))) return false;
     if (spec->n_hidden < 1 || spec->n_hidden > F16_NH_MAX || spec->in_dim > 32 * F16_KB_MAX) return false;
-    return f16_gen_bwd_lds(spec) <= (size_t)LNR_LDS_LIMIT;
+    const size_t lds = lnr_f16_gen_bwd_lds(spec);
+    return lds > 0 && lds <= (size_t)LNR_LDS_LIMIT;
 }
 
 static size_t f16_bwd_lds(const LnrNetSpec* spec) {
@@ -792,31 +373,9 @@ int lnr_mlp_bwd_f16(const LnrNetSpec* spec, const float* params, const void* fea
 #undef LNR_F16_BWD
         return LNR_OK;
     }
-    // general kernels: one workgroup per CU (LDS), persistent over the steps
-    if (blocks > 256) blocks = 256;
+    if (blocks > 256) blocks = 256;                                    // general kernels: one workgroup per CU (LDS), persistent over the steps
     *n_slabs = (int)blocks;
-    const dim3 grid((unsigned)blocks);
-    const size_t lds = f16_gen_bwd_lds(spec);
-    const int akind = spec->activation;
-#define LNR_F16_GEN_BWD(HT, ACT)                                                                                                  \
-    do {                                                                                                                         \
-        int rc_ = f16_set_lds(mlp_backward_f16_gen_kernel<HT, ACT>, lds, "lnr_density_backward");                                \
-        if (rc_) return rc_;                                                                                                     \
-        for (int target = 0; target < spec->n_hidden; ++target)      /* target 0 also yields d_feature and the output row */     \
-            hipLaunchKernelGGL((mlp_backward_f16_gen_kernel<HT, ACT>), grid, block, lds, st, *spec, params, fp, m_pad, pt->n_points, \
-                               pt->n_rays_dev, pt->n_rays, pt->n_samples, d_sigma, dfeat, slabs, want_dfeat, target);            \
-    } while (0)
-#define LNR_F16_GEN_BWD_A(HT) do { if (akind == LNR_ACT_RELU) LNR_F16_GEN_BWD(HT, LNR_ACT_RELU); else if (akind == LNR_ACT_SINE) LNR_F16_GEN_BWD(HT, LNR_ACT_SINE); else LNR_F16_GEN_BWD(HT, -1); } while (0)
-    switch (spec->n_neurons / 16) {
-        case 1: LNR_F16_GEN_BWD_A(1); break;
-        case 2: LNR_F16_GEN_BWD_A(2); break;
-        case 4: LNR_F16_GEN_BWD_A(4); break;
-        case 8: LNR_F16_GEN_BWD_A(8); break;
-        default: LNR_F16_GEN_BWD_A(16); break;
-    }
-#undef LNR_F16_GEN_BWD_A
-#undef LNR_F16_GEN_BWD
-    return LNR_OK;
+    return lnr_mlp_bwd_f16_gen(spec, params, fp, m_pad, pt, d_sigma, dfeat, slabs, want_dfeat, (int)blocks, st);
 }
 
 // ------------------------------------------------------------------------------------------------ layout self-test

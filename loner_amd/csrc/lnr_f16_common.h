@@ -49,3 +49,7 @@ static inline int f16_set_lds(K kernel, size_t lds, const char* who) {
 // the general forward (any supported width / depth / activation), lnr_density_f16_fwd.hip
 int lnr_mlp_fwd_f16_gen(const LnrNetSpec* spec, const float* params, const uint32_t* featp, int64_t m_pad, const MlpPoints* pt, float* sigma,
                         int64_t blocks, hipStream_t st);
+// the general backward, lnr_density_f16_bwd.hip: one launch, `blocks` workgroups = weight-gradient slabs; its LDS need (0: no kernel)
+int lnr_mlp_bwd_f16_gen(const LnrNetSpec* spec, const float* params, const uint32_t* featp, int64_t m_pad, const MlpPoints* pt, const float* d_sigma,
+                        float* dfeat, float* slabs, int want_dfeat, int blocks, hipStream_t st);
+size_t lnr_f16_gen_bwd_lds(const LnrNetSpec* spec);
