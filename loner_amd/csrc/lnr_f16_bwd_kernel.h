@@ -1,7 +1,12 @@
 // General fp16-mode backward of the density MLP (any supported width / depth / activation): weight gradients of every layer, the
 // output row's gradient and the feature gradient (d_feature planes) in ONE launch.  Host dispatch: lnr_density_f16_bwd.hip.
-// Semantics = oracle/network.py with precision="fp16": every 32-sample tile's dZ is scaled by the exact power of two of its largest
-// |d_sigma| before the fp16 conversion and un-scaled in fp32 behind the MFMA; products accumulate in fp32.
+// Semantics = oracle/network.py with precision="fp16": dZ is scaled by an exact power of two before its fp16 conversion so that no
+// gradient underflows whatever the loss magnitude, and un-scaled in fp32; products accumulate in fp32.  The oracle scales every
+// 32-sample tile by the power of two of its largest |d_sigma|; this kernel keeps ONE unit 2^e for the workgroup - the exponent of the
+// largest |d_sigma| of a step's 128 samples, kept while that maximum stays within [2^-4, 2) of it - and rescales the fp32
+// accumulators by the exact power of two whenever the unit moves.  The weight-gradient MFMAs then accumulate straight into their
+// registers (a per-wave scale meant a separate product, four v_accvgpr_read and two v_pk_fma per MFMA, 1000 VALU instructions a
+// step); values differ from the oracle's only where an element lies 2^-20 below its tile's maximum (fp16 subnormals).
 //
 // Shapes are compile time (HT row tiles, NH hidden layers, KT first-layer K blocks), the weights sit in LDS in the forward kernel's
 // layout (lnr_f16_fwd_kernel.h: first-layer rows zero-padded to KT blocks, hidden rows K-permuted, 256-byte rows XOR-swizzled, the
@@ -33,8 +38,8 @@ struct BwdLds {
     static constexpr int TILE = 32 * 16;                                    // halves of one [32 samples][16 columns] image tile
     static constexpr int IMG_X = HT * TILE, IMG_WAVE = (HT + NT) * TILE;    // per wave: dZ tiles, then the layer-input tiles
     static constexpr int OFF_IMG = W::N_W + 2 * W::H;                       // halves: behind the weights and the fp32 bias
-    static constexpr int OFF_SC = OFF_IMG + 4 * IMG_WAVE;                   // 4 floats (the waves' scales), then dWo partials [4][H]
-    static constexpr size_t BYTES = (size_t)OFF_SC * sizeof(f16) + 4 * sizeof(float) + 4 * (size_t)W::H * sizeof(float);
+    static constexpr int OFF_SC = OFF_IMG + 4 * IMG_WAVE;                   // 2 x 4 floats (the waves' |d_sigma| maxima, this step / next), then dWo partials [4][H]
+    static constexpr size_t BYTES = (size_t)OFF_SC * sizeof(f16) + 8 * sizeof(float) + 4 * (size_t)W::H * sizeof(float);
 };
 
 // K = 32 fragment (8 halves per lane) from two transposing reads: p = the lane's address in the first [4][16] block, the second
@@ -73,13 +78,13 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
     static_assert(KBH <= F16_KB_MAX || NH == 1, "256 neurons: one hidden layer");
     fwd_fill_weights<HT, NH, KT>(Ws, params, spec.in_dim, spec.enc_dim);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = lane & 15, g = lane >> 4;
-    const int act = spec.activation, enc_pairs = spec.enc_dim / 2, in_pairs = spec.in_dim / 2;
+    int c = lane & 15, g = lane >> 4;                                       // (re-laundered every step: see the loop head)
+    const int act = spec.activation, enc_pairs = spec.enc_dim / 2;
     const float* bias_lane = reinterpret_cast<const float*>(Ws + L::N_W) + 4 * g;
     f16* img_all = Ws + B::OFF_IMG;
     f16* img = img_all + wave * B::IMG_WAVE;                                // own images: dZ tiles [HT], input tiles [NT]
-    float* sc_s = reinterpret_cast<float*>(Ws + B::OFF_SC);
-    float* dwo_s = sc_s + 4;
+    float* mx_s = reinterpret_cast<float*>(Ws + B::OFF_SC);
+    float* dwo_s = mx_s + 8;
     __syncthreads();
 
     const int64_t M = live_samples(n_points, n_rays_dev, n_rays, n_samples);
@@ -90,24 +95,18 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
     __amdgpu_buffer_rsrc_t rsrc[KT];
 #pragma unroll
     for (int kb = 0; kb < KT; ++kb) rsrc[kb] = fwd_block_rsrc(featp, plane_bytes, kb, enc_pairs);
-    uint32_t qoff[4], pad1[KT][4];                                          // plane offsets; the constant-one input padding (half2 1.0 | 1.0)
+    uint32_t qoff[4];                                                       // byte offsets of the lane's four planes inside a K block, + its column
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        qoff[q] = (uint32_t)(4 * g + q) * plane_bytes + (uint32_t)c * 4u;
-#pragma unroll
-        for (int kb = 0; kb < KT; ++kb) {
-            const int pair = 16 * kb + 4 * g + q;
-            pad1[kb][q] = (pair >= enc_pairs && pair < in_pairs) ? 0x3C003C00u : 0u;
-        }
-    }
+    for (int q = 0; q < 4; ++q) qoff[q] = (uint32_t)(4 * g + q) * plane_bytes + (uint32_t)c * 4u;
     int koff0[F16_KB_MAX], koffh[F16_KB_MAX];
     fwd_frag_offsets<KT, L::S0, L::SWZ0>(c, g, koff0);
     fwd_frag_offsets<(NH > 1 ? KBH : 0), L::SH, L::SWZH>(c, g, koffh);
-    float wo[HT][4], dwo[HT][4];                                            // the lane's entries of the output row, and of its gradient
+    float dwo[HT][4];                                                       // the lane's entries of the output row's gradient
 #pragma unroll
     for (int jt = 0; jt < HT; ++jt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { wo[jt][r] = (float)Ws[L::OFF_O + 16 * jt + 4 * g + r]; dwo[jt][r] = 0.0f; }
+        for (int r = 0; r < 4; ++r) dwo[jt][r] = 0.0f;
+    const f16* wo_lane = Ws + L::OFF_O + 4 * g;                             // the output row: the lane's entries of row tile jt at + 16 jt
     f32x4 acc0[NO][2 * KT];                                                 // dW of the first layer: owned row tiles x 16-column tiles of the inputs
     f32x4 acch[NHID > 0 ? NHID : 1][NO][KBH <= F16_KB_MAX ? HT : 1];       // dW of the hidden matrices
 #pragma unroll
@@ -121,10 +120,13 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
                 for (int k = 0; k < HT; ++k) acch[l][i][k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
     }
+    f32x4 accb[NO];                                                         // first layer, constant-one padding columns: every column = the row sums of dZ
+#pragma unroll
+    for (int i = 0; i < NO; ++i) accb[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     const int nt0 = (spec.in_dim + 15) / 16;                                // column tiles of the first layer's gradient
 
-    // features (B operands of the first layer, the padding as ones) and d_sigma of a step; a wave without a tile re-reads the last
-    // one with d_sigma = 0 (finite operands, zero gradient)
+    // features (B operands of the first layer; the constant-one padding reads as zero, its weights' gradient is accb below) and
+    // d_sigma of a step; a wave without a tile re-reads the last one with d_sigma = 0 (finite operands, zero gradient)
     auto load_step = [&](int64_t step, u32x4 (&x)[F16_KB_MAX][2], float (&ds)[2]) {
         const int64_t tile = step * per_step + (int64_t)blockIdx.x * 4 + wave;
         const bool have = tile < n_tiles;
@@ -136,7 +138,7 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
             for (int kb = 0; kb < F16_KB_MAX; ++kb)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    x[kb][t][q] = kb < KT ? ((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc[kb < KT ? kb : 0], (int)(qoff[q] + m0) + 64 * t, 0, 0) | pad1[kb < KT ? kb : 0][q]) : 0u;
+                    x[kb][t][q] = kb < KT ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc[kb < KT ? kb : 0], (int)(qoff[q] + m0) + 64 * t, 0, 0) : 0u;
             const int64_t m = tc * 32 + 16 * t + c;
             const bool ok = have && m < M;
             const float v = d_sigma[ok ? m : 0];
@@ -153,14 +155,17 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
                         uint32_t (&dzp)[HT][2][2], const float (&dsd)[2], const float (&ds)[2]) {
         constexpr bool LASTH = decltype(last_tag)::value, BIAS = decltype(bias_tag)::value;
         constexpr int KB = decltype(kb_tag)::value, S = decltype(s_tag)::value;
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
         f16x8 a[2][KB];
         f32x4 Z[2][2], z0[2];
-        auto frags = [&](int jt, f16x8 (&dst)[KB], f32x4& zb) {
+        f16x4 wo4[3];                                                       // LASTH: the output row's entries of row tiles jt - 1 (being finished), jt, jt + 1 (in flight)
+        auto frags = [&](int jt, f16x8 (&dst)[KB], f32x4& zb, f16x4& wv) {
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) dst[kb] = *reinterpret_cast<const f16x8*>(Wl + 16 * jt * S + koff[kb]);
             zb = BIAS ? *reinterpret_cast<const f32x4*>(bias_lane + 16 * jt) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (LASTH) wv = *reinterpret_cast<const f16x4*>(wo_lane + 16 * jt);
         };
-        auto finish = [&](int jt, const f32x4 (&z)[2]) {
+        auto finish = [&](int jt, const f32x4 (&z)[2], const f16x4& wv) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 if constexpr (LASTH) {
@@ -168,7 +173,7 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         dwo[jt][r] = __builtin_fmaf(ds[t], fwd_act<ACT>(z[t][r], act), dwo[jt][r]);
-                        dz[r] = (dsd[t] * wo[jt][r]) * gact_d<ACT>(z[t][r], act);
+                        dz[r] = (dsd[t] * (float)wv[r]) * gact_d<ACT>(z[t][r], act);
                     }
                     dzp[jt][t][0] = pack_h2(dz[0], dz[1]);
                     dzp[jt][t][1] = pack_h2(dz[2], dz[3]);
@@ -192,10 +197,10 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
                     for (int q = 0; q < 4; ++q) Dout[kb][t][q] = 0u;
                 }
         }
-        frags(0, a[0], z0[0]);
+        frags(0, a[0], z0[0], wo4[0]);
 #pragma unroll
         for (int jt = 0; jt < HT; ++jt) {
-            if (jt + 1 < HT) frags(jt + 1, a[(jt + 1) & 1], z0[(jt + 1) & 1]);
+            if (jt + 1 < HT) frags(jt + 1, a[(jt + 1) & 1], z0[(jt + 1) & 1], wo4[(jt + 1) % 3]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 2; ++t) Z[jt & 1][t] = z0[jt & 1];
@@ -204,61 +209,82 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
                     Z[jt & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[jt & 1][kb], __builtin_bit_cast(f16x8, Bin[kb][t]), Z[jt & 1][t], 0, 0, 0);
-            if (jt > 0) finish(jt - 1, Z[(jt - 1) & 1]);
+            if (jt > 0) finish(jt - 1, Z[(jt - 1) & 1], wo4[(jt - 1) % 3]);
         }
-        finish(HT - 1, Z[(HT - 1) & 1]);
+        finish(HT - 1, Z[(HT - 1) & 1], wo4[(HT - 1) % 3]);
     };
 
-    // ---- images: dZ tiles (both layers' kinds) and the layer-input tiles, [32 samples][16 columns] halves each
+    // ---- images: dZ tiles and the layer-input tiles, [32 samples][16 columns] halves each, in 8-byte pieces (sample s, column
+    // quad q).  A fragment's first transposing read takes samples 4g..4g+3, its second 16+4g..: K slot 8g+i = sample 4g+i (i < 4) or
+    // 16+4g+i-4 - the same permutation on both operands of the product, and the four lane groups of a read cover one contiguous
+    // 256-byte block per 32 lanes (rows 8g.. put every group on the same banks: SQ_LDS_BANK_CONFLICT was 56 % of the LDS cycles).
+    // Pieces are swizzled inside their 32-byte row so that the 16 lanes of a store, whose rows are 32 bytes apart, spread over the
+    // banks too: q ^ (s / 4 % 4) for the 8-byte stores, 16-byte halves p ^ (s / 4 % 2) for the 16-byte stores of the features.
     auto write_dz_image = [&](const uint32_t (&dzp)[HT][2][2]) {
 #pragma unroll
         for (int jt = 0; jt < HT; ++jt)
 #pragma unroll
             for (int t = 0; t < 2; ++t)
-                *reinterpret_cast<uint2*>(img + jt * B::TILE + (16 * t + c) * 16 + 4 * g) = make_uint2(dzp[jt][t][0], dzp[jt][t][1]);
+                *reinterpret_cast<uint2*>(img + jt * B::TILE + (16 * t + c) * 16 + 4 * (g ^ (c >> 2))) = make_uint2(dzp[jt][t][0], dzp[jt][t][1]);
     };
     auto write_x_image_first = [&](const u32x4 (&x)[F16_KB_MAX][2]) {       // natural K order: 8 consecutive inputs per lane
 #pragma unroll
         for (int kb = 0; kb < KT; ++kb)
 #pragma unroll
             for (int t = 0; t < 2; ++t)
-                *reinterpret_cast<u32x4*>(img + B::IMG_X + (2 * kb + (g >> 1)) * B::TILE + (16 * t + c) * 16 + 8 * (g & 1)) = x[kb][t];
+                *reinterpret_cast<u32x4*>(img + B::IMG_X + (2 * kb + (g >> 1)) * B::TILE + (16 * t + c) * 16 + 8 * ((g & 1) ^ ((c >> 2) & 1))) = x[kb][t];
     };
     auto write_x_image_hidden = [&](const u32x4 (&A)[F16_KB_MAX][2]) {      // permuted K order: neurons 4g..4g+3 of tiles 2kb and 2kb+1
 #pragma unroll
         for (int kb = 0; kb < (KBH <= F16_KB_MAX ? KBH : 0); ++kb)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                *reinterpret_cast<uint2*>(img + B::IMG_X + (2 * kb) * B::TILE + (16 * t + c) * 16 + 4 * g) = make_uint2(A[kb][t][0], A[kb][t][1]);
+                *reinterpret_cast<uint2*>(img + B::IMG_X + (2 * kb) * B::TILE + (16 * t + c) * 16 + 4 * (g ^ (c >> 2))) = make_uint2(A[kb][t][0], A[kb][t][1]);
                 if (2 * kb + 1 < HT)
-                    *reinterpret_cast<uint2*>(img + B::IMG_X + (2 * kb + 1) * B::TILE + (16 * t + c) * 16 + 4 * g) = make_uint2(A[kb][t][2], A[kb][t][3]);
+                    *reinterpret_cast<uint2*>(img + B::IMG_X + (2 * kb + 1) * B::TILE + (16 * t + c) * 16 + 4 * (g ^ (c >> 2))) = make_uint2(A[kb][t][2], A[kb][t][3]);
             }
     };
-    const int tr_lane = (8 * g + (c >> 2)) * 16 + 4 * (c & 3);              // the lane's address inside an image tile (halves)
+    // the lane's address inside an image tile (halves): row 4g + c/4 (s / 4 % 4 = g), column quad c % 4; second read 16 rows on
+    const int tr_lane_q = (4 * g + (c >> 2)) * 16 + 4 * ((c & 3) ^ g);                                  // 8-byte swizzle
+    const int tr_lane_p = (4 * g + (c >> 2)) * 16 + 8 * (((c >> 1) & 1) ^ (g & 1)) + 4 * (c & 1);      // 16-byte swizzle
 
-    // dW += sum over the four waves' images of 2^e dZ^T (own row tiles) x inputs^T; NT_L column tiles (nt of them live)
-    auto accumulate_dw = [&](auto nt_tag, f32x4 (&acc)[NO][decltype(nt_tag)::value], int nt) {
+    // dW += dZ^T (own row tiles) x inputs^T over the four waves' images, accumulated by the MFMAs themselves; NT_L column tiles
+    // (nt of them live).  Work units = (wave image, half of the column tiles); the fragments of the next unit are requested before
+    // the products of the current one are issued.
+    auto accumulate_dw = [&](auto nt_tag, auto ones_tag, f32x4 (&acc)[NO][decltype(nt_tag)::value], int nt, int xlane) {
         constexpr int NT_L = decltype(nt_tag)::value;
-        for (int w2 = 0; w2 < 4; ++w2) {
-            const float s = sc_s[w2];
-            if (s == 0.0f) continue;                                        // workgroup-uniform per w2
-            const f16* iw = img_all + w2 * B::IMG_WAVE + tr_lane;
-            f16x8 a[NO];
+        constexpr bool ONES = decltype(ones_tag)::value;                    // also accumulate dZ^T x 1 (the padding columns of the first layer)
+        constexpr int HALF = NT_L >= 4 ? NT_L / 2 : NT_L, NU = 4 * (NT_L / HALF);
+        f16x8 a[2][NO], b[2][HALF];
+        auto frags = [&](int u, f16x8 (&af)[NO], f16x8 (&bf)[HALF]) {
+            const int w2 = u / (NT_L / HALF), k0 = (u % (NT_L / HALF)) * HALF;
+            const f16* iw = img_all + w2 * B::IMG_WAVE;
 #pragma unroll
             for (int i = 0; i < NO; ++i) {
                 const int jt = wave + 4 * i;
-                a[i] = tr_frag(iw + (jt < HT ? jt : 0) * B::TILE, 64);
+                af[i] = tr_frag(iw + (jt < HT ? jt : 0) * B::TILE + tr_lane_q, 256);
             }
 #pragma unroll
-            for (int kt = 0; kt < NT_L; ++kt) {
-                if (kt < nt) {
-                    const f16x8 b = tr_frag(iw + B::IMG_X + kt * B::TILE, 64);
+            for (int k = 0; k < HALF; ++k) bf[k] = tr_frag(iw + B::IMG_X + (k0 + k < nt ? k0 + k : 0) * B::TILE + xlane, 256);
+        };
+        frags(0, a[0], b[0]);
 #pragma unroll
-                    for (int i = 0; i < NO; ++i) {
-                        const f32x4 D = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b, f32x4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+        for (int u = 0; u < NU; ++u) {
+            if (u + 1 < NU) frags(u + 1, a[(u + 1) & 1], b[(u + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int k0 = (u % (NT_L / HALF)) * HALF;
+            if constexpr (ONES) {
+                if (k0 == 0) {
+                    const f16x8 ones = frag_from_dwords(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[i][kt][r] = __builtin_fmaf(s, D[r], acc[i][kt][r]);
-                    }
+                    for (int i = 0; i < NO; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u & 1][i], ones, accb[i], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < HALF; ++k) {
+                if (k0 + k < nt) {
+#pragma unroll
+                    for (int i = 0; i < NO; ++i) acc[i][k0 + k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u & 1][i], b[u & 1][k], acc[i][k0 + k], 0, 0, 0);
                 }
             }
         }
@@ -286,17 +312,47 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
 
     u32x4 x[F16_KB_MAX][2], xn[F16_KB_MAX][2];
     float ds[2], dsn[2];
-    if (n_steps > 0) load_step(0, x, ds);
+    uint32_t e_unit = 127u;                                                 // biased exponent of the unit dZ is expressed in (workgroup-uniform)
+    bool have_unit = false;
+    if (n_steps > 0) {
+        load_step(0, x, ds);
+        const float mx0 = wave_max(fmaxf(fabsf(ds[0]), fabsf(ds[1])));
+        if (lane == 0) mx_s[wave] = mx0;
+    }
+    __syncthreads();
     for (int64_t step = 0; step < n_steps; ++step) {
         const int64_t tile = step * per_step + (int64_t)blockIdx.x * 4 + wave;
         const bool have_tile = tile < n_tiles;
-        load_step(step + 1 < n_steps ? step + 1 : step, xn, dsn);          // next step's operands in flight (clamped: a static number of loads)
-        // per-step power-of-two scale: the largest |d_sigma| of the 32 samples lands in [1, 2)
-        const float mx = wave_max(fmaxf(fabsf(ds[0]), fabsf(ds[1])));
-        uint32_t be = (__float_as_uint(mx) >> 23) & 0xFFu;
-        be = be < 1u ? 127u : (be > 253u ? 253u : be);
-        const float sc_dn = __uint_as_float((254u - be) << 23), sc_up = __uint_as_float(be << 23);
-        if (lane == 0) sc_s[wave] = mx > 0.0f ? sc_up : 0.0f;
+        // The lane addresses of the W^T fragments and the image stores (dozens of distinct values of c and g) are cheap to recompute;
+        // hoisted out of this loop as invariants they were spilled to scratch and re-read every step (85 scratch loads a step).
+        asm volatile("" : "+v"(c), "+v"(g));
+        // the unit: exponent of the step's largest |d_sigma| (its maximum then lies in [1, 2)), kept while that stays within [2^-4, 2)
+        const float* mxb = mx_s + 4 * (int)(step & 1);
+        const float mxg = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(fmaxf(fmaxf(mxb[0], mxb[1]), fmaxf(mxb[2], mxb[3])))));
+        uint32_t be = (__float_as_uint(mxg) >> 23) & 0xFFu;
+        be = be < 1u ? 1u : (be > 253u ? 253u : be);
+        if (mxg > 0.0f && (!have_unit || be > e_unit || be + 4u < e_unit)) {
+            if (have_unit) {
+                if (be + 96u < e_unit) be = e_unit - 96u;                   // the accumulators grow by 2^(e_unit - be): bounded
+                const int sh = (int)e_unit - (int)be;                       // exact: a power of two (0 when nothing of the old sum would survive)
+                const float f = sh < -126 ? 0.0f : __uint_as_float((uint32_t)(127 + sh) << 23);
+#pragma unroll
+                for (int i = 0; i < NO; ++i) {
+#pragma unroll
+                    for (int k = 0; k < 2 * KT; ++k) acc0[i][k] *= f;
+                    accb[i] *= f;
+                    if constexpr (NHID > 0) {
+#pragma unroll
+                        for (int l = 0; l < NHID; ++l)
+#pragma unroll
+                            for (int k = 0; k < HT; ++k) acch[l][i][k] *= f;
+                    }
+                }
+            }
+            e_unit = be;
+            have_unit = true;
+        }
+        const float sc_dn = __uint_as_float((254u - e_unit) << 23), sc_up = __uint_as_float(e_unit << 23);
         const float dsd[2] = {ds[0] * sc_dn, ds[1] * sc_dn};
 
         // ---- forward, once: A[l] = inputs of hidden matrix l + 1 (B operands), Dv[l] = derivative of layer l's activation
@@ -325,14 +381,21 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
                 write_x_image_hidden(A[l - 1]);
                 // dA_{l-1} = W_l^T dZ_l (scaled domain), gated by layer l-1's derivative -> dZ_{l-1}
                 uint32_t dzn[HT][2][2];
+                f16x8 wt[2][KBH];                                          // W^T fragments of row tile it + 1 in flight behind the products of it
+#pragma unroll
+                for (int kb = 0; kb < KBH; ++kb) wt[0][kb] = wt_frag_hidden(Wl, 0, kb);
 #pragma unroll
                 for (int it = 0; it < HT; ++it) {
+                    if (it + 1 < HT) {
+#pragma unroll
+                        for (int kb = 0; kb < KBH; ++kb) wt[(it + 1) & 1][kb] = wt_frag_hidden(Wl, it + 1, kb);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                     f32x4 Dq[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
 #pragma unroll
                     for (int kb = 0; kb < KBH; ++kb) {
-                        const f16x8 a = wt_frag_hidden(Wl, it, kb);
 #pragma unroll
-                        for (int t = 0; t < 2; ++t) Dq[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, dz_frag(dzp, kb, t), Dq[t], 0, 0, 0);
+                        for (int t = 0; t < 2; ++t) Dq[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wt[it & 1][kb], dz_frag(dzp, kb, t), Dq[t], 0, 0, 0);
                     }
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
@@ -348,7 +411,7 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
                     }
                 }
                 __syncthreads();
-                accumulate_dw(std::integral_constant<int, HT>{}, acch[l - 1], HT);
+                accumulate_dw(std::integral_constant<int, HT>{}, F{}, acch[l - 1], HT, tr_lane_q);
                 __syncthreads();                                           // the images are rewritten by the next layer
 #pragma unroll
                 for (int jt = 0; jt < HT; ++jt)
@@ -358,7 +421,10 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
         }
         // ---- first layer: its weight gradient and the feature gradient (un-scaled, to the d_feature planes)
         write_dz_image(dzp);
-        write_x_image_first(x);
+        // The features are not kept across the hidden layers (32 registers at the point of highest pressure): they are read again
+        // here (L2) for the input image, together with the next step's operands (a static number of loads: the last step re-reads itself)
+        load_step(step, x, ds);
+        load_step(step + 1 < n_steps ? step + 1 : step, xn, dsn);
         if (want_dfeat) {
             for (int it = 0; it < nt0; ++it) {
                 f32x4 Dq[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
@@ -381,9 +447,14 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
                 }
             }
         }
+        write_x_image_first(x);
+        {
+            const float mxn = wave_max(fmaxf(fabsf(dsn[0]), fabsf(dsn[1])));   // the next step's maximum, exchanged through the other buffer
+            if (lane == 0) mx_s[4 * (int)((step + 1) & 1) + wave] = mxn;
+        }
         __syncthreads();
-        accumulate_dw(std::integral_constant<int, 2 * KT>{}, acc0, nt0);
-        __syncthreads();                                                   // images and scales are rewritten by the next step
+        accumulate_dw(std::integral_constant<int, 2 * KT>{}, T{}, acc0, nt0, tr_lane_p);
+        __syncthreads();                                                   // the images are rewritten by the next step
 #pragma unroll
         for (int kb = 0; kb < F16_KB_MAX; ++kb) { x[kb][0] = xn[kb][0]; x[kb][1] = xn[kb][1]; }
         ds[0] = dsn[0]; ds[1] = dsn[1];
@@ -391,6 +462,7 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
 
     // ---- the workgroup's slab (parameter layout, unpadded): every row tile is owned by exactly one wave
     const int n_mlp = spec.n_mlp_params, in_dim = spec.in_dim;
+    const float unit = __uint_as_float(e_unit << 23);
     float* slab = slabs + (size_t)blockIdx.x * n_mlp;
 #pragma unroll
     for (int i = 0; i < NO; ++i) {
@@ -401,7 +473,7 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int col = 16 * kt + c;
-                    if (col < in_dim) slab[(16 * jt + 4 * g + r) * in_dim + col] = acc0[i][kt][r];
+                    if (col < in_dim) slab[(16 * jt + 4 * g + r) * in_dim + col] = unit * (col < spec.enc_dim ? acc0[i][kt][r] : accb[i][r]);
                 }
             if constexpr (NHID > 0) {
 #pragma unroll
@@ -409,7 +481,7 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
 #pragma unroll
                     for (int kt = 0; kt < HT; ++kt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) slab[H * in_dim + l * H * H + (16 * jt + 4 * g + r) * H + 16 * kt + c] = acch[l][i][kt][r];
+                        for (int r = 0; r < 4; ++r) slab[H * in_dim + l * H * H + (16 * jt + 4 * g + r) * H + 16 * kt + c] = unit * acch[l][i][kt][r];
             }
         }
     }
