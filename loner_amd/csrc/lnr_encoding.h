@@ -197,16 +197,3 @@ __device__ __forceinline__ void freq_features4(const LnrNetSpec& spec, const flo
     }
 }
 
-__device__ __forceinline__ void freq_features4_bwd(const LnrNetSpec& spec, const float x[3], int k0,
-                                                   const float d_out[4], float dx[3]) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int k = k0 + r;
-        if (k < spec.enc_dim && d_out[r] != 0.0f) {
-            float d; int dim;
-            float ph = freq_phase(spec, x, k, &d, &dim);
-            float v = d_out[r] * cosf(ph) * d;
-            if (dim == 0) dx[0] += v; else if (dim == 1) dx[1] += v; else dx[2] += v;
-        }
-    }
-}
