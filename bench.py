@@ -38,6 +38,8 @@ def parse():
                     help="arithmetic of the density network: f32 (default, stricter than the reference) or f16 "
                          "(the reference's storage types: fp16 features and weights on MFMA, fp32 accumulation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-every", type=int, default=4,
+                    help="HIP-event timing of the kernels on every N-th iteration of the timed region (0: none - then no roofline / kernels_ms)")
     ap.add_argument("--mode", choices=["train", "render"], default="train",
                     help="train (default): the mapping iteration, with the inference leg as a `render` block in the line; "
                          "render: only the inference leg (Model.forward(testing=True) over a whole scan), for profiling")
@@ -449,7 +451,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     timer.calls = {n: 0 for n in timer.names}
-    timer.enabled = True              # (it also switches the library's kernel events on, for every 4th iteration)
+    timer.every = max(args.profile_every, 1)
+    timer.enabled = args.profile_every > 0              # (it also switches the library's kernel events on, for every 4th iteration)
     t0 = time.perf_counter()
     opt._do_iterate_optimizer(my_window, [None], optimizer_settings=phase(args.steps))
     torch.cuda.synchronize()
