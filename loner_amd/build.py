@@ -29,7 +29,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-a
 EXACT = {"lnr_sampler.hip", "lnr_rays.hip"}
 # (source, object name, extra flags); the density kernels are compiled once per hidden width (n_neurons/16)
 SOURCES = [("lnr_density_ht.hip", f"lnr_density_ht{ht}.o", [f"-DLNR_HT={ht}"]) for ht in (16, 8, 4, 2, 1)] + \
-          [("lnr_density_f16_bwd.hip", f"lnr_density_f16_bwd{part}.o", [f"-DLNR_BWD_PART={part}"]) for part in (0, 1)] + \
+          [("lnr_density_f16_bwd.hip", f"lnr_density_f16_bwd{part}.o", [f"-DLNR_BWD_PART={part}"]) for part in (0, 1, 2)] + \
           [(s, s.replace(".hip", ".o"), []) for s in
            ("lnr_core.hip", "lnr_density.hip", "lnr_density_f16.hip", "lnr_density_f16_fwd.hip", "lnr_encode.hip", "lnr_sampler.hip", "lnr_render.hip", "lnr_rays.hip", "lnr_optim.hip", "lnr_pose.hip")]
 

@@ -1,14 +1,16 @@
 // General fp16-mode backward of the density MLP: host dispatch over the kernel's compile-time shape (lnr_f16_bwd_kernel.h).
-// Compiled as two objects (LNR_BWD_PART: 0 = ReLU and Sine kernels + the entry points, 1 = the run-time-activation kernels) so that
-// the two halves of the instantiations build side by side.
+// Compiled as three objects (LNR_BWD_PART: 0 = ReLU and Sine kernels + the entry points, 1 / 2 = the run-time-activation kernels up to
+// 64 neurons / from 128) so that the instantiations build side by side (the run-time-activation kernels are the slow ones to compile).
 #include "lnr_f16_bwd_kernel.h"
 
 #ifndef LNR_BWD_PART
-#error "compile with -DLNR_BWD_PART=0 or 1 (loner_amd/build.py)"
+#error "compile with -DLNR_BWD_PART=0, 1 or 2 (loner_amd/build.py)"
 #endif
 
 int lnr_mlp_bwd_f16_gen_other(const LnrNetSpec* spec, const float* params, const uint32_t* featp, int64_t m_pad, const MlpPoints* pt, const float* d_sigma,
                               float* dfeat, float* slabs, int want_dfeat, int blocks, hipStream_t st);
+int lnr_mlp_bwd_f16_gen_other_wide(const LnrNetSpec* spec, const float* params, const uint32_t* featp, int64_t m_pad, const MlpPoints* pt, const float* d_sigma,
+                                   float* dfeat, float* slabs, int want_dfeat, int blocks, hipStream_t st);
 
 static int f16_gen_kt(const LnrNetSpec* spec) { return (spec->in_dim + 31) / 32 <= 2 ? 2 : 4; }   // first-layer K blocks (as the forward)
 
@@ -62,7 +64,7 @@ int lnr_mlp_bwd_f16_gen(const LnrNetSpec* spec, const float* params, const uint3
 #undef LNR_F16_GEN_BWD
     return LNR_OK;
 }
-#else
+#elif LNR_BWD_PART == 1
 int lnr_mlp_bwd_f16_gen_other(const LnrNetSpec* spec, const float* params, const uint32_t* featp, int64_t m_pad, const MlpPoints* pt, const float* d_sigma,
                         float* dfeat, float* slabs, int want_dfeat, int blocks, hipStream_t st) {
     const int kt = f16_gen_kt(spec);
@@ -77,19 +79,38 @@ int lnr_mlp_bwd_f16_gen_other(const LnrNetSpec* spec, const float* params, const
     } while (0)
 #define LNR_F16_GEN_BWD(HT, ACT, NH) do { if (kt == 2) LNR_F16_GEN_BWD_K(HT, ACT, NH, 2); else LNR_F16_GEN_BWD_K(HT, ACT, NH, 4); } while (0)
 #define LNR_F16_GEN_BWD_N(HT, ACT) do { if (spec->n_hidden == 1) LNR_F16_GEN_BWD(HT, ACT, 1); else if (spec->n_hidden == 2) LNR_F16_GEN_BWD(HT, ACT, 2); else LNR_F16_GEN_BWD(HT, ACT, 3); } while (0)
-#define LNR_F16_GEN_BWD_A(HT) LNR_F16_GEN_BWD_N(HT, -1)
-#define LNR_F16_GEN_BWD_W(ACT) LNR_F16_GEN_BWD(16, ACT, 1)           /* 256 neurons: one hidden layer (lnr_f16_supported) */
     switch (spec->n_neurons / 16) {
-        case 1: LNR_F16_GEN_BWD_A(1); break;
-        case 2: LNR_F16_GEN_BWD_A(2); break;
-        case 4: LNR_F16_GEN_BWD_A(4); break;
-        case 8: LNR_F16_GEN_BWD_A(8); break;
-        default: LNR_F16_GEN_BWD_W(-1); break;
+        case 1: LNR_F16_GEN_BWD_N(1, -1); break;
+        case 2: LNR_F16_GEN_BWD_N(2, -1); break;
+        case 4: LNR_F16_GEN_BWD_N(4, -1); break;
+        default: return lnr_mlp_bwd_f16_gen_other_wide(spec, params, featp, m_pad, pt, d_sigma, dfeat, slabs, want_dfeat, blocks, st);
     }
-#undef LNR_F16_GEN_BWD_W
 #undef LNR_F16_GEN_BWD_N
 #undef LNR_F16_GEN_BWD_K
-#undef LNR_F16_GEN_BWD_A
+#undef LNR_F16_GEN_BWD
+    return LNR_OK;
+}
+#else
+int lnr_mlp_bwd_f16_gen_other_wide(const LnrNetSpec* spec, const float* params, const uint32_t* featp, int64_t m_pad, const MlpPoints* pt, const float* d_sigma,
+                        float* dfeat, float* slabs, int want_dfeat, int blocks, hipStream_t st) {
+    const int kt = f16_gen_kt(spec);
+    const dim3 grid((unsigned)blocks), block(LNR_DENSITY_BLOCK);          // one workgroup per CU (LDS), persistent over the steps
+#define LNR_F16_GEN_BWD_K(HT, ACT, NH, KT)                                                                                        \
+    do {                                                                                                                         \
+        const size_t lds = BwdLds<HT, NH, KT>::BYTES;                                                                            \
+        int rc_ = f16_set_lds(mlp_backward_f16_gen_kernel<HT, ACT, NH, KT>, lds, "lnr_density_backward");                        \
+        if (rc_) return rc_;                                                                                                     \
+        hipLaunchKernelGGL((mlp_backward_f16_gen_kernel<HT, ACT, NH, KT>), grid, block, lds, st, *spec, params, featp, m_pad, pt->n_points, \
+                           pt->n_rays_dev, pt->n_rays, pt->n_samples, d_sigma, dfeat, slabs, want_dfeat);                        \
+    } while (0)
+#define LNR_F16_GEN_BWD(HT, ACT, NH) do { if (kt == 2) LNR_F16_GEN_BWD_K(HT, ACT, NH, 2); else LNR_F16_GEN_BWD_K(HT, ACT, NH, 4); } while (0)
+#define LNR_F16_GEN_BWD_N(HT, ACT) do { if (spec->n_hidden == 1) LNR_F16_GEN_BWD(HT, ACT, 1); else if (spec->n_hidden == 2) LNR_F16_GEN_BWD(HT, ACT, 2); else LNR_F16_GEN_BWD(HT, ACT, 3); } while (0)
+    switch (spec->n_neurons / 16) {
+        case 8: LNR_F16_GEN_BWD_N(8, -1); break;
+        default: LNR_F16_GEN_BWD(16, -1, 1); break;           /* 256 neurons: one hidden layer (lnr_f16_supported) */
+    }
+#undef LNR_F16_GEN_BWD_N
+#undef LNR_F16_GEN_BWD_K
 #undef LNR_F16_GEN_BWD
     return LNR_OK;
 }

@@ -180,6 +180,7 @@ NETS = {
     "freq_sine16": (dict(otype="Frequency", n_frequencies=3), dict(activation="Sine", n_neurons=16, n_hidden_layers=2)),
     "freq12_small": (dict(otype="Frequency", n_frequencies=12), dict(activation="ReLU", n_neurons=32, n_hidden_layers=1)),
     "freq16_h16": (dict(otype="Frequency", n_frequencies=16), dict(activation="Softplus", n_neurons=16, n_hidden_layers=1)),
+    "freq_tanh128": (dict(otype="Frequency", n_frequencies=5), dict(activation="Tanh", n_neurons=128, n_hidden_layers=2)),
 }
 
 
@@ -711,7 +712,7 @@ def test_fp16_mode_config5_4096x256(ops):
 
 
 @pytest.mark.parametrize("name", ["hash_f4_2hidden", "hash_f8", "freq_siren", "freq_relu128", "small_hash", "freq_wide256", "freq_relu3",
-                                  "freq_tanh2", "freq_sine16", "freq12_small", "freq16_h16"])
+                                  "freq_tanh2", "freq_sine16", "freq12_small", "freq16_h16", "freq_tanh128"])
 def test_fp16_mode_general_networks(ops, name):
     """precision fp16 beyond the reference's default shape: frequency encoding + SIREN / wide ReLU MLPs, several hidden layers,
     4 or 8 features per level - forward and every gradient against the oracle with the same storage rounding (fp16 features,
