@@ -132,20 +132,44 @@ __device__ void aten_row_sum(const float* x, int K, float* part /*[32]*/, float*
     __syncthreads();
 }
 
-// bitonic sort of n_pow2 floats in LDS (ascending)
+// bitonic sort of n_pow2 floats in LDS (ascending).  Each of the four waves owns a contiguous quarter of the array: a pass whose
+// partner distance j is at most an eighth of the array exchanges inside the quarters, so it needs no workgroup barrier (a wave's LDS
+// operations complete in order) - of the 45 passes of a 512-element sort (78 of a 4096-element one) only the three with j >= n / 4 do.
 __device__ void bitonic_sort_lds(float* a, int n_pow2) {
+    auto exchange = [&](int t, int j, int k) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));       // lower index of the pair
+        const int p = i | j;
+        const bool up = ((i & k) == 0);
+        const float x = a[i], y = a[p];
+        if ((x > y) == up) { a[i] = y; a[p] = x; }
+    };
+    if (n_pow2 < 512) {
+        for (int k = 2; k <= n_pow2; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = threadIdx.x; t < n_pow2 / 2; t += SAMPLER_BLOCK) exchange(t, j, k);
+                __syncthreads();
+            }
+        }
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int quarter_pairs = n_pow2 / 8;                          // pairs inside a wave's quarter (n / 4 elements)
+    bool local_before = false;
     for (int k = 2; k <= n_pow2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < n_pow2 / 2; t += SAMPLER_BLOCK) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // lower index of the pair
-                const int p = i | j;
-                const bool up = ((i & k) == 0);
-                const float x = a[i], y = a[p];
-                if ((x > y) == up) { a[i] = y; a[p] = x; }
+            if (8 * j <= n_pow2) {                                  // partners inside the wave's quarter
+                for (int t = wave * quarter_pairs + lane; t < (wave + 1) * quarter_pairs; t += 64) exchange(t, j, k);
+                __builtin_amdgcn_wave_barrier();
+                local_before = true;
+            } else {
+                if (local_before) __syncthreads();
+                for (int t = threadIdx.x; t < n_pow2 / 2; t += SAMPLER_BLOCK) exchange(t, j, k);
+                __syncthreads();
+                local_before = false;
             }
-            __syncthreads();
         }
     }
+    __syncthreads();
 }
 
 // LDS (floats): zc[H] | tmp[H] (reused as probs) | pdf[H] | cdf[H] | merged[P2] | part[32] | scalars[4]
@@ -194,11 +218,24 @@ sample_occ_kernel(const float* __restrict__ rays, int n_rays, const int32_t* __r
     const float total = scal[0];
     for (int k = threadIdx.x; k < K; k += SAMPLER_BLOCK) pdf[k] = pdf[k] / total;
     __syncthreads();
-    // cdf = [0, cumsum(pdf)] with the running sum in float64 (torch.cumsum on CPU)
-    if (threadIdx.x == 0) {
-        double run = 0.0;
-        cdf[0] = 0.0f;
-        for (int k = 0; k < K; ++k) {
+    // cdf = [0, cumsum(pdf)] with the running sum in float64 (torch.cumsum on CPU).  The float64 sums are EXACT here - every pdf
+    // value is a float32 >= 1e-5 / (K (1 + 1e-5)) > 2^-29 for K <= 4094, i.e. a multiple of 2^-52, and every partial sum is below 2 -
+    // so the order of the additions does not matter: the first wave sums 64 chunks side by side and combines them with an exclusive
+    // scan, instead of one thread walking K dependent additions (with K = 1022 at test time, ~40 k cycles per ray).
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x, chunk = (K + 63) / 64;
+        const int k0 = lane * chunk, k1 = min(K, k0 + chunk);
+        double own = 0.0;
+        for (int k = k0; k < k1; ++k) own = own + (double)pdf[k];
+        double incl = own;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl = incl + up;
+        }
+        double run = incl - own;                                   // exclusive prefix (exact)
+        if (lane == 0) cdf[0] = 0.0f;
+        for (int k = k0; k < k1; ++k) {
             run = run + (double)pdf[k];
             cdf[k + 1] = (float)run;
         }
