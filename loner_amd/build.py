@@ -27,10 +27,14 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-a
          os.environ.get("LNR_EXTRA_HIPCC_FLAGS", "").split()        # development switches, e.g. -DLNR_PHASE_TIMING (tools/README.md)
 # files whose float arithmetic must round exactly like the reference's torch CPU ops
 EXACT = {"lnr_sampler.hip", "lnr_rays.hip"}
+# per-source flags.  lnr_render.hip: its 32-samples-per-lane instantiations (2048-sample rays, the inference path) exceed the default
+# threshold for "#pragma unroll"; with a loop left rolled the per-lane arrays become scratch memory (820 bytes per lane: the compositing of
+# a rendered scan ran at 230 GB/s)
+EXTRA = {"lnr_render.hip": ["-mllvm", "-pragma-unroll-threshold=1000000", "-mllvm", "-unroll-threshold=100000"]}
 # (source, object name, extra flags); the density kernels are compiled once per hidden width (n_neurons/16)
 SOURCES = [("lnr_density_ht.hip", f"lnr_density_ht{ht}.o", [f"-DLNR_HT={ht}"]) for ht in (16, 8, 4, 2, 1)] + \
           [("lnr_density_f16_bwd.hip", f"lnr_density_f16_bwd{part}.o", [f"-DLNR_BWD_PART={part}"]) for part in (0, 1, 2)] + \
-          [(s, s.replace(".hip", ".o"), []) for s in
+          [(s, s.replace(".hip", ".o"), EXTRA.get(s, [])) for s in
            ("lnr_core.hip", "lnr_density.hip", "lnr_density_f16.hip", "lnr_density_f16_fwd.hip", "lnr_encode.hip", "lnr_sampler.hip", "lnr_render.hip", "lnr_rays.hip", "lnr_optim.hip", "lnr_pose.hip")]
 
 

@@ -37,13 +37,53 @@ struct RayState {
 };
 
 // forward volume rendering of one ray held by one wave
+// A lane's C consecutive values of a ray's row through LDS: the wave loads the row in 1 KB instructions (lane l of instruction k takes
+// elements 256 k + 4 l ..) and each lane reads its own chunk back.  Loaded directly, a lane's chunk of C = 32 floats starts 128 bytes
+// after its neighbour's: every load instruction touches 64 cache lines for 16 bytes each, and the 8 instructions that walk a chunk
+// evict each other's lines (four waves x two 8 KB rows against a 32 KB L1) - the compositing of a 2048-sample scan ran at 7 TB/s of L2
+// traffic for 1 GB of input.  Rows of 32 floats are padded by 4 in LDS (lane stride 144 bytes: conflict-free ds_read_b128).
+template <int C>
+__device__ __forceinline__ void load_chunk_staged(const float* __restrict__ src_row, float* stage, int lane, float (&out)[C]) {
+    static_assert(C % 4 == 0, "float4 pieces");
+#pragma unroll
+    for (int k = 0; k < C / 4; ++k) {
+        const int i = 256 * k + 4 * lane;
+        *reinterpret_cast<float4*>(stage + i + 4 * (i / C)) = *reinterpret_cast<const float4*>(src_row + i);
+    }
+    __builtin_amdgcn_wave_barrier();                            // a wave's LDS operations complete in order
+#pragma unroll
+    for (int q = 0; q < C / 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(stage + lane * (C + 4) + 4 * q);
+        out[4 * q] = v.x; out[4 * q + 1] = v.y; out[4 * q + 2] = v.z; out[4 * q + 3] = v.w;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <int C>
 __device__ __forceinline__ void render_ray(RayState<C>& st, const float* __restrict__ sigma, const float* __restrict__ z,
                                            const float* __restrict__ noise, float noise_std, uint64_t seed, int ray,
-                                           int S, int lane, const float* __restrict__ rayrec) {
+                                           int S, int lane, const float* __restrict__ rayrec, float* stage = nullptr) {
     const int base = lane * C;
     const size_t row = (size_t)ray * S;
     float dens[C];
+    bool staged = false;
+    if constexpr (C >= 16) {
+        if (stage != nullptr && S == 64 * C) {                 // wave-uniform: whole rows
+            load_chunk_staged<C>(z + row, stage, lane, st.z);
+            load_chunk_staged<C>(sigma + row, stage, lane, dens);
+            if (noise) {
+                float nz[C];
+                load_chunk_staged<C>(noise + row, stage, lane, nz);
+#pragma unroll
+                for (int t = 0; t < C; ++t) dens[t] += nz[t];
+            } else if (noise_std > 0.0f) {
+#pragma unroll
+                for (int t = 0; t < C; ++t) dens[t] += lnr_rand_normal(seed, (uint64_t)ray, (uint32_t)(base + t)) * noise_std;
+            }
+            staged = true;
+        }
+    }
+    if (!staged) {
 #pragma unroll
     for (int t = 0; t < C; ++t) {
         const int i = base + t;
@@ -57,6 +97,7 @@ __device__ __forceinline__ void render_ray(RayState<C>& st, const float* __restr
             st.z[t] = 0.0f;
             dens[t] = 0.0f;
         }
+    }
     }
     const float dx = rayrec[3], dy = rayrec[4], dz = rayrec[5];
     st.dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
@@ -149,7 +190,9 @@ render_forward_kernel(const float* __restrict__ sigma, const float* __restrict__
     if (ray >= lnr_live_rays(n_rays, n_rays_dev)) return;
     const float* rr = rays + (size_t)ray * LNR_RAY_STRIDE;
     RayState<C> st;
-    render_ray<C>(st, sigma, z, noise, noise_std, seed, ray, S, lane, rr);
+    extern __shared__ __attribute__((aligned(16))) float render_stage[];       // C >= 16: 64 (C + 4) floats per wave (the host sizes it)
+    float* stage = C >= 16 ? render_stage + (threadIdx.x >> 6) * 64 * (C + 4) : nullptr;
+    render_ray<C>(st, sigma, z, noise, noise_std, seed, ray, S, lane, rr, stage);
     if (weights) {
 #pragma unroll
         for (int t = 0; t < C; ++t) if (lane * C + t < S) weights[(size_t)ray * S + lane * C + t] = st.w[t];
@@ -469,8 +512,8 @@ extern "C" int lnr_render_forward(const float* sigma, const float* z, const floa
     if (n_rays == 0) return LNR_OK;
     const dim3 grid(lnr_div_up(n_rays, RAYS_PER_BLOCK)), block(RENDER_BLOCK);
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH_C(n_samples, hipLaunchKernelGGL(render_forward_kernel<C>, grid, block, 0, st, sigma, z, rays, n_rays, n_rays_dev, n_samples,
-                                             noise, noise_std, seed, depth, weights, opacity, variance));
+    DISPATCH_C(n_samples, hipLaunchKernelGGL(render_forward_kernel<C>, grid, block, C >= 16 ? RAYS_PER_BLOCK * 64 * (C + 4) * sizeof(float) : 0, st,
+                                             sigma, z, rays, n_rays, n_rays_dev, n_samples, noise, noise_std, seed, depth, weights, opacity, variance));
     LNR_CHECK_LAUNCH("lnr_render_forward");
     return LNR_OK;
 }
