@@ -1,13 +1,17 @@
 // General fp16-mode forward of the density MLP: host dispatch over the kernel's compile-time shape (lnr_f16_fwd_kernel.h).
+// Compiled as two objects (LNR_FWD_PART: 0 = ReLU and Sine kernels + the entry point, 1 = the run-time-activation kernels, whose
+// every activation carries the switch over the libm evaluations: they are the slow ones to compile).
 #include "lnr_f16_fwd_kernel.h"
+
+#ifndef LNR_FWD_PART
+#error "compile with -DLNR_FWD_PART=0 or 1 (loner_amd/build.py)"
+#endif
 
 #define LNR_F16_FWD_CT 2             // 16-sample column tiles per wave step
 
-int lnr_mlp_fwd_f16_gen(const LnrNetSpec* spec, const float* params, const uint32_t* featp, int64_t m_pad, const MlpPoints* pt, float* sigma,
-                        int64_t blocks, hipStream_t st) {
-    const int akind = spec->activation;
-    const int kt = (spec->in_dim + 31) / 32 <= 2 ? 2 : 4;              // first-layer K blocks: at most one block of zero padding
-    const dim3 block(LNR_DENSITY_BLOCK);
+int lnr_mlp_fwd_f16_gen_other(const LnrNetSpec* spec, const float* params, const uint32_t* featp, int64_t m_pad, const MlpPoints* pt, float* sigma,
+                              int64_t blocks, hipStream_t st);
+
 #define LNR_F16_GEN_FWD_K(HT, ACT, NH, KT)                                                                                        \
     do {                                                                                                                         \
         const size_t lds = FwdLds<HT, NH, KT>::BYTES;                                                                            \
@@ -21,19 +25,37 @@ int lnr_mlp_fwd_f16_gen(const LnrNetSpec* spec, const float* params, const uint3
     } while (0)
 #define LNR_F16_GEN_FWD(HT, ACT, NH) do { if (kt == 2) LNR_F16_GEN_FWD_K(HT, ACT, NH, 2); else LNR_F16_GEN_FWD_K(HT, ACT, NH, 4); } while (0)
 #define LNR_F16_GEN_FWD_N(HT, ACT) do { if (spec->n_hidden == 1) LNR_F16_GEN_FWD(HT, ACT, 1); else if (spec->n_hidden == 2) LNR_F16_GEN_FWD(HT, ACT, 2); else LNR_F16_GEN_FWD(HT, ACT, 3); } while (0)
-#define LNR_F16_GEN_FWD_A(HT) do { if (akind == LNR_ACT_RELU) LNR_F16_GEN_FWD_N(HT, LNR_ACT_RELU); else if (akind == LNR_ACT_SINE) LNR_F16_GEN_FWD_N(HT, LNR_ACT_SINE); else LNR_F16_GEN_FWD_N(HT, -1); } while (0)
-#define LNR_F16_GEN_FWD_W(ACT) LNR_F16_GEN_FWD(16, ACT, 1)           /* 256 neurons: one hidden layer (lnr_f16_supported) */
+
+#if LNR_FWD_PART == 0
+int lnr_mlp_fwd_f16_gen(const LnrNetSpec* spec, const float* params, const uint32_t* featp, int64_t m_pad, const MlpPoints* pt, float* sigma,
+                        int64_t blocks, hipStream_t st) {
+    const int akind = spec->activation;
+    if (akind != LNR_ACT_RELU && akind != LNR_ACT_SINE) return lnr_mlp_fwd_f16_gen_other(spec, params, featp, m_pad, pt, sigma, blocks, st);
+    const int kt = (spec->in_dim + 31) / 32 <= 2 ? 2 : 4;              // first-layer K blocks: at most one block of zero padding
+    const dim3 block(LNR_DENSITY_BLOCK);
+#define LNR_F16_GEN_FWD_A(HT) do { if (akind == LNR_ACT_RELU) LNR_F16_GEN_FWD_N(HT, LNR_ACT_RELU); else LNR_F16_GEN_FWD_N(HT, LNR_ACT_SINE); } while (0)
     switch (spec->n_neurons / 16) {
         case 1: LNR_F16_GEN_FWD_A(1); break;
         case 2: LNR_F16_GEN_FWD_A(2); break;
         case 4: LNR_F16_GEN_FWD_A(4); break;
         case 8: LNR_F16_GEN_FWD_A(8); break;
-        default: if (akind == LNR_ACT_RELU) LNR_F16_GEN_FWD_W(LNR_ACT_RELU); else if (akind == LNR_ACT_SINE) LNR_F16_GEN_FWD_W(LNR_ACT_SINE); else LNR_F16_GEN_FWD_W(-1); break;
+        default: if (akind == LNR_ACT_RELU) LNR_F16_GEN_FWD(16, LNR_ACT_RELU, 1); else LNR_F16_GEN_FWD(16, LNR_ACT_SINE, 1); break;   /* 256 neurons: one hidden layer */
     }
-#undef LNR_F16_GEN_FWD_W
-#undef LNR_F16_GEN_FWD_N
-#undef LNR_F16_GEN_FWD_K
 #undef LNR_F16_GEN_FWD_A
-#undef LNR_F16_GEN_FWD
     return LNR_OK;
 }
+#else
+int lnr_mlp_fwd_f16_gen_other(const LnrNetSpec* spec, const float* params, const uint32_t* featp, int64_t m_pad, const MlpPoints* pt, float* sigma,
+                              int64_t blocks, hipStream_t st) {
+    const int kt = (spec->in_dim + 31) / 32 <= 2 ? 2 : 4;
+    const dim3 block(LNR_DENSITY_BLOCK);
+    switch (spec->n_neurons / 16) {
+        case 1: LNR_F16_GEN_FWD_N(1, -1); break;
+        case 2: LNR_F16_GEN_FWD_N(2, -1); break;
+        case 4: LNR_F16_GEN_FWD_N(4, -1); break;
+        case 8: LNR_F16_GEN_FWD_N(8, -1); break;
+        default: LNR_F16_GEN_FWD(16, -1, 1); break;                     /* 256 neurons: one hidden layer */
+    }
+    return LNR_OK;
+}
+#endif

@@ -186,7 +186,7 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
         for (int r = 0; r < 4; ++r) wo[jt][r] = (float)Ws[L::OFF_O + 16 * jt + 4 * g + r];
     // the features of the NEXT step are in flight while this one goes through the layers
     // (samples past M: their planes are padded to m_pad, whatever they hold only reaches columns that are never stored)
-    auto load_tile = [&](int64_t tile, u32x4 (&x)[F16_KB_MAX][CT]) {
+    auto load_tile = [&](int64_t tile, u32x4 (&x)[F16_KB_MAX][CT]) __attribute__((always_inline)) {
         const uint32_t m0 = (uint32_t)(tile * TS) * 4u;
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
@@ -198,7 +198,9 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
             }
         }
     };
-    auto run_tile = [&](int64_t tile, const u32x4 (&x)[F16_KB_MAX][CT]) {
+    // (always inlined: with a run-time activation the body is large enough for the inliner to leave it a FUNCTION, and a call passes
+    // the operand arrays through scratch memory - 500 bytes per lane)
+    auto run_tile = [&](int64_t tile, const u32x4 (&x)[F16_KB_MAX][CT]) __attribute__((always_inline)) {
         float part[CT];
 #pragma unroll
         for (int t = 0; t < CT; ++t) part[t] = 0.0f;
@@ -226,12 +228,26 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
     int64_t tile = (int64_t)blockIdx.x * nw + wave;
     u32x4 xa[F16_KB_MAX][CT], xb[F16_KB_MAX][CT];
     if (tile < n_tiles) load_tile(tile, xa);
-    for (; tile < n_tiles; tile += 2 * stride) {                          // two steps per trip: the feature buffers alternate
-        const int64_t t1 = tile + stride, t2 = tile + 2 * stride;
-        load_tile(t1 < n_tiles ? t1 : tile, xb);                          // unconditional (clamped): a static number of loads in flight
-        run_tile(tile, xa);
-        if (t1 >= n_tiles) break;
-        load_tile(t2 < n_tiles ? t2 : t1, xa);
-        run_tile(t1, xb);
+    if constexpr (ACT >= 0) {
+        for (; tile < n_tiles; tile += 2 * stride) {                      // two steps per trip: the feature buffers alternate
+            const int64_t t1 = tile + stride, t2 = tile + 2 * stride;
+            load_tile(t1 < n_tiles ? t1 : tile, xb);                      // unconditional (clamped): a static number of loads in flight
+            run_tile(tile, xa);
+            if (t1 >= n_tiles) break;
+            load_tile(t2 < n_tiles ? t2 : t1, xa);
+            run_tile(t1, xb);
+        }
+    } else {
+        // run-time activation: ONE copy of the step body (every activation of it carries the whole switch over the libm
+        // evaluations: two copies were 90 k instructions per kernel), the prefetched features copied instead of alternated
+        for (; tile < n_tiles; tile += stride) {
+            const int64_t t1 = tile + stride;
+            load_tile(t1 < n_tiles ? t1 : tile, xb);
+            run_tile(tile, xa);
+#pragma unroll
+            for (int kb = 0; kb < F16_KB_MAX; ++kb)
+#pragma unroll
+                for (int t = 0; t < CT; ++t) xa[kb][t] = xb[kb][t];
+        }
     }
 }
