@@ -1,0 +1,67 @@
+"""The argument behind freq_forward_h16_kernel / freq_backward_kernel (loner_amd/csrc/lnr_encode.hip), restated in float32 numpy: ONE range
+reduction per (sin, cos) pair of the frequency encoding reproduces the reference's two features sin(ph), sin(rn(ph + pi/2)) with
+ph = rn(rn(x 2^f) pi) (oracle/encoding.py; tinycudann frequency.h) to ~1e-7, so that their fp16 roundings agree except on a rounding
+boundary.  No GPU."""
+import numpy as np
+
+f32 = np.float32
+
+
+def fma(a, b, c):
+    return f32(np.float64(a) * np.float64(b) + np.float64(c))          # (double rounding is negligible at this scale)
+
+
+def sincos_f32(ph):
+    """sincos_f32 of lnr_encode.hip: k = rint(ph 2/pi), three-term Cody-Waite, minimax polynomials on [-pi/4, pi/4], quadrant"""
+    k = np.rint(ph * f32(0.636619772367581343)).astype(f32)
+    r = fma(-k, f32(1.57079637050628662109375), ph)
+    r = fma(-k, f32(-4.37113900018624283e-8), r)
+    r = fma(-k, f32(-1.7151245100059e-15), r).astype(f32)
+    z = (r * r).astype(f32)
+    sp = fma(z, f32(-1.9515295891e-4), f32(8.3321608736e-3)); sp = fma(z, sp, f32(-1.6666654611e-1))
+    s = fma((z * r).astype(f32), sp, r)
+    cp = fma(z, f32(2.443315711809948e-5), f32(-1.388731625493765e-3)); cp = fma(z, cp, f32(4.166664568298827e-2))
+    c = fma((z * z).astype(f32), cp, fma(z, f32(-0.5), f32(1.0)))
+    q = k.astype(np.int64)
+    a = np.where(q & 1, c, s); b = np.where(q & 1, s, c)
+    return np.where(q & 2, -a, a).astype(f32), np.where((q + 1) & 2, -b, b).astype(f32)
+
+
+def test_pair_reduction_reproduces_both_features():
+    rng = np.random.default_rng(0)
+    x = rng.random(100000).astype(f32)
+    PI, H = f32(np.pi), f32(np.pi / 2)
+    worst_s = worst_c = 0.0
+    differ = total = 0
+    for f in range(12):
+        ph = ((x * f32(2 ** f)).astype(f32) * PI).astype(f32)
+        s, c = sincos_f32(ph)
+        h = (ph + H).astype(f32)                                         # the reference's second phase
+        bb = (h - ph).astype(f32)
+        e = ((ph - (h - bb).astype(f32)).astype(f32) + (H - bb).astype(f32)).astype(f32)      # rounding error of ph + fl(pi/2), exact (TwoSum)
+        d = (f32(4.371139000186243e-8) - e).astype(f32)                  # fl(pi/2) - pi/2 = +4.37e-8
+        c2 = fma(-d, s, c)                                               # cos(ph + d) to first order
+        ref_s, ref_c = np.sin(ph.astype(np.float64)), np.sin(h.astype(np.float64))
+        worst_s = max(worst_s, float(np.abs(s - ref_s).max())); worst_c = max(worst_c, float(np.abs(c2 - ref_c).max()))
+        differ += int((s.astype(np.float16) != ref_s.astype(f32).astype(np.float16)).sum() +
+                      (c2.astype(np.float16) != ref_c.astype(f32).astype(np.float16)).sum())
+        total += 2 * len(x)
+    assert worst_s < 2e-7 and worst_c < 2e-7, (worst_s, worst_c)
+    assert differ < 2e-4 * total, (differ, total)                        # fp16 features: the same value except on a rounding boundary
+
+
+def test_sampler_prefix_sums_are_exact_in_float64():
+    """sample_occ_kernel's parallel cumsum (lnr_sampler.hip) relies on the float64 prefix sums of the pdf being exact, hence independent of
+    the order of the additions: a sequential float64 cumsum (torch.cumsum on the CPU) equals a chunked one bit for bit."""
+    rng = np.random.default_rng(1)
+    for K in (62, 254, 1022, 4094):
+        w = (rng.random(K).astype(f32) ** 8).astype(f32) + f32(1e-5)     # many nearly empty bins, like a trained occupancy grid
+        pdf = (w / f32(np.float32(w.astype(np.float64).sum()))).astype(f32)
+        seq = np.cumsum(pdf.astype(np.float64))
+        chunk = (K + 63) // 64
+        out = np.empty(K)
+        sums = [pdf[i:i + chunk].astype(np.float64).sum() for i in range(0, K, chunk)]
+        pre = np.concatenate([[0.0], np.cumsum(sums)[:-1]])
+        for j, i in enumerate(range(0, K, chunk)):
+            out[i:i + chunk] = pre[j] + np.cumsum(pdf[i:i + chunk].astype(np.float64))
+        assert np.array_equal(seq.astype(f32), out.astype(f32)) and np.array_equal(seq, out)
