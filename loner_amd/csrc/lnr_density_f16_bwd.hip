@@ -34,6 +34,12 @@ size_t lnr_f16_gen_bwd_lds(const LnrNetSpec* spec) {
 
 int lnr_mlp_bwd_f16_gen(const LnrNetSpec* spec, const float* params, const uint32_t* featp, int64_t m_pad, const MlpPoints* pt, const float* d_sigma,
                         float* dfeat, float* slabs, int want_dfeat, int blocks, hipStream_t st) {
+    // a K block's 16 feature planes are one buffer descriptor (32-bit record count, 32-bit lane offsets); the feature gradient is
+    // stored with 32-bit byte offsets over all its planes
+    if (m_pad * 4 * 16 > (int64_t)0x7FFFFFFF || (want_dfeat && (int64_t)spec->enc_dim * m_pad * 4 > (int64_t)0xFFFFFFFFll)) {
+        lnr_set_error("lnr_density_backward: too many points per call for the general fp16 kernels (a plane of %lld samples: 64 x plane bytes and enc_dim x plane bytes must fit 32 bits)", (long long)m_pad);
+        return LNR_ERR_UNSUPPORTED;
+    }
     const int akind = spec->activation;
     if (akind != LNR_ACT_RELU && akind != LNR_ACT_SINE) return lnr_mlp_bwd_f16_gen_other(spec, params, featp, m_pad, pt, d_sigma, dfeat, slabs, want_dfeat, blocks, st);
     const int kt = f16_gen_kt(spec);

@@ -29,6 +29,11 @@ int lnr_mlp_fwd_f16_gen_other(const LnrNetSpec* spec, const float* params, const
 #if LNR_FWD_PART == 0
 int lnr_mlp_fwd_f16_gen(const LnrNetSpec* spec, const float* params, const uint32_t* featp, int64_t m_pad, const MlpPoints* pt, float* sigma,
                         int64_t blocks, hipStream_t st) {
+    // a K block's 16 feature planes are one buffer descriptor (32-bit record count, 32-bit lane offsets)
+    if (m_pad * 4 * 16 > (int64_t)0x7FFFFFFF) {
+        lnr_set_error("lnr_density_forward: at most 2^25 points per call for the general fp16 kernels (got a plane of %lld samples)", (long long)m_pad);
+        return LNR_ERR_UNSUPPORTED;
+    }
     const int akind = spec->activation;
     if (akind != LNR_ACT_RELU && akind != LNR_ACT_SINE) return lnr_mlp_fwd_f16_gen_other(spec, params, featp, m_pad, pt, sigma, blocks, st);
     const int kt = (spec->in_dim + 31) / 32 <= 2 ? 2 : 4;              // first-layer K blocks: at most one block of zero padding

@@ -136,7 +136,6 @@ freq_forward_h16_kernel(const LnrNetSpec spec, const PointSrc src, uint32_t* __r
     const int nf = spec.n_frequencies;
     const int64_t M = live_points(src);
     const int64_t M32 = (M + 31) / 32 * 32;
-    const uint32_t plane_bytes = (uint32_t)m_pad * 4u;
     for (int64_t m = (int64_t)chunk * ENC_BLOCK + threadIdx.x; m < M32; m += (int64_t)bpg * ENC_BLOCK) {
         float xv = 0.0f;
         const bool live = m < M;
@@ -156,7 +155,7 @@ freq_forward_h16_kernel(const LnrNetSpec spec, const PointSrc src, uint32_t* __r
             const float d = 4.371139000186243e-8f - e;
             const float c2 = __builtin_fmaf(-d, s, c);
             const uint32_t v = live ? __builtin_bit_cast(uint32_t, h2{(_Float16)s, (_Float16)c2}) : 0u;
-            st32<uint32_t>(pairs, (uint32_t)(dim * nf + f) * plane_bytes + (uint32_t)m * 4u, v);
+            pairs[(size_t)(dim * nf + f) * (size_t)m_pad + (size_t)m] = v;                       // (64-bit index: up to 2^28 points per call)
         }
     }
 }
@@ -919,7 +918,6 @@ __global__ void __launch_bounds__(ENC_BLOCK)
 freq_backward_kernel(const LnrNetSpec spec, const PointSrc src, const float* __restrict__ dfeat, float* __restrict__ dxl, int64_t m_pad) {
     const int64_t M = live_points(src);
     const int nf = spec.n_frequencies;
-    const uint32_t plane_bytes = (uint32_t)m_pad * 4u;
     for (int64_t m = (int64_t)blockIdx.x * ENC_BLOCK + threadIdx.x; m < M; m += (int64_t)gridDim.x * ENC_BLOCK) {
         float x[3];
         load_unit_point(src, m, x);
@@ -929,7 +927,7 @@ freq_backward_kernel(const LnrNetSpec spec, const PointSrc src, const float* __r
             float acc = 0.0f;
             for (int f = 0; f < nf; ++f) {
                 const uint32_t k = (uint32_t)(2 * (dim * nf + f));
-                const float d0 = ld32<float>(dfeat, k * plane_bytes + (uint32_t)m * 4u), d1 = ld32<float>(dfeat, (k + 1u) * plane_bytes + (uint32_t)m * 4u);
+                const float d0 = dfeat[(size_t)k * (size_t)m_pad + (size_t)m], d1 = dfeat[(size_t)(k + 1u) * (size_t)m_pad + (size_t)m];   // (64-bit index)
                 const float mult = __uint_as_float((uint32_t)(127 + f) << 23);      // 2^f
                 const float ph = lnr_mul_rn(lnr_mul_rn(x[dim], mult), LNR_PI_F);
                 float sn, cs;
