@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--keyframes", type=int, default=8)
     ap.add_argument("--rays", type=int, default=512)
@@ -38,6 +38,9 @@ def parse():
                     help="arithmetic of the density network: f32 (default, stricter than the reference) or f16 "
                          "(the reference's storage types: fp16 features and weights on MFMA, fp32 accumulation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quick", action="store_true",
+                    help="development: only the timed region and its kernel table (no other-dtype leg, no north-star network leg, no render leg, "
+                         "no extended run, no baselines) - for A/B runs of a kernel")
     ap.add_argument("--profile-every", type=int, default=4,
                     help="HIP-event timing of the kernels on every N-th iteration of the timed region (0: none - then no roofline / kernels_ms)")
     ap.add_argument("--mode", choices=["train", "render"], default="train",
@@ -125,11 +128,12 @@ class _Shape:
 # where the REFERENCE's own optimiser was recorded: 30.0 m before training, 14.55 m after 50 iterations.
 QUALITY_SHAPE = _Shape(keyframes=2, rays=256, samples=128)
 QUALITY_ITERS = 100
+QUALITY_SEEDS = 8        # runs per GPU leg (each with its own random draws): the spread of L1 after 100 Adam iterations is part of the answer
 QUALITY_REFERENCE = {"l1_initial_m": 30.02, "l1_after_50_iterations_m": 14.55, "l1_after_100_iterations_m": 10.86,
                      "source": "tests/golden/g13_l1_curve.npz: the reference's Optimizer + compute_l1_depth on this configuration (512 held-out rays, 256 samples)"}
 
 
-def oracle_leg(args, device, budget_s, max_iters, min_iters=2):
+def oracle_leg(args, device, budget_s, max_iters, min_iters=2, seed=0):
     """A baseline leg: the oracle (oracle/mapping_step.py - the reference's mapping iteration restated op for op in torch, with
     the reference's own sampler op sequence, oracle/torch_sampling.py) on the SAME workload as the HIP path: the whole
     keyframe window, joint optimisation of the density field and the non-anchored poses, occupancy step at global steps 0, 10, ...
@@ -176,7 +180,7 @@ def oracle_leg(args, device, budget_s, max_iters, min_iters=2):
                            torch.tensor([1.0, 50.0], device=dev), 256, torch.rand(L1_RAYS, 128).to(dev), (torch.randn(L1_RAYS, 256) * 1.0).to(dev),
                            sampler="torch")[0]
     l1_before = probe()
-    torch.manual_seed(0)
+    torch.manual_seed(seed)
     t0 = time.time()
     n_valid, iters = 0, 0
     while iters < max_iters and (iters < min_iters or time.time() - t0 < budget_s):
@@ -462,6 +466,8 @@ def main():
     elapsed = time.perf_counter() - t0
     timer.enabled = False
 
+    final_loss = float(opt.last_stats["loss_terms"][-1, 0])
+    n_valid_timed = float(opt.last_stats["n_valid_rays"])          # (the extended run below overwrites last_stats)
     n_valid = torch.tensor([float(opt.last_stats["n_valid_rays"]), elapsed], device="cuda", dtype=torch.float64)
     if world > 1:
         rays_total = n_valid[0:1].clone(); dist.all_reduce(rays_total)
@@ -490,9 +496,23 @@ def main():
             return f"failed: {e}"
     l1_depth = l1_of(opt, my_window[0], 4096)
 
+    # A longer look at the same loop, OUTSIDE the official timed region (which is whatever --steps asked for; the driver uses 20 steps =
+    # ~45 ms, where run-to-run spread is the size of a typical kernel gain): 200 further iterations of the same optimiser, timed the same
+    # way, no per-kernel events.  The iteration gets cheaper as the map forms (dead samples produce no gradient records), so this is a
+    # companion figure, not a replacement for ms_per_step.
+    extended = None
+    if world == 1 and not args.quick:
+        torch.cuda.synchronize()
+        t_e = time.perf_counter()
+        opt._do_iterate_optimizer(my_window, [None], optimizer_settings=phase(200))
+        torch.cuda.synchronize()
+        dt_e = time.perf_counter() - t_e
+        extended = {"steps": 200, "after_iterations": args.warmup + args.steps, "ms_per_step": 1e3 * dt_e / 200,
+                    "value": opt.last_stats["n_valid_rays"] / dt_e, "unit": "rays/s"}
+
     # the other arithmetic mode of the density network, same workload, same step counts (outside the headline's timed region)
     other = None
-    if world == 1:
+    if world == 1 and not args.quick:
         try:
             od = "f16" if args.dtype == "f32" else "f32"
             o2, w2 = make_optimizer(od), build_window(args.keyframes)
@@ -512,20 +532,20 @@ def main():
             other = {"error": str(e)}
 
     ns_net = None
-    if world == 1:
+    if world == 1 and not args.quick:
         try:
             ns_net = north_star_network_leg(args.keyframes * args.rays, args.samples, "cuda")
         except Exception as e:
             ns_net = {"error": str(e)}
     render = None
-    if world == 1:
+    if world == 1 and not args.quick:
         try:
             render = render_leg(opt, my_window[0], scans=2, dtype=args.dtype)
         except Exception as e:
             render = {"error": str(e)}
     ksum = timer.summary()
     spec = opt._model.nerf_model._model_sigma.spec
-    n_local = opt.last_stats["n_valid_rays"] / max(args.steps, 1)          # rays per launch on this rank
+    n_local = n_valid_timed / max(args.steps, 1)          # rays per launch on this rank
     pts = n_local * args.samples
     F = int(spec.n_features)
     n_rec = int(spec.n_levels)                                      # every level goes through the record kernel
@@ -536,7 +556,9 @@ def main():
     #   encode_backward: d_feature planes in, z and the ray records once, 6 ray-gradient floats out, the table gradient once
     #   mlp_backward:    forward recompute + input gradient + weight gradient GEMMs of the fp32 MLP
     alg = {
-        "encode_backward": {"bytes": pts * (n_rec * F * 4.0 + 4.0) + n_local * (24.0 + 24.0) + rec_table_floats * 4.0},
+        "encode_backward": {"bytes": pts * (n_rec * F * 4.0 + 4.0) + n_local * 24.0 + rec_table_floats * 4.0},
+        # encode_dx (the input gradient as its own launch): d_feature planes and z in, the ray records once, 6 ray-gradient floats out
+        "encode_dx": {"bytes": pts * (n_rec * F * 4.0 + 4.0) + n_local * (24.0 + 24.0)},
         "encode_forward": {"bytes": pts * (4.0 + int(spec.n_levels) * F * 4.0) + n_local * 24.0 + (float(spec.n_params) - spec.n_mlp_params) * 4.0},
         "table_grad_reduce": {"bytes": rec_table_floats * 8.0},
         "mlp_backward": {"flops": pts * 2.0 * (3 * mac + h), "bytes": pts * (3 * spec.enc_dim * 4.0 + 4.0)},
@@ -579,7 +601,7 @@ def main():
                             "pipe ~45 % busy, 56 % of a wave's cycles parked in s_waitcnt / barriers, scalar unit 15 % - whose parts add up when "
                             "switched off one by one (profiles/r03_ablate_binned_partition.txt): hashing and weights, the table gathers of the d/dx term "
                             "(2 clk per active lane and line, tools/gather_bench.hip), the in-LDS radix partition of the gradient records - DESIGN.md 4.3",
-                    "secondary": {k: v for k, v in kernels.items() if k != dom and k in ("encode_backward", "mlp_backward", "mlp_forward", "encode_forward", "table_grad_reduce")}}
+                    "secondary": {k: v for k, v in kernels.items() if k != dom and k in ("encode_backward", "encode_dx", "mlp_backward", "mlp_forward", "encode_forward", "table_grad_reduce")}}
     line = {
         "metric": "training rays/sec", "value": total_rays / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True,
@@ -599,8 +621,8 @@ def main():
             72.0 + 28.0 * float(spec.n_params) / max(total_rays / max(args.steps, 1) / world, 1.0)),
         "kernels_ms": {k: v["avg_ms"] for k, v in kernels.items()},
         "ops_ms": {k: round(v["avg_ms"], 4) for k, v in ksum.items()},
-        "final_loss": float(opt.last_stats["loss_terms"][-1, 0]),
-        "l1_depth_m": l1_depth, "iterations_trained": args.warmup + args.steps,
+        "final_loss": final_loss,
+        "l1_depth_m": l1_depth, "iterations_trained": args.warmup + args.steps, "extended_run": extended,
         "other_dtype": other,
         "disclosures": {
             "table_gradient_records": "hash-table gradient contributions travel as 8-byte records whose two values are rounded to 26 bits "
@@ -611,7 +633,7 @@ def main():
         },
     }
     print(json.dumps({k: v for k, v in line.items() if k != "cpu_baseline"}), file=sys.stderr, flush=True)   # progress copy
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not args.quick:
         # baseline legs on the SAME workload, each bounded; then the HIP path's L1 after the same number of iterations as the CPU leg
         cpu = oracle_leg(args, "cpu", budget_s=14.0, max_iters=6)
         try:
@@ -620,61 +642,95 @@ def main():
             rocm = {"error": str(e)}
         line["cpu_baseline"] = cpu
         line["torch_rocm_baseline"] = rocm
-        line["speedup_vs_cpu_oracle_same_workload"] = line["value"] / cpu["value"] if args.dtype == "f32" else None
-        if isinstance(rocm.get("value"), float):
-            line["speedup_vs_torch_rocm_oracle_same_workload"] = line["value"] / rocm["value"]
-        # "at matched L1 depth": every leg trains the REDUCED configuration of the G13 fixture from the same initial parameters for the
-        # same number of iterations - long enough to leave the plateau (the reference: 30.0 -> 14.55 m after 50, 10.86 m after 100
-        # iterations) - and is scored the same way; the speed-ups are quoted as "at matched quality" only if the legs end within 25 % of
-        # each other AND below half of where they started.  Why 25 %: 100 Adam iterations amplify rounding differences into different
-        # maps - the torch-ROCm leg ALONE, same code and same seeds, ended at 11.13 m in one run and 9.45 m in the next (atomics order),
-        # the CPU leg at 10.94 / 11.13 m, the reference itself at 10.86 m, the HIP path at 12.39 m (its own random numbers; 11.07 m on
-        # the reference's draws, G13).  (The full workload cannot be taken that far on the CPU within a benchmark run.)
+        # "at matched L1 depth" (BASELINE.json metric).  Every leg trains the REDUCED configuration of the G13 fixture - the one on which the
+        # REFERENCE's own optimiser was recorded (tests/golden/make_golden3.py: 30.0 m -> 14.55 m after 50, 10.86 m after 100 iterations) -
+        # from the same initial parameters for the same number of iterations and is scored the same way.  100 Adam iterations turn
+        # rounding and draw differences into different maps, so ONE run per leg says little (round 3: 9.5 / 11.1 / 12.4 m): the two GPU
+        # legs run QUALITY_SEEDS times each, every run with its own random draws, and what is compared is the distribution -
+        # "matched" = the HIP leg's mean L1 within one pooled standard deviation AND within 10 % of the torch-ROCm oracle leg's mean,
+        # both below half of where they started.  The speed-ups on the full workload are reported as "at matched quality" only then.
         q = _Shape(QUALITY_SHAPE.keyframes, QUALITY_SHAPE.rays, QUALITY_SHAPE.samples)
+        seeds = list(range(QUALITY_SEEDS))
         legs = {}
         try:
-            legs["cpu_oracle"] = oracle_leg(q, "cpu", budget_s=0.0, max_iters=QUALITY_ITERS, min_iters=QUALITY_ITERS)
+            legs["cpu_oracle"] = [oracle_leg(q, "cpu", budget_s=0.0, max_iters=QUALITY_ITERS, min_iters=QUALITY_ITERS, seed=0)]
         except Exception as e:
-            legs["cpu_oracle"] = {"error": str(e)}
-        try:
-            legs["torch_rocm_oracle"] = oracle_leg(q, "cuda", budget_s=0.0, max_iters=QUALITY_ITERS, min_iters=QUALITY_ITERS)
-        except Exception as e:
-            legs["torch_rocm_oracle"] = {"error": str(e)}
+            legs["cpu_oracle"] = [{"error": str(e)}]
+        legs["torch_rocm_oracle"] = []
+        for sd in seeds:
+            try:
+                legs["torch_rocm_oracle"].append(oracle_leg(q, "cuda", budget_s=0.0, max_iters=QUALITY_ITERS, min_iters=QUALITY_ITERS, seed=sd))
+            except Exception as e:
+                legs["torch_rocm_oracle"].append({"error": str(e)})
+        legs["hip_f32"] = []
         try:
             from oracle import network as NW
             from loner_amd.common.settings import default_nerf_config
             nc = default_nerf_config()
             p0 = NW.init_params(NW.NetworkSpec.from_config(nc["pos_encoding_sigma"], nc["sigma_network"]), 0)     # the legs' initial parameters
             keep = (args.rays, args.samples)
-            args.rays, args.samples = q.rays, q.samples
-            o3, w3 = make_optimizer("f32", params0=p0), build_window(q.keyframes)
-            args.rays, args.samples = keep
-            o3._model.cfg["render"]["N_samples_test"] = 256
-            l1_0 = l1_of(o3, w3[0], L1_RAYS)
-            torch.cuda.synchronize(); t3 = time.perf_counter()
-            o3._do_iterate_optimizer(w3, [None], optimizer_settings=phase(QUALITY_ITERS))
-            torch.cuda.synchronize(); dt3 = time.perf_counter() - t3
-            legs["hip_f32"] = {"value": o3.last_stats["n_valid_rays"] / dt3, "unit": "rays/s", "ms_per_iter": 1e3 * dt3 / QUALITY_ITERS,
-                               "l1_depth_m_before": l1_0, "l1_depth_m_after": l1_of(o3, w3[0], L1_RAYS)}
+            for sd in seeds:
+                args.rays, args.samples = q.rays, q.samples
+                try:
+                    o3, w3 = make_optimizer("f32", params0=p0), build_window(q.keyframes)
+                finally:
+                    args.rays, args.samples = keep
+                o3._model.cfg["render"]["N_samples_test"] = 256
+                torch.manual_seed(123)
+                l1_0 = l1_of(o3, w3[0], L1_RAYS)
+                torch.manual_seed(sd)
+                torch.cuda.synchronize(); t3 = time.perf_counter()
+                o3._do_iterate_optimizer(w3, [None], optimizer_settings=phase(QUALITY_ITERS))
+                torch.cuda.synchronize(); dt3 = time.perf_counter() - t3
+                torch.manual_seed(123)
+                legs["hip_f32"].append({"value": o3.last_stats["n_valid_rays"] / dt3, "unit": "rays/s", "ms_per_iter": 1e3 * dt3 / QUALITY_ITERS,
+                                        "l1_depth_m_before": l1_0, "l1_depth_m_after": l1_of(o3, w3[0], L1_RAYS)})
+                del o3, w3
         except Exception as e:
-            legs["hip_f32"] = {"error": str(e)}
-        after = {k: v.get("l1_depth_m_after") for k, v in legs.items()}
-        before = {k: v.get("l1_depth_m_before") for k, v in legs.items()}
-        vals = [v for v in after.values() if isinstance(v, float)]
-        off_plateau = all(isinstance(after[k], float) and isinstance(before[k], float) and after[k] < 0.5 * before[k] for k in after)
-        agree = len(vals) == len(after) and (max(vals) - min(vals)) <= 0.25 * max(vals)
+            legs["hip_f32"].append({"error": str(e)})
+
+        def stats_of(runs, key):
+            v = [r[key] for r in runs if isinstance(r.get(key), float)]
+            if not v:
+                return None
+            m = sum(v) / len(v)
+            sdv = (sum((x - m) ** 2 for x in v) / (len(v) - 1)) ** 0.5 if len(v) > 1 else None
+            return {"n": len(v), "mean": m, "sd": sdv, "min": min(v), "max": max(v), "runs": [round(x, 4) for x in v]}
+        after = {k: stats_of(v, "l1_depth_m_after") for k, v in legs.items()}
+        before = {k: stats_of(v, "l1_depth_m_before") for k, v in legs.items()}
+        hs, rs = after.get("hip_f32"), after.get("torch_rocm_oracle")
+        matched, detail = False, {}
+        if hs and rs and hs["sd"] is not None and rs["sd"] is not None:
+            pooled = (((hs["n"] - 1) * hs["sd"] ** 2 + (rs["n"] - 1) * rs["sd"] ** 2) / max(hs["n"] + rs["n"] - 2, 1)) ** 0.5
+            diff = hs["mean"] - rs["mean"]
+            off_plateau = all(a and b and a["max"] < 0.5 * b["mean"] for a, b in ((after[k], before[k]) for k in ("hip_f32", "torch_rocm_oracle")))
+            detail = {"mean_difference_m": diff, "pooled_sd_m": pooled, "relative_difference": diff / rs["mean"],
+                      "within_one_pooled_sd": abs(diff) <= pooled, "within_10pct": abs(diff) <= 0.10 * rs["mean"],
+                      "all_runs_below_half_of_initial": bool(off_plateau),
+                      "hip_mean_vs_reference_curve": hs["mean"] / QUALITY_REFERENCE["l1_after_100_iterations_m"] - 1.0}
+            matched = bool(detail["within_one_pooled_sd"] and detail["within_10pct"] and off_plateau)
+        ms_of = lambda runs: (lambda v: sum(v) / len(v) if v else None)([r["ms_per_iter"] for r in runs if isinstance(r.get("ms_per_iter"), float)])
+        rate_of = lambda runs: (lambda v: sum(v) / len(v) if v else None)([r["value"] for r in runs if isinstance(r.get("value"), float)])
         line["matched_quality"] = {
             "config": f"{q.keyframes} keyframes x {q.rays} rays x {q.samples} samples, default network, joint map + pose optimisation, {QUALITY_ITERS} iterations",
-            "reference": QUALITY_REFERENCE, "l1_depth_m_before": before, "l1_depth_m_after": after, "rays": L1_RAYS,
-            "rays_per_s": {k: v.get("value") for k, v in legs.items()}, "ms_per_iter": {k: v.get("ms_per_iter") for k, v in legs.items()},
-            "all_below_half_of_initial": bool(off_plateau), "agree_within_25pct": bool(agree), "matched": bool(off_plateau and agree),
+            "runs_per_leg": {k: len(v) for k, v in legs.items()}, "reference": QUALITY_REFERENCE,
+            "l1_depth_m_before": before, "l1_depth_m_after": after, "rays": L1_RAYS,
+            "rays_per_s": {k: rate_of(v) for k, v in legs.items()}, "ms_per_iter": {k: ms_of(v) for k, v in legs.items()},
+            "comparison_hip_vs_torch_rocm": detail, "matched": matched,
+            "errors": [r["error"] for v in legs.values() for r in v if "error" in r],
             "note": "L1 depth with analysis/compute_l1_depth.py semantics (Model.forward(testing=True), 256 samples, the same held-out rays "
-                    "of keyframe 0) before and after the SAME number of iterations from the same initial parameters on every leg (each leg "
-                    "draws its own random numbers); tests/test_gpu_mapping.py::test_l1_depth_curve_matches_the_reference_on_its_own_draws "
-                    "ties the HIP path to the reference's own curve on this configuration"}
-        if line["matched_quality"]["matched"]:
-            hv, cv, rv = (legs[k].get("value") for k in ("hip_f32", "cpu_oracle", "torch_rocm_oracle"))
-            line["matched_quality"]["speedup_at_matched_quality"] = {"vs_cpu_oracle": hv / cv, "vs_torch_rocm_oracle": hv / rv}
+                    "of keyframe 0, the same probe seed) before and after the SAME number of iterations from the same initial parameters; the GPU "
+                    f"legs {QUALITY_SEEDS} runs each with different random draws (HIP: the in-kernel generator, tests/test_gpu_rng.py), the CPU leg one run; "
+                    "tests/test_gpu_mapping.py::test_l1_depth_curve_matches_the_reference_on_its_own_draws ties the HIP path to the reference's own curve"}
+        # speed-ups: on the full workload only as "same workload" figures with the quality flag beside them; "at matched quality" on the
+        # configuration where quality was actually compared
+        line["quality_matched"] = matched
+        if matched:
+            hv, cv, rv = rate_of(legs["hip_f32"]), rate_of(legs["cpu_oracle"]), rate_of(legs["torch_rocm_oracle"])
+            line["matched_quality"]["speedup_at_matched_quality"] = {"vs_cpu_oracle": hv / cv if cv else None, "vs_torch_rocm_oracle": hv / rv if rv else None}
+            line["speedup_vs_cpu_oracle_same_workload"] = line["value"] / cpu["value"] if args.dtype == "f32" else None
+            if isinstance(rocm.get("value"), float):
+                line["speedup_vs_torch_rocm_oracle_same_workload"] = line["value"] / rocm["value"]
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -229,6 +229,14 @@ int lnr_compact_rays(const float* rays_in, const float* depths_in, const uint8_t
                      float* rays_out, float* depths_out, int64_t* src_index_out,
                      int32_t* out_seg_start, int32_t* n_out_dev, void* stream);
 
+/* Sharded windows (one process per GPU, keyframes round-robin): the reference's `depth > far[0]` test (optimizer.py:460-461) uses the
+ * FIRST ray of the whole batch = the first kept ray of the first keyframe, in window order, that kept any.  Each rank reports its
+ * candidate as one 64-bit key = (seg_order of its first segment with a kept ray) << 32 | bits of that ray's far; INT64_MAX when it kept
+ * none.  A MIN all-reduce over the ranks then leaves the batch's first ray's key everywhere (low word = far[0] as float bits).
+ * rays / out_seg_start: the outputs of lnr_compact_rays; seg_order [n_seg] (host): ascending position of each segment in the window. */
+int lnr_first_ray_key(const float* rays, const int32_t* out_seg_start /*[n_seg+1] device*/, const int32_t* seg_order /*[n_seg] host*/,
+                      int32_t n_seg, int64_t* key_out /*[1] device*/, void* stream);
+
 /* Backward of lnr_build_lidar_rays for a window: dL/drays -> dL/d[R|t] per keyframe
  * (the autograd tail ray_utils.py:281-305 <- keyframe.py:80-88).  d_transform [n_seg,12]. */
 int lnr_lidar_rays_backward(const float* d_rays /*[n,13]*/, const float* rays /*[n,13]*/,
@@ -257,6 +265,20 @@ int lnr_sample_rays_occ(const float* rays, int32_t n_rays, const int32_t* n_rays
 int lnr_sample_rays_uniform(const float* rays, int32_t n_rays, const int32_t* n_rays_dev,
                             int32_t n_samples, float perturb, const float* steps,
                             const float* u_jitter, uint64_t seed, float* z_out, void* stream);
+
+/* The random numbers the kernels draw when the caller passes no random tensors, as tensors (diagnostics: distribution tests, and
+ * the proof that a seeded call equals the same call with these draws handed in).  The reference draws, per forward,
+ * torch.rand [n_rays, n_samples/2] twice (ray_sampling.py:72, rendering_tcnn.py:48) and torch.randn [n_rays, n_samples] once
+ * (rendering_tcnn.py:104); per keyframe torch.randint (optimizer.py:288).
+ *   which = LNR_DRAW_JITTER / LNR_DRAW_PDF: the uniforms in [0,1) that lnr_sample_rays_* use for element [ray][j] under `seed`;
+ *   which = LNR_DRAW_NOISE: the N(0,1) values that lnr_render_* / lnr_los_loss_fused add (x noise_std) to sigma [ray][i] under `seed`;
+ *   which = LNR_DRAW_RAY_INDEX + segment: the uniforms behind the ray indices lnr_build_window_rays draws for that segment
+ *           (out [n_rays * n_per_ray] in draw order: index = min(floor(u * n_points), n_points - 1)). */
+#define LNR_DRAW_JITTER 0
+#define LNR_DRAW_PDF 1
+#define LNR_DRAW_NOISE 2
+#define LNR_DRAW_RAY_INDEX 16
+int lnr_rng_draws(int32_t which, uint64_t seed, int32_t n_rays, int32_t n_per_ray, float* out /*[n_rays,n_per_ray]*/, void* stream);
 
 /* ---- volume rendering ---------------------------------------------------------------------------- */
 /* raw2outputs(sigma_only=True, far, ret_var=True) (rendering_tcnn.py:71-147).

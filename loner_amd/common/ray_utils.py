@@ -6,6 +6,8 @@ the MI355X: the scan (the keyframe point buffer) is kept resident in HBM, rays a
 `lnr_lidar_rays_backward`, so that the 6-vector pose tail stays in stock torch autograd
 (tensor_to_transform) exactly as in the reference.
 """
+import weakref
+
 import torch
 
 from .. import ops
@@ -20,17 +22,24 @@ def mapping_device():
     return torch.device("cuda", torch.cuda.current_device())
 
 
+_scan_cache = weakref.WeakKeyDictionary()      # scan object -> (key, directions, distances) on the device
+
+
 def device_scan(scan: LidarScan, device):
-    """HBM-resident copy of a scan's SoA buffers, cached on the scan object (uploaded once per keyframe)."""
-    cache = getattr(scan, "_lnr_dev", None)
+    """HBM-resident copy of a scan's SoA buffers (uploaded once per keyframe).  The cache lives HERE, keyed weakly by the scan
+    object - nothing is written onto the caller's LidarScan (in an integration that is the reference's own class)."""
     key = (scan.ray_directions.data_ptr(), scan.distances.data_ptr(), str(device))
+    try:
+        cache = _scan_cache.get(scan)
+    except TypeError:                  # an object that cannot be weakly referenced: no caching
+        cache = None
     if cache is None or cache[0] != key:
         dirs = scan.ray_directions.detach().to(device=device, dtype=torch.float32).contiguous()
         dist = scan.distances.detach().to(device=device, dtype=torch.float32).contiguous()
         cache = (key, dirs, dist)
         try:
-            scan._lnr_dev = cache
-        except AttributeError:
+            _scan_cache[scan] = cache
+        except TypeError:
             pass
     return cache[1], cache[2]
 

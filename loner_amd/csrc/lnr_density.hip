@@ -411,7 +411,7 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
     L.off_dfeat = off; off += align256((size_t)spec->enc_dim * L.m_pad * sizeof(float));
     L.off_dxl = off; off += align256((size_t)L.n_groups * 3 * L.m_pad * sizeof(float));
     L.off_dpts = off; off += align256((size_t)3 * L.m_pad * sizeof(float));      // d_pts scratch of the general d_rays route
-    L.off_rayacc = off; off += align256(((size_t)(L.m_pad / 64) * 6 + 1) * sizeof(long long));   // per-ray sums of the d_rays route (n_samples >= 64 there) + its non-finite word
+    L.off_rayacc = off; off += align256(((size_t)(L.m_pad / 64) * 7 + 2) * sizeof(long long));   // per-ray sums of the d_rays route (n_samples >= 64 there) + a non-finite word per ray
     L.off_slabs = off; off += align256((size_t)LNR_BWD_MAX_BLOCKS * spec->n_mlp_params * sizeof(float));
     L.off_ovf = off; off += align256(ovf_total * sizeof(long long));
     L.off_counts = off; off += align256(hash ? (size_t)blocks * L.maxo * sizeof(int) : 0);
@@ -648,12 +648,21 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
                                     void* stream) {
     int rc = check_spec(spec, "lnr_density_backward");
     if (rc) return rc;
-    if (n_points == 0 && (pts != nullptr || n_rays == 0)) return LNR_OK;          // empty batch: nothing to do, nothing to check
+    // an empty batch has nothing to compute, but the input-gradient event is part of the contract of every successful call: a caller's
+    // second stream waits for it, and an unrecorded event would let that stream run against the PREVIOUS call's record
+    auto empty_batch = [&]() -> int {
+        if (input_grad_event != nullptr && hipEventRecord((hipEvent_t)input_grad_event, (hipStream_t)stream) != hipSuccess) {
+            lnr_set_error("lnr_density_backward: hipEventRecord failed");
+            return LNR_ERR_LAUNCH;
+        }
+        return LNR_OK;
+    };
+    if (n_points == 0 && (pts != nullptr || n_rays == 0)) return empty_batch();
     PointSrc src; MlpPoints mp;
     rc = make_src(&src, &mp, pts, n_points, rays, z, n_rays, n_samples, n_rays_dev, "lnr_density_backward");
     if (rc) return rc;
     const int64_t cap = mp.n_points;
-    if (cap == 0) return LNR_OK;
+    if (cap == 0) return empty_batch();
     LNR_REQUIRE(params && d_sigma && workspace, "lnr_density_backward: null argument");
     LNR_REQUIRE(grad_params || d_pts || d_rays, "lnr_density_backward: nothing to compute (no grad_params, d_pts or d_rays)");
     LNR_REQUIRE(cap * (spec->n_features > 4 ? spec->n_features : 4) < (1ll << 30),
@@ -720,18 +729,15 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     float* grad_table = want_grad ? grad_params + spec->n_mlp_params : nullptr;
     ReduceCtx rctx{spec, regions, counts, ovf, grad_table, rplan, L.bpg, L.maxo, L.shift, spec->n_params - spec->n_mlp_params,
                    (flags & LNR_BWD_TABLE_ATOMICS) ? 0 : L.n_split};
+    // hash grids (LNR_SPLIT_DX): the input gradient first, as launches of its own; the table-gradient partition follows behind the event
+    const bool split = LNR_SPLIT_DX && hash;
     if (want_dfeat) {
         rc = lnr_encode_backward(spec, params, &src, cap, dfeat, dxl, L.m_pad, grad_table, want_grad ? regions : nullptr, &rplan, counts,
                                  L.bpg, L.maxo, L.shift,
-                                 ovf, d_pts_eff, ray_accum ? d_rays : nullptr, (long long*)(ws + L.off_rayacc), (flags & LNR_BWD_BINS_W8) != 0, st);
+                                 ovf, d_pts_eff, ray_accum ? d_rays : nullptr, (long long*)(ws + L.off_rayacc), (flags & LNR_BWD_BINS_W8) != 0,
+                                 split ? LNR_ENC_PART_DX : (LNR_ENC_PART_DX | LNR_ENC_PART_RECORDS), st);
         if (rc) return rc;
         LNR_CHECK_LAUNCH("lnr_density_backward(encode backward)");
-        if (hash && want_grad && (flags & LNR_BWD_REPORT_REGIONS)) {           // diagnostic, call-time flag: synchronises the stream
-            int64_t live = cap;
-            int32_t nr = 0;
-            if (n_rays_dev && hipStreamSynchronize(st) == hipSuccess && hipMemcpy(&nr, n_rays_dev, sizeof(nr), hipMemcpyDeviceToHost) == hipSuccess) live = (int64_t)nr * n_samples;
-            report_regions(spec, L, rplan, counts, dfeat, live, st);
-        }
     }
     if (d_rays && !ray_accum) {
         rc = lnr_points_grad_to_rays(d_pts_eff, z, n_rays, n_rays_dev, n_samples, d_rays, stream);
@@ -745,6 +751,20 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
         return LNR_ERR_LAUNCH;
     }
     if (!want_grad) return LNR_OK;       // frozen parameters: no table reduce, no weight-gradient fold
+    if (want_dfeat) {
+        if (split) {
+            rc = lnr_encode_backward(spec, params, &src, cap, dfeat, dxl, L.m_pad, grad_table, regions, &rplan, counts, L.bpg, L.maxo, L.shift,
+                                     ovf, nullptr, nullptr, nullptr, (flags & LNR_BWD_BINS_W8) != 0, LNR_ENC_PART_RECORDS, st);
+            if (rc) return rc;
+            LNR_CHECK_LAUNCH("lnr_density_backward(table-gradient partition)");
+        }
+        if (hash && (flags & LNR_BWD_REPORT_REGIONS)) {           // diagnostic, call-time flag: synchronises the stream
+            int64_t live = cap;
+            int32_t nr = 0;
+            if (n_rays_dev && hipStreamSynchronize(st) == hipSuccess && hipMemcpy(&nr, n_rays_dev, sizeof(nr), hipMemcpyDeviceToHost) == hipSuccess) live = (int64_t)nr * n_samples;
+            report_regions(spec, L, rplan, counts, dfeat, live, st);
+        }
+    }
     if (hash && L.nown > 0) {          // also with cap_rec == 0 (all-atomic test path): it folds in the overflow accumulators
         rc = launch_table_reduce(rctx, L.nown, st);
         if (rc) return rc;

@@ -38,6 +38,15 @@ struct PointSrc {
 #define LNR_XPAIR_SCALE_MIN 3000.0f   /* hashed power-of-two levels at least this fine take x-pair records (below: run-length combined 8-byte records) */
 #endif
 
+#ifndef LNR_PAIR_FWD
+#define LNR_PAIR_FWD 1      /* encode_forward_pair_kernel (two lanes per sample) instead of encode_forward_kernel */
+#endif
+#ifndef LNR_SPLIT_DX
+#define LNR_SPLIT_DX 1      /* hash grids: the input gradient as a kernel of its own (encode_dx_pair_kernel), not inside the partition kernels */
+#endif
+#define LNR_ENC_PART_DX 1        /* lnr_encode_backward: the input gradient (d_pts / d_rays) */
+#define LNR_ENC_PART_RECORDS 2   /* lnr_encode_backward: the table-gradient records */
+
 // rn(v * 2^42) as a 64-bit integer.  There is no f32 -> i64 convert instruction (the compiler's expansion is ~20 VALU
 // instructions, and these kernels are VALU-issue bound): for |v| < 2^8 the sum (double)v * 2^42 + 1.5 * 2^52 is exact up to
 // its one rounding to an integer (nearest even, like __float2ll_rn) and leaves that integer in the mantissa - a convert, an
@@ -187,4 +196,4 @@ int lnr_f16_bwd_slabs(const LnrNetSpec* spec, int64_t n_points);
 int lnr_selftest_mfma_f16(float* out, hipStream_t st);
 int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, const float* dfeat,
                         float* dxl, int64_t m_pad, float* grad_table, void* regions, const RegionPlan* plan, int* counts, int bpg,
-                        int maxo, int shift, long long* ovf, float* d_pts, float* d_rays_acc, long long* ray_acc, bool bins_w8, hipStream_t st);
+                        int maxo, int shift, long long* ovf, float* d_pts, float* d_rays_acc, long long* ray_acc, bool bins_w8, int parts, hipStream_t st);

@@ -19,6 +19,13 @@
 
 #define ENC_BLOCK 256
 
+// the n-th (0-based) set bit of mask: the level a workgroup group works on (level_mask = all levels outside ablation builds)
+__device__ __forceinline__ int nth_level(uint32_t mask, int n) {
+    for (int i = 0; i < n; ++i) mask &= mask - 1u;
+    return __builtin_ctz(mask);
+}
+
+
 // ------------------------------------------------------------------------------------------------ forward
 template <int F>
 __device__ __forceinline__ void gather_entries(const float* __restrict__ table, const uint32_t e[8], float tv[8][F]) {
@@ -42,9 +49,9 @@ __device__ __forceinline__ void gather_entries(const float* __restrict__ table, 
 template <int F, bool H16>
 __global__ void __launch_bounds__(ENC_BLOCK)
 encode_forward_kernel(const LnrNetSpec spec, const float* __restrict__ table, const PointSrc src, float* __restrict__ feat,
-                      int64_t m_pad, int bpg) {
+                      int64_t m_pad, int bpg, uint32_t level_mask) {
     static_assert(!H16 || F >= 2, "half2 planes pair up the features of a level");
-    const int lv = blockIdx.x / bpg, chunk = blockIdx.x % bpg;
+    const int lv = nth_level(level_mask, blockIdx.x / bpg), chunk = blockIdx.x % bpg;
     const LevelInfo L = level_info(spec, lv);
     const uint32_t M = (uint32_t)live_points(src);
     // the MLP kernels read whole tiles of 16 (fp32) / 32 (fp16) samples: zero the ragged tail
@@ -80,6 +87,119 @@ encode_forward_kernel(const LnrNetSpec spec, const float* __restrict__ table, co
         } else {
 #pragma unroll
             for (int f = 0; f < F; ++f) st32<float>(planes, (uint32_t)f * plane_bytes + cur.m * 4u, out[f]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ paired lanes
+// Two lanes per sample: lane 2i takes the four corners of the cell with x = b0, lane 2i+1 those with x = b0 + 1.
+// Why: a random table gather costs one L2 LINE per distinct line an instruction touches (tools/gather_bench.hip: 0.5 lines/clk/CU
+// whatever the access width), and the two x-neighbours of a corner pair sit in the same 64-byte line most of the time - dense levels:
+// e1 = e0 + 1; hashed levels: e1 = e0 ^ (2^(t+1) - 1), t = trailing one bits of x, i.e. inside one aligned group of 8 entries for
+// 7 of 8 cells.  With one lane per sample the two neighbours are fetched by DIFFERENT instructions (corner k and k + 1) and the line
+// is paid twice; with the pair in adjacent lanes of ONE instruction it is paid once: ~1.1 instead of 2 lines per corner pair on the
+// fine levels, where no two samples share a cell.  The price is the cell arithmetic done twice - VALU these kernels have to spare
+// (the gathers of 64 samples occupy a CU's L1 path for ~1000 clocks, their arithmetic the four SIMDs for ~40).
+__device__ __forceinline__ float pair_partner_f(float v) {       // the other lane of the pair (quad_perm [1,0,3,2]); all lanes active
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+
+// entries of the 4 (y, z) rows of a cell at x = b0 + hx: row r = (y bit) + 2 (z bit) is corner k = hx + 2 r of cell_entries
+__device__ __forceinline__ void cell_entries_x(const LevelInfo& L, const Cell& c, uint32_t hx, uint32_t e[4]) {
+    if (L.hashed) {
+        const uint32_t x = c.b[0] + hx;
+        const uint32_t hy0 = c.b[1] * PRIME_Y, hy1 = hy0 + PRIME_Y;
+        const uint32_t hz0 = c.b[2] * PRIME_Z, hz1 = hz0 + PRIME_Z;
+        e[0] = x ^ (hy0 ^ hz0); e[1] = x ^ (hy1 ^ hz0); e[2] = x ^ (hy0 ^ hz1); e[3] = x ^ (hy1 ^ hz1);
+    } else {
+        const uint32_t sy = L.res, sz = L.res * L.res;
+        const uint32_t i0 = c.b[0] + hx + c.b[1] * sy + c.b[2] * sz;
+        e[0] = i0; e[1] = i0 + sy; e[2] = i0 + sz; e[3] = i0 + sy + sz;
+    }
+    if (L.pow2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = (e[r] & (L.size - 1u)) + L.offset;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = e[r] % L.size + L.offset;
+    }
+}
+
+template <int F>
+__device__ __forceinline__ void gather_entries4(const float* __restrict__ table, const uint32_t e[4], float tv[4][F]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t off = e[r] * (uint32_t)(F * 4);
+        if constexpr (F == 1) tv[r][0] = ld32<float>(table, off);
+        else if constexpr (F == 2) { const float2 t2 = ld32<float2>(table, off); tv[r][0] = t2.x; tv[r][1] = t2.y; }
+        else {
+#pragma unroll
+            for (int q = 0; q < F / 4; ++q) {
+                const float4 t4 = ld32<float4>(table, off + 16u * q);
+                tv[r][4 * q] = t4.x; tv[r][4 * q + 1] = t4.y; tv[r][4 * q + 2] = t4.z; tv[r][4 * q + 3] = t4.w;
+            }
+        }
+    }
+}
+
+template <int F, bool H16>
+__global__ void __launch_bounds__(ENC_BLOCK)
+encode_forward_pair_kernel(const LnrNetSpec spec, const float* __restrict__ table, const PointSrc src, float* __restrict__ feat,
+                           int64_t m_pad, int bpg, uint32_t level_mask) {
+    static_assert(!H16 || F >= 2, "half2 planes pair up the features of a level");
+    const int lv = nth_level(level_mask, blockIdx.x / bpg), chunk = blockIdx.x % bpg;
+    const LevelInfo L = level_info(spec, lv);
+    const uint32_t M = (uint32_t)live_points(src);
+    const uint32_t Mt = H16 ? (M + 31u) / 32u * 32u : (M + 15u) / 16u * 16u;      // the MLP kernels read whole tiles: zero the ragged tail
+    float* planes = feat + (size_t)(H16 ? lv * (F / 2) : lv * F) * m_pad;
+    const uint32_t plane_bytes = (uint32_t)m_pad * 4u;
+    const uint32_t hx = threadIdx.x & 1u;
+    SampleCursor cur;
+    cur.init((uint32_t)chunk * (ENC_BLOCK / 2) + (threadIdx.x >> 1), (uint32_t)bpg * (ENC_BLOCK / 2), src.pts ? 1u : (uint32_t)src.n_samples);
+    for (; cur.m < Mt; cur.advance()) {            // both lanes of a pair leave the loop together
+        float part[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) part[f] = 0.0f;
+        if (cur.m < M) {
+            RawPoint rp;
+            load_raw_point(src, cur.m, cur.ray, rp);
+            float x[3];
+            unit_point(src, rp, x);
+            const Cell c = cell_of(L, x);
+            uint32_t e[4]; float tv[4][F];
+            cell_entries_x(L, c, hx, e);
+            gather_entries4<F>(table, e, tv);
+            // weights associated like cell_weights: (wx * wy) * wz
+            const float wxl = hx ? c.frac[0] : 1.0f - c.frac[0];
+            const float wxy[2] = {wxl * (1.0f - c.frac[1]), wxl * c.frac[1]};
+            const float wz[2] = {1.0f - c.frac[2], c.frac[2]};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float w = wxy[r & 1] * wz[r >> 1];
+#pragma unroll
+                for (int f = 0; f < F; ++f) part[f] += w * tv[r][f];
+            }
+        }
+        float out[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) out[f] = part[f] + pair_partner_f(part[f]);       // (commutative: both lanes hold the same sum)
+        if constexpr (H16) {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            if constexpr (F == 2) {
+                if (hx == 0u) st32<uint32_t>(planes, cur.m * 4u, __builtin_bit_cast(uint32_t, h2{(_Float16)out[0], (_Float16)out[1]}));
+            } else {
+#pragma unroll
+                for (int q = 0; q < F / 4; ++q) {              // lane hx stores pair planes 2q + hx
+                    const float a = hx ? out[4 * q + 2] : out[4 * q], b = hx ? out[4 * q + 3] : out[4 * q + 1];
+                    st32<uint32_t>(planes, (uint32_t)(2 * q + (int)hx) * plane_bytes + cur.m * 4u, __builtin_bit_cast(uint32_t, h2{(_Float16)a, (_Float16)b}));
+                }
+            }
+        } else if constexpr (F == 1) {
+            if (hx == 0u) st32<float>(planes, cur.m * 4u, out[0]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < F / 2; ++q)                     // lane hx stores feature plane 2q + hx: one instruction covers two planes
+                st32<float>(planes, (uint32_t)(2 * q + (int)hx) * plane_bytes + cur.m * 4u, hx ? out[2 * q + 1] : out[2 * q]);
         }
     }
 }
@@ -298,22 +418,108 @@ __device__ __forceinline__ void ray_accumulate_dx(float* __restrict__ ray_acc_f,
             if (v != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(ray_acc) + (size_t)ray * 6 + lane,
                                      (unsigned long long)__float2ll_rn(0.5f * v * LNR_FIX_SCALE));         // x = (xyz + 1) / 2
         } else {
-            // an integer sum cannot carry inf / NaN: the word behind the sums says that one occurred, and ray_grad_apply_kernel turns
-            // the ray gradient into NaN - what a float sum would have produced, and what the pose check of the reference looks for
-            // (optimizer.py:368-370)
-            ray_acc[(size_t)n_rays_cap * 6] = 1ll;
+            // an integer sum cannot carry inf / NaN: the ray's word behind the sums says that one occurred, and ray_grad_apply_kernel
+            // turns THAT ray's gradient into NaN - what a float sum would have produced, and what the pose check of the reference looks
+            // for (optimizer.py:368-370); the other rays keep their gradients, so d_rays still says which keyframe failed
+            ray_acc[(size_t)n_rays_cap * 6 + ray] = 1ll;
         }
     }
 }
 
-// d_rays[ray, 0:6] += the per-ray sums of ray_accumulate_dx (ray_acc[n_rays * 6] != 0: a non-finite term occurred -> NaN)
+// d_rays[ray, 0:6] += the per-ray sums of ray_accumulate_dx (ray_acc[n_rays * 6 + ray] != 0: a non-finite term occurred on that ray -> NaN)
 __global__ void __launch_bounds__(ENC_BLOCK)
 ray_grad_apply_kernel(const long long* __restrict__ ray_acc, int n_rays, const int32_t* __restrict__ n_rays_dev, float* __restrict__ d_rays) {
     const int i = blockIdx.x * ENC_BLOCK + threadIdx.x;
     if (i >= lnr_live_rays(n_rays, n_rays_dev) * 6) return;
     const long long q = ray_acc[i];
-    if (__builtin_expect(ray_acc[(size_t)n_rays * 6] != 0ll, 0)) d_rays[(size_t)(i / 6) * LNR_RAY_STRIDE + (i % 6)] = __builtin_nanf("");
+    if (__builtin_expect(ray_acc[(size_t)n_rays * 6 + i / 6] != 0ll, 0)) d_rays[(size_t)(i / 6) * LNR_RAY_STRIDE + (i % 6)] = __builtin_nanf("");
     else if (q != 0ll) d_rays[(size_t)(i / 6) * LNR_RAY_STRIDE + (i % 6)] += (float)((double)q * (1.0 / (double)LNR_FIX_SCALE));
+}
+
+// The input gradient d(level features . g)/dx as a kernel of its own, two lanes per sample (see encode_forward_pair_kernel): level-major
+// like the forward, no LDS, no barriers, 8 waves per SIMD.  Inside the partition kernel the term's gathers (the 8 corner entries of
+// every live sample, one line each on the fine levels) sat in a wave's dependent chain between three workgroup barriers at 4 waves per
+// SIMD, and the parts of that kernel ADDED (profiles/r03_ablate_binned_partition.txt); here they are all a wave does.
+//   lane hx holds the dots d_r = g . entry(x = b0 + hx, row r) of the cell's four (y, z) rows;
+//   d/dx from the differences to the partner lane's dots (even lanes only), d/dy and d/dz from differences of the lane's own dots,
+//   weighted with the lane's x weight: per-lane PARTIAL sums that the per-ray reduction (or the pair add of the planes form) completes.
+template <int F, int DXM>
+__global__ void __launch_bounds__(ENC_BLOCK)
+encode_dx_pair_kernel(const LnrNetSpec spec, const float* __restrict__ table, const PointSrc src, const float* __restrict__ dfeat,
+                      float* __restrict__ dxl, int64_t m_pad, int bpg, uint32_t level_mask) {
+    static_assert(DXM != ENC_DX_NONE, "nothing to compute");
+    const int lv = nth_level(level_mask, blockIdx.x / bpg), chunk = blockIdx.x % bpg;
+    const LevelInfo L = level_info(spec, lv);
+    const int lane = threadIdx.x & 63;
+    const uint32_t hx = threadIdx.x & 1u;
+    const uint32_t M = (uint32_t)live_points(src);
+    if (M == 0u) return;
+    const uint32_t step = (uint32_t)bpg * (ENC_BLOCK / 2);
+    const uint32_t n_iter = (M + step - 1u) / step;                     // wave-uniform trip count: the body uses DPP
+    const float* gplanes = dfeat + (size_t)(lv * F) * m_pad;
+    float* dxplanes = dxl + (size_t)(lv * 3) * m_pad;
+    const uint32_t plane_bytes = (uint32_t)m_pad * 4u;
+    SampleCursor cur;
+    cur.init((uint32_t)chunk * (ENC_BLOCK / 2) + (threadIdx.x >> 1), step, src.pts ? 1u : (uint32_t)src.n_samples);
+    const uint32_t last_ray = src.pts ? 0u : (M - 1u) / cur.S;
+    for (uint32_t it = 0; it < n_iter; ++it) {
+        const uint32_t m = cur.m;
+        const bool live = m < M;
+        const uint32_t mc = live ? m : M - 1u;                           // unconditional (clamped) loads
+        float g[F];
+        bool any = false;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const float v = ld32_stream<float>(gplanes, (uint32_t)f * plane_bytes + mc * 4u);
+            g[f] = live ? v : 0.0f;
+            any |= (g[f] != 0.0f);
+        }
+        RawPoint p;
+        load_raw_point(src, mc, live ? cur.ray : last_ray, p);
+        const uint32_t ray_cur = cur.ray;
+        cur.advance();
+        const bool wave_any = __ballot(any) != 0ull;
+        float dx[3] = {0.0f, 0.0f, 0.0f};
+        if (wave_any) {                                                  // wave-uniform: all lanes active inside
+            float x[3];
+            unit_point(src, p, x);
+            const Cell c = cell_of(L, x);
+            uint32_t e[4];
+            cell_entries_x(L, c, hx, e);
+            float d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (any) {                                                   // (a gather costs per ACTIVE lane and line: dead samples must not gather)
+                float tv[4][F];
+                gather_entries4<F>(table, e, tv);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int f = 0; f < F; ++f) d[r] += g[f] * tv[r][f];
+            }
+            float dd[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dd[r] = pair_partner_f(d[r]) - d[r];          // even lanes: dot(x + 1) - dot(x) of row r
+            const float fx = c.frac[0], fy = c.frac[1], fz = c.frac[2];
+            const float gy = 1.0f - fy, gz = 1.0f - fz;
+            const float wxl = hx ? fx : 1.0f - fx;
+            // differences along one axis, interpolated along the other two (rows: 0 = y0 z0, 1 = y1 z0, 2 = y0 z1, 3 = y1 z1)
+            const float dxv = (dd[0] * gy + dd[1] * fy) * gz + (dd[2] * gy + dd[3] * fy) * fz;
+            const float dyv = ((d[1] - d[0]) * gz + (d[3] - d[2]) * fz) * wxl;
+            const float dzv = ((d[2] - d[0]) * gy + (d[3] - d[1]) * fy) * wxl;
+            dx[0] = hx ? 0.0f : dxv * L.scale; dx[1] = dyv * L.scale; dx[2] = dzv * L.scale;
+        }
+        if constexpr (DXM == ENC_DX_RAYS) {
+            // a wave's 32 samples lie on one ray (n_samples % 64 == 0, checked by the caller); lane 0 holds the wave's first sample
+            if (wave_any) ray_accumulate_dx(dxl, (uint32_t)__builtin_amdgcn_readfirstlane((int)ray_cur), p.z, dx, lane, src.n_rays);
+        } else {
+            float s[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s[k] = dx[k] + pair_partner_f(dx[k]);
+            if (live && hx == 0u) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) st32<float>(dxplanes, (uint32_t)k * plane_bytes + m * 4u, s[k]);
+            }
+        }
+    }
 }
 
 __device__ __forceinline__ void store_stream_b128(uint64_t global_addr, uint4 v) {
@@ -980,39 +1186,105 @@ int lnr_encode_forward(const LnrNetSpec* spec, const float* params, const PointS
         }
         return LNR_OK;
     }
+    uint32_t level_mask = spec->n_levels >= 32 ? 0xFFFFFFFFu : (1u << spec->n_levels) - 1u;
+#ifdef LNR_ABLATE
+    static const long fwd_levels = getenv("LNR_X_FWD_LEVELS") ? strtol(getenv("LNR_X_FWD_LEVELS"), nullptr, 0) : -1;      // time a subset of the levels
+    level_mask &= (uint32_t)fwd_levels;
+    if (level_mask == 0u) return LNR_OK;
+#endif
+    const dim3 mgrid((unsigned)(__builtin_popcount(level_mask) * bpg));
+#if LNR_PAIR_FWD
+    {
+        const dim3 pgrid((unsigned)(__builtin_popcount(level_mask) * bpg));
+#define LNR_FWD_PAIR(F, H) hipLaunchKernelGGL((encode_forward_pair_kernel<F, H>), pgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask)
+        if (half_planes) {
+            switch (spec->n_features) {
+                case 2: LNR_FWD_PAIR(2, true); break;
+                case 4: LNR_FWD_PAIR(4, true); break;
+                case 8: LNR_FWD_PAIR(8, true); break;
+                default: lnr_set_error("fp16 feature planes pair up features: n_features_per_level must be even"); return LNR_ERR_UNSUPPORTED;
+            }
+        } else {
+            switch (spec->n_features) {
+                case 1: LNR_FWD_PAIR(1, false); break;
+                case 2: LNR_FWD_PAIR(2, false); break;
+                case 4: LNR_FWD_PAIR(4, false); break;
+                default: LNR_FWD_PAIR(8, false); break;
+            }
+        }
+#undef LNR_FWD_PAIR
+        return LNR_OK;
+    }
+#endif
     if (half_planes) {
         switch (spec->n_features) {
-            case 2: hipLaunchKernelGGL((encode_forward_kernel<2, true>), grid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg); break;
-            case 4: hipLaunchKernelGGL((encode_forward_kernel<4, true>), grid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg); break;
-            case 8: hipLaunchKernelGGL((encode_forward_kernel<8, true>), grid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg); break;
+            case 2: hipLaunchKernelGGL((encode_forward_kernel<2, true>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask); break;
+            case 4: hipLaunchKernelGGL((encode_forward_kernel<4, true>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask); break;
+            case 8: hipLaunchKernelGGL((encode_forward_kernel<8, true>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask); break;
             default: lnr_set_error("fp16 feature planes pair up features: n_features_per_level must be even"); return LNR_ERR_UNSUPPORTED;
         }
         return LNR_OK;
     }
     switch (spec->n_features) {
-        case 1: hipLaunchKernelGGL((encode_forward_kernel<1, false>), grid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg); break;
-        case 2: hipLaunchKernelGGL((encode_forward_kernel<2, false>), grid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg); break;
-        case 4: hipLaunchKernelGGL((encode_forward_kernel<4, false>), grid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg); break;
-        default: hipLaunchKernelGGL((encode_forward_kernel<8, false>), grid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg); break;
+        case 1: hipLaunchKernelGGL((encode_forward_kernel<1, false>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask); break;
+        case 2: hipLaunchKernelGGL((encode_forward_kernel<2, false>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask); break;
+        case 4: hipLaunchKernelGGL((encode_forward_kernel<4, false>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask); break;
+        default: hipLaunchKernelGGL((encode_forward_kernel<8, false>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask); break;
     }
     return LNR_OK;
 }
 
 int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, const float* dfeat,
                         float* dxl, int64_t m_pad, float* grad_table, void* regions, const RegionPlan* plan, int* counts, int bpg,
-                        int maxo, int shift, long long* ovf, float* d_pts, float* d_rays_acc, long long* ray_acc, bool bins_w8, hipStream_t st) {
+                        int maxo, int shift, long long* ovf, float* d_pts, float* d_rays_acc, long long* ray_acc, bool bins_w8, int parts, hipStream_t st) {
     const float* table = params + spec->n_mlp_params;
+    const bool hash = spec->encoding == LNR_ENC_HASHGRID;
     // d/dx mode: d_rays_acc (rays form, n_samples % 64 == 0, checked by the caller) > d_pts (planes) > none
     const int dxm = d_rays_acc ? ENC_DX_RAYS : (d_pts ? ENC_DX_PLANES : ENC_DX_NONE);
     float* dx_out = d_rays_acc ? reinterpret_cast<float*>(ray_acc) : dxl;
-    // sums + the non-finite word, rounded up to 16 bytes (one fill kernel instead of an aligned part and a tail; the workspace has the room)
-    if (d_rays_acc && hipMemsetAsync(ray_acc, 0, ((((size_t)src->n_rays * 6 + 1) * sizeof(long long)) + 15) & ~(size_t)15, st) != hipSuccess) {
+    // parts (LNR_ENC_PART_*): the input gradient and the table-gradient partition are separate launches of a hash grid's backward
+    // (LNR_SPLIT_DX), so that the caller can hand the input gradient on before the partition starts; the partition kernels then carry no d/dx
+    const bool do_dx = (parts & LNR_ENC_PART_DX) != 0, do_part = (parts & LNR_ENC_PART_RECORDS) != 0;
+#if LNR_SPLIT_DX
+    const int dxm_part = hash ? ENC_DX_NONE : dxm;
+#else
+    const int dxm_part = dxm;
+    LNR_REQUIRE(do_dx && do_part, "lnr_encode_backward: this build computes d/dx inside the partition kernels");
+#endif
+    // six sums + one non-finite word per ray, rounded up to 16 bytes (one fill kernel instead of an aligned part and a tail; the workspace has the room)
+    if (do_dx && d_rays_acc && hipMemsetAsync(ray_acc, 0, ((((size_t)src->n_rays * 7) * sizeof(long long)) + 15) & ~(size_t)15, st) != hipSuccess) {
         lnr_set_error("lnr_density_backward: hipMemsetAsync failed");
         return LNR_ERR_LAUNCH;
     }
     int n_groups = 1;
-    if (spec->encoding == LNR_ENC_HASHGRID) {
-        n_groups = spec->n_levels;
+#if LNR_SPLIT_DX
+    if (hash && do_dx && dxm != ENC_DX_NONE) {
+        uint32_t level_mask = spec->n_levels >= 32 ? 0xFFFFFFFFu : (1u << spec->n_levels) - 1u;
+#ifdef LNR_ABLATE
+        static const long dx_levels = getenv("LNR_X_LEVELS") ? strtol(getenv("LNR_X_LEVELS"), nullptr, 0) : -1;
+        level_mask &= (uint32_t)dx_levels;
+#endif
+        int64_t b = (cap_points + ENC_BLOCK * 4 - 1) / (ENC_BLOCK * 4);          // ~8 samples per lane pair
+        if (b < 1) b = 1;
+        if (b > 2048) b = 2048;
+        const dim3 dgrid((unsigned)(__builtin_popcount(level_mask) * b)), dblock(ENC_BLOCK);
+        LnrProfScope prof("encode_dx", st);
+#define LNR_LAUNCH_DXP(F)                                                                                                                   \
+        do {                                                                                                                               \
+            if (dxm == ENC_DX_RAYS) hipLaunchKernelGGL((encode_dx_pair_kernel<F, ENC_DX_RAYS>), dgrid, dblock, 0, st, *spec, table, *src, dfeat, dx_out, m_pad, (int)b, level_mask); \
+            else hipLaunchKernelGGL((encode_dx_pair_kernel<F, ENC_DX_PLANES>), dgrid, dblock, 0, st, *spec, table, *src, dfeat, dx_out, m_pad, (int)b, level_mask);               \
+        } while (0)
+        if (level_mask != 0u) switch (spec->n_features) {
+            case 1: LNR_LAUNCH_DXP(1); break;
+            case 2: LNR_LAUNCH_DXP(2); break;
+            case 4: LNR_LAUNCH_DXP(4); break;
+            default: LNR_LAUNCH_DXP(8); break;
+        }
+#undef LNR_LAUNCH_DXP
+    }
+#endif
+    if (hash) n_groups = spec->n_levels;
+    if (hash && do_part && (regions != nullptr || dxm_part != ENC_DX_NONE)) {
         LevelList rec_levels, xp_levels, brec_levels, bxp_levels;          // 8-byte record levels, x-pair record levels, and their binned forms: one launch each
         rec_levels.n = xp_levels.n = brec_levels.n = bxp_levels.n = 0;
         const bool allow_binned = regions != nullptr && maxo <= LNR_BIN_MAX_OWNERS;
@@ -1033,13 +1305,13 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
 #define LNR_LAUNCH_DXM(KERNEL, F, XP, ...)                                                                                    \
         do {                                                                                                                  \
             hipError_t e_ = hipSuccess;                                                                                       \
-            const void* fn_ = dxm == ENC_DX_RAYS ? reinterpret_cast<const void*>(KERNEL<F, ENC_DX_RAYS, XP>)                  \
-                            : dxm == ENC_DX_PLANES ? reinterpret_cast<const void*>(KERNEL<F, ENC_DX_PLANES, XP>)              \
+            const void* fn_ = dxm_part == ENC_DX_RAYS ? reinterpret_cast<const void*>(KERNEL<F, ENC_DX_RAYS, XP>)                  \
+                            : dxm_part == ENC_DX_PLANES ? reinterpret_cast<const void*>(KERNEL<F, ENC_DX_PLANES, XP>)              \
                                                    : reinterpret_cast<const void*>(KERNEL<F, ENC_DX_NONE, XP>);               \
             e_ = hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
             if (e_ != hipSuccess) { lnr_set_error("lnr_density_backward: hipFuncSetAttribute(%zu) failed", lds); return LNR_ERR_LAUNCH; } \
-            if (dxm == ENC_DX_RAYS) hipLaunchKernelGGL((KERNEL<F, ENC_DX_RAYS, XP>), grid, block, lds, st, __VA_ARGS__);   \
-            else if (dxm == ENC_DX_PLANES) hipLaunchKernelGGL((KERNEL<F, ENC_DX_PLANES, XP>), grid, block, lds, st, __VA_ARGS__); \
+            if (dxm_part == ENC_DX_RAYS) hipLaunchKernelGGL((KERNEL<F, ENC_DX_RAYS, XP>), grid, block, lds, st, __VA_ARGS__);   \
+            else if (dxm_part == ENC_DX_PLANES) hipLaunchKernelGGL((KERNEL<F, ENC_DX_PLANES, XP>), grid, block, lds, st, __VA_ARGS__); \
             else hipLaunchKernelGGL((KERNEL<F, ENC_DX_NONE, XP>), grid, block, lds, st, __VA_ARGS__);                      \
         } while (0)
 #define LNR_LAUNCH_F(KERNEL, ...)                                                   \
@@ -1080,11 +1352,11 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
                 do {                                                                                                                \
                     const dim3 grid_b((unsigned)((LIST).n * bpg));                                                                  \
                     const void* fn_ = nullptr;                                                                                      \
-                    if (nw == 8) fn_ = dxm == ENC_DX_RAYS ? (const void*)encode_backward_binned_kernel<F, ENC_DX_RAYS, XP, 8>       \
-                                     : dxm == ENC_DX_PLANES ? (const void*)encode_backward_binned_kernel<F, ENC_DX_PLANES, XP, 8>   \
+                    if (nw == 8) fn_ = dxm_part == ENC_DX_RAYS ? (const void*)encode_backward_binned_kernel<F, ENC_DX_RAYS, XP, 8>       \
+                                     : dxm_part == ENC_DX_PLANES ? (const void*)encode_backward_binned_kernel<F, ENC_DX_PLANES, XP, 8>   \
                                                             : (const void*)encode_backward_binned_kernel<F, ENC_DX_NONE, XP, 8>;    \
-                    else fn_ = dxm == ENC_DX_RAYS ? (const void*)encode_backward_binned_kernel<F, ENC_DX_RAYS, XP, 4>               \
-                             : dxm == ENC_DX_PLANES ? (const void*)encode_backward_binned_kernel<F, ENC_DX_PLANES, XP, 4>           \
+                    else fn_ = dxm_part == ENC_DX_RAYS ? (const void*)encode_backward_binned_kernel<F, ENC_DX_RAYS, XP, 4>               \
+                             : dxm_part == ENC_DX_PLANES ? (const void*)encode_backward_binned_kernel<F, ENC_DX_PLANES, XP, 4>           \
                                                     : (const void*)encode_backward_binned_kernel<F, ENC_DX_NONE, XP, 4>;            \
                     if (hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b) != hipSuccess) {           \
                         lnr_set_error("lnr_density_backward: hipFuncSetAttribute(%zu) failed", lds_b); return LNR_ERR_LAUNCH;       \
@@ -1118,12 +1390,13 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
         }
 #undef LNR_LAUNCH_F
 #undef LNR_LAUNCH_DXM
-    } else if (dxm != ENC_DX_NONE) {
+    } else if (!hash && do_dx && dxm != ENC_DX_NONE) {
         // frequency encoding: no table, one plane group; the per-ray mode is served through the planes by the caller
         int64_t blocks = (cap_points + ENC_BLOCK - 1) / ENC_BLOCK;
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(freq_backward_kernel, dim3((unsigned)blocks), dim3(ENC_BLOCK), 0, st, *spec, *src, dfeat, dxl, m_pad);
     }
+    if (!do_dx) return LNR_OK;
     if (dxm == ENC_DX_RAYS) {
         hipLaunchKernelGGL(ray_grad_apply_kernel, dim3((unsigned)((src->n_rays * 6 + ENC_BLOCK - 1) / ENC_BLOCK)), dim3(ENC_BLOCK), 0, st,
                            ray_acc, src->n_rays, src->n_rays_dev, d_rays_acc);

@@ -222,6 +222,37 @@ extern "C" int lnr_compact_rays(const float* rays_in, const float* depths_in, co
     return LNR_OK;
 }
 
+// Sharded windows: which ray is "the first ray of the whole batch" (the reference compares every depth with ITS far, optimizer.py:460-461).
+// Every rank reports {window order of its first segment that kept a ray, the far of that ray} as one 64-bit key - order in the high
+// word, the float's bits in the low word - and a MIN all-reduce over the ranks leaves the key of the batch's first ray everywhere.
+struct SegOrder { int n; int order[LNR_MAX_SEG]; };
+__global__ void first_ray_key_kernel(const float* __restrict__ rays, const int32_t* __restrict__ out_seg_start, const SegOrder ord, long long* __restrict__ key) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    long long k = 0x7FFFFFFFFFFFFFFFll;                      // no live ray on this rank
+    for (int s = 0; s < ord.n; ++s) {
+        const int lo = out_seg_start[s], hi = out_seg_start[s + 1];
+        if (hi > lo) {
+            k = ((long long)ord.order[s] << 32) | (long long)__float_as_uint(rays[(size_t)lo * LNR_RAY_STRIDE + 12]);
+            break;
+        }
+    }
+    *key = k;
+}
+
+extern "C" int lnr_first_ray_key(const float* rays, const int32_t* out_seg_start, const int32_t* seg_order, int32_t n_seg, int64_t* key_out, void* stream) {
+    LNR_REQUIRE(rays && out_seg_start && seg_order && key_out, "lnr_first_ray_key: null argument");
+    LNR_REQUIRE(n_seg >= 1 && n_seg <= LNR_MAX_SEG, "lnr_first_ray_key: n_seg must be in [1,%d]", LNR_MAX_SEG);
+    SegOrder ord;
+    ord.n = n_seg;
+    for (int s = 0; s < n_seg; ++s) {
+        LNR_REQUIRE(seg_order[s] >= 0 && (s == 0 || seg_order[s] > seg_order[s - 1]), "lnr_first_ray_key: seg_order must be non-negative and ascending");
+        ord.order[s] = seg_order[s];
+    }
+    hipLaunchKernelGGL(first_ray_key_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, rays, out_seg_start, ord, reinterpret_cast<long long*>(key_out));
+    LNR_CHECK_LAUNCH("lnr_first_ray_key");
+    return LNR_OK;
+}
+
 // one workgroup per keyframe: reduce the 12 entries of dL/d[R|t]
 __global__ void __launch_bounds__(256)
 lidar_rays_backward_kernel(const float* __restrict__ d_rays, const float* __restrict__ rays, const int64_t* __restrict__ src_index,

@@ -315,3 +315,29 @@ extern "C" int lnr_sample_rays_uniform(const float* rays, int32_t n_rays, const 
     LNR_CHECK_LAUNCH("lnr_sample_rays_uniform");
     return LNR_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------ diagnostics
+// the draws of the in-kernel generator as tensors (include/loner_hip.h): the SAME device functions, indexed as the kernels index them
+__global__ void rng_draws_kernel(int which, uint64_t seed, int n_rays, int n_per_ray, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n_rays * n_per_ray) return;
+    const uint64_t ray = (uint64_t)(i / n_per_ray);
+    const uint32_t j = (uint32_t)(i % n_per_ray);
+    float v;
+    if (which == LNR_DRAW_JITTER) v = lnr_rand_uniform(seed, LNR_STREAM_JITTER, ray, j);
+    else if (which == LNR_DRAW_PDF) v = lnr_rand_uniform(seed, LNR_STREAM_PDF, ray, j);
+    else if (which == LNR_DRAW_NOISE) v = lnr_rand_normal(seed, ray, j);
+    else v = lnr_rand_uniform(seed, 0x44ull + (uint64_t)(which - LNR_DRAW_RAY_INDEX), (uint64_t)i >> 2, (uint32_t)i & 3u);   // build_window_rays_kernel
+    out[i] = v;
+}
+
+extern "C" int lnr_rng_draws(int32_t which, uint64_t seed, int32_t n_rays, int32_t n_per_ray, float* out, void* stream) {
+    LNR_REQUIRE(out != nullptr && n_rays >= 0 && n_per_ray > 0, "lnr_rng_draws: bad argument");
+    LNR_REQUIRE(which == LNR_DRAW_JITTER || which == LNR_DRAW_PDF || which == LNR_DRAW_NOISE || which >= LNR_DRAW_RAY_INDEX, "lnr_rng_draws: unknown draw %d", which);
+    const int64_t n = (int64_t)n_rays * n_per_ray;
+    if (n == 0) return LNR_OK;
+    hipLaunchKernelGGL(rng_draws_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, which, seed, n_rays, n_per_ray, out);
+    LNR_CHECK_LAUNCH("lnr_rng_draws");
+    return LNR_OK;
+}

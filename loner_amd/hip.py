@@ -32,6 +32,7 @@ BWD_DEFER_WEIGHT_FOLD = 16   # LNR_BWD_DEFER_WEIGHT_FOLD
 BWD_BINS = 4                 # LNR_BWD_BINS
 BWD_BINS_W8 = 8              # LNR_BWD_BINS_W8
 WORKSPACE_STATUS_BYTES, STATUS_CLIPPED = 256, 0            # LNR_WORKSPACE_STATUS_BYTES, LNR_STATUS_CLIPPED
+DRAW_JITTER, DRAW_PDF, DRAW_NOISE, DRAW_RAY_INDEX = 0, 1, 2, 16      # LNR_DRAW_*
 POISON_NAN_LOSS, POISON_POSE_GRAD, POISON_POSE = 1, 2, 3      # LNR_POISON_* codes of the failure guard (int32[2] device word)
 
 
@@ -95,6 +96,8 @@ _SIGNATURES = {
                                     C.c_float, C.c_float, P, P]),
     "lnr_occ_grid_apply": (C.c_int, [P, P, C.c_int64, C.c_float, C.c_int32, P, P]),
     "lnr_selftest_mfma": (C.c_int, [P, P]),
+    "lnr_first_ray_key": (C.c_int, [P, P, C.POINTER(C.c_int32), C.c_int32, P, P]),
+    "lnr_rng_draws": (C.c_int, [C.c_int32, C.c_uint64, C.c_int32, C.c_int32, P, P]),
 }
 
 _lib = None

@@ -181,15 +181,33 @@ class Optimizer:
             if cumulative_kf_idx >= self._keyframe_count + 1 or kf_count == -1:
                 break
         num_its = sum(i["num_iterations"] for i in iteration_schedule)
-        start_time = time.time()
-        result = self._do_iterate_optimizer(keyframe_window, iteration_schedule, optimizer_settings=optimizer_settings)
-        torch.cuda.synchronize(self._device)
-        elapsed_time = time.time() - start_time
-        os.makedirs(self._settings.log_directory, exist_ok=True)
-        with open(f"{self._settings.log_directory}/timing.csv", 'a+') as f:
-            f.write(f"{num_its},{elapsed_time}\n")
-        if self._progress_bar is None:
+        if self._settings.debug.profile_optimizer:
+            # optimizer.py:158-176: a torch profiler around the phase (one step per iteration: wait 1, warm up 1, record the rest),
+            # TensorBoard traces under <log_directory>/profile/tensorboard_optimizer/, no timing.csv row.  The profiler's CUDA activity
+            # is the HIP activity on ROCm; the loop takes its single-stream form while a profiler is attached.
+            from torch.profiler import ProfilerActivity, profile, schedule, tensorboard_trace_handler
+            prof_dir = f"{self._settings.log_directory}/profile"
+            os.makedirs(prof_dir, exist_ok=True)
+            prof = profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], profile_memory=True, record_shapes=True,
+                           with_stack=True, with_modules=True, schedule=schedule(wait=1, warmup=1, active=max(num_its - 2, 1)),
+                           on_trace_ready=tensorboard_trace_handler(f"{prof_dir}/tensorboard_optimizer/"))
+            prof.start()
+            start_time = time.time()
+            result = self._do_iterate_optimizer(keyframe_window, iteration_schedule, prof, optimizer_settings=optimizer_settings)
+            torch.cuda.synchronize(self._device)
+            elapsed_time = time.time() - start_time
+            prof.stop()
             print(f"Elapsed Time: {elapsed_time}. Per Iteration: {elapsed_time / num_its}, Its/Sec: {num_its / elapsed_time}")
+        else:
+            start_time = time.time()
+            result = self._do_iterate_optimizer(keyframe_window, iteration_schedule, optimizer_settings=optimizer_settings)
+            torch.cuda.synchronize(self._device)
+            elapsed_time = time.time() - start_time
+            os.makedirs(self._settings.log_directory, exist_ok=True)
+            with open(f"{self._settings.log_directory}/timing.csv", 'a+') as f:
+                f.write(f"{num_its},{elapsed_time}\n")
+            if self._progress_bar is None:
+                print(f"Elapsed Time: {elapsed_time}. Per Iteration: {elapsed_time / num_its}, Its/Sec: {num_its / elapsed_time}")
         self._keyframe_count += 1
         return result
 
@@ -237,6 +255,8 @@ class Optimizer:
             else:
                 active_all = list(keyframe_window)
             active = self._dist.owned(active_all) if self._dist is not None else active_all
+            # positions of this rank's keyframes in the window (the sharded far[0] agreement needs them)
+            self._active_order = self._dist.owned_indices(len(active_all)) if self._dist is not None else list(range(len(active_all)))
             for kf in active:
                 if not kf.is_anchored:
                     kf.get_lidar_pose().set_fixed(not optimize_poses)
@@ -248,14 +268,29 @@ class Optimizer:
             if not tracking and sigma_params:
                 density_group = len(groups)
                 groups.append({'params': sigma_params, 'lr': self._model_config.train.lrate_sigma_mlp})
-            # poses are optimised on the device as one [K,6] tensor (rows of fixed/anchored keyframes get zero gradient)
-            pose_cpu = [kf.get_lidar_pose().get_pose_tensor() for kf in active]
+            # poses are optimised on the device as one [K,6] tensor (rows of fixed/anchored keyframes get zero gradient).
+            # Which pose a keyframe's rays are built from is the reference's choice: the ground-truth pose when the optimiser was
+            # constructed with use_gt_poses (keyframe.py:83-86 via optimizer.py:305), else the lidar pose.  A pose that is NOT optimised
+            # in this phase enters as the 4x4 matrix its get_transformation_matrix() hands out - which is what the reference's ray
+            # builder reads (pose.py:140-144: for a fixed pose that is the matrix cached at construction, whatever happened to the
+            # 6-vector since) - not as a matrix re-derived from get_pose_tensor().
+            pose_objs = [(kf._frame._gt_lidar_pose if self._use_gt_poses else kf.get_lidar_pose()) for kf in active]
+            free_list = [bool(optimize_poses and not kf.is_anchored) for kf in active]
+            pose_cpu = [p.get_pose_tensor() for p in pose_objs]
             if active:
                 pose_dev = torch.stack([p.detach().to(self._device, torch.float32) for p in pose_cpu]).contiguous()
             else:
                 pose_dev = torch.zeros(0, 6, device=self._device)
-            free_rows = torch.tensor([(optimize_poses and not kf.is_anchored) for kf in active], device=self._device).to(torch.uint8)
+            free_rows = torch.tensor(free_list, device=self._device).to(torch.uint8)
             tab = self._window_tables(active) if active else None
+            if tab is not None and not all(free_list):
+                with torch.no_grad():
+                    fixed = [(torch.zeros(12) if fr else p.get_transformation_matrix().detach().float().cpu()[:3, :4].reshape(12))
+                             for p, fr in zip(pose_objs, free_list)]
+                tab.fixed_T12 = torch.stack(fixed).to(self._device).contiguous()
+                tab.free_col = free_rows.bool()[:, None]
+            elif tab is not None:
+                tab.fixed_T12 = None
             any_free = bool(optimize_poses and any(not kf.is_anchored for kf in active))
             pose_dev.requires_grad_(any_free)
             if any_free:
@@ -295,7 +330,7 @@ class Optimizer:
 
                 def front_end():
                     b = self._build_window_rays(active, pose_dev, tab)
-                    b["front"] = self._sample_front(b["rays"], b["depths"], b["n_dev"])
+                    b["front"] = self._sample_front(b["rays"], b["depths"], b["n_dev"], first_key=b["first_key"])
                     return b
                 batch = front_end() if n_it > 0 else None
                 if n_it > 0:
@@ -353,7 +388,7 @@ class Optimizer:
                                                self._model.nerf_model._model_sigma.params, it_idx, want_ray_grads=any_free,
                                                want_param_grads=not os_.freeze_sigma_mlp, n_rays_dev=batch["n_dev"],
                                                loss_out=loss_log[it_idx], accumulate_into_param_grad=True, want_stats=False,
-                                               defer_grad_wait=True, poison=poison)
+                                               defer_grad_wait=True, poison=poison, first_key=batch["first_key"])
                 else:
                     out = self._join_without_rays(sigma_params[0] if sigma_params else None, want_param_grads=not os_.freeze_sigma_mlp)
                 if any_free:
@@ -386,8 +421,11 @@ class Optimizer:
             # ---- one host sync per phase.  The checks the reference makes in every iteration (:368-374,:590) were made on the
             # device, by the kernels of that iteration; the state below is the one the failing iteration started from ----
             if self._dist is not None:
-                # a failure on any rank is everybody's (the other ranks kept stepping until here - the run is lost either way)
-                self._dist.all_reduce_max(poison)
+                # A failure on any rank is everybody's.  The guarantee "parameters as the failing iteration began" is a SINGLE-GPU one:
+                # the word is per rank until here, so the healthy ranks kept stepping (with the failing rank's non-finite gradient in
+                # their all-reduce) - the run is lost either way.  What all ranks agree on is WHICH failure to report: the earliest
+                # iteration, with the code that belongs to it (one packed value, so code and iteration cannot come from different ranks).
+                poison.copy_(self._dist.earliest_failure(poison))
             code, failed_it = (int(v) for v in poison.cpu())
             self._poison = None
             self._model.nerf_model.warn_if_clipped(self._device)      # nerf_tcnn.py:70-78, once per phase instead of per forward
@@ -395,7 +433,8 @@ class Optimizer:
             if code != 0:
                 with torch.no_grad():           # hand the poses of the last good iteration back, like every other phase end
                     for k, p in enumerate(pose_cpu):
-                        p.data.copy_(pose_dev[k].detach().to(p.device))
+                        if free_list[k]:
+                            p.data.copy_(pose_dev[k].detach().to(p.device))
                 self.last_failure = {"code": code, "iteration": failed_it}
                 if code == hip.POISON_NAN_LOSS:
                     raise AssertionError("NaN Loss Encountered")
@@ -415,7 +454,8 @@ class Optimizer:
                     raise AssertionError("ray origins are outside the world cube")
             with torch.no_grad():
                 for k, p in enumerate(pose_cpu):
-                    p.data.copy_(pose_dev[k].detach().to(p.device))
+                    if free_list[k]:            # (the others were not stepped: their tensors are left exactly as they are)
+                        p.data.copy_(pose_dev[k].detach().to(p.device))
             sigma = self._model.nerf_model._model_sigma.params
             if sigma.grad is not None and os_.freeze_sigma_mlp:
                 sigma.grad = None
@@ -455,6 +495,10 @@ class Optimizer:
                 is_sky.append(True); lens.append(sdirs.shape[1])
         tab = ops.WindowTables(dirs_l, dist_l, const_l, counts, poses)
         tab.is_sky, tab.seg_kf, tab.lens, tab.dirs_list = is_sky, poses, lens, dirs_l
+        # window position of every segment (lidar before sky inside a keyframe): the order of the single-GPU batch
+        order_of = getattr(self, "_active_order", None) or list(range(len(active)))
+        tab.seg_order = [2 * order_of[k] + (1 if sky_ else 0) for k, sky_ in zip(poses, is_sky)]
+        tab.fixed_T12 = None           # set per phase: the matrices of the poses that are not optimised (_do_iterate_optimizer)
         tab.seg_kf_dev = torch.tensor(poses, device=dev)
         tab.lidar_seg_mask = torch.tensor([0.0 if s else 1.0 for s in is_sky], device=dev)[:, None]
         tab.has_sky = any(is_sky)
@@ -488,12 +532,15 @@ class Optimizer:
         """optimizer.py:285-340 on the device: pose -> [R|t], index draw + ray build for the whole window in one
         launch, one order-preserving compaction."""
         T12 = ops.pose_forward(pose_dev)
+        if tab.fixed_T12 is not None:                      # poses that are not optimised in this phase: the matrix their Pose hands out
+            T12 = torch.where(tab.free_col, T12, tab.fixed_T12)
         rr = [float(self._ray_range[0]), float(self._ray_range[1])]
         index = self._draw_window_indices(active, tab)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if index is None else 0
         rays_c, depths_c, keep, src_c = ops.build_window_rays(tab, T12, rr, self._scale_f, self._shift_f, index=index, seed=seed)
         rays, depths, src, out_seg, n_dev = ops.compact_rays(rays_c, depths_c, keep, src_c, tab.seg_start_list)
-        return dict(rays=rays, depths=depths, src=src, seg_start=out_seg, n_dev=n_dev, T12=T12, tab=tab)
+        first_key = ops.first_ray_key(rays, out_seg, tab.seg_order) if self._dist is not None else None
+        return dict(rays=rays, depths=depths, src=src, seg_start=out_seg, n_dev=n_dev, T12=T12, tab=tab, first_key=first_key)
 
     def _pose_backward(self, batch, d_rays, pose_dev, free_mask_u8, poison=None, poison_tag=0):
         """dL/drays -> dL/d[R|t] per segment (HIP) -> dL/dpose6 (HIP, analytic axis-angle Jacobian)."""
@@ -530,7 +577,7 @@ class Optimizer:
             cfg.fixed_eps = lc.depth_eps
         return cfg
 
-    def _sample_front(self, rays, depths, n_rays_dev, draws=None):
+    def _sample_front(self, rays, depths, n_rays_dev, draws=None, first_key=None):
         """The part of an iteration that does not touch the density parameters: loss normalisers and sample depths for `rays`
         (optimizer.py:437-470 up to the network call).  -> dict(counts, counts_work, z, seed, far0)"""
         draws = draws if draws is not None else self._draws
@@ -548,7 +595,7 @@ class Optimizer:
                 u2 = draws.pdf(n, S // 2).to(dev)
         # Sharded: the reference compares every ground-truth depth with far[0], the first ray of the WHOLE batch
         # (optimizer.py:460-461) = rank 0's first ray (it owns the first active keyframe); one float broadcast.
-        far0 = self._dist.broadcast_far0(rays) if self._dist is not None else None
+        far0 = self._dist.broadcast_far0(rays, first_key=first_key) if self._dist is not None else None
         # loss normalisers first: in the sharded mode their (2-int) all-reduce is pure latency and runs behind the sampler and
         # the density forward; it is waited for right before the loss kernel, its first consumer
         counts = ops.count_opaque(rays, depths, n_rays_dev=n_rays_dev, far0=far0)
@@ -562,7 +609,7 @@ class Optimizer:
 
     def _loss_and_grads(self, rays, depths, params, iteration_idx, want_ray_grads, want_param_grads, n_rays_dev=None,
                         loss_out=None, accumulate_into_param_grad=False, draws=None, want_stats=True, defer_grad_wait=False,
-                        poison=None, front=None, input_grad_event=None, defer_weight_fold=False):
+                        poison=None, front=None, input_grad_event=None, defer_weight_fold=False, first_key=None):
         """sample -> density -> fused render+loss(+backward) -> density backward.  rays [N,13], depths [N] on device.
         front: the result of _sample_front for these rays when the caller already ran it (the pipelined training loop);
         input_grad_event: recorded by the density backward as soon as d_rays is complete (ops.density_backward)."""
@@ -573,7 +620,7 @@ class Optimizer:
         dev = self._device
         n = rays.shape[0]
         if front is None:
-            front = self._sample_front(rays, depths, n_rays_dev, draws)
+            front = self._sample_front(rays, depths, n_rays_dev, draws, first_key=first_key)
         counts, counts_work, z, seed, far0 = front["counts"], front["counts_work"], front["z"], front["seed"], front["far0"]
         noise = None
         if draws is not None and noise_std > 0:

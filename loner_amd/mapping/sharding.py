@@ -12,7 +12,8 @@ by keyframe with ONE exchange step per iteration:
     torch.distributed backend "nccl"; every rank then applies the identical Adam step, so replicas
     stay bit-equal (the reduced buffer is used as produced by the collective on every rank);
   * the loss compares every ground-truth depth with `far` of the first ray of the batch (the far[0] quirk,
-    optimizer.py:460-461): rank 0 broadcasts that float, so the sharded loss equals the single-GPU one;
+    optimizer.py:460-461): the ranks agree on that ray with one 8-byte MIN all-reduce (window order of each rank's
+    first kept ray | its far), so the sharded loss equals the single-GPU one also when a keyframe lost all its rays;
   * every N_iters_acc-th step the occupancy-grid pseudo-gradient (V^3 floats) is all-reduced the
     same way so that the samplers do not diverge.
 
@@ -38,6 +39,25 @@ from typing import List, Sequence
 
 import torch
 import torch.distributed as dist
+
+
+NO_RAY_KEY = 0x7FFFFFFFFFFFFFFF      # first_ray_key of a rank without a kept ray (its low word read as a float is NaN: no ray uses it)
+
+
+def first_ray_key(rays: torch.Tensor, seg_start: torch.Tensor, seg_order: Sequence[int]) -> torch.Tensor:
+    """int64 [1]: (seg_order of the first segment with a kept ray) << 32 | float bits of that ray's far, NO_RAY_KEY without one.
+    rays [n,13], seg_start int32 [n_seg+1] (compacted segment starts), seg_order ascending window positions of the segments.
+    Plain torch ops (any device, no host sync) - on the MI355X the optimiser uses ops.first_ray_key, one launch."""
+    order = torch.as_tensor(list(seg_order), dtype=torch.int64, device=rays.device)
+    lo, hi = seg_start[:-1].long(), seg_start[1:].long()
+    live = hi > lo
+    cand = torch.where(live, order, torch.full_like(order, 1 << 31))
+    o, s = cand.min(0)
+    row = lo[s].clamp(max=max(rays.shape[0] - 1, 0))
+    far = rays[row, 12] if rays.shape[0] else torch.zeros((), device=rays.device)
+    bits = far.reshape(1).contiguous().view(torch.int32).long() & 0xFFFFFFFF
+    key = (o.reshape(1) << 32) | bits
+    return torch.where(live.any().reshape(1), key, torch.full_like(key, NO_RAY_KEY))
 
 
 def shard_window(n_keyframes: int, world_size: int, rank: int) -> List[int]:
@@ -132,26 +152,34 @@ class DistContext:
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         return work if async_op else flat
 
-    def all_reduce_max(self, t: torch.Tensor) -> torch.Tensor:
-        """element-wise maximum over the ranks, in place (the failure guard's {code, iteration} word at the end of a phase)"""
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-        return t
+    def earliest_failure(self, poison: torch.Tensor) -> torch.Tensor:
+        """The failure guard's {code, iteration} word (int32 [2], code 0 = none) of every rank -> the word of the EARLIEST failing
+        iteration over all ranks (ties: the smallest code), as one packed MIN all-reduce so that the pair stays a pair."""
+        none = torch.iinfo(torch.int64).max
+        packed = torch.where(poison[0:1] != 0, poison[1:2].long() * 256 + poison[0:1].long(), torch.full((1,), none, dtype=torch.int64, device=poison.device))
+        dist.all_reduce(packed, op=dist.ReduceOp.MIN, group=self.group)
+        failed = packed != none
+        code = torch.where(failed, packed % 256, torch.zeros_like(packed))
+        it = torch.where(failed, packed // 256, torch.zeros_like(packed))
+        return torch.cat([code, it]).to(torch.int32)
 
-    def broadcast_far0(self, rays, device=None) -> torch.Tensor:
-        """The reference's `depth > far[0]` test (optimizer.py:460-461) uses the first ray of the whole batch.  Rank 0 owns the
-        first active keyframe, hence that ray: it sends `rays[0, 12]`, everyone gets a device float [1] to hand to
-        lnr_count_opaque / lnr_los_loss_fused.  `rays` may be None on ranks without rays.
-        Limitation (documented): if the cube test drops EVERY candidate ray of the first active keyframe,
-        the single-GPU batch starts with a later keyframe's ray while rank 0 still sends the first row of its own compacted
-        batch (its next keyframe's first ray, or a dead row if it has none left); finding the true first ray would cost a
-        second small collective and several device-side index operations per iteration for a case that needs a whole
-        keyframe of 512 rays to miss the world cube."""
-        if self.rank == 0:
-            far0 = rays[0:1, 12].clone()
-        else:
-            far0 = torch.zeros(1, device=rays.device if rays is not None else device, dtype=torch.float32)
-        dist.broadcast(far0, src=0, group=self.group)
-        return far0
+    def owned_indices(self, n_keyframes: int) -> List[int]:
+        return shard_window(n_keyframes, self.world_size, self.rank)
+
+    def broadcast_far0(self, rays, device=None, first_key=None) -> torch.Tensor:
+        """The reference's `depth > far[0]` test (optimizer.py:460-461) uses the first ray of the whole batch: the first kept ray of the
+        first keyframe, in window order, that kept any (the cube test may drop every candidate of a keyframe, ray_utils.py:322).
+        Every rank contributes `first_key` (first_ray_key below / ops.first_ray_key: window order << 32 | bits of its own first ray's
+        far, INT64_MAX without a ray) and one MIN all-reduce leaves the key of the batch's first ray everywhere; its low word is far[0],
+        returned as a device float [1] for lnr_count_opaque / lnr_los_loss_fused.  Without first_key the rank's position stands in for
+        the window order and `rays` (None: no ray) is taken as a batch of kept rays - right whenever rank order is keyframe order."""
+        if first_key is None:
+            if rays is None or rays.shape[0] == 0:
+                first_key = torch.full((1,), NO_RAY_KEY, dtype=torch.int64, device=rays.device if rays is not None else device)
+            else:
+                first_key = first_ray_key(rays, torch.tensor([0, rays.shape[0]], device=rays.device, dtype=torch.int32), [self.rank])
+        dist.all_reduce(first_key, op=dist.ReduceOp.MIN, group=self.group)
+        return first_key.view(torch.float32)[0:1]          # little endian: the low word
 
     def broadcast_(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
         dist.broadcast(t, src=src, group=self.group)

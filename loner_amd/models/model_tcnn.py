@@ -53,7 +53,7 @@ class Model(nn.Module):
         r = self.cfg.render
         return (r.N_samples_test, 0.) if testing else (r.N_samples_train, r.perturb)
 
-    def _render_no_grad(self, rays, ray_sampler, n_samples, perturb, want_weights, want_variance):
+    def _render_no_grad(self, rays, ray_sampler, n_samples, perturb, want_weights):
         """Rendering without autograd (Model.forward under no_grad / for inputs that need no gradient, render_depth): the whole
         batch goes through sampler -> density forward -> compositing in launches of _POINTS_PER_LAUNCH samples, whatever
         cfg.render.chunk says (the reference's chunk loop, model_tcnn.py:81-101, bounds ITS memory; results do not depend on
@@ -107,7 +107,9 @@ class Model(nn.Module):
         """Rendered depth per ray and nothing else (what compute_l1_depth, renderer_lidar and the meshing consumers read from the
         result dictionary: analysis/compute_l1_depth.py:56-58): the lean form of forward(testing=True, camera=False)."""
         n_samples, perturb = self._sample_counts(testing)
-        return self._render_no_grad(rays, ray_sampler, n_samples, perturb, want_weights=False, want_variance=False)["depth"]
+        if rays.shape[0] == 0:
+            return torch.empty(0, device=rays.device, dtype=torch.float32)
+        return self._render_no_grad(rays, ray_sampler, n_samples, perturb, want_weights=False)["depth"]
 
     def forward(self, rays, ray_sampler, scale_factor, testing=False, camera=True, detach_sigma=True, return_variance=False):
         """Batched rendering with the reference's signature and result dictionary (model_tcnn.py:70-105).  When a gradient can
@@ -115,10 +117,12 @@ class Model(nn.Module):
         differentiable render_rays; otherwise the batch takes the forward-only route in a few large launches."""
         if camera:
             raise NotImplementedError("Model.forward: colour rendering (camera=True) is not part of the LiDAR mapping path")
+        if rays.shape[0] == 0:
+            return {}                 # the reference's chunk loop does not run and its result dictionary stays empty (model_tcnn.py:81-105)
         n_samples, perturb = self._sample_counts(testing)
         sig = self.nerf_model._model_sigma.params
         if not (torch.is_grad_enabled() and (rays.requires_grad or sig.requires_grad)):
-            r = self._render_no_grad(rays, ray_sampler, n_samples, perturb, want_weights=True, want_variance=return_variance)
+            r = self._render_no_grad(rays, ray_sampler, n_samples, perturb, want_weights=True)
             results = {'rgb_fine': torch.tensor([-1.]).repeat(-(-rays.shape[0] // self.cfg.render.chunk)), 'depth_fine': r["depth"],
                        'weights_fine': r["weights"], 'opacity_fine': r["opacity"]}
             if return_variance:

@@ -266,6 +266,17 @@ def compact_rays(rays, depths, keep, src_index, seg_start):
     return rays_out, depths_out, src_out, out_seg, n_out
 
 
+def first_ray_key(rays, out_seg_start, seg_order):
+    """int64 [1] on the device: (window order of this rank's first segment with a kept ray) << 32 | float bits of that ray's far,
+    INT64_MAX without one (mapping/sharding.py: the far[0] of a sharded batch)."""
+    require_device(rays, out_seg_start)
+    n_seg = len(seg_order)
+    key = torch.empty(1, device=rays.device, dtype=torch.int64)
+    order = (C.c_int32 * n_seg)(*[int(v) for v in seg_order])
+    check(load().lnr_first_ray_key(_ptr(rays), _ptr(out_seg_start), order, n_seg, _ptr(key), _stream()), "lnr_first_ray_key")
+    return key
+
+
 def lidar_rays_backward(d_rays, rays, src_index, seg_start_dev, directions_list, transforms, scale):
     """-> d_transform [n_seg, 12]"""
     require_device(d_rays, rays, src_index, seg_start_dev, transforms)
@@ -443,6 +454,13 @@ def occ_grid_apply(grid, grad_buf, lr, zero_grad=True, poison=None):
     assert grad_buf.dtype == torch.int64 and grad_buf.is_contiguous()
     check(load().lnr_occ_grid_apply(_ptr(grid), _ptr(grad_buf), grid.numel(), float(lr), int(zero_grad), _ptr(poison), _stream()),
           "lnr_occ_grid_apply")
+
+
+def rng_draws(which, seed, n_rays, n_per_ray, device="cuda"):
+    """The in-kernel generator's draws as a tensor [n_rays, n_per_ray] (hip.DRAW_JITTER / DRAW_PDF / DRAW_NOISE / DRAW_RAY_INDEX + segment)."""
+    out = torch.empty(int(n_rays), int(n_per_ray), device=device, dtype=torch.float32)
+    check(load().lnr_rng_draws(int(which), int(seed) & (2 ** 64 - 1), int(n_rays), int(n_per_ray), _ptr(out), _stream()), "lnr_rng_draws")
+    return out
 
 
 def selftest_mfma(device="cuda"):

@@ -800,3 +800,92 @@ def test_pipelined_loop_equals_the_single_stream_loop():
     for n, x, y in zip(["params", "occupancy grid", "poses", "loss trace (joint)", "loss trace (tracking)"], a, b):
         assert torch.equal(x, y), f"{n} differ between the pipelined and the single-stream loop"
     assert float((a[2][1:] - a[2][0]).abs().max()) > 0
+
+
+def _ref_shaped_window(pose6_list, scale_settings=None):
+    """keyframes, world cube and settings as the reference's Mapper hands them to the Optimizer: its own classes (tests/support.py
+    stand-ins that expose exactly the reference's members), CPU tensors, AttrDict settings"""
+    from loner_amd.utils import synthetic as SY
+    from tests.support import RefShapedFrame, RefShapedKeyFrame, RefShapedLidarScan, RefShapedPose, RefShapedSettings, RefShapedWorldCube
+    dirs, ts = SY.lidar_pattern()
+    base = SY.trajectory_pose6(8)
+    kfs = []
+    for i, p6 in enumerate(pose6_list):
+        dist = SY.scene_ranges(dirs, OP.transform_from_pose6(base[i]))
+        fr = RefShapedFrame(None, RefShapedLidarScan(dirs.clone(), dist, ts + float(i), sky_rays=torch.Tensor()), RefShapedPose())
+        fr._lidar_pose = RefShapedPose(pose_tensor=p6.clone(), fixed=True)
+        fr._gt_lidar_pose = RefShapedPose(pose_tensor=base[i].clone(), fixed=True)
+        kfs.append(RefShapedKeyFrame(fr))
+    scale, shift = SY.world_cube()
+    wc = RefShapedWorldCube(torch.tensor(scale), torch.from_numpy(shift))
+    s = small_settings(96, 64)
+    s["data_prep_on_cpu"] = True
+    s["keyframe_schedule"] = [{"num_keyframes": 1, "iteration_schedule": [{"num_iterations": 6, "freeze_poses": True, "freeze_sigma_mlp": False, "freeze_rgb_mlp": True}]},
+                              {"num_keyframes": -1, "iteration_schedule": [
+                                  {"num_iterations": 3, "freeze_poses": False, "latest_kf_only": True, "freeze_sigma_mlp": True, "freeze_rgb_mlp": True},
+                                  {"num_iterations": 5, "freeze_poses": False, "freeze_sigma_mlp": False, "freeze_rgb_mlp": True}]}]
+    s["skip_pose_refinement"] = False
+    import json
+    return kfs, wc, RefShapedSettings(json.loads(json.dumps(s)))        # plain nested dicts / LISTS, as yaml.load produces them
+
+
+def test_optimizer_is_driven_by_reference_shaped_callers(tmp_path):
+    """The drop-in boundary from the caller's side (mapper.py:62-66,104-130,161-175): the reference's Mapper constructs the
+    Optimizer from ITS Settings (AttrDict: lists become tuples on attribute access) and ITS WorldCube, hands iterate_optimizer windows
+    of ITS KeyFrame objects (CPU tensors, data_prep_on_cpu; Pose with get_pose_tensor / set_fixed / get_transformation_matrix) and
+    reads state back through _keyframe_count, _global_step and four state_dict() calls.  The stand-ins refuse every member the
+    reference classes do not have, so this run also proves that loner_amd touches nothing beyond that surface."""
+    from loner_amd.mapping.optimizer import Optimizer
+    from loner_amd.utils import synthetic as SY
+    gen = torch.Generator().manual_seed(3)
+    base = SY.trajectory_pose6(2)
+    init = [base[0].clone(), base[1] + torch.cat([torch.randn(3, generator=gen) * 0.02, torch.randn(3, generator=gen) * 0.003])]
+    kfs, wc, settings = _ref_shaped_window(init)
+    settings["log_directory"] = str(tmp_path)
+    assert isinstance(settings.keyframe_schedule, tuple) and isinstance(settings.model_config.model.ray_range, tuple)
+    torch.manual_seed(0)
+    opt = Optimizer(settings, None, wc, 0, False, True, False)              # the Mapper's call: mapper.py:62-66
+    # keyframe 0 alone (mapper.py:104: first keyframe), then the two-keyframe window
+    opt.iterate_optimizer([kfs[0]])
+    assert kfs[0].is_anchored and opt._keyframe_count == 1 and opt._global_step == 6
+    p0 = kfs[0].get_lidar_pose().get_pose_tensor().clone()
+    p1_before = kfs[1].get_lidar_pose().get_pose_tensor().detach().clone()
+    opt.iterate_optimizer(kfs)
+    assert opt._keyframe_count == 2 and opt._global_step == 6 + 3 + 5
+    # the anchored pose did not move, the other one was optimised IN PLACE on its CPU tensor (the Mapper keeps references to it)
+    assert torch.equal(kfs[0].get_lidar_pose().get_pose_tensor(), p0)
+    p1 = kfs[1].get_lidar_pose().get_pose_tensor()
+    assert p1.device.type == "cpu" and p1.requires_grad and not torch.equal(p1.detach(), p1_before)
+    assert torch.isfinite(p1).all() and float((p1.detach() - p1_before).abs().max()) < 0.1
+    # what Mapper.build_ckpt reads (mapper.py:161-175)
+    ck = {"global_step": opt._global_step, "network_state_dict": opt._model.state_dict(), "optimizer_state_dict": opt._optimizer.state_dict(),
+          "poses": [kf.get_pose_state() for kf in kfs], "occ_model_state_dict": opt._occupancy_grid_model.state_dict(),
+          "occ_optimizer_state_dict": opt._occupancy_grid_optimizer.state_dict()}
+    torch.save(ck, str(tmp_path / "ckpt.tar"))
+    assert set(ck["optimizer_state_dict"]) == {"state", "param_groups"} and len(ck["optimizer_state_dict"]["param_groups"]) == 2
+    assert [l.split(",")[0] for l in (tmp_path / "timing.csv").read_text().splitlines()] == ["6", "8"]     # optimizer.py:179-186
+    opt._global_step = 100                                                   # (rw: mapper.py:117)
+    # a pose that was optimised and is frozen afterwards enters with the matrix ITS Pose hands out - for the reference's class the one
+    # cached at construction (pose.py:140-144) - and use_gt_poses builds the rays from the ground-truth poses (keyframe.py:83-86)
+    kfs[1].get_lidar_pose().set_fixed(True)
+    stale = kfs[1].get_lidar_pose().get_transformation_matrix()
+    fresh = OP.transform_from_pose6(kfs[1].get_lidar_pose().get_pose_tensor().detach())
+    assert float((stale - fresh).abs().max()) > 1e-5                          # the cached matrix no longer matches the stepped vector
+    from loner_amd.mapping.optimizer import OptimizationSettings
+    seen = {}
+    import loner_amd.ops as OPS
+    orig = OPS.build_window_rays
+
+    def spy(tab, transforms, *a, **k):
+        seen["T"] = transforms.detach().cpu().clone()
+        return orig(tab, transforms, *a, **k)
+    OPS.build_window_rays = spy
+    try:
+        opt._do_iterate_optimizer(kfs, [None], optimizer_settings=OptimizationSettings(1, True, False, False, True))
+        assert rel(seen["T"][1].reshape(3, 4), stale[:3, :4]) < 1e-7
+        opt_gt = Optimizer(settings, None, wc, 0, True, True, False)
+        opt_gt._do_iterate_optimizer(kfs, [None], optimizer_settings=OptimizationSettings(1, False, False, False, True))
+        for k in range(2):
+            assert rel(seen["T"][k].reshape(3, 4), kfs[k]._frame._gt_lidar_pose.get_transformation_matrix()[:3, :4]) < 1e-7
+    finally:
+        OPS.build_window_rays = orig

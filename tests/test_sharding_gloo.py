@@ -173,3 +173,56 @@ def test_shard_window_round_robin():
     assert shard_window(8, 2, 1) == [1, 3, 5, 7]
     assert shard_window(3, 4, 3) == []
     assert sorted(sum((shard_window(8, 4, r) for r in range(4)), [])) == list(range(8))
+
+
+def _far0_window():
+    window, _ = _window()
+    for k, item in enumerate(window):            # give the first ray of every keyframe its own `far`: four distinguishable candidates
+        item[0][0, 12] = item[0][0, 11] + (0.2 + 0.1 * k) * (item[0][0, 12] - item[0][0, 11])
+    return window
+
+
+def _far0_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from loner_amd.mapping.sharding import NO_RAY_KEY, DistContext, first_ray_key
+    ctx = DistContext()
+    window = _far0_window()
+    out = {}
+    # which keyframes lost every candidate ray to the cube test (ray_utils.py:322): none / the first / both of rank 0 / all
+    for name, empty in (("none", ()), ("kf0", (0,)), ("kf0_kf2", (0, 2)), ("kf0_kf1", (0, 1)), ("all", (0, 1, 2, 3))):
+        idx = ctx.owned_indices(len(window))
+        kept = [window[i][0] if i not in empty else window[i][0][:0] for i in idx]
+        rays = torch.cat(kept)
+        seg_start = torch.tensor([0] + list(np.cumsum([k.shape[0] for k in kept])), dtype=torch.int32)
+        key = first_ray_key(rays, seg_start, [2 * i for i in idx])
+        if all(i in empty for i in idx):
+            assert int(key) == NO_RAY_KEY
+        far0 = ctx.broadcast_far0(rays, first_key=key)
+        assert far0.shape == (1,) and far0.dtype == torch.float32
+        out[name] = float(far0)
+        # a rank that owns no keyframe at all joins with rays = None (Optimizer._join_without_rays)
+    assert float(ctx.broadcast_far0(None, device="cpu") if rank == 1 else ctx.broadcast_far0(window[0][0])) == float(window[0][0][0, 12])
+    # the failure word at the end of a sharded phase: the earliest failing iteration wins, code and iteration stay a pair
+    word = lambda c, i: torch.tensor([c, i], dtype=torch.int32)
+    assert ctx.earliest_failure(word(0, 0)).tolist() == [0, 0]
+    assert ctx.earliest_failure(word(2, 7) if rank == 0 else word(1, 4)).tolist() == [1, 4]
+    assert ctx.earliest_failure(word(0, 0) if rank == 0 else word(3, 9)).tolist() == [3, 9]
+    assert ctx.earliest_failure(word(2, 5) if rank == 0 else word(1, 5)).tolist() == [1, 5]
+    ret[rank] = out
+    dist.destroy_process_group()
+
+
+def test_far0_is_the_first_kept_ray_of_the_window_whoever_owns_it():
+    """optimizer.py:460-461 compares every depth with far[0] of the WHOLE batch.  When the cube test drops every ray of the first
+    keyframe(s), that ray belongs to a later keyframe - possibly another rank's: one MIN all-reduce of (window order | far bits)."""
+    port = 30900 + (os.getpid() % 1000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_far0_worker, args=(2, port, ret), nprocs=2, join=True)
+    window = _far0_window()
+    first = lambda k: float(window[k][0][0, 12])
+    assert len({first(k) for k in range(4)}) == 4                       # the four candidates are distinguishable
+    for r in (0, 1):
+        assert ret[r]["none"] == first(0) and ret[r]["kf0"] == first(1) and ret[r]["kf0_kf2"] == first(1) and ret[r]["kf0_kf1"] == first(2)
+        assert np.isnan(ret[r]["all"])                                   # nobody has a ray: the value is never used
