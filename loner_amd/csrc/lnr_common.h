@@ -37,6 +37,9 @@ struct LnrProfScope {
     ~LnrProfScope() { lnr_profile_end(span, st); }
 };
 
+// lnr_rng_draws(LNR_DRAW_NOISE): the N(0,1) values lnr_render_* / lnr_los_loss_fused draw, from their own translation unit (lnr_render.hip)
+int lnr_render_noise_draws(uint64_t seed, int n_rays, int n_per_ray, float* out, hipStream_t st);
+
 static inline int lnr_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // Separately rounded float multiply / add.  __fmul_rn/__fadd_rn inline to plain fmul/fadd, which the backend may

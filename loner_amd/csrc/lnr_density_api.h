@@ -42,7 +42,7 @@ struct PointSrc {
 #define LNR_PAIR_FWD 1      /* encode_forward_pair_kernel (two lanes per sample) instead of encode_forward_kernel */
 #endif
 #ifndef LNR_SPLIT_DX
-#define LNR_SPLIT_DX 1      /* hash grids: the input gradient as a kernel of its own (encode_dx_pair_kernel), not inside the partition kernels */
+#define LNR_SPLIT_DX 0      /* 1: hash grids take the input gradient as a kernel of its own (encode_dx_pair_kernel); measured SLOWER */
 #endif
 #define LNR_ENC_PART_DX 1        /* lnr_encode_backward: the input gradient (d_pts / d_rays) */
 #define LNR_ENC_PART_RECORDS 2   /* lnr_encode_backward: the table-gradient records */

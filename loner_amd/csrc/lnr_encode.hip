@@ -60,13 +60,14 @@ encode_forward_kernel(const LnrNetSpec spec, const float* __restrict__ table, co
     const uint32_t plane_bytes = (uint32_t)m_pad * 4u;
     SampleCursor cur;
     cur.init((uint32_t)chunk * ENC_BLOCK + threadIdx.x, (uint32_t)bpg * ENC_BLOCK, src.pts ? 1u : (uint32_t)src.n_samples);
+    const bool uni = ray_uniform(src, 64u);
     for (; cur.m < Mt; cur.advance()) {
         float out[F];
 #pragma unroll
         for (int f = 0; f < F; ++f) out[f] = 0.0f;
         if (cur.m < M) {
             RawPoint rp;
-            load_raw_point(src, cur.m, cur.ray, rp);
+            load_raw_point(src, cur.m, cur.ray, rp, uni);
             float x[3];
             unit_point(src, rp, x);
             const Cell c = cell_of(L, x);
@@ -156,13 +157,14 @@ encode_forward_pair_kernel(const LnrNetSpec spec, const float* __restrict__ tabl
     const uint32_t hx = threadIdx.x & 1u;
     SampleCursor cur;
     cur.init((uint32_t)chunk * (ENC_BLOCK / 2) + (threadIdx.x >> 1), (uint32_t)bpg * (ENC_BLOCK / 2), src.pts ? 1u : (uint32_t)src.n_samples);
+    const bool uni = ray_uniform(src, 32u);
     for (; cur.m < Mt; cur.advance()) {            // both lanes of a pair leave the loop together
         float part[F];
 #pragma unroll
         for (int f = 0; f < F; ++f) part[f] = 0.0f;
         if (cur.m < M) {
             RawPoint rp;
-            load_raw_point(src, cur.m, cur.ray, rp);
+            load_raw_point(src, cur.m, cur.ray, rp, uni);
             float x[3];
             unit_point(src, rp, x);
             const Cell c = cell_of(L, x);
@@ -462,6 +464,7 @@ encode_dx_pair_kernel(const LnrNetSpec spec, const float* __restrict__ table, co
     SampleCursor cur;
     cur.init((uint32_t)chunk * (ENC_BLOCK / 2) + (threadIdx.x >> 1), step, src.pts ? 1u : (uint32_t)src.n_samples);
     const uint32_t last_ray = src.pts ? 0u : (M - 1u) / cur.S;
+    const bool uni = ray_uniform(src, 32u);
     for (uint32_t it = 0; it < n_iter; ++it) {
         const uint32_t m = cur.m;
         const bool live = m < M;
@@ -475,7 +478,7 @@ encode_dx_pair_kernel(const LnrNetSpec spec, const float* __restrict__ table, co
             any |= (g[f] != 0.0f);
         }
         RawPoint p;
-        load_raw_point(src, mc, live ? cur.ray : last_ray, p);
+        load_raw_point(src, mc, live ? cur.ray : last_ray, p, uni);
         const uint32_t ray_cur = cur.ray;
         cur.advance();
         const bool wave_any = __ballot(any) != 0ull;
@@ -618,6 +621,7 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
     SampleCursor cur;
     cur.init((uint32_t)chunk * ENC_BWD_BLOCK + threadIdx.x, step, src.pts ? 1u : (uint32_t)src.n_samples);
     const uint32_t last_ray = src.pts ? 0u : (M - 1u) / cur.S;
+    const bool uni = ray_uniform(src, 64u);          // (workgroups of 256 / 512 threads: a wave's 64 samples start at a multiple of 64)
     float g_next[F];
     RawPoint p_next;
     {
@@ -625,7 +629,7 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
         const uint32_t mc = in ? cur.m : M - 1u;
 #pragma unroll
         for (int f = 0; f < F; ++f) g_next[f] = ld32_stream<float>(gplanes, (uint32_t)f * plane_bytes + mc * 4u);
-        load_raw_point(src, mc, in ? cur.ray : last_ray, p_next);
+        load_raw_point(src, mc, in ? cur.ray : last_ray, p_next, uni);
     }
     PHASE_INIT();
     for (uint32_t it = 0; it < n_iter; ++it) {
@@ -644,7 +648,7 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
             const uint32_t mc = in ? cur.m : M - 1u;          // unconditional (clamped) loads: a static number in flight
 #pragma unroll
             for (int f = 0; f < F; ++f) g_next[f] = DBG_SKIP(32) ? ld32<float>(gplanes, (uint32_t)f * plane_bytes + mc * 4u) : ld32_stream<float>(gplanes, (uint32_t)f * plane_bytes + mc * 4u);
-            load_raw_point(src, mc, in ? cur.ray : last_ray, p_next);
+            load_raw_point(src, mc, in ? cur.ray : last_ray, p_next, uni);
         }
         const bool wave_any = __ballot(any) != 0ull;
         PHASE(0);
@@ -906,6 +910,7 @@ encode_backward_binned_kernel(const LnrNetSpec spec, const float* __restrict__ t
     SampleCursor cur;
     cur.init((uint32_t)chunk * BLK + threadIdx.x, step, src.pts ? 1u : (uint32_t)src.n_samples);
     const uint32_t last_ray = src.pts ? 0u : (M - 1u) / cur.S;
+    const bool uni = ray_uniform(src, 64u);          // (workgroups of 256 / 512 threads: a wave's 64 samples start at a multiple of 64)
     float g_next[F];
     RawPoint p_next;
     {
@@ -913,7 +918,7 @@ encode_backward_binned_kernel(const LnrNetSpec spec, const float* __restrict__ t
         const uint32_t mc = in ? cur.m : M - 1u;
 #pragma unroll
         for (int f = 0; f < F; ++f) g_next[f] = ld32_stream<float>(gplanes, (uint32_t)f * plane_bytes + mc * 4u);
-        load_raw_point(src, mc, in ? cur.ray : last_ray, p_next);
+        load_raw_point(src, mc, in ? cur.ray : last_ray, p_next, uni);
     }
     for (uint32_t it = 0; it < n_iter; ++it) {
         const uint32_t m = cur.m;
@@ -930,7 +935,7 @@ encode_backward_binned_kernel(const LnrNetSpec spec, const float* __restrict__ t
             const uint32_t mc = in ? cur.m : M - 1u;
 #pragma unroll
             for (int f = 0; f < F; ++f) g_next[f] = ld32_stream<float>(gplanes, (uint32_t)f * plane_bytes + mc * 4u);
-            load_raw_point(src, mc, in ? cur.ray : last_ray, p_next);
+            load_raw_point(src, mc, in ? cur.ray : last_ray, p_next, uni);
         }
         const bool wave_any = __ballot(any) != 0ull;
         Cell c;

@@ -68,10 +68,26 @@ struct SampleCursor {
 // written differently by the two modes ends up in scratch memory.
 struct RawPoint { float o0, o1, o2, d0, d1, d2, z; };
 
-__device__ __forceinline__ void load_raw_point(const PointSrc& s, uint32_t m, uint32_t ray, RawPoint& r) {
+// Ray records through the SCALAR cache when every lane of the wave sits on the same ray (rays form, samples per ray a multiple of the
+// wave's sample count: ray_uniform below).  A vector load costs the CU's address path ~16 clocks per wave instruction even when all 64
+// lanes read one dword (tools/gather_bench.hip: 3.3 lanes per clock and CU at best) - six of them per step were a tenth of the fine
+// levels' gather time and most of the coarse levels'; the scalar unit fetches the same six floats with one or two s_load instructions
+// that never touch that path.  The rays are read-only for the whole launch (constant address space: always selected as SMEM).
+typedef const float __attribute__((address_space(4))) lnr_cfloat;
+__device__ __forceinline__ bool ray_uniform(const PointSrc& s, uint32_t samples_per_wave) {
+    return s.pts == nullptr && ((uint32_t)s.n_samples % samples_per_wave) == 0u;
+}
+
+// uni: ray_uniform() holds for the calling wave (wave-uniform flag); `ray` of the first active lane then stands for all of them
+__device__ __forceinline__ void load_raw_point(const PointSrc& s, uint32_t m, uint32_t ray, RawPoint& r, bool uni = false) {
     if (s.pts) {
         r.o0 = ld32<float>(s.pts, m * 12u); r.o1 = ld32<float>(s.pts, m * 12u + 4u); r.o2 = ld32<float>(s.pts, m * 12u + 8u);
         r.d0 = 0.0f; r.d1 = 0.0f; r.d2 = 0.0f; r.z = 0.0f;
+    } else if (uni) {
+        const uint32_t ru = (uint32_t)__builtin_amdgcn_readfirstlane((int)ray);
+        const lnr_cfloat* rp = (const lnr_cfloat*)(uintptr_t)(s.rays + (size_t)ru * LNR_RAY_STRIDE);
+        r.o0 = rp[0]; r.o1 = rp[1]; r.o2 = rp[2]; r.d0 = rp[3]; r.d1 = rp[4]; r.d2 = rp[5];
+        r.z = ld32<float>(s.z, m * 4u);
     } else {
         const uint32_t ro = ray * (uint32_t)(LNR_RAY_STRIDE * 4);
         r.o0 = ld32<float>(s.rays, ro); r.o1 = ld32<float>(s.rays, ro + 4u); r.o2 = ld32<float>(s.rays, ro + 8u);

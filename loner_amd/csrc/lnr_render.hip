@@ -594,3 +594,19 @@ extern "C" int lnr_points_grad_to_rays(const float* d_pts, const float* z, int32
     LNR_CHECK_LAUNCH("lnr_points_grad_to_rays");
     return LNR_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------ diagnostics
+// lnr_rng_draws(LNR_DRAW_NOISE) (include/loner_hip.h): lnr_rand_normal exactly as render_ray evaluates it
+__global__ void noise_draws_kernel(uint64_t seed, int n_rays, int n_per_ray, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n_rays * n_per_ray) return;
+    out[i] = lnr_rand_normal(seed, (uint64_t)(i / n_per_ray), (uint32_t)(i % n_per_ray));
+}
+
+int lnr_render_noise_draws(uint64_t seed, int n_rays, int n_per_ray, float* out, hipStream_t st) {
+    const int64_t n = (int64_t)n_rays * n_per_ray;
+    hipLaunchKernelGGL(noise_draws_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, seed, n_rays, n_per_ray, out);
+    LNR_CHECK_LAUNCH("lnr_rng_draws");
+    return LNR_OK;
+}

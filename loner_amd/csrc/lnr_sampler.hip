@@ -327,7 +327,6 @@ __global__ void rng_draws_kernel(int which, uint64_t seed, int n_rays, int n_per
     float v;
     if (which == LNR_DRAW_JITTER) v = lnr_rand_uniform(seed, LNR_STREAM_JITTER, ray, j);
     else if (which == LNR_DRAW_PDF) v = lnr_rand_uniform(seed, LNR_STREAM_PDF, ray, j);
-    else if (which == LNR_DRAW_NOISE) v = lnr_rand_normal(seed, ray, j);
     else v = lnr_rand_uniform(seed, 0x44ull + (uint64_t)(which - LNR_DRAW_RAY_INDEX), (uint64_t)i >> 2, (uint32_t)i & 3u);   // build_window_rays_kernel
     out[i] = v;
 }
@@ -337,6 +336,9 @@ extern "C" int lnr_rng_draws(int32_t which, uint64_t seed, int32_t n_rays, int32
     LNR_REQUIRE(which == LNR_DRAW_JITTER || which == LNR_DRAW_PDF || which == LNR_DRAW_NOISE || which >= LNR_DRAW_RAY_INDEX, "lnr_rng_draws: unknown draw %d", which);
     const int64_t n = (int64_t)n_rays * n_per_ray;
     if (n == 0) return LNR_OK;
+    // the density noise is evaluated in the translation unit of the kernels that use it (lnr_render.hip: this file is compiled with
+    // -ffp-contract=off, that one is not, and the libm calls of the Box-Muller step inline differently under the two)
+    if (which == LNR_DRAW_NOISE) return lnr_render_noise_draws(seed, n_rays, n_per_ray, out, (hipStream_t)stream);
     hipLaunchKernelGGL(rng_draws_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, which, seed, n_rays, n_per_ray, out);
     LNR_CHECK_LAUNCH("lnr_rng_draws");
     return LNR_OK;

@@ -149,7 +149,14 @@ class OracleMapper:
 
     # ---- the optimisation loop ---------------------------------------------------------
     def iterate(self, window: List[OracleKeyframe], n_iters: int, freeze_poses=False,
-                freeze_sigma=False, draws=None, latest_kf_only=False):
+                freeze_sigma=False, draws=None, latest_kf_only=False, stop_after_s=None, min_iters=0, sync=None):
+        """stop_after_s / min_iters / sync (bench.py's bounded baseline legs): leave the loop once that much wall time has passed
+        (after at least min_iters iterations; sync() is called per iteration to finish the device's work first) - ONE optimisation
+        phase with ONE Adam, cut short, instead of many one-iteration phases that would each start a fresh Adam.
+        self.last_iterations says how many iterations ran."""
+        import time as _time
+        t_start = _time.time()
+        self.last_iterations = 0
         draws = draws or self.draws
         cfg = self.cfg
         if len(window) == 1:
@@ -197,6 +204,12 @@ class OracleMapper:
                 g = depths.reshape(-1, 1) * self.scale
                 self.grid = OC.grid_step(self.grid, aux["xyz"], aux["z"] * self.scale, g, cfg.occ_lr)
             self.global_step += 1
+            self.last_iterations = it + 1
+            if stop_after_s is not None:
+                if sync is not None:
+                    sync()
+                if it + 1 >= min_iters and _time.time() - t_start >= stop_after_s:
+                    break
         self.params.requires_grad_(False)
         for kf in window:
             kf.pose6.requires_grad_(False)

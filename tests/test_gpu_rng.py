@@ -109,7 +109,7 @@ def test_seeded_kernels_use_exactly_these_draws():
     a = ops.render_forward(sigma, z_seed, rays, noise_std=1.0, seed=seed)
     b = ops.render_forward(sigma, z_seed, rays, noise=noise, noise_std=1.0)
     for x, y in zip(a, b):
-        assert torch.equal(x, y)
+        assert torch.equal(x, y), float((x - y).abs().max())
     depths = torch.full((n,), 0.2, device=DEV)
     cfg = hip.LossConfig(selection=0, min_js=1.0, max_js=10.0, js_alpha=1.0, los_lambda=1000.0, depth_lambda=0.005, min_eps=0.5, fixed_eps=3.0)
     counts = ops.count_opaque(rays, depths)
