@@ -695,7 +695,10 @@ def test_fp16_mode_config5_4096x256(ops):
           f"drays {e_gr_model:.2e} / {e_gr_fp32:.2e}; rendered depth fp16-vs-fp32 rel {e_depth:.2e}")
     # (a) kernel vs the same storage model: forward is fp32-accumulated either way -> fp32 noise; backward adds the fp16 rounding
     # of dZ (2^-11 relative per element, averaged down by the sums it enters)
-    assert e_sig_model < 2e-5
+    # (sigma: the encoded features are rounded to fp16, so an fp32 feature one ulp off the oracle's - the pair kernel of the forward
+    # sums the eight corner terms as two interleaved chains of four, the oracle as one chain of eight - lands on the neighbouring fp16
+    # value once in ~2^13 features: 2^-11 of one feature's contribution, 6e-5 of max |sigma| in the worst sample; 2e-7 otherwise)
+    assert e_sig_model < 1e-4
     assert e_gp_model < 1e-3 and e_gr_model < 2e-3
     # (b) storage error of fp16 features and weights: 2^-11 per rounded operand; sigma sums 32 + 64 rounded products.  The ray
     # gradient is the most sensitive output: d/dx multiplies each level's d_feature (perturbed by ~5e-4) with differences of
