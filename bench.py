@@ -353,6 +353,61 @@ def north_star_network_leg(n_rays, n_samples, device):
             "note": "backward = weight + input gradients incl. the encoding's backward, features reused from the forward (the training loop's route)"}
 
 
+def make_bench_optimizer(rays, samples, dtype="f32", device_index=0, rank=0, params0=None):
+    """The Optimizer of the benchmark: default settings, `rays` per keyframe x `samples` per ray, no sky rays, density network in
+    `dtype`; params0 (optional): initial density parameters (the quality legs all start from oracle.network.init_params(spec, 0))."""
+    from loner_amd.common.pose_utils import WorldCube
+    from loner_amd.common.settings import default_optimizer_settings
+    from loner_amd.mapping.optimizer import Optimizer
+    from loner_amd.utils import synthetic as SY
+    scale, shift = SY.world_cube()
+    settings = default_optimizer_settings(log_directory=f"/tmp/loner_amd_bench_{rank}")
+    settings["num_samples"]["lidar"] = rays
+    settings["num_samples"]["sky"] = 0
+    settings["model_config"]["model"]["render"]["N_samples_train"] = samples
+    settings["model_config"]["model"]["nerf_config"]["sigma_network"]["precision"] = "fp16" if dtype == "f16" else "fp32"
+    torch.manual_seed(0)                               # identical initial parameters on every rank
+    o = Optimizer(settings, None, WorldCube(torch.tensor(scale), torch.from_numpy(shift)), device_index, False, True, False)
+    if params0 is not None:
+        with torch.no_grad():
+            o._model.nerf_model._model_sigma.params.copy_(params0.to(o._device))
+    return o
+
+
+def l1_probe(o, kf0, max_rays):
+    """analysis/compute_l1_depth.py semantics on keyframe kf0 with the optimiser's map"""
+    from loner_amd.analysis.l1_depth import compute_l1_depth
+    from loner_amd.common.ray_utils import LidarRayDirections
+    return compute_l1_depth(kf0.get_lidar_pose(), LidarRayDirections(kf0.get_lidar_scan(), chunk_size=2048), o._model,
+                            o._ray_sampler, o._world_cube, o._ray_range, o._device, max_rays=max_rays)
+
+
+def quality_initial_params():
+    from oracle import network as NW
+    from loner_amd.common.settings import default_nerf_config
+    nc = default_nerf_config()
+    return NW.init_params(NW.NetworkSpec.from_config(nc["pos_encoding_sigma"], nc["sigma_network"]), 0)
+
+
+def hip_quality_run(seed, iters=None, shape=None, device_index=0):
+    """One run of the HIP path on the quality configuration (QUALITY_SHAPE, the G13 fixture's) with its own random draws seeded by
+    `seed`: L1 depth of L1_RAYS held-out rays of keyframe 0 before and after `iters` iterations of ONE optimisation phase."""
+    from loner_amd.mapping.optimizer import OptimizationSettings
+    q = shape or QUALITY_SHAPE
+    iters = QUALITY_ITERS if iters is None else iters
+    o, w = make_bench_optimizer(q.rays, q.samples, "f32", device_index, params0=quality_initial_params()), build_window(q.keyframes)
+    o._model.cfg["render"]["N_samples_test"] = 256
+    torch.manual_seed(123)
+    l1_0 = l1_probe(o, w[0], L1_RAYS)
+    torch.manual_seed(seed)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    o._do_iterate_optimizer(w, [None], optimizer_settings=OptimizationSettings(iters, False, False, False, True))
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    torch.manual_seed(123)
+    return {"value": o.last_stats["n_valid_rays"] / dt, "unit": "rays/s", "ms_per_iter": 1e3 * dt / max(iters, 1),
+            "l1_depth_m_before": l1_0, "l1_depth_m_after": l1_probe(o, w[0], L1_RAYS)}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -412,17 +467,7 @@ def main():
     scale, shift = SY.world_cube()
 
     def make_optimizer(dtype, params0=None):
-        settings = default_optimizer_settings(log_directory=f"/tmp/loner_amd_bench_{rank}")
-        settings["num_samples"]["lidar"] = args.rays
-        settings["num_samples"]["sky"] = 0
-        settings["model_config"]["model"]["render"]["N_samples_train"] = args.samples
-        settings["model_config"]["model"]["nerf_config"]["sigma_network"]["precision"] = "fp16" if dtype == "f16" else "fp32"
-        torch.manual_seed(0)                               # identical initial parameters on every rank
-        o = Optimizer(settings, None, WorldCube(torch.tensor(scale), torch.from_numpy(shift)), local, False, True, False)
-        if params0 is not None:
-            with torch.no_grad():
-                o._model.nerf_model._model_sigma.params.copy_(params0.to(o._device))
-        return o
+        return make_bench_optimizer(args.rays, args.samples, dtype, local, rank, params0)
 
     opt = make_optimizer(args.dtype)
     window = build_window(args.keyframes)
@@ -664,31 +709,11 @@ def main():
             except Exception as e:
                 legs["torch_rocm_oracle"].append({"error": str(e)})
         legs["hip_f32"] = []
-        try:
-            from oracle import network as NW
-            from loner_amd.common.settings import default_nerf_config
-            nc = default_nerf_config()
-            p0 = NW.init_params(NW.NetworkSpec.from_config(nc["pos_encoding_sigma"], nc["sigma_network"]), 0)     # the legs' initial parameters
-            keep = (args.rays, args.samples)
-            for sd in seeds:
-                args.rays, args.samples = q.rays, q.samples
-                try:
-                    o3, w3 = make_optimizer("f32", params0=p0), build_window(q.keyframes)
-                finally:
-                    args.rays, args.samples = keep
-                o3._model.cfg["render"]["N_samples_test"] = 256
-                torch.manual_seed(123)
-                l1_0 = l1_of(o3, w3[0], L1_RAYS)
-                torch.manual_seed(sd)
-                torch.cuda.synchronize(); t3 = time.perf_counter()
-                o3._do_iterate_optimizer(w3, [None], optimizer_settings=phase(QUALITY_ITERS))
-                torch.cuda.synchronize(); dt3 = time.perf_counter() - t3
-                torch.manual_seed(123)
-                legs["hip_f32"].append({"value": o3.last_stats["n_valid_rays"] / dt3, "unit": "rays/s", "ms_per_iter": 1e3 * dt3 / QUALITY_ITERS,
-                                        "l1_depth_m_before": l1_0, "l1_depth_m_after": l1_of(o3, w3[0], L1_RAYS)})
-                del o3, w3
-        except Exception as e:
-            legs["hip_f32"].append({"error": str(e)})
+        for sd in seeds:
+            try:
+                legs["hip_f32"].append(hip_quality_run(sd, device_index=local))
+            except Exception as e:
+                legs["hip_f32"].append({"error": str(e)})
 
         def stats_of(runs, key):
             v = [r[key] for r in runs if isinstance(r.get(key), float)]

@@ -19,6 +19,40 @@
 
 #define ENC_BLOCK 256
 
+// Which level group ("slot") and which chunk of it a workgroup works on.
+// Plain order: slot = blockIdx / bpg - the chip walks the levels one after the other, and EVERY XCD pulls every level's table (<= 2 MB)
+// into its own L2: 8 x 30 MB of fabric reads per launch whatever the batch size (the per-launch floor of a one-keyframe shard:
+// profiles/r03_trace_one_keyframe_iteration.txt, 86 us for 262 k samples against 0.46 ms for 2.1 M).
+// XCD-affine order (n_slots a multiple of 8): the hardware hands workgroup b to XCD b % 8 (MI355X_MICROARCH.md; used for speed only,
+// nothing depends on it), so slot = (b % 8) + 8 * ((b / 8) / bpg) gives every XCD its own levels - x, x + 8, ... one after the other:
+// a table is read into ONE L2, and a coarse and a fine level per XCD keep the eight XCDs' work even (default network: 16 levels).
+__device__ __forceinline__ bool level_slot(int bpg, int n_slots, bool xcd_affine, int& slot, int& chunk) {
+    if (xcd_affine) {
+        const int r = (int)(blockIdx.x >> 3);
+        slot = (int)(blockIdx.x & 7u) + 8 * (r / bpg);
+        chunk = r % bpg;
+    } else {
+        slot = (int)blockIdx.x / bpg;
+        chunk = (int)blockIdx.x % bpg;
+    }
+    return slot < n_slots;
+}
+// Measured (profiles/r04_call3_xcd_affine_ab.log): the forward of a one-keyframe shard (262 k samples) 113 -> 77 us, of the bench window
+// (2.1 M samples) 0.43 -> 0.50 ms - with eight XCDs each walking its own two levels the chip is never on ONE level's working set, and a
+// long launch is dispatched less regularly than b % 8; the backward's partition kernels lose at both sizes.  Hence: the forward only,
+// and only for launches small enough that the table fills dominate.
+#ifndef LNR_XCD_AFFINE_MAX_POINTS
+#define LNR_XCD_AFFINE_MAX_POINTS (1 << 19)
+#endif
+static inline bool lnr_xcd_affine(int n_slots, int64_t n_points, bool forward) {
+    bool on = forward && n_points <= LNR_XCD_AFFINE_MAX_POINTS;
+#ifdef LNR_ABLATE
+    static const char* env = getenv("LNR_X_XCD");                 // development builds: 0 / 1 force it off / on for every encode kernel
+    if (env) on = atoi(env) != 0;
+#endif
+    return on && n_slots > 0 && n_slots % 8 == 0;
+}
+
 // the n-th (0-based) set bit of mask: the level a workgroup group works on (level_mask = all levels outside ablation builds)
 __device__ __forceinline__ int nth_level(uint32_t mask, int n) {
     for (int i = 0; i < n; ++i) mask &= mask - 1u;
@@ -49,9 +83,11 @@ __device__ __forceinline__ void gather_entries(const float* __restrict__ table, 
 template <int F, bool H16>
 __global__ void __launch_bounds__(ENC_BLOCK)
 encode_forward_kernel(const LnrNetSpec spec, const float* __restrict__ table, const PointSrc src, float* __restrict__ feat,
-                      int64_t m_pad, int bpg, uint32_t level_mask) {
+                      int64_t m_pad, int bpg, uint32_t level_mask, int xcd_affine) {
     static_assert(!H16 || F >= 2, "half2 planes pair up the features of a level");
-    const int lv = nth_level(level_mask, blockIdx.x / bpg), chunk = blockIdx.x % bpg;
+    int slot, chunk;
+    if (!level_slot(bpg, __builtin_popcount(level_mask), xcd_affine != 0, slot, chunk)) return;
+    const int lv = nth_level(level_mask, slot);
     const LevelInfo L = level_info(spec, lv);
     const uint32_t M = (uint32_t)live_points(src);
     // the MLP kernels read whole tiles of 16 (fp32) / 32 (fp16) samples: zero the ragged tail
@@ -146,9 +182,11 @@ __device__ __forceinline__ void gather_entries4(const float* __restrict__ table,
 template <int F, bool H16>
 __global__ void __launch_bounds__(ENC_BLOCK)
 encode_forward_pair_kernel(const LnrNetSpec spec, const float* __restrict__ table, const PointSrc src, float* __restrict__ feat,
-                           int64_t m_pad, int bpg, uint32_t level_mask) {
+                           int64_t m_pad, int bpg, uint32_t level_mask, int xcd_affine) {
     static_assert(!H16 || F >= 2, "half2 planes pair up the features of a level");
-    const int lv = nth_level(level_mask, blockIdx.x / bpg), chunk = blockIdx.x % bpg;
+    int slot, chunk;
+    if (!level_slot(bpg, __builtin_popcount(level_mask), xcd_affine != 0, slot, chunk)) return;
+    const int lv = nth_level(level_mask, slot);
     const LevelInfo L = level_info(spec, lv);
     const uint32_t M = (uint32_t)live_points(src);
     const uint32_t Mt = H16 ? (M + 31u) / 32u * 32u : (M + 15u) / 16u * 16u;      // the MLP kernels read whole tiles: zero the ragged tail
@@ -297,6 +335,7 @@ struct EncSink {
     RegionPlan plan;
     int* counts;            // [level][maxo][chunk]
     int maxo, shift;
+    int xcd_affine;         // level_slot(): the launch's levels one per XCD (list.n a multiple of 8)
 #ifdef LNR_ABLATE
     int dbg;                // ablation bits (LNR_X_DBG), development builds only
 #endif
@@ -448,9 +487,11 @@ ray_grad_apply_kernel(const long long* __restrict__ ray_acc, int n_rays, const i
 template <int F, int DXM>
 __global__ void __launch_bounds__(ENC_BLOCK)
 encode_dx_pair_kernel(const LnrNetSpec spec, const float* __restrict__ table, const PointSrc src, const float* __restrict__ dfeat,
-                      float* __restrict__ dxl, int64_t m_pad, int bpg, uint32_t level_mask) {
+                      float* __restrict__ dxl, int64_t m_pad, int bpg, uint32_t level_mask, int xcd_affine) {
     static_assert(DXM != ENC_DX_NONE, "nothing to compute");
-    const int lv = nth_level(level_mask, blockIdx.x / bpg), chunk = blockIdx.x % bpg;
+    int slot, chunk;
+    if (!level_slot(bpg, __builtin_popcount(level_mask), xcd_affine != 0, slot, chunk)) return;
+    const int lv = nth_level(level_mask, slot);
     const LevelInfo L = level_info(spec, lv);
     const int lane = threadIdx.x & 63;
     const uint32_t hx = threadIdx.x & 1u;
@@ -585,7 +626,9 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
     void* stage = reinterpret_cast<void*>(dyn + 2 * maxo4 + 4 * maxo);
     for (int i = threadIdx.x; i < maxo; i += ENC_BWD_BLOCK) { cnt[i] = 0; gcur[i] = 0; }
     __syncthreads();
-    const int lv = list.lv[blockIdx.x / bpg], chunk = blockIdx.x % bpg;
+    int slot, chunk;
+    if (!level_slot(bpg, list.n, sink.xcd_affine != 0, slot, chunk)) return;          // (workgroup-uniform)
+    const int lv = list.lv[slot];
     const LevelInfo L = level_info(spec, lv);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t M = (uint32_t)live_points(src);
@@ -599,7 +642,7 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
     const int cap_rec = (int)(region_bytes / rec_bytes);                   // a region's capacity in records of this level's format
     const char* level_regions = reinterpret_cast<const char*>(sink.regions) + sink.plan.off[lv];
     // region of (level, owner o, chunk): [level][owner][chunk] - the reduce of one owner streams its chunks' regions back to back
-    const int ovf_off = list.slab_off[blockIdx.x / bpg];
+    const int ovf_off = list.slab_off[slot];
     long long* ovf = ovf_off >= 0 ? sink.ovf + ovf_off : nullptr;                // indexed by float index inside the level
     const uint32_t level_base = L.offset * F;
     const size_t region0 = (size_t)lv * maxo * bpg + chunk;
@@ -872,7 +915,9 @@ encode_backward_binned_kernel(const LnrNetSpec spec, const float* __restrict__ t
     int* fill = dyn;                                             // [64] bytes in the owner's bin (tail + this batch's records)
     char* stage = reinterpret_cast<char*>(dyn + 64);             // [64][BIN]
     const int maxo = sink.maxo;                                  // <= 64 (host)
-    const int lv = list.lv[blockIdx.x / bpg], chunk = blockIdx.x % bpg;
+    int slot, chunk;
+    if (!level_slot(bpg, list.n, sink.xcd_affine != 0, slot, chunk)) return;          // (workgroup-uniform)
+    const int lv = list.lv[slot];
     const LevelInfo L = level_info(spec, lv);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t M = (uint32_t)live_points(src);
@@ -880,7 +925,7 @@ encode_backward_binned_kernel(const LnrNetSpec spec, const float* __restrict__ t
     const bool combine = !xp && L.scale < sink.combine_scale_max;
     const uint32_t region_bytes = sink.plan.bytes[lv];
     char* level_regions = reinterpret_cast<char*>(sink.regions) + sink.plan.off[lv];
-    const int ovf_off = list.slab_off[blockIdx.x / bpg];
+    const int ovf_off = list.slab_off[slot];
     long long* ovf = sink.ovf + ovf_off;
     const uint32_t level_base = L.offset * F;
     const size_t region0 = (size_t)lv * maxo * bpg + chunk;
@@ -1198,10 +1243,11 @@ int lnr_encode_forward(const LnrNetSpec* spec, const float* params, const PointS
     if (level_mask == 0u) return LNR_OK;
 #endif
     const dim3 mgrid((unsigned)(__builtin_popcount(level_mask) * bpg));
+    const int xcd = lnr_xcd_affine(__builtin_popcount(level_mask), cap_points, true) ? 1 : 0;
 #if LNR_PAIR_FWD
     {
         const dim3 pgrid((unsigned)(__builtin_popcount(level_mask) * bpg));
-#define LNR_FWD_PAIR(F, H) hipLaunchKernelGGL((encode_forward_pair_kernel<F, H>), pgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask)
+#define LNR_FWD_PAIR(F, H) hipLaunchKernelGGL((encode_forward_pair_kernel<F, H>), pgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask, xcd)
         if (half_planes) {
             switch (spec->n_features) {
                 case 2: LNR_FWD_PAIR(2, true); break;
@@ -1223,18 +1269,18 @@ int lnr_encode_forward(const LnrNetSpec* spec, const float* params, const PointS
 #endif
     if (half_planes) {
         switch (spec->n_features) {
-            case 2: hipLaunchKernelGGL((encode_forward_kernel<2, true>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask); break;
-            case 4: hipLaunchKernelGGL((encode_forward_kernel<4, true>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask); break;
-            case 8: hipLaunchKernelGGL((encode_forward_kernel<8, true>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask); break;
+            case 2: hipLaunchKernelGGL((encode_forward_kernel<2, true>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask, xcd); break;
+            case 4: hipLaunchKernelGGL((encode_forward_kernel<4, true>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask, xcd); break;
+            case 8: hipLaunchKernelGGL((encode_forward_kernel<8, true>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask, xcd); break;
             default: lnr_set_error("fp16 feature planes pair up features: n_features_per_level must be even"); return LNR_ERR_UNSUPPORTED;
         }
         return LNR_OK;
     }
     switch (spec->n_features) {
-        case 1: hipLaunchKernelGGL((encode_forward_kernel<1, false>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask); break;
-        case 2: hipLaunchKernelGGL((encode_forward_kernel<2, false>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask); break;
-        case 4: hipLaunchKernelGGL((encode_forward_kernel<4, false>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask); break;
-        default: hipLaunchKernelGGL((encode_forward_kernel<8, false>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask); break;
+        case 1: hipLaunchKernelGGL((encode_forward_kernel<1, false>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask, xcd); break;
+        case 2: hipLaunchKernelGGL((encode_forward_kernel<2, false>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask, xcd); break;
+        case 4: hipLaunchKernelGGL((encode_forward_kernel<4, false>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask, xcd); break;
+        default: hipLaunchKernelGGL((encode_forward_kernel<8, false>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask, xcd); break;
     }
     return LNR_OK;
 }
@@ -1273,11 +1319,12 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
         if (b < 1) b = 1;
         if (b > 2048) b = 2048;
         const dim3 dgrid((unsigned)(__builtin_popcount(level_mask) * b)), dblock(ENC_BLOCK);
+        const int xcd = lnr_xcd_affine(__builtin_popcount(level_mask), cap_points, false) ? 1 : 0;
         LnrProfScope prof("encode_dx", st);
 #define LNR_LAUNCH_DXP(F)                                                                                                                   \
         do {                                                                                                                               \
-            if (dxm == ENC_DX_RAYS) hipLaunchKernelGGL((encode_dx_pair_kernel<F, ENC_DX_RAYS>), dgrid, dblock, 0, st, *spec, table, *src, dfeat, dx_out, m_pad, (int)b, level_mask); \
-            else hipLaunchKernelGGL((encode_dx_pair_kernel<F, ENC_DX_PLANES>), dgrid, dblock, 0, st, *spec, table, *src, dfeat, dx_out, m_pad, (int)b, level_mask);               \
+            if (dxm == ENC_DX_RAYS) hipLaunchKernelGGL((encode_dx_pair_kernel<F, ENC_DX_RAYS>), dgrid, dblock, 0, st, *spec, table, *src, dfeat, dx_out, m_pad, (int)b, level_mask, xcd); \
+            else hipLaunchKernelGGL((encode_dx_pair_kernel<F, ENC_DX_PLANES>), dgrid, dblock, 0, st, *spec, table, *src, dfeat, dx_out, m_pad, (int)b, level_mask, xcd);               \
         } while (0)
         if (level_mask != 0u) switch (spec->n_features) {
             case 1: LNR_LAUNCH_DXP(1); break;
@@ -1342,10 +1389,12 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
             const size_t lds = (size_t)(2 * maxo4 + 4 * maxo) * sizeof(int) + (size_t)ENC_STAGE_RECORDS * (spec->n_features >= 2 ? 16 : 8);
             if (rec_levels.n > 0) {
                 const dim3 grid((unsigned)(rec_levels.n * bpg));
+                sink.xcd_affine = lnr_xcd_affine(rec_levels.n, cap_points, false) ? 1 : 0;
                 LNR_LAUNCH_F(encode_backward_kernel, *spec, table, *src, dfeat, dx_out, m_pad, bpg, rec_levels, sink);
             }
             if (xp_levels.n > 0) {                                          // n_features == 2
                 const dim3 grid((unsigned)(xp_levels.n * bpg));
+                sink.xcd_affine = lnr_xcd_affine(xp_levels.n, cap_points, false) ? 1 : 0;
                 LNR_LAUNCH_DXM(encode_backward_kernel, 2, true, *spec, table, *src, dfeat, dx_out, m_pad, bpg, xp_levels, sink);
             }
             {
@@ -1356,6 +1405,7 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
 #define LNR_LAUNCH_BINNED(F, XP, LIST)                                                                                              \
                 do {                                                                                                                \
                     const dim3 grid_b((unsigned)((LIST).n * bpg));                                                                  \
+                    sink.xcd_affine = lnr_xcd_affine((LIST).n, cap_points, false) ? 1 : 0;                                                             \
                     const void* fn_ = nullptr;                                                                                      \
                     if (nw == 8) fn_ = dxm_part == ENC_DX_RAYS ? (const void*)encode_backward_binned_kernel<F, ENC_DX_RAYS, XP, 8>       \
                                      : dxm_part == ENC_DX_PLANES ? (const void*)encode_backward_binned_kernel<F, ENC_DX_PLANES, XP, 8>   \

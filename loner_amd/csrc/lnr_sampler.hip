@@ -135,16 +135,18 @@ __device__ void aten_row_sum(const float* x, int K, float* part /*[32]*/, float*
 // bitonic sort of n_pow2 floats in LDS (ascending).  Each of the four waves owns a contiguous quarter of the array: a pass whose
 // partner distance j is at most an eighth of the array exchanges inside the quarters, so it needs no workgroup barrier (a wave's LDS
 // operations complete in order) - of the 45 passes of a 512-element sort (78 of a 4096-element one) only the three with j >= n / 4 do.
-__device__ void bitonic_sort_lds(float* a, int n_pow2) {
+// descending: the mirrored network (every comparison flipped).  k_first: the first stage to run - n_pow2 runs only the last stage,
+// the bitonic MERGE of an array whose first half ascends and whose second half descends.
+__device__ void bitonic_sort_lds(float* a, int n_pow2, bool descending = false, int k_first = 2) {
     auto exchange = [&](int t, int j, int k) {
         const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));       // lower index of the pair
         const int p = i | j;
-        const bool up = ((i & k) == 0);
+        const bool up = ((i & k) == 0) != descending;
         const float x = a[i], y = a[p];
         if ((x > y) == up) { a[i] = y; a[p] = x; }
     };
-    if (n_pow2 < 512) {
-        for (int k = 2; k <= n_pow2; k <<= 1) {
+    if (n_pow2 < 256) {                                             // (a quarter of fewer than 64 elements: not worth the wave-local form)
+        for (int k = k_first; k <= n_pow2; k <<= 1) {
             for (int j = k >> 1; j > 0; j >>= 1) {
                 for (int t = threadIdx.x; t < n_pow2 / 2; t += SAMPLER_BLOCK) exchange(t, j, k);
                 __syncthreads();
@@ -155,7 +157,7 @@ __device__ void bitonic_sort_lds(float* a, int n_pow2) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int quarter_pairs = n_pow2 / 8;                          // pairs inside a wave's quarter (n / 4 elements)
     bool local_before = false;
-    for (int k = 2; k <= n_pow2; k <<= 1) {
+    for (int k = k_first; k <= n_pow2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             if (8 * j <= n_pow2) {                                  // partners inside the wave's quarter
                 for (int t = wave * quarter_pairs + lane; t < (wave + 1) * quarter_pairs; t += 64) exchange(t, j, k);
@@ -244,6 +246,7 @@ sample_occ_kernel(const float* __restrict__ rays, int n_rays, const int32_t* __r
     if (dbg_cdf) for (int k = threadIdx.x; k <= K; k += SAMPLER_BLOCK) dbg_cdf[(size_t)ray * (K + 1) + k] = cdf[k];
 
     // inverse-cdf samples (rendering_tcnn.py:50-67); bins[k] = 0.5*(zc[k]+zc[k+1]), k = 0..K
+    bool unsorted = false;
     for (int j = threadIdx.x; j < H; j += SAMPLER_BLOCK) {
         const float u = u_pdf ? u_pdf[(size_t)ray * H + j] : lnr_rand_uniform(seed, LNR_STREAM_PDF, (uint64_t)ray, (uint32_t)j);
         // searchsorted(right=True): number of cdf entries <= u (cdf has K+1 entries, ascending)
@@ -263,11 +266,21 @@ sample_occ_kernel(const float* __restrict__ rays, int n_rays, const int32_t* __r
         const float smp = b0 + (u - c0) / denom * (b1 - b0);
         merged[H + j] = smp;
         merged[j] = zc[j];
+        unsorted |= (j + 1 < H) && (zc[j] > zc[j + 1]);
         if (dbg_inds) dbg_inds[(size_t)ray * H + j] = ind;
     }
     for (int j = S + threadIdx.x; j < P2; j += SAMPLER_BLOCK) merged[j] = __builtin_inff();
-    __syncthreads();
-    bitonic_sort_lds(merged, P2);
+    // sort(cat(coarse, importance)) (ray_sampling.py:90; only the values matter).  The coarse depths already ascend (a jittered depth
+    // stays inside its stratum), so when S is a power of two the full network is not needed: the importance half is sorted DESCENDING
+    // by the four waves (a network of half the size), and the last stage of the full network merges the two halves - 36 + 9 instead
+    // of 45 passes at S = 512, the 36 of them over half the pairs.  Same values out, whatever the route; any inversion among the coarse
+    // depths (none has been seen) sends the ray down the full sort.
+    if (__syncthreads_or(unsorted ? 1 : 0) == 0 && P2 == S && H >= 64) {
+        bitonic_sort_lds(merged + H, H, true);
+        bitonic_sort_lds(merged, P2, false, P2);
+    } else {
+        bitonic_sort_lds(merged, P2);
+    }
     for (int j = threadIdx.x; j < S; j += SAMPLER_BLOCK) z_out[(size_t)ray * S + j] = merged[j];
 }
 

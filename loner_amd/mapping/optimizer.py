@@ -289,6 +289,7 @@ class Optimizer:
                              for p, fr in zip(pose_objs, free_list)]
                 tab.fixed_T12 = torch.stack(fixed).to(self._device).contiguous()
                 tab.free_col = free_rows.bool()[:, None]
+                tab.any_free = any(free_list)
             elif tab is not None:
                 tab.fixed_T12 = None
             any_free = bool(optimize_poses and any(not kf.is_anchored for kf in active))
@@ -328,13 +329,11 @@ class Optimizer:
                 side, ev = self._side_stream, self._grad_event
                 sp = sigma_params[0] if sigma_params else self._model.nerf_model._model_sigma.params
 
-                def front_end():
-                    b = self._build_window_rays(active, pose_dev, tab)
+                def front_end(it_next):
+                    b = self._build_window_rays(active, pose_dev, tab, n_out=valid_log[it_next:it_next + 1])
                     b["front"] = self._sample_front(b["rays"], b["depths"], b["n_dev"], first_key=b["first_key"])
                     return b
-                batch = front_end() if n_it > 0 else None
-                if n_it > 0:
-                    valid_log[0:1] = batch["n_dev"]
+                batch = front_end(0) if n_it > 0 else None
                 for it_idx in range(n_it):
                     out = self._loss_and_grads(batch["rays"], batch["depths"], sp, it_idx, want_ray_grads=any_free,
                                                want_param_grads=not os_.freeze_sigma_mlp, n_rays_dev=batch["n_dev"],
@@ -363,8 +362,7 @@ class Optimizer:
                                 self._global_step % self._model_config.model.occ_model.N_iters_acc == 0:
                             self._step_occupancy_grid()
                         if it_idx + 1 < n_it:
-                            batch = front_end()
-                            valid_log[it_idx + 1:it_idx + 2] = batch["n_dev"]
+                            batch = front_end(it_idx + 1)
                     if groups and dg is not None:
                         if density_group is None:
                             main.wait_stream(side)                        # (the pose check of this iteration may still mark the failure word)
@@ -382,8 +380,7 @@ class Optimizer:
                 if not self.should_enable_lidar():
                     break
                 if active:
-                    batch = self._build_window_rays(active, pose_dev, tab)
-                    valid_log[it_idx:it_idx + 1] = batch["n_dev"]
+                    batch = self._build_window_rays(active, pose_dev, tab, n_out=valid_log[it_idx:it_idx + 1])
                     out = self._loss_and_grads(batch["rays"], batch["depths"], sigma_params[0] if sigma_params else
                                                self._model.nerf_model._model_sigma.params, it_idx, want_ray_grads=any_free,
                                                want_param_grads=not os_.freeze_sigma_mlp, n_rays_dev=batch["n_dev"],
@@ -528,17 +525,20 @@ class Optimizer:
             out.append(idx.to(self._device))
         return torch.cat(out)
 
-    def _build_window_rays(self, active, pose_dev, tab):
+    def _build_window_rays(self, active, pose_dev, tab, n_out=None):
         """optimizer.py:285-340 on the device: pose -> [R|t], index draw + ray build for the whole window in one
-        launch, one order-preserving compaction."""
-        T12 = ops.pose_forward(pose_dev)
-        if tab.fixed_T12 is not None:                      # poses that are not optimised in this phase: the matrix their Pose hands out
-            T12 = torch.where(tab.free_col, T12, tab.fixed_T12)
+        launch, one order-preserving compaction.  n_out: where the live ray count goes (a row of the phase's log)."""
+        if tab.fixed_T12 is not None and not tab.any_free:
+            T12 = tab.fixed_T12                            # nothing is optimised (e.g. the anchored keyframe of a one-keyframe shard)
+        else:
+            T12 = ops.pose_forward(pose_dev)
+            if tab.fixed_T12 is not None:                  # poses that are not optimised in this phase: the matrix their Pose hands out
+                T12 = torch.where(tab.free_col, T12, tab.fixed_T12)
         rr = [float(self._ray_range[0]), float(self._ray_range[1])]
         index = self._draw_window_indices(active, tab)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if index is None else 0
         rays_c, depths_c, keep, src_c = ops.build_window_rays(tab, T12, rr, self._scale_f, self._shift_f, index=index, seed=seed)
-        rays, depths, src, out_seg, n_dev = ops.compact_rays(rays_c, depths_c, keep, src_c, tab.seg_start_list)
+        rays, depths, src, out_seg, n_dev = ops.compact_rays(rays_c, depths_c, keep, src_c, tab.seg_start_list, n_out=n_out)
         first_key = ops.first_ray_key(rays, out_seg, tab.seg_order) if self._dist is not None else None
         return dict(rays=rays, depths=depths, src=src, seg_start=out_seg, n_dev=n_dev, T12=T12, tab=tab, first_key=first_key)
 
@@ -633,7 +633,7 @@ class Optimizer:
         loss, d_sigma, d_rays, stats, _ = ops.los_loss_fused(sigma, z, rays, depths, self._scale_f, self._loss_config(iteration_idx),
                                                             counts, noise=noise, noise_std=noise_std, seed=seed + 1,
                                                             n_rays_dev=n_rays_dev, want_stats=want_stats, loss_out=loss_out, far0=far0,
-                                                            poison=poison, poison_tag=iteration_idx)
+                                                            poison=poison, poison_tag=iteration_idx, zero_dead_rows=not defer_grad_wait)
         grad_params = None
         grad_work = None
         if want_param_grads or want_ray_grads:

@@ -246,9 +246,10 @@ def pose_backward(pose6, d_transforms, mask=None, out=None, accumulate=False, po
     return out
 
 
-def compact_rays(rays, depths, keep, src_index, seg_start):
+def compact_rays(rays, depths, keep, src_index, seg_start, n_out=None):
     """seg_start: python list [n_seg+1].  -> (rays_out [cap,13], depths_out, src_out, out_seg_start dev int32
-    [n_seg+1], n_out dev int32 [1]); only the first n_out rows are meaningful."""
+    [n_seg+1], n_out dev int32 [1]); only the first n_out rows are meaningful.  n_out (optional): an int32 [1] device tensor the
+    live count is written into (the training loop hands in a row of its per-iteration log instead of copying into it afterwards)."""
     require_device(rays, depths, keep, src_index)
     n_in = rays.shape[0]
     dev = rays.device
@@ -258,7 +259,11 @@ def compact_rays(rays, depths, keep, src_index, seg_start):
     src_out = torch.empty_like(src_index) if src_index is not None else None
     # (both are written in full by the kernel: no fill launches - the front end of an iteration is a chain of small kernels)
     out_seg = torch.empty(n_seg + 1, device=dev, dtype=torch.int32)
-    n_out = torch.empty(1, device=dev, dtype=torch.int32)
+    if n_out is None:
+        n_out = torch.empty(1, device=dev, dtype=torch.int32)
+    else:
+        require_device(n_out)
+        assert n_out.dtype == torch.int32 and n_out.numel() == 1 and n_out.is_contiguous()
     seg = (C.c_int32 * (n_seg + 1))(*[int(v) for v in seg_start])
     check(load().lnr_compact_rays(_ptr(rays), _ptr(depths), _ptr(keep), _ptr(src_index), n_in, seg, n_seg,
                                   _ptr(rays_out), _ptr(depths_out), _ptr(src_out), _ptr(out_seg), _ptr(n_out), _stream()),
@@ -410,7 +415,10 @@ def count_opaque(rays, depth_gt, n_rays_dev=None, far0=None):
 
 
 def los_loss_fused(sigma, z, rays, depth_gt, scale, cfg: hip.LossConfig, counts, noise=None, noise_std=0.0, seed=0,
-                   n_rays_dev=None, want_stats=False, want_weights=False, loss_out=None, far0=None, poison=None, poison_tag=0):
+                   n_rays_dev=None, want_stats=False, want_weights=False, loss_out=None, far0=None, poison=None, poison_tag=0,
+                   zero_dead_rows=True):
+    """zero_dead_rows=False: d_rays rows at and beyond *n_rays_dev are left uninitialised (the kernel writes every column of every live
+    row; the training loop never reads the others and saves a fill launch per iteration)."""
     require_device(sigma, z, rays, depth_gt, counts, noise, far0, poison)
     sigma, z, rays, depth_gt = _f32c(sigma), _f32c(z), _f32c(rays), _f32c(depth_gt)
     n, s = z.shape
@@ -418,7 +426,7 @@ def los_loss_fused(sigma, z, rays, depth_gt, scale, cfg: hip.LossConfig, counts,
     if loss_out is None:
         loss_out = torch.zeros(8, device=dev)
     d_sigma = torch.empty(n, s, device=dev)
-    d_rays = torch.zeros(n, hip.RAY_STRIDE, device=dev)
+    d_rays = (torch.zeros if (zero_dead_rows and n_rays_dev is not None) else torch.empty)(n, hip.RAY_STRIDE, device=dev)
     stats = torch.zeros(n, 8, device=dev) if want_stats else None
     w = torch.zeros(n, s, device=dev) if want_weights else None
     partials = torch.empty(((n + hip.LOSS_RAYS_PER_BLOCK - 1) // hip.LOSS_RAYS_PER_BLOCK) * 8, device=dev)

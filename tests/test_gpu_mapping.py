@@ -889,3 +889,23 @@ def test_optimizer_is_driven_by_reference_shaped_callers(tmp_path):
             assert rel(seen["T"][k].reshape(3, 4), kfs[k]._frame._gt_lidar_pose.get_transformation_matrix()[:3, :4]) < 1e-7
     finally:
         OPS.build_window_rays = orig
+
+
+def test_training_with_the_in_kernel_generator_reaches_the_oracles_l1_distribution():
+    """The quality half of the metric, on the kernels' OWN random numbers: several runs of the HIP path and of the oracle (its torch
+    ops on this GPU, torch's generator) on the G13 configuration, each run with different draws, ONE optimisation phase (one Adam)
+    each - the means of L1 depth after the same number of iterations must agree within one pooled standard deviation (with a floor of
+    3 %) and both legs must have left the plateau.  (BENCH_r03's 12.4 m vs 9.5 - 11.1 m was not a biased generator: the baseline legs
+    restarted Adam in every iteration.)  bench.py reports the same comparison with 8 runs per leg at 100 iterations."""
+    import bench
+    iters, seeds = 60, (0, 1, 2)
+    q = bench._Shape(bench.QUALITY_SHAPE.keyframes, bench.QUALITY_SHAPE.rays, bench.QUALITY_SHAPE.samples)
+    hip = [bench.hip_quality_run(s, iters=iters) for s in seeds]
+    ora = [bench.oracle_leg(q, "cuda", budget_s=0.0, max_iters=iters, min_iters=iters, seed=s) for s in seeds]
+    h = np.array([r["l1_depth_m_after"] for r in hip]); o = np.array([r["l1_depth_m_after"] for r in ora])
+    h0 = np.array([r["l1_depth_m_before"] for r in hip]); o0 = np.array([r["l1_depth_m_before"] for r in ora])
+    print(f"L1 after {iters} iterations: HIP {h.round(3).tolist()} (from {h0.mean():.2f}), torch-ROCm oracle {o.round(3).tolist()} (from {o0.mean():.2f})")
+    assert abs(h0.mean() - o0.mean()) < 0.02 * o0.mean()                         # same untrained map, same probe
+    assert h.max() < 0.6 * h0.mean() and o.max() < 0.6 * o0.mean()                # both trained
+    pooled = np.sqrt((h.var(ddof=1) + o.var(ddof=1)) / 2)
+    assert abs(h.mean() - o.mean()) < max(pooled, 0.03 * o.mean()), (h.mean(), o.mean(), pooled)

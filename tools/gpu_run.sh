@@ -5,7 +5,8 @@
 #   tests[:<pytest -k expression>]   pytest -m gpu (whole suite, or the subset that matches)
 #   smoke                            __graft_entry__.smoke()
 #   bench[:<tag>[:<extra args>]]     python bench.py with the library of build tag <tag> ("" = the product's); extra args verbatim
-#   quick:<tag>:<ENV=..,ENV=..>      bench.py --quick --steps 20 --warmup 5 with environment variables (ablation masks), prints the kernel table
+#   quick:<tag>:<ENV=..,ENV=..>[:<args>]   bench.py --quick (default --steps 20 --warmup 5) with environment variables (ablation switches), prints the kernel table
+#   trace[:<tag>]                    tools/trace_iteration.py on the kernel trace of the preceding stats step
 #   stats[:<tag>[:<bench args>]]     rocprofv3 --kernel-trace --stats of the bench command -> gpurun_out/prof_<tag>/
 #   pmc:<counters>[:<tag>[:<bench args>]]   one rocprofv3 --pmc pass (counters space-separated with '+'), kernel-trace only
 #   py:<script and args>             python <script> (tools/*.py probes)
@@ -26,8 +27,11 @@ for step in "$@"; do
       LNR_LIB_PATH=$(lib_of "$tag") timeout 900 python bench.py $args > gpurun_out/bench_${tag:-product}.log 2> gpurun_out/bench_${tag:-product}.err
       echo "exit $?"; tail -1 gpurun_out/bench_${tag:-product}.log | python tools/bench_kernels.py --all ;;
     quick)
-      tag=${rest%%:*}; envs=${rest#*:}; [ "$envs" == "$rest" ] && envs=""
-      env $(echo $envs | tr ',' ' ') LNR_LIB_PATH=$(lib_of "$tag") timeout 300 python bench.py --quick --steps 20 --warmup 5 2>/dev/null | python tools/bench_kernels.py --all | grep -E "ms_per_step|kernel " ;;
+      tag=${rest%%:*}; r2=${rest#*:}; [ "$r2" == "$rest" ] && r2=""
+      envs=${r2%%:*}; args=${r2#*:}; [ "$args" == "$r2" ] && args="--steps 20 --warmup 5"
+      env $(echo $envs | tr ',' ' ') LNR_LIB_PATH=$(lib_of "$tag") timeout 300 python bench.py --quick $args 2>/dev/null | python tools/bench_kernels.py --all | grep -E "ms_per_step|kernel " ;;
+    trace)   # timeline of one iteration from the kernel trace of a stats step: trace:<tag>
+      f=$(find gpurun_out/prof_${rest:-product} -name "*kernel_trace.csv" | head -1); python tools/trace_iteration.py $f | tee gpurun_out/trace_${rest:-product}.txt | tail -40 ;;
     stats)
       tag=${rest%%:*}; args=${rest#*:}; [ "$args" == "$rest" ] && args="--steps 30 --warmup 10 --no-cpu-baseline"
       rm -rf gpurun_out/prof_${tag:-product}

@@ -3,7 +3,7 @@
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("void encode_forward_kernel<2, false>") and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) < 600000]
+starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(("void encode_forward_kernel<2, false>", "void encode_forward_pair_kernel<2, false>")) and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) < 600000]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts) // 2
 seg = rows[starts[k]:starts[k + 1]]
 t0 = int(seg[0]["Start_Timestamp"])
