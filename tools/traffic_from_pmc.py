@@ -2,7 +2,9 @@
 import collections, csv, glob, json, sys
 
 def per_kernel(counter):
-    files = glob.glob(f"gpurun_out/pmc_{counter}/*counter_collection.csv")
+    # tools/gpu_run.sh pmc:<counter> writes gpurun_out/pmc_<counter>_<tag>/ (tag "product" by default); tools/pmc.sh gpurun_out/pmc_<counter>/
+    suffix = sys.argv[2] if len(sys.argv) > 2 else "_product"
+    files = glob.glob(f"gpurun_out/pmc_{counter}{suffix}/**/*counter_collection.csv", recursive=True)
     agg = collections.defaultdict(list)
     for f in files:
         for r in csv.DictReader(open(f)):
@@ -10,12 +12,13 @@ def per_kernel(counter):
                 agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
-ALIAS = {"encode_backward_kernel": "encode_backward", "encode_forward_kernel<2, false>": "encode_forward", "encode_forward_kernel<2, true>": "encode_forward_f16", "table_grad_reduce2_kernel": "table_grad_reduce",
+ALIAS = {"encode_backward_kernel": "encode_backward", "encode_forward_kernel<2, false>": "encode_forward", "encode_forward_pair_kernel<2, false>": "encode_forward",
+         "encode_forward_pair_kernel<2, true>": "encode_forward_f16", "encode_forward_kernel<2, true>": "encode_forward_f16", "table_grad_reduce2_kernel": "table_grad_reduce",
          "table_grad_reduce_split_kernel": "table_grad_reduce_split",
          "mlp_backward_relu32_kernel": "mlp_backward", "mlp_forward_relu32_kernel": "mlp_forward",
          "sum_dx_planes_kernel": "sum_dx_planes", "adam_kernel": "adam", "los_loss_fused_kernel": "los_loss_fused"}
 fetch, write = per_kernel("FETCH_SIZE"), per_kernel("WRITE_SIZE")
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace), bench.py --steps 6 --warmup 2, 1x MI355X",
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace), bench.py --quick --steps 8 --warmup 4 (tools/gpu_run.sh pmc:FETCH_SIZE pmc:WRITE_SIZE), 1x MI355X",
        "units": "counter values are KiB; bytes = value*1024.  bytes_corrected doubles FETCH_SIZE as MI355X_MICROARCH.md prescribes for gfx950 "
                 "(64 B tallied per 128-B request on wide streaming reads; for 8-byte gathers the factor is uncalibrated, so it is an upper bound); "
                 "Infinity-Cache hits are counted, not excluded",
