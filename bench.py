@@ -643,10 +643,11 @@ def main():
                                       "(tools/pmc.sh), NOT measured by this run; FETCH_SIZE doubled as the microarchitecture guide prescribes for gfx950",
                     "note": "dominant kernel by total time over the timed region, timed with HIP events recorded by the library on the "
                             "launch stream (lnr_profile_*).  It moves few algorithmic bytes and is not HBM-bound: the SQ counters "
-                            "(profiles/r03_pmc_sq_instmix_scan.txt) show a latency-bound kernel - 296 M VALU wave instructions per backward, the VALU "
-                            "pipe ~45 % busy, 56 % of a wave's cycles parked in s_waitcnt / barriers, scalar unit 15 % - whose parts add up when "
-                            "switched off one by one (profiles/r03_ablate_binned_partition.txt): hashing and weights, the table gathers of the d/dx term "
-                            "(2 clk per active lane and line, tools/gather_bench.hip), the in-LDS radix partition of the gradient records - DESIGN.md 4.3",
+                            "(profiles/r04_pmc_sq_instmix.txt) show a latency-bound kernel pair - 181 M + 121 M VALU wave instructions per backward, "
+                            "57 % of a wave's cycles parked in s_waitcnt / barriers, 15-22 % issue stalls - whose in-LDS radix partition of the "
+                            "gradient records, hashing, and the d/dx term's table re-gather (47 M L2 line reads = 6 GB over the L2 -> L1 path, "
+                            "profiles/r04_pmc_tcp_tcc_encode.txt) overlap only partly; four structural variants were measured in round 4 "
+                            "(DESIGN.md 4.3, 8)",
                     "secondary": {k: v for k, v in kernels.items() if k != dom and k in ("encode_backward", "encode_dx", "mlp_backward", "mlp_forward", "encode_forward", "table_grad_reduce")}}
     line = {
         "metric": "training rays/sec", "value": total_rays / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,

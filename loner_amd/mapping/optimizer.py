@@ -277,7 +277,9 @@ class Optimizer:
             pose_objs = [(kf._frame._gt_lidar_pose if self._use_gt_poses else kf.get_lidar_pose()) for kf in active]
             free_list = [bool(optimize_poses and not kf.is_anchored) for kf in active]
             pose_cpu = [p.get_pose_tensor() for p in pose_objs]
-            if active:
+            if active and all(p.device.type == "cpu" for p in pose_cpu):
+                pose_dev = torch.stack([p.detach().float() for p in pose_cpu]).to(self._device).contiguous()      # one upload
+            elif active:
                 pose_dev = torch.stack([p.detach().to(self._device, torch.float32) for p in pose_cpu]).contiguous()
             else:
                 pose_dev = torch.zeros(0, 6, device=self._device)
@@ -423,15 +425,39 @@ class Optimizer:
                 # their all-reduce) - the run is lost either way.  What all ranks agree on is WHICH failure to report: the earliest
                 # iteration, with the code that belongs to it (one packed value, so code and iteration cannot come from different ranks).
                 poison.copy_(self._dist.earliest_failure(poison))
-            code, failed_it = (int(v) for v in poison.cpu())
+            # Everything the host needs from the phase travels in ONE device -> host copy (round 3 made eight small ones, each a
+            # sync: ~1 ms per phase together with the per-keyframe pose copies, 2 % of a 20-iteration phase): the failure word, the
+            # per-iteration live-ray counts and loss terms, the poses, a finite-poses flag and the origin check of the last batch.
+            n_log = max(n_it, 1)
+            res = self._results_lidar
+            if active and n_it and res is not None:
+                last = res["rays"]
+                n_live_t = res["n_rays_dev"].reshape(1).float() if res["n_rays_dev"] is not None else \
+                    torch.full((1,), float(last.shape[0]), device=self._device)
+                row = torch.arange(last.shape[0], device=self._device, dtype=torch.float32)[:, None]
+                outside = ((last[:, :3].abs() > 1) & (row < n_live_t)).any().reshape(1).float()
+            else:
+                outside = torch.zeros(1, device=self._device)
+            pose_ok = torch.isfinite(pose_dev.detach()).all().reshape(1).float()
+            packed = torch.cat([poison.float(), valid_log.float(), loss_log.detach().reshape(-1), pose_dev.detach().reshape(-1).float(),
+                                pose_ok, outside]).cpu()
+            code, failed_it = int(packed[0]), int(packed[1])
+            valid_host = packed[2:2 + n_log]
+            loss_terms_host = packed[2 + n_log:2 + n_log + 8 * n_log].reshape(n_log, 8).clone()
+            o = 2 + 9 * n_log
+            pose_host = packed[o:o + pose_dev.numel()].reshape(pose_dev.shape)
+            pose_finite, origins_outside = bool(packed[-2] != 0), bool(packed[-1] != 0)
             self._poison = None
             self._model.nerf_model.warn_if_clipped(self._device)      # nerf_tcnn.py:70-78, once per phase instead of per forward
-            loss_host = loss_log[:, 0].cpu()
+            loss_host = loss_terms_host[:, 0]
+
+            def hand_poses_back():
+                with torch.no_grad():
+                    for k, p_ in enumerate(pose_cpu):
+                        if free_list[k]:        # (the others were not stepped: their tensors are left exactly as they are)
+                            p_.data.copy_(pose_host[k].to(p_.device))
             if code != 0:
-                with torch.no_grad():           # hand the poses of the last good iteration back, like every other phase end
-                    for k, p in enumerate(pose_cpu):
-                        if free_list[k]:
-                            p.data.copy_(pose_dev[k].detach().to(p.device))
+                hand_poses_back()               # the poses of the last good iteration, like every other phase end
                 self.last_failure = {"code": code, "iteration": failed_it}
                 if code == hip.POISON_NAN_LOSS:
                     raise AssertionError("NaN Loss Encountered")
@@ -440,27 +466,20 @@ class Optimizer:
                 raise RuntimeError("Fatal: Encountered invalid pose tensor.")
             if n_it and torch.isnan(loss_host).any():
                 raise AssertionError("NaN Loss Encountered")
-            if any_free and not torch.isfinite(pose_dev.detach()).all():
+            if any_free and not pose_finite:
                 raise RuntimeError("Fatal: Encountered invalid pose tensor.")
             # the reference asserts on every ray build that the ray origins lie inside the world cube (ray_utils.py:301-303);
             # here once per phase, on the last batch (all rays of a keyframe share its origin)
-            if active and n_it and self._results_lidar is not None:
-                last = self._results_lidar["rays"]
-                n_live = int(self._results_lidar["n_rays_dev"].item()) if self._results_lidar["n_rays_dev"] is not None else last.shape[0]
-                if n_live and bool((last[:n_live, :3].abs() > 1).any()):
-                    raise AssertionError("ray origins are outside the world cube")
-            with torch.no_grad():
-                for k, p in enumerate(pose_cpu):
-                    if free_list[k]:            # (the others were not stepped: their tensors are left exactly as they are)
-                        p.data.copy_(pose_dev[k].detach().to(p.device))
+            if origins_outside:
+                raise AssertionError("ray origins are outside the world cube")
+            hand_poses_back()
             sigma = self._model.nerf_model._model_sigma.params
             if sigma.grad is not None and os_.freeze_sigma_mlp:
                 sigma.grad = None
             losses_log.append(loss_host.tolist())
-            depth_eps_log.append((loss_log[:, 4] / valid_log.clamp(min=1).float()).cpu().tolist())
+            depth_eps_log.append((loss_terms_host[:, 4] / valid_host.clamp(min=1)).tolist())
             self._depth_eps = depth_eps_log[-1][-1] if n_it else None
-            self.last_stats = {"n_valid_rays": int(valid_log.sum().item()), "iterations": n_it,
-                               "loss_terms": loss_log.detach().cpu()}
+            self.last_stats = {"n_valid_rays": int(valid_host.sum().item()), "iterations": n_it, "loss_terms": loss_terms_host}
 
         if self._settings.debug.log_losses:
             for name, logs in (("losses", losses_log), ("depth_eps", depth_eps_log)):

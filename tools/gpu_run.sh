@@ -9,12 +9,15 @@
 #   trace[:<tag>]                    tools/trace_iteration.py on the kernel trace of the preceding stats step
 #   stats[:<tag>[:<bench args>]]     rocprofv3 --kernel-trace --stats of the bench command -> gpurun_out/prof_<tag>/
 #   pmc:<counters>[:<tag>[:<bench args>]]   one rocprofv3 --pmc pass (counters space-separated with '+'), kernel-trace only
+#   keep:<name>                      copy the kernel-stats csv of the preceding stats step to gpurun_out/<name>_kernel_stats.csv
 #   py:<script and args>             python <script> (tools/*.py probes)
 set +e
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 lib_of() { [ -n "$1" ] && echo "$PWD/loner_amd/_lib/libloner_hip_$1.so"; }
+n_step=0
 for step in "$@"; do
+  n_step=$((n_step + 1))
   kind=${step%%:*}; rest=${step#*:}; [ "$rest" == "$step" ] && rest=""
   echo "===== $step"
   case $kind in
@@ -24,8 +27,9 @@ for step in "$@"; do
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; tail -3 gpurun_out/smoke.log ;;
     bench)
       tag=${rest%%:*}; args=${rest#*:}; [ "$args" == "$rest" ] && args=""
-      LNR_LIB_PATH=$(lib_of "$tag") timeout 900 python bench.py $args > gpurun_out/bench_${tag:-product}.log 2> gpurun_out/bench_${tag:-product}.err
-      echo "exit $?"; tail -1 gpurun_out/bench_${tag:-product}.log | python tools/bench_kernels.py --all ;;
+      out=gpurun_out/bench_${tag:-product}_step${n_step}       # (one log per step: two bench steps of a call do not overwrite each other)
+      LNR_LIB_PATH=$(lib_of "$tag") timeout 900 python bench.py $args > $out.log 2> $out.err
+      echo "exit $? -> $out.log"; tail -1 $out.log | python tools/bench_kernels.py --all ;;
     quick)
       tag=${rest%%:*}; r2=${rest#*:}; [ "$r2" == "$rest" ] && r2=""
       envs=${r2%%:*}; args=${r2#*:}; [ "$args" == "$r2" ] && args="--steps 20 --warmup 5"
@@ -43,6 +47,8 @@ for step in "$@"; do
       out=gpurun_out/pmc_$(echo $ctr | tr '+' '_' | cut -c1-60)_${tag:-product}; rm -rf $out
       LNR_LIB_PATH=$(lib_of "$tag") timeout 600 rocprofv3 --pmc $(echo $ctr | tr '+' ' ') --kernel-trace --output-format csv -d $out -o run -- python bench.py $args > $out.log 2>&1
       echo "exit $?"; python tools/pmc_mean.py $out encode_ table_grad mlp_ | head -60 ;;
+    keep)    # keep:<name>: copy the kernel-stats summary of the preceding stats step to gpurun_out/<name>_kernel_stats.csv
+      cp gpurun_out/prof_product/run_kernel_stats.csv gpurun_out/${rest}_kernel_stats.csv && head -12 gpurun_out/${rest}_kernel_stats.csv ;;
     py) timeout 900 python $rest 2>&1 | tail -40 ;;
     *) echo "unknown step $step" ;;
   esac
