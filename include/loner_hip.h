@@ -77,6 +77,12 @@ typedef enum LnrPosRounding { LNR_POS_FMA = 0, LNR_POS_MUL_ADD = 1 } LnrPosRound
                                        with lnr_density_fold_weight_grads (same points capacity) - e.g. on another stream, beside the
                                        table-gradient reduce, instead of behind it */
 #define LNR_BWD_REPORT_REGIONS 2  /* diagnostic: print to stderr how full the record regions ran (synchronises the stream) */
+#define LNR_BWD_OVERWRITE_GRAD 32 /* grad_params RECEIVES this call's gradient instead of accumulating it: the table-gradient reduce writes
+                                       every float of its slice (zeros included) without reading it, the weight-gradient fold stores
+                                       instead of adding.  A training loop that steps after every backward then needs neither the 30 MB
+                                       read here nor the optimiser's zeroing of the gradient (lnr_adam_step zero_grad = 0): 60 MB of HBM
+                                       traffic per iteration.  With LNR_BWD_DEFER_WEIGHT_FOLD pass the same flag to
+                                       lnr_density_fold_weight_grads. */
 
 typedef enum LnrActivation {
     LNR_ACT_NONE = 0, LNR_ACT_RELU = 1, LNR_ACT_SINE = 2, LNR_ACT_LEAKY_RELU = 3,
@@ -153,6 +159,11 @@ size_t lnr_density_workspace_forward(const LnrNetSpec* spec /*host*/, int64_t n_
  *                         (nerf_tcnn.py:70-78); the caller prints the reference's "Clipping infinite outputs" warning once. */
 #define LNR_WORKSPACE_STATUS_BYTES 256
 #define LNR_STATUS_CLIPPED 0
+#define LNR_STATUS_OVF_LEVEL0 16      /* [16 .. 16 + LNR_MAX_LEVELS): internal - the call stamp of the last lnr_density_backward that used a level's
+                                          64-bit overflow accumulators (those are kept all-zero between calls instead of cleared per call).
+                                          Between two density calls on a workspace its content belongs to the library: a caller that writes
+                                          into it - or hands it to another network / batch size - is fine (that is detected by layout), one
+                                          that scribbles over it from outside must call lnr_density_workspace_init again. */
 int lnr_density_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
 
 /* sigma = MLP(enc((xyz+1)/2))[0]           replaces tinycudann forward at nerf_tcnn.py:63-72
@@ -186,10 +197,11 @@ int lnr_density_backward(const LnrNetSpec* spec /*host*/, const float* params,
                                                    sampling can then run on another stream beside the rest of this call */,
                          void* stream);
 
-/* grad_params[0 : n_mlp_params] += the weight-gradient slabs a lnr_density_backward call with LNR_BWD_DEFER_WEIGHT_FOLD left in
- * `workspace` (n_points: the n_points / n_rays * n_samples of that call).  Fixed summation order: reproducible. */
+/* grad_params[0 : n_mlp_params] += (flags & LNR_BWD_OVERWRITE_GRAD: =) the weight-gradient slabs a lnr_density_backward call with
+ * LNR_BWD_DEFER_WEIGHT_FOLD left in `workspace` (n_points: the n_points / n_rays * n_samples of that call).  Fixed summation order:
+ * reproducible. */
 int lnr_density_fold_weight_grads(const LnrNetSpec* spec /*host*/, int64_t n_points, float* grad_params,
-                                  void* workspace, size_t workspace_bytes, void* stream);
+                                  void* workspace, size_t workspace_bytes, int32_t flags, void* stream);
 
 /* ---- rays ------------------------------------------------------------------------------------- */
 /* LidarRayDirections.build_lidar_rays (ray_utils.py:269-322) + get_far_val (:31-60) for one

@@ -10,16 +10,70 @@
 #include <cstdlib>
 #include <cstdio>
 
+#include <mutex>
+#include <unordered_map>
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define LNR_ENC_BWD_MAX_BPG 2048
+
+// ------------------------------------------------------------------------------------------------
+// Host-side note per workspace (keyed by its address): which layout last used it, whether the 64-bit overflow accumulators of that layout
+// are known to be all-zero, and the call counter ("epoch") the kernels stamp a level's status word with when they add to its accumulators.
+// The accumulators are zeroed once per layout change instead of once per backward (59 MB at the default size), and the reduce reads and
+// re-zeroes only the levels that were stamped in THIS call (table_grad_reduce2_kernel).  What breaks the note - another network or batch
+// size on the same workspace (its planes and regions lie elsewhere), lnr_density_workspace_init, an error between the first and the last
+// launch of a backward - marks the accumulators unknown, and the next backward clears them.  The caller's side of the contract
+// (include/loner_hip.h): between two density calls the workspace belongs to the library.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct WsNote { uint64_t layout; uint32_t epoch; bool ovf_zero; };
+std::mutex g_ws_mutex;
+std::unordered_map<const void*, WsNote> g_ws_notes;
+
+uint64_t layout_signature(const LnrNetSpec* spec, int64_t cap) {
+    uint64_t h = 1469598103934665603ull;                        // FNV-1a over the spec and the point capacity
+    auto mix = [&](const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } };
+    mix(spec, sizeof(LnrNetSpec));
+    mix(&cap, sizeof(cap));
+    return h;
+}
+// a density call with this layout touches the workspace: a different layout than the note's leaves the accumulators unknown
+void ws_touch(const void* ws, uint64_t layout) {
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    auto it = g_ws_notes.find(ws);
+    if (it == g_ws_notes.end()) g_ws_notes[ws] = WsNote{layout, 0u, false};
+    else if (it->second.layout != layout) { it->second.layout = layout; it->second.ovf_zero = false; }
+}
+// start of a backward that writes table gradients: -> {epoch of this call, must the accumulators be cleared first}; they count as unknown
+// until ws_backward_done
+void ws_backward_begin(const void* ws, uint64_t layout, int* epoch, bool* clear) {
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    WsNote& n = g_ws_notes[ws];
+    if (n.layout != layout) { n.layout = layout; n.ovf_zero = false; }
+    *clear = !n.ovf_zero;
+    n.ovf_zero = false;
+    n.epoch = n.epoch >= 0x7FFFFFF0u ? 1u : n.epoch + 1u;
+    if (n.epoch == 1u) *clear = true;                          // (first call, or the counter wrapped: stale stamps must go too)
+    *epoch = (int)n.epoch;
+}
+void ws_backward_done(const void* ws) {
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    auto it = g_ws_notes.find(ws);
+    if (it != g_ws_notes.end()) it->second.ovf_zero = true;
+}
+void ws_forget(const void* ws) {
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    g_ws_notes.erase(ws);
+}
+}  // namespace
 
 // grad[i] += sum over workgroup slabs.  A 64 x 16 workgroup: 64 consecutive parameters, the slabs split over 16 thread rows
 // (a thousand threads share the reads instead of one per parameter), rows combined through LDS in a fixed order: no
 // atomics, bit-reproducible.
 #define LNR_SLAB_GROUPS 16
 __global__ void __launch_bounds__(64 * LNR_SLAB_GROUPS)
-reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs, int n_mlp, float* __restrict__ grad) {
+reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs, int n_mlp, float* __restrict__ grad, int overwrite) {
     __shared__ float part[LNR_SLAB_GROUPS][64];
     const int px = threadIdx.x & 63, gy = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + px;
@@ -40,7 +94,7 @@ reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs, int n_mlp, flo
         float s = 0.0f;
 #pragma unroll
         for (int k = 0; k < LNR_SLAB_GROUPS; ++k) s += part[k][px];
-        grad[i] += s;
+        grad[i] = overwrite ? s : grad[i] + s;
     }
 }
 
@@ -258,7 +312,8 @@ table_grad_reduce_split_kernel(const LnrNetSpec spec, const void* __restrict__ r
 template <int PAIR, int RED_U, int MINW>
 __global__ void __launch_bounds__(1024, MINW)   // HIP: (max threads, min waves per SIMD)
 table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ regions_v, const RegionPlan plan, const int* __restrict__ counts, int bpg,
-                          int maxo, const long long* __restrict__ ovf, float* __restrict__ grad_table, int64_t n_table_floats) {
+                          int maxo, long long* __restrict__ ovf, const int* __restrict__ ovf_flag, int epoch, float* __restrict__ grad_table,
+                          int64_t n_table_floats, int overwrite) {
     extern __shared__ long long acc[];
     // Owners in DESCENDING table order: the hardware starts workgroups in blockIdx order, the chip holds 512 of the ~900 at a time, and
     // the owners of the fine (x-pair) levels - the heaviest, and with the default network exactly 512 of them - sit at the END of the
@@ -281,10 +336,12 @@ table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ region
         const int64_t my_ovf = ovf_off;
         ovf_off += (int64_t)(hi - lo);                                      // every level has overflow accumulators
         if (hi <= base || lo >= (uint64_t)base + slice) continue;
-        {
-            // records that did not fit their region were summed into 64-bit accumulators by the encode kernel (and, on split levels, all
-            // records by the split kernel): same fixed point, so region records + overflow add up exactly, whatever the (arrival-order
-            // dependent) split between the two was
+        // records that did not fit their region were summed into 64-bit accumulators by the encode kernel (and, on split levels, all
+        // records by the split kernel): same fixed point, so region records + overflow add up exactly, whatever the (arrival-order
+        // dependent) split between the two was.  [r4] The accumulators are ALL ZERO between calls: a kernel that adds to a level's
+        // stores the call's epoch in the level's status word, only then are they read here - and put back to zero by this, their only,
+        // reader (no 59 MB memset per call, no 59 MB of reads for levels nothing overflowed on; split levels always carry sums)
+        if (plan.split[l] > 1 || ovf_flag[l] == epoch) {               // workgroup-uniform
             long long v[slice / 1024];
 #pragma unroll
             for (int k = 0; k < slice / 1024; ++k) {
@@ -292,7 +349,12 @@ table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ region
                 v[k] = (gi >= lo && gi < hi) ? ovf[my_ovf + (int64_t)(gi - lo)] : 0ll;
             }
 #pragma unroll
-            for (int k = 0; k < slice / 1024; ++k) if (v[k] != 0ll) acc[threadIdx.x + k * 1024] += v[k];
+            for (int k = 0; k < slice / 1024; ++k) {
+                if (v[k] != 0ll) {
+                    acc[threadIdx.x + k * 1024] += v[k];
+                    ovf[my_ovf + (int64_t)((uint64_t)base + threadIdx.x + k * 1024 - lo)] = 0ll;
+                }
+            }
             __syncthreads();
             PHASE(1);
         }
@@ -312,17 +374,18 @@ table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ region
     __syncthreads();
     PHASE(5);
     {
+        // LNR_BWD_OVERWRITE_GRAD (workgroup-uniform): the slice IS this call's gradient - every float is stored, none is read
         float g[slice / 1024];
 #pragma unroll
         for (int k = 0; k < slice / 1024; ++k) {
             const int64_t gi = (int64_t)base + threadIdx.x + k * 1024;
-            g[k] = gi < n_table_floats ? grad_table[gi] : 0.0f;
+            g[k] = (!overwrite && gi < n_table_floats) ? grad_table[gi] : 0.0f;
         }
 #pragma unroll
         for (int k = 0; k < slice / 1024; ++k) {
             const int64_t gi = (int64_t)base + threadIdx.x + k * 1024;
             const long long q = acc[threadIdx.x + k * 1024];
-            if (gi < n_table_floats && q != 0ll) grad_table[gi] = g[k] + (float)((double)q * (1.0 / (double)LNR_FIX_SCALE));
+            if (gi < n_table_floats && (overwrite || q != 0ll)) grad_table[gi] = g[k] + (float)((double)q * (1.0 / (double)LNR_FIX_SCALE));
         }
     }
     PHASE(6);
@@ -518,8 +581,8 @@ static int plan_launch(const LnrNetSpec* spec, int64_t n_points, bool backward, 
 namespace {
 struct ReduceCtx {
     const LnrNetSpec* spec;
-    const void* regions; const int* counts; const long long* ovf; float* grad_table;
-    RegionPlan plan; int bpg, maxo, shift; int64_t n_table; int n_split;
+    const void* regions; const int* counts; long long* ovf; const int* ovf_flag; int epoch; float* grad_table;
+    RegionPlan plan; int bpg, maxo, shift; int64_t n_table; int n_split; int overwrite;
 };
 
 template <int PAIR, int U, int W>
@@ -532,11 +595,11 @@ static int launch_reduce_variant(const ReduceCtx& c, int n_owners, hipStream_t s
     if (c.n_split > 0) {
         LnrProfScope prof("table_grad_reduce_split", st);
         hipLaunchKernelGGL((table_grad_reduce_split_kernel<PAIR, U, W>), dim3(c.n_split), dim3(1024), lds, st, *c.spec, c.regions, c.plan, c.counts, c.bpg, c.maxo,
-                           const_cast<long long*>(c.ovf));
+                           c.ovf);
     }
     LnrProfScope prof("table_grad_reduce", st);
     hipLaunchKernelGGL((table_grad_reduce2_kernel<PAIR, U, W>), dim3(n_owners), dim3(1024), lds, st, *c.spec, c.regions, c.plan, c.counts, c.bpg, c.maxo,
-                       c.ovf, c.grad_table, c.n_table);
+                       c.ovf, c.ovf_flag, c.epoch, c.grad_table, c.n_table, c.overwrite);
     return LNR_OK;
 }
 // 2 regions in flight per wave at 8 waves per SIMD (two workgroups per CU) measured best: 0.35 ms against 0.37 (4 in flight, 8 waves),
@@ -581,6 +644,7 @@ extern "C" size_t lnr_density_workspace_forward(const LnrNetSpec* spec, int64_t 
 
 extern "C" int lnr_density_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
     LNR_REQUIRE(workspace != nullptr && workspace_bytes >= LNR_WORKSPACE_STATUS_BYTES, "lnr_density_workspace_init: workspace too small");
+    ws_forget(workspace);
     if (hipMemsetAsync(workspace, 0, LNR_WORKSPACE_STATUS_BYTES, (hipStream_t)stream) != hipSuccess) {
         lnr_set_error("lnr_density_workspace_init: hipMemsetAsync failed");
         return LNR_ERR_LAUNCH;
@@ -614,6 +678,7 @@ extern "C" int lnr_density_forward(const LnrNetSpec* spec, const float* params, 
     rc = plan_launch(spec, cap, false, &plan, "lnr_density_forward");
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    ws_touch(workspace, layout_signature(spec, cap));
     float* feat = (float*)((char*)workspace + L.off_feat);
     mp.clip_flag = reinterpret_cast<int32_t*>((char*)workspace + L.off_status) + LNR_STATUS_CLIPPED;
     {
@@ -727,14 +792,29 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     if (rc) return rc;
     LNR_CHECK_LAUNCH("lnr_density_backward(mlp)");
     float* grad_table = want_grad ? grad_params + spec->n_mlp_params : nullptr;
-    ReduceCtx rctx{spec, regions, counts, ovf, grad_table, rplan, L.bpg, L.maxo, L.shift, spec->n_params - spec->n_mlp_params,
-                   (flags & LNR_BWD_TABLE_ATOMICS) ? 0 : L.n_split};
+    // the overflow accumulators: all-zero between calls (WsNote above); cleared here only when that is not known
+    int* ovf_flag = reinterpret_cast<int32_t*>(ws + L.off_status) + LNR_STATUS_OVF_LEVEL0;
+    int epoch = 0;
+    const bool uses_ovf = hash && want_grad;
+    if (uses_ovf) {
+        bool clear = false;
+        ws_backward_begin(workspace, layout_signature(spec, cap), &epoch, &clear);
+        if (clear && (hipMemsetAsync(ovf, 0, L.off_counts - L.off_ovf, st) != hipSuccess ||
+                      hipMemsetAsync(ovf_flag, 0, LNR_MAX_LEVELS * sizeof(int32_t), st) != hipSuccess)) {
+            lnr_set_error("lnr_density_backward: hipMemsetAsync failed");
+            return LNR_ERR_LAUNCH;
+        }
+    } else {
+        ws_touch(workspace, layout_signature(spec, cap));
+    }
+    ReduceCtx rctx{spec, regions, counts, ovf, ovf_flag, epoch, grad_table, rplan, L.bpg, L.maxo, L.shift, spec->n_params - spec->n_mlp_params,
+                   (flags & LNR_BWD_TABLE_ATOMICS) ? 0 : L.n_split, (flags & LNR_BWD_OVERWRITE_GRAD) ? 1 : 0};
     // hash grids (LNR_SPLIT_DX): the input gradient first, as launches of its own; the table-gradient partition follows behind the event
     const bool split = LNR_SPLIT_DX && hash;
     if (want_dfeat) {
         rc = lnr_encode_backward(spec, params, &src, cap, dfeat, dxl, L.m_pad, grad_table, want_grad ? regions : nullptr, &rplan, counts,
                                  L.bpg, L.maxo, L.shift,
-                                 ovf, d_pts_eff, ray_accum ? d_rays : nullptr, (long long*)(ws + L.off_rayacc), (flags & LNR_BWD_BINS_W8) != 0,
+                                 ovf, ovf_flag, epoch, d_pts_eff, ray_accum ? d_rays : nullptr, (long long*)(ws + L.off_rayacc), (flags & LNR_BWD_BINS_W8) != 0,
                                  split ? LNR_ENC_PART_DX : (LNR_ENC_PART_DX | LNR_ENC_PART_RECORDS), st);
         if (rc) return rc;
         LNR_CHECK_LAUNCH("lnr_density_backward(encode backward)");
@@ -754,7 +834,7 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     if (want_dfeat) {
         if (split) {
             rc = lnr_encode_backward(spec, params, &src, cap, dfeat, dxl, L.m_pad, grad_table, regions, &rplan, counts, L.bpg, L.maxo, L.shift,
-                                     ovf, nullptr, nullptr, nullptr, (flags & LNR_BWD_BINS_W8) != 0, LNR_ENC_PART_RECORDS, st);
+                                     ovf, ovf_flag, epoch, nullptr, nullptr, nullptr, (flags & LNR_BWD_BINS_W8) != 0, LNR_ENC_PART_RECORDS, st);
             if (rc) return rc;
             LNR_CHECK_LAUNCH("lnr_density_backward(table-gradient partition)");
         }
@@ -769,6 +849,7 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
         rc = launch_table_reduce(rctx, L.nown, st);
         if (rc) return rc;
         LNR_CHECK_LAUNCH("lnr_density_backward(table reduce)");
+        ws_backward_done(workspace);                  // the reduce has put every accumulator it read back to zero
 #ifdef LNR_PHASE_TIMING
         if (getenv("LNR_PHASE_TIMING")) {
             static const char* names[LNR_N_PHASES] = {"zero LDS", "overflow fold", "-", "records", "-", "final barrier", "write-out"};
@@ -781,13 +862,14 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     if (flags & LNR_BWD_DEFER_WEIGHT_FOLD) return LNR_OK;            // the caller folds them with lnr_density_fold_weight_grads
     const int n_mlp = spec->n_mlp_params;
     LnrProfScope prof_slabs("reduce_slabs", st);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(lnr_div_up(n_mlp, 64)), dim3(64 * LNR_SLAB_GROUPS), 0, st, slabs, n_slabs, n_mlp, grad_params);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(lnr_div_up(n_mlp, 64)), dim3(64 * LNR_SLAB_GROUPS), 0, st, slabs, n_slabs, n_mlp, grad_params,
+                       (flags & LNR_BWD_OVERWRITE_GRAD) ? 1 : 0);
     LNR_CHECK_LAUNCH("lnr_density_backward(reduce)");
     return LNR_OK;
 }
 
 extern "C" int lnr_density_fold_weight_grads(const LnrNetSpec* spec, int64_t n_points, float* grad_params, void* workspace,
-                                             size_t workspace_bytes, void* stream) {
+                                             size_t workspace_bytes, int32_t flags, void* stream) {
     int rc = check_spec(spec, "lnr_density_fold_weight_grads");
     if (rc) return rc;
     LNR_REQUIRE(grad_params && workspace && n_points > 0, "lnr_density_fold_weight_grads: bad argument");
@@ -805,7 +887,7 @@ extern "C" int lnr_density_fold_weight_grads(const LnrNetSpec* spec, int64_t n_p
     hipStream_t st = (hipStream_t)stream;
     LnrProfScope prof_slabs("reduce_slabs", st);
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(lnr_div_up(n_mlp, 64)), dim3(64 * LNR_SLAB_GROUPS), 0, st,
-                       (const float*)((const char*)workspace + L.off_slabs), n_slabs, n_mlp, grad_params);
+                       (const float*)((const char*)workspace + L.off_slabs), n_slabs, n_mlp, grad_params, (flags & LNR_BWD_OVERWRITE_GRAD) ? 1 : 0);
     LNR_CHECK_LAUNCH("lnr_density_fold_weight_grads");
     return LNR_OK;
 }

@@ -196,4 +196,5 @@ int lnr_f16_bwd_slabs(const LnrNetSpec* spec, int64_t n_points);
 int lnr_selftest_mfma_f16(float* out, hipStream_t st);
 int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, const float* dfeat,
                         float* dxl, int64_t m_pad, float* grad_table, void* regions, const RegionPlan* plan, int* counts, int bpg,
-                        int maxo, int shift, long long* ovf, float* d_pts, float* d_rays_acc, long long* ray_acc, bool bins_w8, int parts, hipStream_t st);
+                        int maxo, int shift, long long* ovf, int* ovf_flag, int epoch, float* d_pts, float* d_rays_acc, long long* ray_acc, bool bins_w8, int parts,
+                        hipStream_t st);

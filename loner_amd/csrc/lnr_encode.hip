@@ -336,6 +336,8 @@ struct EncSink {
     int* counts;            // [level][maxo][chunk]
     int maxo, shift;
     int xcd_affine;         // level_slot(): the launch's levels one per XCD (list.n a multiple of 8)
+    int* ovf_flag;          // [level] workspace status words: a kernel that adds to a level's overflow accumulators stores `epoch` there, and
+    int epoch;              // only then does the reduce read (and zero) them - the accumulators are all-zero between calls (lnr_density.hip)
 #ifdef LNR_ABLATE
     int dbg;                // ablation bits (LNR_X_DBG), development builds only
 #endif
@@ -732,7 +734,19 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
                     if ((a0 != 0.0f) | (a1 != 0.0f)) {
                         const uint32_t fi = e[2 * k2] * F;
                         if (xt < 12u) rrank[k2] = atomicAdd(&cnt[(int)(fi >> sink.shift) - first_owner], 1);
-                        else xpair_overflow(ovf, fi - level_base, e[2 * k2 + 1] * F - level_base, xt, a0, a1, c.frac[0]);   // corners in two owner slices
+                        else {
+                            // x ends in >= 12 one bits (2^-12 of the cells): e(x + 1) = e(x) ^ (2^(t+1) - 1) lies in ANOTHER owner slice.  Two
+                            // single-corner records instead of one x-pair - each an x-pair record with t = 0, fx = 0, whose one live corner
+                            // carries the x weight already (the reduce adds a to the record's entry and 0 to its neighbour) - so that these
+                            // cells no longer go through the overflow accumulators in every launch (round 2-3: ~8 k of them per launch kept
+                            // all 59 MB of accumulators in play)
+                            const uint32_t fj = e[2 * k2 + 1] * F;
+                            const float gx = 1.0f - c.frac[0];
+                            rv0[k2] = gx * a0; rv1[k2] = gx * a1;
+                            rv0[4 + k2] = c.frac[0] * a0; rv1[4 + k2] = c.frac[0] * a1;
+                            rrank[k2] = atomicAdd(&cnt[(int)(fi >> sink.shift) - first_owner], 1);
+                            rrank[4 + k2] = atomicAdd(&cnt[(int)(fj >> sink.shift) - first_owner], 1);
+                        }
                     }
                 }
             } else if (wave_any) {
@@ -785,13 +799,24 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
             // ---- C: scatter into the staging buffer, grouped by owner
             if (xp) {
                 // x-pair: (float index of the x corner, a0, a1, fx rounded to 28 bits with t in the freed low nibble)
-                const uint32_t fxt = ((__float_as_uint(c.frac[0]) + 8u) & ~0xFu) | xt;
+                const bool straddle = xt >= 12u;                 // single-corner records: t = 0, fx = 0
+                const uint32_t fxt = straddle ? 0u : ((((__float_as_uint(c.frac[0]) + 8u) & ~0xFu)) | xt);
 #pragma unroll
                 for (int k2 = 0; k2 < 4; ++k2) {
                     if (rrank[k2] >= 0) {
                         const uint32_t fi = e[2 * k2] * F;
                         const int at = oslot[(int)(fi >> sink.shift) - first_owner].scan + rrank[k2];
                         reinterpret_cast<uint4*>(stage)[at] = make_uint4(fi, __float_as_uint(rv0[k2]), __float_as_uint(rv1[k2]), fxt);
+                    }
+                }
+                if (straddle) {
+#pragma unroll
+                    for (int k2 = 0; k2 < 4; ++k2) {
+                        if (rrank[4 + k2] >= 0) {
+                            const uint32_t fj = e[2 * k2 + 1] * F;
+                            const int at = oslot[(int)(fj >> sink.shift) - first_owner].scan + rrank[4 + k2];
+                            reinterpret_cast<uint4*>(stage)[at] = make_uint4(fj, __float_as_uint(rv0[4 + k2]), __float_as_uint(rv1[4 + k2]), 0u);
+                        }
                     }
                 }
             } else
@@ -824,6 +849,7 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
                     } else {
                         const uint32_t in_level = idx - level_base;                       // e1 = e0 ^ (2^(t+1) - 1): float index ^ (mask << 1)
                         xpair_overflow(ovf, in_level, in_level ^ (((2u << t) - 1u) << 1), t, a0, a1, fx);
+                        sink.ovf_flag[lv] = sink.epoch;
                     }
                 }
             } else
@@ -841,6 +867,7 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
                     store_stream_b64((((uint64_t)os.ptr_hi << 32) | os.ptr_lo) + (uint64_t)k * 8u, r2);
                 } else if (ovf) {
                     // same 26-bit rounding as a packed record: which records overflow depends on arrival order, the sum must not
+                    sink.ovf_flag[lv] = sink.epoch;
                     const float q0 = PAIR ? __uint_as_float(lnr_pack26(v0) << 6) : v0, q1 = PAIR ? __uint_as_float(lnr_pack26(v1) << 6) : 0.0f;
                     if (q0 != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(ovf + (idx - level_base)), (unsigned long long)lnr_to_fix(q0));
                     if (PAIR && q1 != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(ovf + (idx - level_base) + 1), (unsigned long long)lnr_to_fix(q1));
@@ -1031,8 +1058,17 @@ encode_backward_binned_kernel(const LnrNetSpec spec, const float* __restrict__ t
                                 dst[0] = rec.a; dst[1] = rec.b; dst[2] = rec.c;
                             }
                         } else {
-                            // bin full, region closed, or the two corners straddle owner slices: same rounding as a packed record
-                            xpair_overflow(ovf, fi - level_base, e[2 * k2 + 1] * F - level_base, xt, a0[k2], a1[k2], c.frac[0]);
+                            // bin full or region closed: same rounding as a packed record.  Corners that straddle owner slices (xt >= 12): as
+                            // the scan partition's two single-corner records (t = 0, fx = 0, the x weight applied here), so that the two
+                            // partitions agree to the bit
+                            if (xt < 12u) xpair_overflow(ovf, fi - level_base, e[2 * k2 + 1] * F - level_base, xt, a0[k2], a1[k2], c.frac[0]);
+                            else {
+                                const uint32_t i0 = fi - level_base, i1 = e[2 * k2 + 1] * F - level_base;
+                                const float gx = 1.0f - c.frac[0];
+                                xpair_overflow(ovf, i0, i0 ^ 2u, 0u, gx * a0[k2], gx * a1[k2], 0.0f);
+                                xpair_overflow(ovf, i1, i1 ^ 2u, 0u, c.frac[0] * a0[k2], c.frac[0] * a1[k2], 0.0f);
+                            }
+                            sink.ovf_flag[lv] = sink.epoch;
                         }
                     }
                 }
@@ -1062,6 +1098,7 @@ encode_backward_binned_kernel(const LnrNetSpec spec, const float* __restrict__ t
                             const int o = (int)(fi >> LNR_SLICE_SHIFT) - first_owner;
                             *reinterpret_cast<uint2*>(stage + (uint32_t)o * BIN + at[k]) = lnr_pack_pair((fi & ((1u << LNR_SLICE_SHIFT) - 1u)) >> 1, v0[k], v1[k]);
                         } else {
+                            sink.ovf_flag[lv] = sink.epoch;
                             const float q0 = __uint_as_float(lnr_pack26(v0[k]) << 6), q1 = __uint_as_float(lnr_pack26(v1[k]) << 6);
                             if (q0 != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(ovf + (fi - level_base)), (unsigned long long)lnr_to_fix(q0));
                             if (q1 != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(ovf + (fi - level_base) + 1), (unsigned long long)lnr_to_fix(q1));
@@ -1287,7 +1324,8 @@ int lnr_encode_forward(const LnrNetSpec* spec, const float* params, const PointS
 
 int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, const float* dfeat,
                         float* dxl, int64_t m_pad, float* grad_table, void* regions, const RegionPlan* plan, int* counts, int bpg,
-                        int maxo, int shift, long long* ovf, float* d_pts, float* d_rays_acc, long long* ray_acc, bool bins_w8, int parts, hipStream_t st) {
+                        int maxo, int shift, long long* ovf, int* ovf_flag, int epoch, float* d_pts, float* d_rays_acc, long long* ray_acc, bool bins_w8,
+                        int parts, hipStream_t st) {
     const float* table = params + spec->n_mlp_params;
     const bool hash = spec->encoding == LNR_ENC_HASHGRID;
     // d/dx mode: d_rays_acc (rays form, n_samples % 64 == 0, checked by the caller) > d_pts (planes) > none
@@ -1375,10 +1413,8 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
         }
         if (rec_levels.n + xp_levels.n + brec_levels.n + bxp_levels.n > 0) {
             EncSink sink;
-            if (regions != nullptr && ovf_total > 0 && hipMemsetAsync(ovf, 0, (size_t)ovf_total * sizeof(long long), st) != hipSuccess) {
-                lnr_set_error("lnr_density_backward: hipMemsetAsync failed");
-                return LNR_ERR_LAUNCH;
-            }
+            // (the overflow accumulators are all-zero here: lnr_density_backward keeps them so between calls, lnr_density.hip)
+            sink.ovf_flag = ovf_flag; sink.epoch = epoch;
             sink.grad_table = grad_table; sink.ovf = ovf; sink.regions = regions; sink.plan = *plan; sink.counts = counts; sink.maxo = maxo; sink.shift = shift;
             sink.combine_scale_max = LNR_COMBINE_SCALE_MAX;
 #ifdef LNR_ABLATE

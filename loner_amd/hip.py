@@ -31,6 +31,7 @@ BWD_REPORT_REGIONS = 2       # LNR_BWD_REPORT_REGIONS
 BWD_DEFER_WEIGHT_FOLD = 16   # LNR_BWD_DEFER_WEIGHT_FOLD
 BWD_BINS = 4                 # LNR_BWD_BINS
 BWD_BINS_W8 = 8              # LNR_BWD_BINS_W8
+BWD_OVERWRITE_GRAD = 32      # LNR_BWD_OVERWRITE_GRAD
 WORKSPACE_STATUS_BYTES, STATUS_CLIPPED = 256, 0            # LNR_WORKSPACE_STATUS_BYTES, LNR_STATUS_CLIPPED
 DRAW_JITTER, DRAW_PDF, DRAW_NOISE, DRAW_RAY_INDEX = 0, 1, 2, 16      # LNR_DRAW_*
 POISON_NAN_LOSS, POISON_POSE_GRAD, POISON_POSE = 1, 2, 3      # LNR_POISON_* codes of the failure guard (int32[2] device word)
@@ -67,7 +68,7 @@ _SIGNATURES = {
     "lnr_density_forward": (C.c_int, [C.POINTER(NetSpec), P, P, C.c_int64, P, P, C.c_int32, C.c_int32, P, P, P, C.c_size_t, P]),
     "lnr_density_backward": (C.c_int, [C.POINTER(NetSpec), P, P, C.c_int64, P, P, C.c_int32, C.c_int32, P, P, P, P, P,
                                        C.c_int32, C.c_int32, P, C.c_size_t, P, P]),
-    "lnr_density_fold_weight_grads": (C.c_int, [C.POINTER(NetSpec), C.c_int64, P, P, C.c_size_t, P]),
+    "lnr_density_fold_weight_grads": (C.c_int, [C.POINTER(NetSpec), C.c_int64, P, P, C.c_size_t, C.c_int32, P]),
     "lnr_build_lidar_rays": (C.c_int, [P, P, C.c_int64, P, C.c_int32, P, C.c_float, C.c_float, C.c_float,
                                        C.POINTER(C.c_float), P, P, P, P]),
     "lnr_build_window_rays": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_float), C.POINTER(C.c_int64),

@@ -121,19 +121,20 @@ def _event(ev):
 
 def density_backward(spec, params, d_sigma, grad_params, pts=None, rays=None, z=None, n_rays_dev=None,
                      want_d_pts=False, reuse_features=False, d_rays=None, table_atomics=False, report_regions=False, bins=False, bins_w8=False, input_grad_event=None,
-                     defer_weight_fold=False):
+                     defer_weight_fold=False, overwrite_grad=False):
     """Accumulates into grad_params [n_params] (None: parameters frozen, only the input gradient is computed);
     returns d_pts ([...,3]) or None.  table_atomics: test hook (LNR_BWD_TABLE_ATOMICS).
     reuse_features: the caller asserts that the last density_forward on this device ran on the same params and
     points (and that neither changed since), so the encoded features still in the workspace are reused.
-    d_rays [n_rays,13] (rays form, instead of want_d_pts): the point gradient is reduced per ray and added to it."""
+    d_rays [n_rays,13] (rays form, instead of want_d_pts): the point gradient is reduced per ray and added to it.
+    overwrite_grad: grad_params receives this call's gradient instead of accumulating it (LNR_BWD_OVERWRITE_GRAD)."""
     assert not (want_d_pts and d_rays is not None)
     require_device(params, d_sigma, grad_params, pts, rays, z)
     params, d_sigma = _f32c(params), _f32c(d_sigma)
     assert grad_params is None or (grad_params.dtype == torch.float32 and grad_params.is_contiguous())
     flags = (hip.BWD_TABLE_ATOMICS if table_atomics else 0) | (hip.BWD_REPORT_REGIONS if report_regions else 0) | \
         (hip.BWD_BINS if (bins or _BINS) else 0) | (hip.BWD_BINS_W8 if (bins_w8 or _BINS_W8) else 0) | \
-        (hip.BWD_DEFER_WEIGHT_FOLD if defer_weight_fold else 0)
+        (hip.BWD_DEFER_WEIGHT_FOLD if defer_weight_fold else 0) | (hip.BWD_OVERWRITE_GRAD if overwrite_grad else 0)
     n_points = (pts.numel() // 3) if pts is not None else z.numel()
     ent, need = _workspace(spec, params.device, n_points)
     if pts is not None:
@@ -159,12 +160,13 @@ def density_backward(spec, params, d_sigma, grad_params, pts=None, rays=None, z=
     return d_pts
 
 
-def density_fold_weight_grads(spec, grad_params, n_points):
+def density_fold_weight_grads(spec, grad_params, n_points, overwrite_grad=False):
     """Adds the weight-gradient slabs a density_backward(defer_weight_fold=True) call left in the workspace to grad_params
     (on the current stream: the training loop does it on its side stream, beside the table-gradient reduce)."""
     require_device(grad_params)
     ent, need = _workspace(spec, grad_params.device, n_points)
-    check(load().lnr_density_fold_weight_grads(C.byref(spec), int(n_points), _ptr(grad_params), _ptr(ent["buf"]), need, _stream()),
+    check(load().lnr_density_fold_weight_grads(C.byref(spec), int(n_points), _ptr(grad_params), _ptr(ent["buf"]), need,
+                                               hip.BWD_OVERWRITE_GRAD if overwrite_grad else 0, _stream()),
           "lnr_density_fold_weight_grads")
 
 

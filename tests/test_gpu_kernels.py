@@ -824,6 +824,17 @@ def test_record_partition_equals_global_accumulation(ops, net):
         g_bin = torch.zeros_like(g_rec); r_bin = torch.zeros_like(r_rec)
         ops.density_backward(spec, params, dv(d_sigma), g_bin, rays=dv(rays), z=dv(z), n_rays_dev=n_dev, d_rays=r_bin, bins=True, bins_w8=w8)
         assert torch.equal(g_bin, g_rec) and torch.equal(r_bin, r_rec)
+    # [r4] the 64-bit overflow accumulators are kept all-zero BETWEEN calls (the reduce re-zeroes what it reads; no per-call clear): a call
+    # behind one that filled every level's accumulators (the all-atomics route) must see none of it
+    g_acc2 = torch.zeros_like(g_rec)
+    ops.density_backward(spec, params, dv(d_sigma), g_acc2, rays=dv(rays), z=dv(z), n_rays_dev=n_dev, d_rays=torch.zeros_like(r_rec), table_atomics=True)
+    g_again = torch.zeros_like(g_rec); r_again = torch.zeros_like(r_rec)
+    ops.density_backward(spec, params, dv(d_sigma), g_again, rays=dv(rays), z=dv(z), n_rays_dev=n_dev, d_rays=r_again)
+    assert torch.equal(g_again, g_rec) and torch.equal(r_again, r_rec) and torch.equal(g_acc2, g_rec)
+    # [r4] LNR_BWD_OVERWRITE_GRAD: the gradient is STORED (every float of the table and of the MLP matrices), whatever the buffer held
+    g_over = torch.full_like(g_rec, 7.0)
+    ops.density_backward(spec, params, dv(d_sigma), g_over, rays=dv(rays), z=dv(z), n_rays_dev=n_dev, d_rays=torch.zeros_like(r_rec), overwrite_grad=True)
+    assert torch.equal(g_over, g_rec)
 
 
 @pytest.mark.parametrize("net", ["default", "hash_f4_2hidden"])

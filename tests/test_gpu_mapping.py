@@ -909,3 +909,29 @@ def test_training_with_the_in_kernel_generator_reaches_the_oracles_l1_distributi
     assert h.max() < 0.6 * h0.mean() and o.max() < 0.6 * o0.mean()                # both trained
     pooled = np.sqrt((h.var(ddof=1) + o.var(ddof=1)) / 2)
     assert abs(h.mean() - o.mean()) < max(pooled, 0.03 * o.mean()), (h.mean(), o.mean(), pooled)
+
+
+@pytest.mark.parametrize("pipeline", [True, False])
+def test_overwrite_gradient_mode_changes_nothing(pipeline):
+    """LNR_BWD_OVERWRITE_GRAD: the training loop lets the table-gradient reduce and the weight-gradient fold STORE the gradient (no read
+    of the old one) and Adam not zero it - 60 MB of HBM traffic less per iteration.  Bit-identical to accumulate + zero, in the pipelined
+    and in the single-stream loop; and the gradient buffer is zero when the phase ends, as after the reference's last zero_grad."""
+    from loner_amd.mapping import optimizer as OM
+    from loner_amd.utils import synthetic as SY
+
+    def run(overwrite):
+        torch.manual_seed(0)
+        opt = OM.Optimizer(small_settings(96, 64), None, world_cube(), 0, False, True, False)
+        opt._overwrite_grads, opt._pipeline = overwrite, pipeline
+        base = SY.trajectory_pose6(2)
+        kfs = make_keyframes([base[0], base[1] + torch.tensor([0.02, 0.0, -0.01, 0.0, 0.0, 0.0])])
+        kfs[0].is_anchored = True
+        torch.manual_seed(3)
+        opt._do_iterate_optimizer(kfs, [None], optimizer_settings=OM.OptimizationSettings(12, False, False, False, True))
+        p = opt._model.nerf_model._model_sigma.params
+        st = opt._optimizer.state[p]
+        assert float(p.grad.abs().max()) == 0.0
+        return p.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(), kfs[1].get_lidar_pose().get_pose_tensor().detach().clone(), \
+            opt._occupancy_grid.detach().clone(), opt.last_stats["loss_terms"].clone()
+    for x, y in zip(run(True), run(False)):
+        assert torch.equal(x, y)

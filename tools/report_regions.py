@@ -14,7 +14,8 @@ from loner_amd import ops                                      # noqa: E402
 if __name__ == "__main__":
     args = bench.parse()
     orig = ops.density_backward
-    ops.density_backward = lambda *a, **k: orig(*a, **dict(k, report_regions=True))
+    state = {"on": False}
+    ops.density_backward = lambda *a, **k: orig(*a, **dict(k, report_regions=state["on"]))
     from loner_amd.common.pose_utils import WorldCube
     from loner_amd.common.settings import default_optimizer_settings
     from loner_amd.mapping.optimizer import OptimizationSettings, Optimizer
@@ -25,5 +26,9 @@ if __name__ == "__main__":
     s["model_config"]["model"]["render"]["N_samples_train"] = args.samples
     torch.manual_seed(0)
     opt = Optimizer(s, None, WorldCube(torch.tensor(scale), torch.from_numpy(shift)), 0, False, True, False)
-    opt._do_iterate_optimizer(bench.build_window(args.keyframes), [None], optimizer_settings=OptimizationSettings(max(args.steps, 1), False, False, False, True))
+    window = bench.build_window(args.keyframes)
+    if args.warmup > 0:            # train silently first: the report is wanted for a map that has formed, not for iteration 0
+        opt._do_iterate_optimizer(window, [None], optimizer_settings=OptimizationSettings(args.warmup, False, False, False, True))
+    state["on"] = True
+    opt._do_iterate_optimizer(window, [None], optimizer_settings=OptimizationSettings(max(args.steps, 1), False, False, False, True))
     torch.cuda.synchronize()
