@@ -446,7 +446,7 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
                 else if (spec->level_scale[l] < LNR_COMBINE_SCALE_MAX) r *= LNR_COMBINE_FILL;   // run-length combined along the rays
                 // twice the expectation + 64 records, in 256-byte units: a record beyond the capacity costs four (two) 64-bit global atomics,
                 // so the capacity is generous (sweep in DESIGN.md; the reduce does not care how full a region is)
-                const double recs = (r * LNR_REGION_HEADROOM + LNR_REGION_SLACK) * shrink;
+                const double recs = (r * (xp ? LNR_REGION_HEADROOM_XP : LNR_REGION_HEADROOM) + LNR_REGION_SLACK) * shrink;
                 uint64_t bytes = (uint64_t)(recs * (xp ? 12.0 : 8.0));
                 // Binned partition (lnr_encode.hip): hashed levels, whose records spread evenly over the owners - a batch (one sample per
                 // thread) must be expected to fill at most half a bin, worst case (nothing dead, nothing combined)

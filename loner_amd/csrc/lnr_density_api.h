@@ -22,8 +22,15 @@ struct PointSrc {
 #define LNR_REGION_BUDGET (24ull << 30)
 #define LNR_COMBINE_SCALE_MAX 3000.0f
 #define LNR_COMBINE_FILL 1.0        // expected records of a run-length combined level, as a fraction of its uncombined count
+#ifndef LNR_REGION_HEADROOM
 #define LNR_REGION_HEADROOM 2.0     // region capacity = expectation x this + LNR_REGION_SLACK records
+#endif
+#ifndef LNR_REGION_SLACK
 #define LNR_REGION_SLACK 64.0
+#endif
+#ifndef LNR_REGION_HEADROOM_XP
+#define LNR_REGION_HEADROOM_XP LNR_REGION_HEADROOM     // the same for the x-pair levels (A/B knob)
+#endif
 #ifndef LNR_ENC_BWD_BLOCK
 #define LNR_ENC_BWD_BLOCK 512       // threads of an encode-backward workgroup = samples of one partition batch
 #endif

@@ -203,3 +203,37 @@ def test_bench_gpus_argument_spawns_that_many_ranks():
     assert r.returncode != 0 and "--gpus 4" in r.stderr
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--launch-check"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_reference_shaped_stand_ins_behave_like_the_classes_they_stand_for():
+    """The boundary test (tests/test_gpu_mapping.py::test_optimizer_is_driven_by_reference_shaped_callers) is only as good as its
+    stand-ins: AttrDict semantics (nested dicts wrapped, lists -> tuples on ATTRIBUTE access only), a Pose whose matrix is cached at
+    construction and re-derived from the 6-vector only while that vector requires a gradient (pose.py:140-144), and surfaces that
+    refuse members the reference classes do not have."""
+    import pytest
+    import torch
+    from oracle import poses as OP
+    from tests.support import RefShapedKeyFrame, RefShapedFrame, RefShapedLidarScan, RefShapedPose, RefShapedSettings
+    s = RefShapedSettings({"a": {"b": [1, 2, {"c": 3}]}, "k": [{"n": 1}]})
+    assert isinstance(s.a, RefShapedSettings) and s.a.b[:2] == (1, 2) and s.a.b[2].c == 3 and isinstance(s["a"]["b"], list)
+    assert isinstance(s.k, tuple) and s.k[0].n == 1
+    with pytest.raises(AttributeError):
+        s.missing
+    p6 = torch.tensor([0.3, -0.2, 0.1, 0.02, -0.4, 0.25])
+    pose = RefShapedPose(pose_tensor=p6.clone(), fixed=True)
+    assert torch.allclose(pose.get_transformation_matrix(), OP.transform_from_pose6(p6), atol=1e-6)
+    with torch.no_grad():
+        pose.get_pose_tensor()[0] += 1.0                                   # an optimiser stepped the vector ...
+    assert float(pose.get_transformation_matrix()[0, 3]) == pytest.approx(0.3)      # ... a FIXED pose still hands out the cached matrix
+    pose.set_fixed(False)
+    assert float(pose.get_transformation_matrix()[0, 3]) == pytest.approx(1.3)      # a free one re-derives it
+    scan = RefShapedLidarScan(torch.zeros(3, 5), torch.ones(5), torch.arange(5.0), sky_rays=torch.Tensor())
+    assert len(scan) == 5
+    with pytest.raises(AssertionError):
+        scan._lnr_dev = 1                                                  # not a member of the reference's LidarScan
+    fr = RefShapedFrame(None, scan, RefShapedPose())
+    fr._lidar_pose = pose
+    kf = RefShapedKeyFrame(fr)
+    assert kf.get_lidar_scan() is scan and kf.get_lidar_pose() is pose and float(kf.get_time()) == 0.0
+    with pytest.raises(AssertionError):
+        kf.extra = 1
