@@ -45,9 +45,6 @@ struct PointSrc {
 #define LNR_XPAIR_SCALE_MIN 3000.0f   /* hashed power-of-two levels at least this fine take x-pair records (below: run-length combined 8-byte records) */
 #endif
 
-#ifndef LNR_PAIR_FWD
-#define LNR_PAIR_FWD 1      /* encode_forward_pair_kernel (two lanes per sample) instead of encode_forward_kernel */
-#endif
 #ifndef LNR_SPLIT_DX
 #define LNR_SPLIT_DX 0      /* 1: hash grids take the input gradient as a kernel of its own (encode_dx_pair_kernel); measured SLOWER */
 #endif

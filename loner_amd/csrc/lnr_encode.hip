@@ -78,57 +78,9 @@ __device__ __forceinline__ void gather_entries(const float* __restrict__ table, 
     }
 }
 
-// H16: the features leave as half2 pairs (plane p holds features 2p, 2p+1: one dword per sample; F/2 planes per level) for the
-// fp16 MLP kernels (lnr_density_f16.hip), rounded to nearest even; the interpolation itself stays fp32.
-template <int F, bool H16>
-__global__ void __launch_bounds__(ENC_BLOCK)
-encode_forward_kernel(const LnrNetSpec spec, const float* __restrict__ table, const PointSrc src, float* __restrict__ feat,
-                      int64_t m_pad, int bpg, uint32_t level_mask, int xcd_affine) {
-    static_assert(!H16 || F >= 2, "half2 planes pair up the features of a level");
-    int slot, chunk;
-    if (!level_slot(bpg, __builtin_popcount(level_mask), xcd_affine != 0, slot, chunk)) return;
-    const int lv = nth_level(level_mask, slot);
-    const LevelInfo L = level_info(spec, lv);
-    const uint32_t M = (uint32_t)live_points(src);
-    // the MLP kernels read whole tiles of 16 (fp32) / 32 (fp16) samples: zero the ragged tail
-    const uint32_t Mt = H16 ? (M + 31u) / 32u * 32u : (M + 15u) / 16u * 16u;
-    float* planes = feat + (size_t)(H16 ? lv * (F / 2) : lv * F) * m_pad;
-    const uint32_t plane_bytes = (uint32_t)m_pad * 4u;
-    SampleCursor cur;
-    cur.init((uint32_t)chunk * ENC_BLOCK + threadIdx.x, (uint32_t)bpg * ENC_BLOCK, src.pts ? 1u : (uint32_t)src.n_samples);
-    const bool uni = ray_uniform(src, 64u);
-    for (; cur.m < Mt; cur.advance()) {
-        float out[F];
-#pragma unroll
-        for (int f = 0; f < F; ++f) out[f] = 0.0f;
-        if (cur.m < M) {
-            RawPoint rp;
-            load_raw_point(src, cur.m, cur.ray, rp, uni);
-            float x[3];
-            unit_point(src, rp, x);
-            const Cell c = cell_of(L, x);
-            uint32_t e[8]; float w[8], tv[8][F];
-            cell_entries(L, c, e);
-            gather_entries<F>(table, e, tv);
-            cell_weights(c, w);
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-#pragma unroll
-                for (int f = 0; f < F; ++f) out[f] += w[k] * tv[k][f];
-        }
-        if constexpr (H16) {
-            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-            for (int q = 0; q < F / 2; ++q)
-                st32<uint32_t>(planes, (uint32_t)q * plane_bytes + cur.m * 4u, __builtin_bit_cast(uint32_t, h2{(_Float16)out[2 * q], (_Float16)out[2 * q + 1]}));
-        } else {
-#pragma unroll
-            for (int f = 0; f < F; ++f) st32<float>(planes, (uint32_t)f * plane_bytes + cur.m * 4u, out[f]);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ paired lanes
+// (helpers of encode_dx_pair_kernel, the -DLNR_SPLIT_DX=1 experiment; the forward ran in this form for part of round 4 - see
+// forward_level_loop for what replaced it)
 // Two lanes per sample: lane 2i takes the four corners of the cell with x = b0, lane 2i+1 those with x = b0 + 1.
 // Why: a random table gather costs one L2 LINE per distinct line an instruction touches (tools/gather_bench.hip: 0.5 lines/clk/CU
 // whatever the access width), and the two x-neighbours of a corner pair sit in the same 64-byte line most of the time - dense levels:
@@ -179,69 +131,174 @@ __device__ __forceinline__ void gather_entries4(const float* __restrict__ table,
     }
 }
 
+// ---- the forward kernel: one workgroup row per level, the per-step loop specialised at compile time
+// Level kinds: what the entry arithmetic of a level needs (wave-uniform; decided once per workgroup, not once per step - the round-4
+// first form carried ~20 uniform branches and the general modulo through every step: SQ_INSTS_SALU 43 M against 127 M VALU per launch).
+enum : int { LK_HASH_POW2 = 0,      // hashed, table size a power of two (every hashed level tiny-cuda-nn builds): xor + mask
+             LK_DENSE = 1,          // not hashed: index arithmetic; the modulo only if an index reaches the table size (points outside
+                                    // the unit cube - the integer result is the same either way)
+             LK_GENERIC = 2 };      // anything else (hashed with another size): flags read at run time
+
+template <int LK, int N>
+__device__ __forceinline__ void wrap_entries(const LevelInfo& L, uint32_t e[N]) {
+    if constexpr (LK == LK_HASH_POW2) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) e[k] = (e[k] & (L.size - 1u)) + L.offset;
+    } else if constexpr (LK == LK_DENSE) {
+        uint32_t any = e[0];
+#pragma unroll
+        for (int k = 1; k < N; ++k) any |= e[k];           // >= every entry: below the size = no entry needs the modulo
+        if (any >= L.size) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) e[k] %= L.size;
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) e[k] += L.offset;
+    } else {
+        if (L.pow2) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) e[k] = (e[k] & (L.size - 1u)) + L.offset;
+        } else {
+#pragma unroll
+            for (int k = 0; k < N; ++k) e[k] = e[k] % L.size + L.offset;
+        }
+    }
+}
+
+// entries of a cell before the wrap: all 8 corners (corner bit 0 = +x, 1 = +y, 2 = +z)
+__device__ __forceinline__ void raw_entries8(const LevelInfo& L, const Cell& c, uint32_t e[8]) {
+    if (L.hashed) {
+        const uint32_t hx0 = c.b[0], hx1 = c.b[0] + 1u;
+        const uint32_t hy0 = c.b[1] * PRIME_Y, hy1 = hy0 + PRIME_Y;
+        const uint32_t hz0 = c.b[2] * PRIME_Z, hz1 = hz0 + PRIME_Z;
+        const uint32_t yz[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = ((k & 1) ? hx1 : hx0) ^ yz[k >> 1];
+    } else {
+        const uint32_t sy = L.res, sz = L.res * L.res;
+        const uint32_t i0 = c.b[0] + c.b[1] * sy + c.b[2] * sz;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = i0 + (uint32_t)(k & 1) + ((k & 2) ? sy : 0u) + ((k & 4) ? sz : 0u);
+    }
+}
+// One level's samples, chunk `chunk` of `bpg`: one lane per (sample, level), 8 gathers.
+// H16: the features leave as half2 pairs (plane p holds features 2p, 2p+1: one dword per sample; F/2 planes per level) for the
+// fp16 MLP kernels (lnr_density_f16.hip), rounded to nearest even; the interpolation itself stays fp32.
+//
+// Software pipeline.  A step as one dependent chain - depth load (HBM) -> cell -> gathers (L2) -> interpolation -> stores - and, gfx9
+// having ONE in-order counter for vector-memory loads and stores, a wait for the next depth that also waits for the stores just
+// issued, took ~8000 clocks with 8 waves per SIMD to cover it, however few lines the gathers touched (profiles/r04_forward_levels.txt:
+// 0.107 ms per coarse level and 16.8 M samples with one lane per sample, with two, with the gathers replaced by scalar loads).
+// Hence, per step i: the point loads of step i + 1 and the STORES of step i - 1 go out together with the gathers of i, and only then
+// the wait for the gathers and the interpolation.  The body is straight-line code (no branch on "is this sample live": the waits the
+// compiler places where divergent branches join are full ones): steps past the last sample - the ragged tail of the last tile - load
+// the last sample's point again and store zeros; the first step's "previous" store writes zeros to the slot the next step fills.
+//
+// Measured and dropped once the loop was pipelined (profiles/r04_forward_levels.txt):
+//   * two lanes per sample (lane 2i the four corners with x = b0, lane 2i+1 those with x = b0 + 1: x-neighbours share a 64-byte line,
+//     one instruction pays it once) - the round-4 first form, 5 % faster than the un-pipelined one-lane loop; against the pipelined
+//     one 0.409 : 0.379 ms on the training window, 3.01 : 2.96 ms on an inference launch, slower on every level of both;
+//   * a wave whose 64 samples sit in <= 4 cells (the coarse levels of the inference path) fetching each cell once through the scalar
+//     cache (v_readlane + 8 s_load per distinct cell instead of 8 vector gathers): no faster on any level, 73 registers against 46.
+template <int F, bool H16, int LK, bool FMA, int SK>
+__device__ __forceinline__ void forward_level_loop(LevelInfo L, const float* __restrict__ table, const PointSrc& src, float* __restrict__ planes,
+                                                   uint32_t plane_bytes, uint32_t M, uint32_t Mt, int chunk, int bpg) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    L.pos_fma = FMA;
+    if constexpr (LK == LK_HASH_POW2) { L.hashed = true; L.pow2 = true; }
+    if constexpr (LK == LK_DENSE) L.hashed = false;
+    constexpr int NV = H16 ? F / 2 : F;                                // dwords a lane stores per step, one per plane
+    SampleCursor cur;
+    const uint32_t per_ray = SK == LNR_SRC_PTS ? 1u : (uint32_t)src.n_samples;
+    cur.init((uint32_t)chunk * ENC_BLOCK + threadIdx.x, (uint32_t)bpg * ENC_BLOCK, per_ray);
+    if (cur.m >= Mt) return;
+    const uint32_t m_last = M - 1u, ray_last = m_last / per_ray;      // (M >= 1 here)
+    RawPoint ahead;
+    load_raw_point_of<SK>(src, cur.m < M ? cur.m : m_last, cur.m < M ? cur.ray : ray_last, ahead);
+    uint32_t held[NV], m_held = cur.m;                 // the step before's results, stored while this step's gathers are on their way
+#pragma unroll
+    for (int v = 0; v < NV; ++v) held[v] = 0u;
+    while (cur.m < Mt) {
+        const uint32_t m = cur.m;
+        const bool live = m < M;
+        const RawPoint rp = ahead;
+        cur.advance();
+        const bool more = cur.m < M;
+        uint32_t m_next = more ? cur.m : m_last, ray_next = more ? cur.ray : ray_last;
+        // (opaque to the optimiser: seen as "the next step's cur.m", the loads below are merged with the loop's first ones and moved
+        // to the top of the next step wherever the body has inner control flow - un-pipelining the loop)
+        asm volatile("" : "+v"(m_next), "+v"(ray_next));
+        float x[3];
+        unit_point_of<SK>(rp, x);
+        const Cell c = cell_of(L, x);
+        uint32_t e[8]; float tv[8][F], w[8];
+        raw_entries8(L, c, e);
+        wrap_entries<LK, 8>(L, e);
+        gather_entries<F>(table, e, tv);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) st32<uint32_t>(planes, (uint32_t)v * plane_bytes + m_held * 4u, held[v]);
+        load_raw_point_of<SK>(src, m_next, ray_next, ahead);
+        __builtin_amdgcn_sched_barrier(0);              // (the scheduler otherwise sinks these loads below the interpolation)
+        cell_weights(c, w);
+        // corner after corner like the reference's loop (oracle/network.py: tiny-cuda-nn accumulates with fmaf)
+        float out[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) out[f] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int f = 0; f < F; ++f) out[f] = __builtin_fmaf(w[k], tv[k][f], out[f]);
+        if (!live) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) out[f] = 0.0f;
+        }
+        if constexpr (H16) {
+#pragma unroll
+            for (int q = 0; q < F / 2; ++q) held[q] = __builtin_bit_cast(uint32_t, h2{(_Float16)out[2 * q], (_Float16)out[2 * q + 1]});
+        } else {
+#pragma unroll
+            for (int f = 0; f < F; ++f) held[f] = __float_as_uint(out[f]);
+        }
+        m_held = m;
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) st32<uint32_t>(planes, (uint32_t)v * plane_bytes + m_held * 4u, held[v]);
+}
+
+template <int F, bool H16, int LK, bool FMA>
+__device__ __forceinline__ void forward_level_by_source(int sk, const LevelInfo& L, const float* __restrict__ table, const PointSrc& src,
+                                                        float* __restrict__ planes, uint32_t plane_bytes, uint32_t M, uint32_t Mt, int chunk, int bpg) {
+    if (sk == LNR_SRC_RAY_UNIFORM) forward_level_loop<F, H16, LK, FMA, LNR_SRC_RAY_UNIFORM>(L, table, src, planes, plane_bytes, M, Mt, chunk, bpg);
+    else if (sk == LNR_SRC_PTS) forward_level_loop<F, H16, LK, FMA, LNR_SRC_PTS>(L, table, src, planes, plane_bytes, M, Mt, chunk, bpg);
+    else forward_level_loop<F, H16, LK, FMA, LNR_SRC_RAY>(L, table, src, planes, plane_bytes, M, Mt, chunk, bpg);
+}
+template <int F, bool H16>
+__device__ __forceinline__ void forward_level(const LevelInfo& L, const float* __restrict__ table, const PointSrc& src, float* __restrict__ planes,
+                                              uint32_t plane_bytes, uint32_t M, uint32_t Mt, int chunk, int bpg) {
+    const int sk = point_source_kind(src, 64u);
+#define LNR_FWD_KIND(LK) do { if (L.pos_fma) forward_level_by_source<F, H16, LK, true>(sk, L, table, src, planes, plane_bytes, M, Mt, chunk, bpg); \
+                              else forward_level_by_source<F, H16, LK, false>(sk, L, table, src, planes, plane_bytes, M, Mt, chunk, bpg); } while (0)
+    if (L.hashed && L.pow2) LNR_FWD_KIND(LK_HASH_POW2);
+    else if (!L.hashed) LNR_FWD_KIND(LK_DENSE);
+    else LNR_FWD_KIND(LK_GENERIC);
+#undef LNR_FWD_KIND
+}
+
 template <int F, bool H16>
 __global__ void __launch_bounds__(ENC_BLOCK)
-encode_forward_pair_kernel(const LnrNetSpec spec, const float* __restrict__ table, const PointSrc src, float* __restrict__ feat,
-                           int64_t m_pad, int bpg, uint32_t level_mask, int xcd_affine) {
+encode_forward_kernel(const LnrNetSpec spec, const float* __restrict__ table, const PointSrc src, float* __restrict__ feat,
+                      int64_t m_pad, int bpg, uint32_t level_mask, int xcd_affine) {
     static_assert(!H16 || F >= 2, "half2 planes pair up the features of a level");
     int slot, chunk;
     if (!level_slot(bpg, __builtin_popcount(level_mask), xcd_affine != 0, slot, chunk)) return;
     const int lv = nth_level(level_mask, slot);
     const LevelInfo L = level_info(spec, lv);
     const uint32_t M = (uint32_t)live_points(src);
-    const uint32_t Mt = H16 ? (M + 31u) / 32u * 32u : (M + 15u) / 16u * 16u;      // the MLP kernels read whole tiles: zero the ragged tail
+    // the MLP kernels read whole tiles of 16 (fp32) / 32 (fp16) samples: zero the ragged tail
+    const uint32_t Mt = H16 ? (M + 31u) / 32u * 32u : (M + 15u) / 16u * 16u;
     float* planes = feat + (size_t)(H16 ? lv * (F / 2) : lv * F) * m_pad;
     const uint32_t plane_bytes = (uint32_t)m_pad * 4u;
-    const uint32_t hx = threadIdx.x & 1u;
-    SampleCursor cur;
-    cur.init((uint32_t)chunk * (ENC_BLOCK / 2) + (threadIdx.x >> 1), (uint32_t)bpg * (ENC_BLOCK / 2), src.pts ? 1u : (uint32_t)src.n_samples);
-    const bool uni = ray_uniform(src, 32u);
-    for (; cur.m < Mt; cur.advance()) {            // both lanes of a pair leave the loop together
-        float part[F];
-#pragma unroll
-        for (int f = 0; f < F; ++f) part[f] = 0.0f;
-        if (cur.m < M) {
-            RawPoint rp;
-            load_raw_point(src, cur.m, cur.ray, rp, uni);
-            float x[3];
-            unit_point(src, rp, x);
-            const Cell c = cell_of(L, x);
-            uint32_t e[4]; float tv[4][F];
-            cell_entries_x(L, c, hx, e);
-            gather_entries4<F>(table, e, tv);
-            // weights associated like cell_weights: (wx * wy) * wz
-            const float wxl = hx ? c.frac[0] : 1.0f - c.frac[0];
-            const float wxy[2] = {wxl * (1.0f - c.frac[1]), wxl * c.frac[1]};
-            const float wz[2] = {1.0f - c.frac[2], c.frac[2]};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float w = wxy[r & 1] * wz[r >> 1];
-#pragma unroll
-                for (int f = 0; f < F; ++f) part[f] += w * tv[r][f];
-            }
-        }
-        float out[F];
-#pragma unroll
-        for (int f = 0; f < F; ++f) out[f] = part[f] + pair_partner_f(part[f]);       // (commutative: both lanes hold the same sum)
-        if constexpr (H16) {
-            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-            if constexpr (F == 2) {
-                if (hx == 0u) st32<uint32_t>(planes, cur.m * 4u, __builtin_bit_cast(uint32_t, h2{(_Float16)out[0], (_Float16)out[1]}));
-            } else {
-#pragma unroll
-                for (int q = 0; q < F / 4; ++q) {              // lane hx stores pair planes 2q + hx
-                    const float a = hx ? out[4 * q + 2] : out[4 * q], b = hx ? out[4 * q + 3] : out[4 * q + 1];
-                    st32<uint32_t>(planes, (uint32_t)(2 * q + (int)hx) * plane_bytes + cur.m * 4u, __builtin_bit_cast(uint32_t, h2{(_Float16)a, (_Float16)b}));
-                }
-            }
-        } else if constexpr (F == 1) {
-            if (hx == 0u) st32<float>(planes, cur.m * 4u, out[0]);
-        } else {
-#pragma unroll
-            for (int q = 0; q < F / 2; ++q)                     // lane hx stores feature plane 2q + hx: one instruction covers two planes
-                st32<float>(planes, (uint32_t)(2 * q + (int)hx) * plane_bytes + cur.m * 4u, hx ? out[2 * q + 1] : out[2 * q]);
-        }
-    }
+    forward_level<F, H16>(L, table, src, planes, plane_bytes, M, Mt, chunk, bpg);
 }
 
 // fp32 feature planes of the frequency encoding: four features per thread (the fp16 mode's pair planes: freq_forward_h16_kernel)
@@ -1275,50 +1332,29 @@ int lnr_encode_forward(const LnrNetSpec* spec, const float* params, const PointS
     }
     uint32_t level_mask = spec->n_levels >= 32 ? 0xFFFFFFFFu : (1u << spec->n_levels) - 1u;
 #ifdef LNR_ABLATE
-    static const long fwd_levels = getenv("LNR_X_FWD_LEVELS") ? strtol(getenv("LNR_X_FWD_LEVELS"), nullptr, 0) : -1;      // time a subset of the levels
-    level_mask &= (uint32_t)fwd_levels;
+    // development builds, read at every call (tools/probe_forward_levels.py walks them in one process): time a subset of the levels
+    if (const char* v = getenv("LNR_X_FWD_LEVELS")) level_mask &= (uint32_t)strtol(v, nullptr, 0);
     if (level_mask == 0u) return LNR_OK;
 #endif
     const dim3 mgrid((unsigned)(__builtin_popcount(level_mask) * bpg));
     const int xcd = lnr_xcd_affine(__builtin_popcount(level_mask), cap_points, true) ? 1 : 0;
-#if LNR_PAIR_FWD
-    {
-        const dim3 pgrid((unsigned)(__builtin_popcount(level_mask) * bpg));
-#define LNR_FWD_PAIR(F, H) hipLaunchKernelGGL((encode_forward_pair_kernel<F, H>), pgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask, xcd)
-        if (half_planes) {
-            switch (spec->n_features) {
-                case 2: LNR_FWD_PAIR(2, true); break;
-                case 4: LNR_FWD_PAIR(4, true); break;
-                case 8: LNR_FWD_PAIR(8, true); break;
-                default: lnr_set_error("fp16 feature planes pair up features: n_features_per_level must be even"); return LNR_ERR_UNSUPPORTED;
-            }
-        } else {
-            switch (spec->n_features) {
-                case 1: LNR_FWD_PAIR(1, false); break;
-                case 2: LNR_FWD_PAIR(2, false); break;
-                case 4: LNR_FWD_PAIR(4, false); break;
-                default: LNR_FWD_PAIR(8, false); break;
-            }
-        }
-#undef LNR_FWD_PAIR
-        return LNR_OK;
-    }
-#endif
+#define LNR_FWD(F, H) hipLaunchKernelGGL((encode_forward_kernel<F, H>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask, xcd)
     if (half_planes) {
         switch (spec->n_features) {
-            case 2: hipLaunchKernelGGL((encode_forward_kernel<2, true>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask, xcd); break;
-            case 4: hipLaunchKernelGGL((encode_forward_kernel<4, true>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask, xcd); break;
-            case 8: hipLaunchKernelGGL((encode_forward_kernel<8, true>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask, xcd); break;
+            case 2: LNR_FWD(2, true); break;
+            case 4: LNR_FWD(4, true); break;
+            case 8: LNR_FWD(8, true); break;
             default: lnr_set_error("fp16 feature planes pair up features: n_features_per_level must be even"); return LNR_ERR_UNSUPPORTED;
         }
-        return LNR_OK;
+    } else {
+        switch (spec->n_features) {
+            case 1: LNR_FWD(1, false); break;
+            case 2: LNR_FWD(2, false); break;
+            case 4: LNR_FWD(4, false); break;
+            default: LNR_FWD(8, false); break;
+        }
     }
-    switch (spec->n_features) {
-        case 1: hipLaunchKernelGGL((encode_forward_kernel<1, false>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask, xcd); break;
-        case 2: hipLaunchKernelGGL((encode_forward_kernel<2, false>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask, xcd); break;
-        case 4: hipLaunchKernelGGL((encode_forward_kernel<4, false>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask, xcd); break;
-        default: hipLaunchKernelGGL((encode_forward_kernel<8, false>), mgrid, block, 0, st, *spec, table, *src, feat, m_pad, (int)bpg, level_mask, xcd); break;
-    }
+#undef LNR_FWD
     return LNR_OK;
 }
 

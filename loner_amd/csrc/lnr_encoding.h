@@ -108,6 +108,42 @@ __device__ __forceinline__ void unit_point(const PointSrc& s, const RawPoint& r,
     for (int d = 0; d < 3; ++d) x[d] = lnr_mul_rn(lnr_add_rn(p[d], 1.0f), 0.5f);   // (xyz+1)/2 rounded like the reference (no fma)
 }
 
+// The same with the kind of source a compile-time constant (encode_forward_kernel's specialised loops: no uniform branch per step).
+enum : int { LNR_SRC_PTS = 0, LNR_SRC_RAY_UNIFORM = 1, LNR_SRC_RAY = 2 };
+__device__ __forceinline__ int point_source_kind(const PointSrc& s, uint32_t samples_per_wave) {
+    return s.pts ? LNR_SRC_PTS : (ray_uniform(s, samples_per_wave) ? LNR_SRC_RAY_UNIFORM : LNR_SRC_RAY);
+}
+// the loads of a point (issued one step ahead of their use by the forward loops) ...
+template <int SK>
+__device__ __forceinline__ void load_raw_point_of(const PointSrc& s, uint32_t m, uint32_t ray, RawPoint& r) {
+    if constexpr (SK == LNR_SRC_PTS) {
+        r.o0 = ld32<float>(s.pts, m * 12u); r.o1 = ld32<float>(s.pts, m * 12u + 4u); r.o2 = ld32<float>(s.pts, m * 12u + 8u);
+        r.d0 = 0.0f; r.d1 = 0.0f; r.d2 = 0.0f; r.z = 0.0f;
+    } else if constexpr (SK == LNR_SRC_RAY_UNIFORM) {
+        const uint32_t ru = (uint32_t)__builtin_amdgcn_readfirstlane((int)ray);
+        const lnr_cfloat* rp = (const lnr_cfloat*)(uintptr_t)(s.rays + (size_t)ru * LNR_RAY_STRIDE);
+        r.o0 = rp[0]; r.o1 = rp[1]; r.o2 = rp[2]; r.d0 = rp[3]; r.d1 = rp[4]; r.d2 = rp[5];
+        r.z = ld32<float>(s.z, m * 4u);
+    } else {
+        const uint32_t ro = ray * (uint32_t)(LNR_RAY_STRIDE * 4);
+        r.o0 = ld32<float>(s.rays, ro); r.o1 = ld32<float>(s.rays, ro + 4u); r.o2 = ld32<float>(s.rays, ro + 8u);
+        r.d0 = ld32<float>(s.rays, ro + 12u); r.d1 = ld32<float>(s.rays, ro + 16u); r.d2 = ld32<float>(s.rays, ro + 20u);
+        r.z = ld32<float>(s.z, m * 4u);
+    }
+}
+// ... and its unit-cube coordinates
+template <int SK>
+__device__ __forceinline__ void unit_point_of(const RawPoint& r, float x[3]) {
+    float p[3] = {r.o0, r.o1, r.o2};
+    if constexpr (SK != LNR_SRC_PTS) {                   // o + d*z, as the reference rounds it
+        p[0] = lnr_add_rn(r.o0, lnr_mul_rn(r.d0, r.z));
+        p[1] = lnr_add_rn(r.o1, lnr_mul_rn(r.d1, r.z));
+        p[2] = lnr_add_rn(r.o2, lnr_mul_rn(r.d2, r.z));
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) x[k] = lnr_mul_rn(lnr_add_rn(p[k], 1.0f), 0.5f);
+}
+
 __device__ __forceinline__ void load_unit_point(const PointSrc& s, int64_t m, float x[3]) {
     RawPoint r;
     load_raw_point(s, (uint32_t)m, s.pts ? 0u : (uint32_t)(m / s.n_samples), r);

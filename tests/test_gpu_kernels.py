@@ -695,10 +695,14 @@ def test_fp16_mode_config5_4096x256(ops):
           f"drays {e_gr_model:.2e} / {e_gr_fp32:.2e}; rendered depth fp16-vs-fp32 rel {e_depth:.2e}")
     # (a) kernel vs the same storage model: forward is fp32-accumulated either way -> fp32 noise; backward adds the fp16 rounding
     # of dZ (2^-11 relative per element, averaged down by the sums it enters)
-    # (sigma: the encoded features are rounded to fp16, so an fp32 feature one ulp off the oracle's - the pair kernel of the forward
-    # sums the eight corner terms as two interleaved chains of four, the oracle as one chain of eight - lands on the neighbouring fp16
-    # value once in ~2^13 features: 2^-11 of one feature's contribution, 6e-5 of max |sigma| in the worst sample; 2e-7 otherwise)
-    assert e_sig_model < 1e-4
+    # (sigma: the encoded features are rounded to fp16, so an fp32 feature one ulp off the oracle's - the forward kernel accumulates
+    # the eight corner terms with fmaf like tiny-cuda-nn, on the fine levels as two chains of four; the oracle multiplies and adds -
+    # lands on the neighbouring fp16 value once in ~2^13 features: 2^-11 of one feature's contribution, ~1e-4 of max |sigma| in the
+    # worst sample of 25 k; one sample in ~256 holds a flipped feature.  Hence: fp32 noise for the bulk, the one-flip bound for the worst.)
+    err = (sig16[sub.to(DEV)].cpu() - res["fp16"][0]).abs().flatten() / s_scale
+    print(f"  sigma error quantiles 0.9 / 0.98 / 0.999 / max: {float(torch.quantile(err, 0.9)):.1e} {float(torch.quantile(err, 0.98)):.1e} "
+          f"{float(torch.quantile(err, 0.999)):.1e} {float(err.max()):.1e}")
+    assert float(torch.quantile(err, 0.9)) < 2e-6 and e_sig_model < 5e-4
     assert e_gp_model < 1e-3 and e_gr_model < 2e-3
     # (b) storage error of fp16 features and weights: 2^-11 per rounded operand; sigma sums 32 + 64 rounded products.  The ray
     # gradient is the most sensitive output: d/dx multiplies each level's d_feature (perturbed by ~5e-4) with differences of
