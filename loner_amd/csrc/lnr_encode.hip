@@ -406,16 +406,7 @@ struct EncSink {
 // plain VALU operands, whereas a 64-lane segmented sum needs ds_bpermute (LDS crossbar) for every step.
 struct RunMask { bool take1, take2, take4, take8; };
 
-__device__ __forceinline__ float row_run_sum(float v, const RunMask& k) {
-    float t;
-    t = row_down_f<1>(v); if (k.take1) v += t;
-    t = row_down_f<2>(v); if (k.take2) v += t;
-    t = row_down_f<4>(v); if (k.take4) v += t;
-    t = row_down_f<8>(v); if (k.take8) v += t;
-    return v;
-}
-
-// The same for N values at once, step by step: one fused multiply-add per value and step (v += neighbour * {1, 0}: the DPP read folds
+// Run sums of N values at once, step by step (v += left neighbour where the run continues): one fused multiply-add per value and step (v += neighbour * {1, 0}: the DPP read folds
 // into v_fmac_f32_dpp; fma(t, 1, v) rounds like t + v, fma(t, 0, v) = v), and consecutive instructions belong to different
 // values, so that the DPP read-after-write wait states are filled with work.  The select form cost an add, a v_cndmask and two idle
 // states per value and step.
@@ -808,13 +799,15 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
                 }
             } else if (wave_any) {
 #pragma unroll
+                for (int k = 0; k < 8; ++k) { rv0[k] = w[k] * g[PAIR ? 2 * pass : 0]; rv1[k] = PAIR ? w[k] * g[2 * pass + 1] : 0.0f; }
+                if (combine) {                       // (all corners of a step together: one v_fmac_f32_dpp per value and step, no idle states)
+                    const RunMul rm = run_multipliers(run);
+                    row_run_sum_n<8>(rv0, rm);
+                    if (PAIR) row_run_sum_n<8>(rv1, rm);
+                }
+#pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    float v0 = w[k] * g[PAIR ? 2 * pass : 0], v1 = PAIR ? w[k] * g[2 * pass + 1] : 0.0f;
-                    if (combine) {
-                        v0 = row_run_sum(v0, run);
-                        if (PAIR) v1 = row_run_sum(v1, run);
-                    }
-                    rv0[k] = v0; rv1[k] = v1;
+                    const float v0 = rv0[k], v1 = rv1[k];
                     if (head & ((v0 != 0.0f) | (v1 != 0.0f))) {
                         const uint32_t fi = e[k] * F + (PAIR ? 2 * pass : 0);
                         const int local = (int)(fi >> sink.shift) - first_owner;
