@@ -33,6 +33,8 @@ EXACT = {"lnr_sampler.hip", "lnr_rays.hip"}
 EXTRA = {"lnr_render.hip": ["-mllvm", "-pragma-unroll-threshold=1000000", "-mllvm", "-unroll-threshold=100000"]}
 # (source, object name, extra flags); the density kernels are compiled once per hidden width (n_neurons/16)
 SOURCES = [("lnr_density_ht.hip", f"lnr_density_ht{ht}.o", [f"-DLNR_HT={ht}"]) for ht in (16, 8, 4, 2, 1)] + \
+          [("lnr_density_regs.hip", f"lnr_density_regs{ht}_{nh}.o", [f"-DLNR_HT={ht}", f"-DLNR_NH={nh}"])
+           for ht in (8, 4, 16) for nh in (3, 2, 1) if not (ht == 16 and nh > 1)] + \
           [("lnr_density_f16_bwd.hip", f"lnr_density_f16_bwd{part}.o", [f"-DLNR_BWD_PART={part}"]) for part in (0, 1, 2)] + \
           [("lnr_density_f16_fwd.hip", f"lnr_density_f16_fwd{part}.o", [f"-DLNR_FWD_PART={part}"]) for part in (0, 1)] + \
           [(s, s.replace(".hip", ".o"), EXTRA.get(s, [])) for s in

@@ -530,7 +530,7 @@ static int check_f16(const LnrNetSpec* spec, const char* who) {
     return LNR_ERR_UNSUPPORTED;
 }
 
-static size_t fwd_lds(const LnrNetSpec* s, int w_lds) { return ((w_lds ? (size_t)s->n_mlp_params : 0) + 4) * sizeof(float); }
+static size_t fwd_lds(const LnrNetSpec* s, int w_lds) { return ((w_lds ? (size_t)lnr_w_lds_floats(s->n_neurons, s->in_dim, s->n_hidden, true) : 0) + 4) * sizeof(float); }
 static size_t bwd_lds(const LnrNetSpec* s, int w_lds, int waves, int dw64) {
     const size_t H = s->n_neurons;
     const size_t scratch = H * 16 + (s->n_hidden > 1 ? (size_t)(s->n_hidden + 1) * H * 16 : 0);
@@ -546,15 +546,35 @@ static int plan_launch(const LnrNetSpec* spec, int64_t n_points, bool backward, 
     // (the register-resident kernels address the planes with 32-bit byte offsets up to 17 planes: n_points <= 2^25)
     if (spec->activation == LNR_ACT_RELU && spec->n_hidden == 1 && spec->in_dim == 32 && spec->enc_dim == 32 && spec->n_neurons <= 64 &&
         n_points <= (1ll << 25)) {
-        plan->fast32 = 1; plan->w_lds = 1; plan->waves = 4; plan->dw64 = 0;
+        plan->fast32 = 1; plan->w_lds = 1; plan->waves = 4; plan->dw64 = 0; plan->regs = 0;
         plan->lds = backward ? (2 * (size_t)spec->n_mlp_params + 4 * (size_t)spec->n_neurons * 20) * sizeof(float)
                              : (size_t)spec->n_mlp_params * sizeof(float);
         int64_t blocks = (tiles + 3) / 4;
         const int64_t max_blocks = backward ? LNR_BWD_MAX_BLOCKS : LNR_DENSITY_MAX_BLOCKS;
         plan->grid = (int)(blocks > max_blocks ? max_blocks : (blocks < 1 ? 1 : blocks));
+        plan->n_slabs = plan->grid;
         return LNR_OK;
     }
-    plan->fast32 = 0; plan->dw64 = 0;
+    plan->fast32 = 0; plan->dw64 = 0; plan->regs = 0;
+    // backward of a general network: the register-accumulating kernel (lnr_density_regs.h) for up to three hidden layers and 128 padded
+    // inputs (256 neurons: one hidden layer) - four waves, their dZ / layer-input images in LDS, the weights too when they fit
+    // (from 64 neurons up: below that the whole gradient is small enough for the LDS-accumulating kernel to win - 32 Tanh x 2: 1.5 against 2.7 ms)
+    if (backward && spec->n_neurons >= 64 && spec->n_hidden <= 3 && spec->in_dim <= 128 && !(spec->n_neurons == 256 && spec->n_hidden > 1)) {
+        const size_t scratch = (size_t)4 * (spec->n_hidden > 1 ? 2 : 1) * spec->n_neurons * 20 * sizeof(float);       // LNR_TDZ_STRIDE rows
+        const size_t weights = (size_t)lnr_w_lds_floats(spec->n_neurons, spec->in_dim, spec->n_hidden, true) * sizeof(float);       // (padded rows)
+        if (scratch <= (size_t)LNR_LDS_LIMIT) {
+            plan->regs = 1; plan->waves = 4;
+            // weights in LDS: all of them, else the hidden matrices + output rows (read twice per step), else none
+            const size_t hidden = (size_t)lnr_w_lds_floats(spec->n_neurons, spec->in_dim, spec->n_hidden, false) * sizeof(float);
+            plan->w_lds = scratch + weights <= (size_t)LNR_LDS_LIMIT ? 1 : (spec->n_hidden > 1 && scratch + hidden <= (size_t)LNR_LDS_LIMIT ? 2 : 0);
+            plan->lds = scratch + (plan->w_lds == 1 ? weights : (plan->w_lds == 2 ? hidden : 0));
+            int64_t blocks = (tiles + 3) / 4;
+            if (blocks > 256) blocks = 256;                          // one workgroup per CU (one wave per SIMD)
+            plan->grid = (int)(blocks < 1 ? 1 : blocks);
+            plan->n_slabs = plan->grid;
+            return LNR_OK;
+        }
+    }
     // {weights in LDS, waves, 64-bit fixed-point weight-gradient accumulators}.  LDS-resident weights matter most (without
     // them every MFMA operand is a global load), then the integer accumulators (LDS float atomics are ~16x slower), then waves.
     static const int opts[12][3] = {{1, 4, 1}, {1, 2, 1}, {1, 1, 1}, {1, 4, 0}, {1, 2, 0}, {1, 1, 0},
@@ -570,12 +590,26 @@ static int plan_launch(const LnrNetSpec* spec, int64_t n_points, bool backward, 
         if (blocks > max_blocks) blocks = max_blocks;
         if (blocks < 1) blocks = 1;
         plan->grid = (int)blocks;
+        plan->n_slabs = plan->grid;
         return LNR_OK;
     }
     lnr_set_error("%s: network (n_neurons=%d, n_hidden_layers=%d, in_dim=%d: %d MLP weights) does not fit the 160 KB LDS of a CU "
                   "even with one wave per workgroup; not supported by the fp32 kernels", who, spec->n_neurons, spec->n_hidden,
                   spec->in_dim, spec->n_mlp_params);
     return LNR_ERR_UNSUPPORTED;
+}
+
+// mlp_backward_regs_kernel: one translation unit per (width, depth)
+static int mlp_bwd_regs(const LnrNetSpec* spec, const float* params, const float* feat, int64_t m_pad, const MlpPoints* pt, const float* d_sigma,
+                        float* dfeat, float* slabs, int want_dfeat, const DensityPlan* plan, hipStream_t st) {
+#define LNR_REGS_CASE(HT, NH) case (HT) * 4 + (NH): return lnr_mlp_bwd_regs_ht##HT##_nh##NH(spec, params, feat, m_pad, pt, d_sigma, dfeat, slabs, want_dfeat, plan, st)
+    switch ((spec->n_neurons / 16) * 4 + spec->n_hidden) {
+        LNR_REGS_CASE(4, 1); LNR_REGS_CASE(4, 2); LNR_REGS_CASE(4, 3);
+        LNR_REGS_CASE(8, 1); LNR_REGS_CASE(8, 2); LNR_REGS_CASE(8, 3);
+        LNR_REGS_CASE(16, 1);
+        default: lnr_set_error("lnr_density_backward: no register-accumulating kernel for %d neurons x %d hidden layers", spec->n_neurons, spec->n_hidden); return LNR_ERR_UNSUPPORTED;
+    }
+#undef LNR_REGS_CASE
 }
 
 namespace {
@@ -777,10 +811,11 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     float* d_pts_eff = d_pts;
     if (d_rays && !ray_accum) d_pts_eff = (float*)(ws + L.off_dpts);
     const int want_dfeat = ((hash && want_grad) || d_pts_eff != nullptr || ray_accum) ? 1 : 0;
-    int n_slabs = plan.grid;
+    int n_slabs = plan.n_slabs;
     {
     LnrProfScope prof("mlp_backward", st);
     if (f16) rc = lnr_mlp_bwd_f16(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &n_slabs, st);
+    else if (plan.regs) rc = mlp_bwd_regs(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &plan, st);
     else switch (spec->n_neurons / 16) {
         case 1: rc = lnr_mlp_bwd_ht1(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &plan, st); break;
         case 2: rc = lnr_mlp_bwd_ht2(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &plan, st); break;
@@ -881,7 +916,7 @@ extern "C" int lnr_density_fold_weight_grads(const LnrNetSpec* spec, int64_t n_p
         DensityPlan plan;
         rc = plan_launch(spec, n_points, true, &plan, "lnr_density_fold_weight_grads");
         if (rc) return rc;
-        n_slabs = plan.grid;
+        n_slabs = plan.n_slabs;
     }
     const int n_mlp = spec->n_mlp_params;
     hipStream_t st = (hipStream_t)stream;

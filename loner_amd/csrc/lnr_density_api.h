@@ -131,13 +131,21 @@ static inline bool lnr_level_can_use_xpairs(const LnrNetSpec& s, int l, float sc
 }
 
 // launch plan chosen by the dispatcher
+// padded LDS copies of the weight matrices (lnr_density_impl.h: lnr_fill_w_lds): row stride and total size in floats
+__host__ __device__ inline int lnr_w_stride(int cols) { return cols + 4; }
+__host__ __device__ inline int lnr_w_lds_floats(int H, int in_dim, int n_hidden, bool with_first) {
+    return (with_first ? H * lnr_w_stride(in_dim) : 0) + (n_hidden - 1) * H * lnr_w_stride(H) + 16 * H;
+}
+
 struct DensityPlan {
     int grid;        // workgroups
     int waves;       // waves per workgroup (1, 2 or 4)
-    int w_lds;       // 1: MLP matrices staged in LDS, 0: read from global memory
+    int w_lds;       // 1: MLP matrices staged in LDS, 0: read from global memory (regs kernel also 2: all but the first layer's in LDS)
     size_t lds;      // dynamic LDS bytes
     int fast32;      // 1: the register-resident kernels for 32 features -> <= 64 ReLU neurons -> 1
     int dw64;        // general backward: weight gradients accumulate in LDS in 64-bit fixed point (1) or fp32 (0)
+    int regs;        // backward: 1 = mlp_backward_regs_kernel (weight gradient in registers, owned by rows; lnr_density_regs.h)
+    int n_slabs;     // weight-gradient slabs the backward writes
 };
 
 // point count description for the MLP kernels (features come from planes)
@@ -154,6 +162,13 @@ struct MlpPoints {
     int lnr_mlp_bwd_ht##HT(const LnrNetSpec* spec, const float* params, const float* feat, int64_t m_pad, const MlpPoints* pt, \
                            const float* d_sigma, float* dfeat, float* slabs, int want_dfeat, const DensityPlan* plan,   \
                            hipStream_t st);
+#define LNR_DECLARE_REGS(HT, NH)                                                                                        \
+    int lnr_mlp_bwd_regs_ht##HT##_nh##NH(const LnrNetSpec* spec, const float* params, const float* feat, int64_t m_pad, \
+                                         const MlpPoints* pt, const float* d_sigma, float* dfeat, float* slabs,         \
+                                         int want_dfeat, const DensityPlan* plan, hipStream_t st);
+LNR_DECLARE_REGS(4, 1) LNR_DECLARE_REGS(4, 2) LNR_DECLARE_REGS(4, 3)
+LNR_DECLARE_REGS(8, 1) LNR_DECLARE_REGS(8, 2) LNR_DECLARE_REGS(8, 3)
+LNR_DECLARE_REGS(16, 1)
 LNR_DECLARE_HT(1)
 LNR_DECLARE_HT(2)
 LNR_DECLARE_HT(4)

@@ -73,7 +73,8 @@ __device__ __forceinline__ float finite_or_clipped(float v, int32_t* __restrict_
 
 // hidden layer: Zn = Wl * act(Z)
 template <int HT>
-__device__ __forceinline__ void hidden_forward(const float* Wl, int H, int act, int c, int g, const f32x4 Z[HT], f32x4 Zn[HT]) {
+__device__ __forceinline__ void hidden_forward(const float* Wl, int H, int act, int c, int g, const f32x4 Z[HT], f32x4 Zn[HT], int row_stride = 0) {
+    if (row_stride == 0) row_stride = H;               // floats between consecutive rows of Wl (padded copies in LDS: lnr_w_stride)
 #pragma unroll
     for (int jt = 0; jt < HT; ++jt) Zn[jt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -81,7 +82,7 @@ __device__ __forceinline__ void hidden_forward(const float* Wl, int H, int act, 
         const float a0 = act_fwd(Z[kt].x, act), a1 = act_fwd(Z[kt].y, act), a2 = act_fwd(Z[kt].z, act), a3 = act_fwd(Z[kt].w, act);
 #pragma unroll
         for (int jt = 0; jt < HT; ++jt) {
-            const float4 wa = *reinterpret_cast<const float4*>(Wl + (16 * jt + c) * H + 16 * kt + 4 * g);
+            const float4 wa = *reinterpret_cast<const float4*>(Wl + (16 * jt + c) * row_stride + 16 * kt + 4 * g);
             MFMA4(Zn[jt], wa, a0, a1, a2, a3);
         }
     }
@@ -93,8 +94,9 @@ __device__ __forceinline__ void hidden_forward(const float* Wl, int H, int act, 
 // ================================================================================================
 template <int HT, int KT>
 __device__ __forceinline__ void layer1_from_planes(const LnrNetSpec& spec, const float* W1, const float* __restrict__ feat,
-                                                   int64_t m_pad, int64_t m, int c, int g, f32x4 Z[HT]) {
+                                                   int64_t m_pad, int64_t m, int c, int g, f32x4 Z[HT], int row_stride = 0) {
     const int in_dim = KT > 0 ? 16 * KT : spec.in_dim;
+    if (row_stride == 0) row_stride = in_dim;
 #pragma unroll
     for (int jt = 0; jt < HT; ++jt) Z[jt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -105,8 +107,60 @@ __device__ __forceinline__ void layer1_from_planes(const LnrNetSpec& spec, const
         for (int r = 0; r < 4; ++r) xf[r] = (k0 + r < spec.enc_dim) ? feat[(size_t)(k0 + r) * m_pad + m] : 1.0f;
 #pragma unroll
         for (int jt = 0; jt < HT; ++jt) {
-            const float4 wa = *reinterpret_cast<const float4*>(W1 + (16 * jt + c) * in_dim + k0);
+            const float4 wa = *reinterpret_cast<const float4*>(W1 + (16 * jt + c) * row_stride + k0);
             MFMA4(Z[jt], wa, xf[0], xf[1], xf[2], xf[3]);
+        }
+    }
+}
+
+// LDS copies of the weight matrices are stored with rows 4 floats longer than the matrix: the MFMA A fragments are read as one float4
+// per lane from 16 consecutive rows (lane & 15), and with row lengths of 16 k floats all 16 rows start in the same LDS bank - a 16-way
+// conflict on every fragment (SQ_LDS_BANK_CONFLICT 17 x SQ_ACTIVE_INST_LDS in mlp_forward_kernel, frequency-12 -> 128 x 2: 33 % of the
+// fp32 MFMA peak); 4 floats of padding spread them over all banks.  Layout: [W1: H rows of in_dim + 4][hidden matrices: H rows of H + 4
+// each][output rows: 16 x H, unpadded].
+// (lnr_w_stride / lnr_w_lds_floats: lnr_density_api.h, shared with the host-side launch plan)
+// params (tinycudann layout) -> the padded copy; with_first = false: everything but the first layer's matrix
+__device__ __forceinline__ void lnr_fill_w_lds(float* dst, const float* __restrict__ params, int H, int in_dim, int n_hidden, bool with_first) {
+    const int n1 = H * in_dim, nh = (n_hidden - 1) * H * H;
+    float* d = dst;
+    if (with_first) {
+        for (int i = threadIdx.x; i < n1; i += blockDim.x) d[(i / in_dim) * lnr_w_stride(in_dim) + i % in_dim] = params[i];
+        d += H * lnr_w_stride(in_dim);
+    }
+    for (int i = threadIdx.x; i < nh; i += blockDim.x) d[(i / H) * lnr_w_stride(H) + i % H] = params[n1 + i];
+    d += (n_hidden - 1) * H * lnr_w_stride(H);
+    for (int i = threadIdx.x; i < 16 * H; i += blockDim.x) d[i] = params[n1 + nh + i];
+}
+
+// The lane's first-layer inputs of one 16-sample tile: features 16 kt + 4 g + r of sample m, for every K block.  They come from HBM
+// (streamed feature planes), ~2 us away: loaded one STEP ahead (load_tile_inputs for step + 1 is issued before step's products).
+template <int KT1M>
+__device__ __forceinline__ void load_tile_inputs(const LnrNetSpec& spec, const float* __restrict__ feat, int64_t m_pad, int64_t m, int g, int kt1,
+                                                 float xf[KT1M][4]) {
+#pragma unroll
+    for (int kt = 0; kt < KT1M; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 16 * kt + 4 * g + r;
+            const bool real = kt < kt1 && k < spec.enc_dim;
+            const float v = feat[(size_t)(real ? k : 0) * m_pad + m];          // (unconditional load, clamped plane)
+            xf[kt][r] = real ? v : 1.0f;                                        // the encoding's padding is the constant 1
+        }
+    }
+}
+// First layer from those registers; the weight fragments of a K block are requested together, then multiplied.
+template <int HT, int KT1M>
+__device__ __forceinline__ void layer1_from_regs(const float* W1, int c, int g, int kt1, int row_stride, const float xf[KT1M][4], f32x4 Z[HT]) {
+#pragma unroll
+    for (int jt = 0; jt < HT; ++jt) Z[jt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int kt = 0; kt < KT1M; ++kt) {
+        if (kt < kt1) {
+            float4 wa[HT];
+#pragma unroll
+            for (int jt = 0; jt < HT; ++jt) wa[jt] = *reinterpret_cast<const float4*>(W1 + (16 * jt + c) * row_stride + 16 * kt + 4 * g);
+#pragma unroll
+            for (int jt = 0; jt < HT; ++jt) MFMA4(Z[jt], wa[jt], xf[kt][0], xf[kt][1], xf[kt][2], xf[kt][3]);
         }
     }
 }
@@ -121,26 +175,51 @@ mlp_forward_kernel(const LnrNetSpec spec, const float* __restrict__ params, cons
     const int H = 16 * HT;
     const int n_mlp = spec.n_mlp_params;
     const int nw = blockDim.x >> 6;
-    if (W_LDS) for (int i = threadIdx.x; i < n_mlp; i += blockDim.x) smem[i] = params[i];
+    if (W_LDS) lnr_fill_w_lds(smem, params, H, spec.in_dim, spec.n_hidden, true);
     __syncthreads();
+    const int s1 = W_LDS ? lnr_w_stride(spec.in_dim) : spec.in_dim, sh = W_LDS ? lnr_w_stride(H) : H;       // row strides
     const float* W1 = W_LDS ? smem : params;
-    const float* Wh = W1 + H * spec.in_dim;
-    const float* Wo = Wh + (spec.n_hidden - 1) * H * H;
+    const float* Wh = W1 + H * s1;
+    const float* Wo = Wh + (spec.n_hidden - 1) * H * sh;
     const int act = ACT >= 0 ? ACT : spec.activation;
     const int64_t M = n_rays_dev ? (int64_t)lnr_live_rays(n_rays, n_rays_dev) * n_samples : n_points;
     if (M <= 0) return;
     const int64_t n_tiles = (M + 15) / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
-    for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < n_tiles; tile += (int64_t)gridDim.x * nw) {
+    // up to 128 (padded) inputs: the features of the NEXT tile are requested before this tile's products (they come from HBM, and at
+    // one wave per SIMD nothing else covers the ~2 us)
+    constexpr int KTP = 8;
+    const int kt1 = spec.in_dim >> 4;
+    const bool ahead = kt1 <= KTP;
+    const int64_t tile_step = (int64_t)gridDim.x * nw;
+    float xf_n[KTP][4];
+    {
+        const int64_t t0 = (int64_t)blockIdx.x * nw + wave;
+        const int64_t m0 = t0 * 16 + c;
+        if (ahead && t0 < n_tiles) load_tile_inputs<KTP>(spec, feat, m_pad, m0 < M ? m0 : M - 1, g, kt1, xf_n);
+    }
+    for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < n_tiles; tile += tile_step) {
         int64_t m = tile * 16 + c;
         const bool valid = m < M;
         if (!valid) m = M - 1;
         f32x4 Z[HT];
-        layer1_from_planes<HT, 0>(spec, W1, feat, m_pad, m, c, g, Z);
+        if (ahead) {
+            float xf[KTP][4];
+#pragma unroll
+            for (int kt = 0; kt < KTP; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xf[kt][r] = xf_n[kt][r];
+            const int64_t tn = tile + tile_step < n_tiles ? tile + tile_step : tile;
+            const int64_t mn = tn * 16 + c;
+            load_tile_inputs<KTP>(spec, feat, m_pad, mn < M ? mn : M - 1, g, kt1, xf_n);
+            layer1_from_regs<HT, KTP>(W1, c, g, kt1, s1, xf, Z);
+        } else {
+            layer1_from_planes<HT, 0>(spec, W1, feat, m_pad, m, c, g, Z, s1);
+        }
         for (int l = 1; l < spec.n_hidden; ++l) {
             f32x4 Zn[HT];
-            hidden_forward<HT>(Wh + (l - 1) * H * H, H, act, c, g, Z, Zn);
+            hidden_forward<HT>(Wh + (l - 1) * H * sh, H, act, c, g, Z, Zn, sh);
 #pragma unroll
             for (int jt = 0; jt < HT; ++jt) Z[jt] = Zn[jt];
         }

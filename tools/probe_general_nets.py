@@ -1,6 +1,6 @@
 """Forward / backward of lnr_density_* in fp16 mode for the general network shapes of DESIGN 4.6, at 4096 rays x 512 samples
 (backward incl. the encoding's backward, features reused from the forward: the training loop's route)."""
-import sys, json
+import argparse, sys, json
 sys.path.insert(0, '.')
 import torch
 from loner_amd import hip, ops
@@ -13,6 +13,10 @@ NETS = {
     "freq6 -> 256 ReLU x 1": (dict(otype="Frequency", n_frequencies=6), dict(activation="ReLU", n_neurons=256, n_hidden_layers=1)),
     "freq10 -> 32 Tanh x 2": (dict(otype="Frequency", n_frequencies=10), dict(activation="Tanh", n_neurons=32, n_hidden_layers=2)),
 }
+ap = argparse.ArgumentParser()
+ap.add_argument("--only", default="", help="substring of the network name")
+ap.add_argument("--precision", default="", help="fp16 | fp32 (default: both)")
+args = ap.parse_args()
 N, S = 4096, 512
 g = torch.Generator().manual_seed(5)
 rays = torch.zeros(N, 13); rays[:, 0:3] = torch.rand(N, 3, generator=g) * 0.2 - 0.1
@@ -33,7 +37,9 @@ def timed(fn, n=5):
 
 
 for name, (enc, net) in NETS.items():
-    for prec in ("fp16", "fp32"):
+    if args.only not in name:
+        continue
+    for prec in ((args.precision,) if args.precision else ("fp16", "fp32")):
         spec = hip.make_net_spec(enc, dict(net, precision=prec))
         p = (torch.rand(int(spec.n_params), generator=g) - 0.5).cuda()
         grad = torch.zeros_like(p); dr = torch.zeros(N, 13, device="cuda")
