@@ -598,6 +598,8 @@ def main():
     rec_table_floats = sum(int(spec.level_size[l]) * F for l in range(int(spec.n_levels)))
     h, ind, nh = spec.n_neurons, spec.in_dim, spec.n_hidden
     mac = h * ind + (nh - 1) * h * h
+    plane_b = 2.0 if args.dtype == "f16" else 4.0                      # bytes of one feature-plane element
+    mfma_peak = 2500.0e12 if args.dtype == "f16" else 157.3e12         # dense MFMA peak of the MLP kernels' arithmetic type
     # Algorithmic work per launch:
     #   encode_backward: d_feature planes in, z and the ray records once, 6 ray-gradient floats out, the table gradient once
     #   mlp_backward:    forward recompute + input gradient + weight gradient GEMMs of the fp32 MLP
@@ -607,8 +609,9 @@ def main():
         "encode_dx": {"bytes": pts * (n_rec * F * 4.0 + 4.0) + n_local * (24.0 + 24.0)},
         "encode_forward": {"bytes": pts * (4.0 + int(spec.n_levels) * F * 4.0) + n_local * 24.0 + (float(spec.n_params) - spec.n_mlp_params) * 4.0},
         "table_grad_reduce": {"bytes": rec_table_floats * 8.0},
-        "mlp_backward": {"flops": pts * 2.0 * (3 * mac + h), "bytes": pts * (3 * spec.enc_dim * 4.0 + 4.0)},
-        "mlp_forward": {"flops": pts * 2.0 * (mac + h), "bytes": pts * (spec.enc_dim * 4.0 + 4.0)},
+        # (fp16 mode: the feature planes the MLP kernels read are half2 pairs, the d_feature planes they write stay fp32)
+        "mlp_backward": {"flops": pts * 2.0 * (3 * mac + h), "bytes": pts * (spec.enc_dim * (2.0 * plane_b + 4.0) + 4.0)},
+        "mlp_forward": {"flops": pts * 2.0 * (mac + h), "bytes": pts * (spec.enc_dim * plane_b + 4.0)},
     }
     traffic = {}
     tf = os.path.join(ROOT, "profiles", "traffic.json")
@@ -626,7 +629,8 @@ def main():
             if "bytes" in a_:
                 ent["hbm_GBps"] = round(a_["bytes"] / t / 1e9, 1); ent["hbm_frac"] = round(a_["bytes"] / t / 8e12, 4)
             if "flops" in a_:
-                ent["fp32_mfma_TFLOPs"] = round(a_["flops"] / t / 1e12, 2); ent["mfma_frac"] = round(a_["flops"] / t / 157.3e12, 4)
+                ent["mfma_TFLOPs"] = round(a_["flops"] / t / 1e12, 2); ent["mfma_peak_TFLOPs"] = mfma_peak / 1e12
+                ent["mfma_frac"] = round(a_["flops"] / t / mfma_peak, 4)
         kernels[name] = ent
     for name, v in ksum.items():
         if name not in ("density_forward", "density_backward"):
@@ -643,8 +647,8 @@ def main():
                                       "(tools/pmc.sh), NOT measured by this run; FETCH_SIZE doubled as the microarchitecture guide prescribes for gfx950",
                     "note": "dominant kernel by total time over the timed region, timed with HIP events recorded by the library on the "
                             "launch stream (lnr_profile_*).  It moves few algorithmic bytes and is not HBM-bound: the SQ counters "
-                            "(profiles/r04_pmc_sq_instmix.txt) show a latency-bound kernel pair - 181 M + 121 M VALU wave instructions per backward, "
-                            "57 % of a wave's cycles parked in s_waitcnt / barriers, 15-22 % issue stalls - whose in-LDS radix partition of the "
+                            "(profiles/r04_pmc_sq_instmix.txt) show an instruction-bound kernel pair - 176 M + 121 M VALU wave instructions per backward "
+                            "(the VALU 72 % / 50 % busy), half of a wave's cycles parked in s_waitcnt / barriers - whose in-LDS radix partition of the "
                             "gradient records, hashing, and the d/dx term's table re-gather (47 M L2 line reads = 6 GB over the L2 -> L1 path, "
                             "profiles/r04_pmc_tcp_tcc_encode.txt) overlap only partly; four structural variants were measured in round 4 "
                             "(DESIGN.md 4.3, 8)",
