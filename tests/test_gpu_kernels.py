@@ -181,6 +181,7 @@ NETS = {
     "freq12_small": (dict(otype="Frequency", n_frequencies=12), dict(activation="ReLU", n_neurons=32, n_hidden_layers=1)),
     "freq16_h16": (dict(otype="Frequency", n_frequencies=16), dict(activation="Softplus", n_neurons=16, n_hidden_layers=1)),
     "freq_tanh128": (dict(otype="Frequency", n_frequencies=5), dict(activation="Tanh", n_neurons=128, n_hidden_layers=2)),
+    "freq_relu128x3": (dict(otype="Frequency", n_frequencies=12), dict(activation="ReLU", n_neurons=128, n_hidden_layers=3)),
 }
 
 
@@ -238,6 +239,34 @@ def test_density_backward_matches_oracle_autograd(ops, name):
     assert e_p < 2e-5
     assert e_x < 2e-4
     # without input gradients the parameter gradient must be the same
+    grad2 = torch.zeros_like(grad)
+    assert ops.density_backward(spec_h, dv(params), dv(d_sigma), grad2, pts=dv(pts), want_d_pts=False) is None
+    assert rel(grad2, grad) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["freq_relu128", "freq_relu128x3", "freq_wide256", "freq_siren", "hash_f4_2hidden"])
+def test_general_fp32_backward_over_many_steps(ops, name):
+    """mlp_backward_regs_kernel (lnr_density_regs.h) beyond one step per workgroup: 256 workgroups x 64 samples per step, so 40 013 points
+    are three steps with a ragged last tile, the inputs of step i + 1 requested during step i; a stretch of 20 000 points without gradient
+    makes whole steps take the workgroup-uniform skip (their d_feature rows must still come out zero), single points without gradient sit
+    inside live tiles.  The five networks cover the three homes of the weights (all in LDS, hidden matrices only, none), 4 / 8 / 16 row
+    tiles and one to three hidden layers."""
+    spec_o, spec_h, params = _net(name, seed=3, table_gain=3000.0)
+    gen = torch.Generator().manual_seed(11)
+    n = 40013
+    pts = (torch.rand(n, 3, generator=gen) * 1.9 - 0.95)
+    d_sigma = torch.randn(n, generator=gen)
+    d_sigma[9000:29000] = 0.0
+    d_sigma[torch.rand(n, generator=gen) < 0.2] = 0.0
+    grad = torch.zeros(int(spec_h.n_params), device=DEV)
+    d_pts = ops.density_backward(spec_h, dv(params), dv(d_sigma), grad, pts=dv(pts), want_d_pts=True)
+    p32 = params.clone().requires_grad_(True)
+    x32 = pts.clone().requires_grad_(True)
+    (NW.density(spec_o, p32, x32) * d_sigma).sum().backward()
+    e_p, e_x = rel(grad, p32.grad), rel(d_pts, x32.grad)
+    print(f"{name}: {n} points, dparams rel {e_p:.2e}, dpts rel {e_x:.2e}")
+    assert e_p < 2e-5 and e_x < 2e-4
+    assert float(d_pts[9000:29000].abs().max()) == 0.0
     grad2 = torch.zeros_like(grad)
     assert ops.density_backward(spec_h, dv(params), dv(d_sigma), grad2, pts=dv(pts), want_d_pts=False) is None
     assert rel(grad2, grad) < 1e-6
