@@ -39,8 +39,9 @@ int LNR_CAT(lnr_mlp_fwd_ht, LNR_HT)(const LnrNetSpec* spec, const float* params,
         return LNR_OK;
     }
 #endif
-    if (plan->w_lds) { if (relu) LNR_LAUNCH_MF(true, LNR_ACT_RELU); else LNR_LAUNCH_MF(true, -1); }
-    else { if (relu) LNR_LAUNCH_MF(false, LNR_ACT_RELU); else LNR_LAUNCH_MF(false, -1); }
+    const bool sine = spec->activation == LNR_ACT_SINE;        // (compile-time activations: ReLU and Sine, the north star's two; the others by a run-time switch)
+    if (plan->w_lds) { if (relu) LNR_LAUNCH_MF(true, LNR_ACT_RELU); else if (sine) LNR_LAUNCH_MF(true, LNR_ACT_SINE); else LNR_LAUNCH_MF(true, -1); }
+    else { if (relu) LNR_LAUNCH_MF(false, LNR_ACT_RELU); else if (sine) LNR_LAUNCH_MF(false, LNR_ACT_SINE); else LNR_LAUNCH_MF(false, -1); }
     return LNR_OK;
 }
 

@@ -25,9 +25,10 @@ static int launch_regs(const LnrNetSpec* spec, const float* params, const float*
 template <int KT1M>
 static int launch_regs_k(const LnrNetSpec* spec, const float* params, const float* feat, int64_t m_pad, const MlpPoints* pt, const float* d_sigma,
                          float* dfeat, float* slabs, int want_dfeat, const DensityPlan* plan, hipStream_t st) {
-    const bool relu = spec->activation == LNR_ACT_RELU;
+    const bool relu = spec->activation == LNR_ACT_RELU, sine = spec->activation == LNR_ACT_SINE;
 #define LNR_REGS_GO(WM) (relu ? launch_regs<KT1M, WM, LNR_ACT_RELU>(spec, params, feat, m_pad, pt, d_sigma, dfeat, slabs, want_dfeat, plan, st) \
-                              : launch_regs<KT1M, WM, -1>(spec, params, feat, m_pad, pt, d_sigma, dfeat, slabs, want_dfeat, plan, st))
+                         : sine ? launch_regs<KT1M, WM, LNR_ACT_SINE>(spec, params, feat, m_pad, pt, d_sigma, dfeat, slabs, want_dfeat, plan, st) \
+                                : launch_regs<KT1M, WM, -1>(spec, params, feat, m_pad, pt, d_sigma, dfeat, slabs, want_dfeat, plan, st))
     if (plan->w_lds == 1) return LNR_REGS_GO(1);
 #if LNR_NH > 1
     if (plan->w_lds == 2) return LNR_REGS_GO(2);
