@@ -221,7 +221,7 @@ mlp_forward_kernel(const LnrNetSpec spec, const float* __restrict__ params, cons
     // one wave per SIMD nothing else covers the ~2 us)
     constexpr int KTP = 8;
     const int kt1 = spec.in_dim >> 4;
-    const bool ahead = kt1 <= KTP;
+    const bool ahead = kt1 <= KTP && HT <= 8;          // (256 neurons: the 64 registers of staging cost more than the wait, 0.65 -> 0.72 ms)
     const int64_t tile_step = (int64_t)gridDim.x * nw;
     float xf_n[KTP][4];
     {
