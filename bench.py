@@ -41,8 +41,9 @@ def parse():
     ap.add_argument("--quick", action="store_true",
                     help="development: only the timed region and its kernel table (no other-dtype leg, no north-star network leg, no render leg, "
                          "no extended run, no baselines) - for A/B runs of a kernel")
-    ap.add_argument("--profile-every", type=int, default=4,
-                    help="HIP-event timing of the kernels on every N-th iteration of the timed region (0: none - then no roofline / kernels_ms)")
+    ap.add_argument("--profile-every", type=int, default=-1,
+                    help="HIP-event timing of the kernels on every N-th iteration of the timed region (0: none - then no roofline / kernels_ms; "
+                         "default: every 4th, every 10th from 100 steps on - about ten sampled iterations)")
     ap.add_argument("--mode", choices=["train", "render"], default="train",
                     help="train (default): the mapping iteration, with the inference leg as a `render` block in the line; "
                          "render: only the inference leg (Model.forward(testing=True) over a whole scan), for profiling")
@@ -214,6 +215,7 @@ class KernelTimer:
         self.enabled = False
         self.every = 4
         self.calls = {n: 0 for n in names}
+        self.pool = []
         self._orig = {}
         for n in names:
             self._orig[n] = getattr(ops, n)
@@ -232,7 +234,7 @@ class KernelTimer:
                 self.ops.profile_enable(True)
             if not sampled:
                 return orig(*a, **k)
-            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0, e1 = self._event(), self._event()
             e0.record()
             r = orig(*a, **k)
             e1.record()
@@ -241,6 +243,17 @@ class KernelTimer:
                 self.ops.profile_enable(False)
             return r
         return inner
+
+    def _event(self):
+        return self.pool.pop() if self.pool else torch.cuda.Event(enable_timing=True)
+
+    def reserve(self, n_sampled_iterations):
+        """Events for that many sampled iterations, created AND recorded once here, outside the timed region (torch creates the HIP
+        event at the first record: ~15 us each - a sampled one-keyframe iteration paid 0.9 ms for them, two and a half iterations)."""
+        for _ in range(2 * len(self.names) * max(int(n_sampled_iterations), 0)):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.pool.append(e)
 
     def summary(self):
         out = {}
@@ -501,8 +514,17 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     timer.calls = {n: 0 for n in timer.names}
-    timer.every = max(args.profile_every, 1)
-    timer.enabled = args.profile_every > 0              # (it also switches the library's kernel events on, for every 4th iteration)
+    # An event record keeps the kernels around it from running back to back (~25 us each, three dozen per sampled iteration: 1.1 % of
+    # an 8-keyframe iteration when every 4th is sampled, but 2.5 iterations' worth for a one-keyframe shard): about ten sampled
+    # iterations on one GPU, two per rank in a sharded run (the per-kernel table is rank 0's and secondary there)
+    every = args.profile_every if args.profile_every >= 0 else \
+        (max(4, args.steps // 2) if world > 1 else (4 if args.steps < 100 else 10))
+    timer.every = max(every, 1)
+    timer.enabled = every > 0                           # (it also switches the library's kernel events on, for the sampled iterations)
+    if timer.enabled:
+        timer.reserve(args.steps // timer.every + 2)
+        ops.profile_enable(True); ops.profile_enable(False)      # (the library fills its own event pool here)
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     opt._do_iterate_optimizer(my_window, [None], optimizer_settings=phase(args.steps))
     torch.cuda.synchronize()
