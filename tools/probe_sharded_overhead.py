@@ -1,0 +1,42 @@
+"""What the SHARDED form of the loop costs on its own: one process, one GPU, torch.distributed over RCCL with world size 1 - every
+collective of an iteration (far[0] key, loss normalisers, the gradient exchange in both forms, the parameter all-gather) is issued
+and is an identity, so the difference to the non-distributed loop on the same one-keyframe window is the price of issuing them
+(host time, stream hand-overs), which a rank of an 8-GPU window pays whatever the links do.
+    python tools/probe_sharded_overhead.py [--steps 300]"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench                                                   # noqa: E402
+from loner_amd.mapping.optimizer import OptimizationSettings   # noqa: E402
+from loner_amd.mapping.sharding import DistContext             # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=300)
+ap.add_argument("--warmup", type=int, default=20)
+a = ap.parse_args()
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29713")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+phase = lambda n: OptimizationSettings(n, False, False, False, True)
+for form in (None, "all_reduce", "reduce_scatter"):
+    opt = bench.make_bench_optimizer(512, 512, "f32")
+    window = bench.build_window(8)[:1]
+    if form is not None:
+        opt.set_distributed(DistContext(exchange=form))
+    opt._do_iterate_optimizer(window, [None], optimizer_settings=phase(a.warmup))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    opt._do_iterate_optimizer(window, [None], optimizer_settings=phase(a.steps))
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / a.steps
+    print(f"one keyframe x 512 rays x 512 samples, {'non-distributed loop' if form is None else 'sharded loop, world size 1, exchange ' + form}: "
+          f"{ms:.4f} ms per iteration")
+dist.destroy_process_group()
