@@ -46,8 +46,8 @@ class Model(nn.Module):
     def inference_points(self, xyz_, dir_, sigma_only):
         return inference(self.nerf_model, xyz_, dir_, netchunk=0, sigma_only=sigma_only, meshing=True)
 
-    # rays per launch of the no-grad route: up to 2^24 samples per launch (8192 rays at 2048 samples: 2 GB of feature planes)
-    _POINTS_PER_LAUNCH = 1 << 24
+    # rays per launch of the no-grad route: up to 2^23 samples per launch (4096 rays at 2048 samples: 1 GB of feature planes)
+    _POINTS_PER_LAUNCH = 1 << 23
 
     def _sample_counts(self, testing):
         r = self.cfg.render
