@@ -268,7 +268,7 @@ def render_leg(opt, kf, scans=3, dtype="f32"):
     """The inference path that defines the metric's quality half (analysis/compute_l1_depth.py:42-64,262-265; renderer_lidar.py:71-93):
     every ray of a 64 x 1024 scan through Model.forward(testing=True) - N_samples_test = 2048 samples per ray, occupancy-guided
     sampling without jitter, density network forward, compositing - here through Model.render_depth, the depth-only form of it (no
-    [N,S] weights, forward-only workspace, launches of 2^24 samples), and through Model.forward for comparison.  A "step" = one scan."""
+    [N,S] weights, forward-only workspace, launches of 2^23 samples), and through Model.forward for comparison.  A "step" = one scan."""
     from loner_amd import ops
     from loner_amd.common.ray_utils import LidarRayDirections
     model, sampler = opt._model, opt._ray_sampler
