@@ -324,7 +324,11 @@ def render_leg(opt, kf, scans=3, dtype="f32"):
     l1 = float(((depth * opt._scale_f)[good] - gt[good]).abs().mean()) if bool(good.any()) else None
     return {"metric": "inference rays/sec (Model.forward(testing=True) depth, every ray of a 64x1024 scan)", "value": n / (ms_depth * 1e-3), "unit": "rays/s",
             "rays": n, "samples_per_ray": S, "ms_per_scan": round(ms_depth, 3), "ms_per_scan_full_result_dictionary": round(ms_full, 3),
-            "dtype": dtype, "kernels_ms_per_scan": kern, "l1_depth_m_of_this_scan": l1,
+            "dtype": dtype, "kernels_ms_per_scan": kern,
+            "kernels_note": "event spans on the stream each kernel runs on: the sampler of launch i + 1 runs on a second stream BESIDE the density "
+                            "forward of launch i (Model._render_no_grad), so its span is stretched by the sharing and the spans do not add up to "
+                            "ms_per_scan; alone it takes 2.3 ms per scan (profiles/r04_render_kernel_stats.csv)",
+            "l1_depth_m_of_this_scan": l1,
             "roofline": {"kernel": "encode_forward", "bound": "hbm", "achieved": enc_bytes / t_enc / 1e9 if t_enc > 0 else None, "peak": 8000.0,
                          "unit": "GB/s", "frac": enc_bytes / t_enc / 8e12 if t_enc > 0 else None, "algorithmic_bytes_per_scan": enc_bytes,
                          "traffic": None,
