@@ -400,10 +400,13 @@ def l1_probe(o, kf0, max_rays):
 
 
 def quality_initial_params():
-    from oracle import network as NW
+    """Initial density parameters of every quality leg: the PRODUCT's initialiser with seed 0.  The oracle legs start from the same
+    tensor - oracle.network.init_params(spec, 0) is bit-identical to it (tests/test_host.py::test_product_initialiser_equals_the_oracles),
+    so the HIP legs need nothing from oracle/."""
     from loner_amd.common.settings import default_nerf_config
+    from loner_amd.models.nerf_tcnn import SigmaNetwork
     nc = default_nerf_config()
-    return NW.init_params(NW.NetworkSpec.from_config(nc["pos_encoding_sigma"], nc["sigma_network"]), 0)
+    return SigmaNetwork(3, 1, nc["pos_encoding_sigma"], nc["sigma_network"], seed=0).params.detach().clone()
 
 
 def hip_quality_run(seed, iters=None, shape=None, device_index=0):
@@ -423,6 +426,60 @@ def hip_quality_run(seed, iters=None, shape=None, device_index=0):
     torch.manual_seed(123)
     return {"value": o.last_stats["n_valid_rays"] / dt, "unit": "rays/s", "ms_per_iter": 1e3 * dt / max(iters, 1),
             "l1_depth_m_before": l1_0, "l1_depth_m_after": l1_probe(o, w[0], L1_RAYS)}
+
+
+def api_parity_leg(args, device_index, iters, warmup):
+    """SURVEY 8d "state both modes": the training throughput in API-PARITY mode - the reference's own loop shape
+    (optimizer.py:276-385) driven through the boundary classes one call at a time: per keyframe torch.randint + KeyFrame.build_lidar_rays
+    (poses on the host, autograd through tensor_to_transform), Optimizer.compute_loss_api = Model.forward -> the result dictionary with
+    its [N,S] weights / samples and [N,S,3] points in HBM -> torch ops for the loss (optimizer.py:437-595) -> loss.backward() through
+    torch autograd -> Adam on the density parameters (the fused kernel) and on the host-side poses (torch.optim.Adam) -> occupancy step
+    every N_iters_acc-th iteration, and one host sync per iteration (the reference's loss.item(), optimizer.py:354).  Same window, same
+    network, same sample counts as the headline, which runs the fused-loss mode (no dictionary, no host sync, poses on the device)."""
+    from loner_amd.mapping.optimizer import HipAdam, OptimizationSettings
+    o, w = make_bench_optimizer(args.rays, args.samples, args.dtype, device_index), build_window(args.keyframes)
+    o._optimization_settings = OptimizationSettings(iters, False, False, False, True)
+    o._model.freeze_sigma_head(False)
+    pose_params = []
+    for kf in w:
+        kf.get_lidar_pose().set_fixed(kf.is_anchored)
+        if not kf.is_anchored:
+            pose_params.append(kf.get_lidar_pose().get_pose_tensor())
+    tr = o._model_config.train
+    adam_sigma = HipAdam([{'params': o._model.get_sigma_parameters(), 'lr': tr.lrate_sigma_mlp}])
+    adam_pose = torch.optim.Adam([{'params': pose_params, 'lr': tr.lrate_pose}])
+    every = int(o._model_config.model.occ_model.N_iters_acc)
+    n_scan = len(w[0].get_lidar_scan())
+
+    def run(n_it):
+        n_rays = 0
+        for it in range(n_it):
+            rays, depths = [], []
+            for kf in w:
+                r, d = kf.build_lidar_rays(torch.randint(n_scan, (args.rays,)), o._ray_range, o._world_cube, False)
+                rays.append(r); depths.append(d)
+            rays, depths = torch.vstack(rays), torch.cat(depths)
+            loss = o.compute_loss_api((rays, depths), it)
+            loss.backward()
+            adam_sigma.step(zero_grad=True)
+            adam_pose.step()
+            adam_pose.zero_grad(set_to_none=True)
+            if o._global_step % every == 0:
+                o._step_occupancy_grid()
+            o._global_step += 1
+            n_rays += rays.shape[0]
+            loss.item()                                    # the reference's per-iteration host sync
+        return n_rays
+    run(warmup)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n = run(iters)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    S = args.samples
+    return {"value": n / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt / max(iters, 1), "steps": iters, "warmup": warmup, "dtype": args.dtype,
+            "result_dictionary_bytes_per_ray": 20 * S + 12,
+            "note": "API-parity mode (SURVEY 8d): KeyFrame.build_lidar_rays per keyframe -> Optimizer.compute_loss_api (Model.forward -> result "
+                    "dictionary -> torch ops) -> torch autograd -> Adam; one host sync per iteration; poses optimised on the host like the "
+                    "reference.  The headline value is the fused-loss mode of the same window."}
 
 
 def main():
@@ -609,6 +666,12 @@ def main():
             ns_net = north_star_network_leg(args.keyframes * args.rays, args.samples, "cuda")
         except Exception as e:
             ns_net = {"error": str(e)}
+    api_mode = None
+    if world == 1 and not args.quick:
+        try:
+            api_mode = api_parity_leg(args, local, iters=min(max(args.steps, 1), 20), warmup=3)
+        except Exception as e:
+            api_mode = {"error": str(e)}
     render = None
     if world == 1 and not args.quick:
         try:
@@ -690,6 +753,7 @@ def main():
                    "parallelism": f"keyframe-sharded x{world}" if world > 1 else "single GPU"},
         "roofline": roofline,
         "north_star_network": ns_net,
+        "api_parity_mode": api_mode,
         "render": render,
         # whole-path HBM roofline of SURVEY 8d: B_ray = 72 B (ray record, gt depth, per-ray outputs) + dense Adam traffic
         # (28 B per parameter: read p,g,m,v, write p,m,v) amortised over the rays of an iteration

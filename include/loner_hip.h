@@ -249,6 +249,23 @@ int lnr_compact_rays(const float* rays_in, const float* depths_in, const uint8_t
 int lnr_first_ray_key(const float* rays, const int32_t* out_seg_start /*[n_seg+1] device*/, const int32_t* seg_order /*[n_seg] host*/,
                       int32_t n_seg, int64_t* key_out /*[1] device*/, void* stream);
 
+/* The sharded loop's one small collective per iteration (loner_amd/mapping/sharding.py; SURVEY 8e collectives (2) + the far[0] quirk).
+ * far[0] of the whole batch and the global normalisers #rays / #opaque rays (optimizer.py:460-463,488-489,569-578) - the second of
+ * which depends on far[0] - come out of ONE all-gather of per-rank "front records" instead of a key exchange followed by a count
+ * exchange.  A record is LNR_FRONT_HEADER + cap float32 words: [0..1] the rank's first-ray key as lnr_first_ray_key defines it (int64
+ * bits), [2] its live-ray count (int32 bits), [3] 0, [4..] the ground-truth depths of its kept rays (zeros beyond the count).
+ * lnr_shard_front_pack writes a rank's record from the outputs of lnr_compact_rays (n_seg = 0: a rank without keyframes - the key is
+ * INT64_MAX, the count 0, every pointer but `record` may be NULL).  lnr_shard_front_reduce reads the `world` gathered records
+ * (consecutive, `stride` = LNR_FRONT_HEADER + cap words each) and writes counts_dev = {sum of the live counts, number of depths d over
+ * all ranks with d > 0 and not d > far[0]} - the values lnr_count_opaque computes for an unsharded batch - and far0_dev = far[0] (NaN
+ * bits when no rank kept a ray), for lnr_los_loss_fused / lnr_occ_grid_step. */
+#define LNR_FRONT_HEADER 4
+int lnr_shard_front_pack(const float* rays, const int32_t* out_seg_start /*[n_seg+1] device*/, const int32_t* seg_order /*[n_seg] host*/,
+                         int32_t n_seg, const float* depths, int32_t n_rays, const int32_t* n_rays_dev, int32_t cap,
+                         float* record /*[LNR_FRONT_HEADER + cap] device*/, void* stream);
+int lnr_shard_front_reduce(const float* records /*[world][stride] device*/, int32_t world, int32_t stride,
+                           int32_t* counts_dev /*[2]*/, float* far0_dev /*[1]*/, void* stream);
+
 /* Backward of lnr_build_lidar_rays for a window: dL/drays -> dL/d[R|t] per keyframe
  * (the autograd tail ray_utils.py:281-305 <- keyframe.py:80-88).  d_transform [n_seg,12]. */
 int lnr_lidar_rays_backward(const float* d_rays /*[n,13]*/, const float* rays /*[n,13]*/,

@@ -253,6 +253,92 @@ extern "C" int lnr_first_ray_key(const float* rays, const int32_t* out_seg_start
     return LNR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The sharded loop's ONE small collective per iteration (mapping/sharding.py).  What the loss needs from the other ranks - far[0] of
+// the whole batch and the two global normalisers #rays / #opaque rays (optimizer.py:460-463,488-489,569-578) - depends on far[0] in
+// its second half (opaque = depth > 0 and not depth > far[0]), so a key exchange followed by a count exchange would be two dependent
+// collectives.  Instead every rank contributes one "front record": its first-ray key, its live-ray count and the ground-truth depths of
+// its kept rays (2 KB for 512 rays), the records are all-gathered, and every rank derives far[0] and both counts from ALL depths
+// locally - identical integer results everywhere, one latency-bound collective that hides behind the sampler and the density forward.
+//   record = float32 words [LNR_FRONT_HEADER + cap]:  [0..1] key (int64 bits)   [2] live rays (int32 bits)   [3] 0   [4..] depths
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+shard_front_pack_kernel(const float* __restrict__ rays, const int32_t* __restrict__ out_seg_start, const SegOrder ord,
+                        const float* __restrict__ depths, int n_rays, const int32_t* __restrict__ n_rays_dev, int cap, float* __restrict__ rec) {
+    const int n = min(lnr_live_rays(n_rays, n_rays_dev), cap);
+    if (threadIdx.x == 0) {
+        long long k = 0x7FFFFFFFFFFFFFFFll;                      // no live ray on this rank
+        for (int s = 0; s < ord.n; ++s) {
+            const int lo = out_seg_start[s], hi = out_seg_start[s + 1];
+            if (hi > lo) {
+                k = ((long long)ord.order[s] << 32) | (long long)__float_as_uint(rays[(size_t)lo * LNR_RAY_STRIDE + 12]);
+                break;
+            }
+        }
+        rec[0] = __uint_as_float((uint32_t)((unsigned long long)k & 0xFFFFFFFFull));
+        rec[1] = __uint_as_float((uint32_t)((unsigned long long)k >> 32));
+        rec[2] = __int_as_float(n);
+        rec[3] = 0.0f;
+    }
+    for (int i = threadIdx.x; i < cap; i += blockDim.x) rec[LNR_FRONT_HEADER + i] = i < n ? depths[i] : 0.0f;
+}
+
+__global__ void __launch_bounds__(1024)
+shard_front_reduce_kernel(const float* __restrict__ recs, int world, int stride, int32_t* __restrict__ counts, float* __restrict__ far0_out) {
+    __shared__ int partial[16];
+    unsigned long long kmin = 0x7FFFFFFFFFFFFFFFull;
+    int n_all = 0;
+    for (int r = 0; r < world; ++r) {
+        const float* rec = recs + (size_t)r * stride;
+        const unsigned long long k = (unsigned long long)__float_as_uint(rec[0]) | ((unsigned long long)__float_as_uint(rec[1]) << 32);
+        kmin = k < kmin ? k : kmin;                              // (keys are non-negative as signed values: the unsigned order is the same)
+        n_all += max(0, min(__float_as_int(rec[2]), stride - LNR_FRONT_HEADER));
+    }
+    const float far0 = __uint_as_float((uint32_t)(kmin & 0xFFFFFFFFull));      // nobody has a ray: NaN bits, and no depth is compared
+    int c = 0;
+    for (int r = 0; r < world; ++r) {
+        const float* rec = recs + (size_t)r * stride;
+        const int n = max(0, min(__float_as_int(rec[2]), stride - LNR_FRONT_HEADER));
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const float d = rec[LNR_FRONT_HEADER + i];
+            c += ((d > 0.0f) && !(d > far0)) ? 1 : 0;            // lnr_count_opaque's test
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += partial[w];
+        counts[0] = n_all;
+        counts[1] = t;
+        far0_out[0] = far0;
+    }
+}
+
+extern "C" int lnr_shard_front_pack(const float* rays, const int32_t* out_seg_start, const int32_t* seg_order, int32_t n_seg,
+                                    const float* depths, int32_t n_rays, const int32_t* n_rays_dev, int32_t cap, float* record, void* stream) {
+    LNR_REQUIRE(record && cap >= 0 && n_rays >= 0 && n_seg >= 0 && n_seg <= LNR_MAX_SEG, "lnr_shard_front_pack: bad argument");
+    LNR_REQUIRE(n_seg == 0 || (rays && out_seg_start && seg_order && depths), "lnr_shard_front_pack: null argument");
+    SegOrder ord;
+    ord.n = n_seg;
+    for (int s = 0; s < n_seg; ++s) {
+        LNR_REQUIRE(seg_order[s] >= 0 && (s == 0 || seg_order[s] > seg_order[s - 1]), "lnr_shard_front_pack: seg_order must be non-negative and ascending");
+        ord.order[s] = seg_order[s];
+    }
+    hipLaunchKernelGGL(shard_front_pack_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rays, out_seg_start, ord, depths,
+                       n_seg == 0 ? 0 : n_rays, n_seg == 0 ? nullptr : n_rays_dev, cap, record);
+    LNR_CHECK_LAUNCH("lnr_shard_front_pack");
+    return LNR_OK;
+}
+
+extern "C" int lnr_shard_front_reduce(const float* records, int32_t world, int32_t stride, int32_t* counts_dev, float* far0_dev, void* stream) {
+    LNR_REQUIRE(records && counts_dev && far0_dev && world >= 1 && stride >= LNR_FRONT_HEADER, "lnr_shard_front_reduce: bad argument");
+    hipLaunchKernelGGL(shard_front_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, records, world, stride, counts_dev, far0_dev);
+    LNR_CHECK_LAUNCH("lnr_shard_front_reduce");
+    return LNR_OK;
+}
+
 // one workgroup per keyframe: reduce the 12 entries of dL/d[R|t]
 __global__ void __launch_bounds__(256)
 lidar_rays_backward_kernel(const float* __restrict__ d_rays, const float* __restrict__ rays, const int64_t* __restrict__ src_index,

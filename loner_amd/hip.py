@@ -19,6 +19,7 @@ LIB_PATH = os.environ.get("LNR_LIB_PATH") or os.path.join(_HERE, "_lib", "liblon
 MAX_LEVELS = 32
 RAY_STRIDE = 13
 LOSS_RAYS_PER_BLOCK = 4      # LNR_LOSS_RAYS_PER_BLOCK
+FRONT_HEADER = 4             # LNR_FRONT_HEADER
 
 ENCODINGS = {"HashGrid": 0, "Grid": 0, "Frequency": 1}
 ACTIVATIONS = {"None": 0, "ReLU": 1, "Sine": 2, "LeakyReLU": 3, "Exponential": 4, "Sigmoid": 5,
@@ -99,6 +100,8 @@ _SIGNATURES = {
     "lnr_selftest_mfma": (C.c_int, [P, P]),
     "lnr_first_ray_key": (C.c_int, [P, P, C.POINTER(C.c_int32), C.c_int32, P, P]),
     "lnr_rng_draws": (C.c_int, [C.c_int32, C.c_uint64, C.c_int32, C.c_int32, P, P]),
+    "lnr_shard_front_pack": (C.c_int, [P, P, C.POINTER(C.c_int32), C.c_int32, P, C.c_int32, P, C.c_int32, P, P]),
+    "lnr_shard_front_reduce": (C.c_int, [P, C.c_int32, C.c_int32, P, P, P]),
 }
 
 _lib = None

@@ -258,6 +258,9 @@ class Optimizer:
             active = self._dist.owned(active_all) if self._dist is not None else active_all
             # positions of this rank's keyframes in the window (the sharded far[0] agreement needs them)
             self._active_order = self._dist.owned_indices(len(active_all)) if self._dist is not None else list(range(len(active_all)))
+            # depth slots of the sharded loop's front record (mapping/sharding.py): the candidate rays of the fullest rank
+            n_sky_cfg = self._settings.num_samples.sky if self._enable_sky_segmentation else 0
+            self._front_cap = self._dist.front_capacity(len(active_all), self._num_lidar_samples + n_sky_cfg) if self._dist is not None else 0
             for kf in active:
                 if not kf.is_anchored:
                     kf.get_lidar_pose().set_fixed(not optimize_poses)
@@ -334,7 +337,7 @@ class Optimizer:
 
                 def front_end(it_next):
                     b = self._build_window_rays(active, pose_dev, tab, n_out=valid_log[it_next:it_next + 1])
-                    b["front"] = self._sample_front(b["rays"], b["depths"], b["n_dev"], first_key=b["first_key"])
+                    b["front"] = self._sample_front(b["rays"], b["depths"], b["n_dev"])
                     return b
                 batch = front_end(0) if n_it > 0 else None
                 for it_idx in range(n_it):
@@ -389,7 +392,7 @@ class Optimizer:
                                                self._model.nerf_model._model_sigma.params, it_idx, want_ray_grads=any_free,
                                                want_param_grads=not os_.freeze_sigma_mlp, n_rays_dev=batch["n_dev"],
                                                loss_out=loss_log[it_idx], accumulate_into_param_grad=True, want_stats=False,
-                                               defer_grad_wait=True, poison=poison, first_key=batch["first_key"])
+                                               defer_grad_wait=True, poison=poison, shard_segments=(batch["seg_start"], tab.seg_order))
                 else:
                     out = self._join_without_rays(sigma_params[0] if sigma_params else None, want_param_grads=not os_.freeze_sigma_mlp)
                 if any_free:
@@ -441,14 +444,16 @@ class Optimizer:
             else:
                 outside = torch.zeros(1, device=self._device)
             pose_ok = torch.isfinite(pose_dev.detach()).all().reshape(1).float()
-            packed = torch.cat([poison.float(), valid_log.float(), loss_log.detach().reshape(-1), pose_dev.detach().reshape(-1).float(),
-                                pose_ok, outside]).cpu()
-            code, failed_it = int(packed[0]), int(packed[1])
-            valid_host = packed[2:2 + n_log]
-            loss_terms_host = packed[2 + n_log:2 + n_log + 8 * n_log].reshape(n_log, 8).clone()
-            o = 2 + 9 * n_log
-            pose_host = packed[o:o + pose_dev.numel()].reshape(pose_dev.shape)
-            pose_finite, origins_outside = bool(packed[-2] != 0), bool(packed[-1] != 0)
+            # (the integer words - failure code and iteration, live-ray counts - travel as their BIT PATTERNS inside the float32 buffer,
+            # so they are exact whatever their size; the pieces are split by the sizes of the tensors that were concatenated)
+            pieces = [poison.view(torch.float32), valid_log.view(torch.float32), loss_log.detach().reshape(-1),
+                      pose_dev.detach().reshape(-1).float(), pose_ok, outside]
+            host = torch.cat(pieces).cpu().split([p_.numel() for p_ in pieces])
+            code, failed_it = (int(v) for v in host[0].view(torch.int32))
+            valid_host = host[1].view(torch.int32).float()
+            loss_terms_host = host[2].reshape(loss_log.shape).clone()
+            pose_host = host[3].reshape(pose_dev.shape)
+            pose_finite, origins_outside = bool(host[4][0] != 0), bool(host[5][0] != 0)
             self._poison = None
             self._model.nerf_model.warn_if_clipped(self._device)      # nerf_tcnn.py:70-78, once per phase instead of per forward
             loss_host = loss_terms_host[:, 0]
@@ -562,8 +567,7 @@ class Optimizer:
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if index is None else 0
         rays_c, depths_c, keep, src_c = ops.build_window_rays(tab, T12, rr, self._scale_f, self._shift_f, index=index, seed=seed)
         rays, depths, src, out_seg, n_dev = ops.compact_rays(rays_c, depths_c, keep, src_c, tab.seg_start_list, n_out=n_out)
-        first_key = ops.first_ray_key(rays, out_seg, tab.seg_order) if self._dist is not None else None
-        return dict(rays=rays, depths=depths, src=src, seg_start=out_seg, n_dev=n_dev, T12=T12, tab=tab, first_key=first_key)
+        return dict(rays=rays, depths=depths, src=src, seg_start=out_seg, n_dev=n_dev, T12=T12, tab=tab)
 
     def _pose_backward(self, batch, d_rays, pose_dev, free_mask_u8, poison=None, poison_tag=0):
         """dL/drays -> dL/d[R|t] per segment (HIP) -> dL/dpose6 (HIP, analytic axis-angle Jacobian)."""
@@ -600,9 +604,10 @@ class Optimizer:
             cfg.fixed_eps = lc.depth_eps
         return cfg
 
-    def _sample_front(self, rays, depths, n_rays_dev, draws=None, first_key=None):
+    def _sample_front(self, rays, depths, n_rays_dev, draws=None, shard_segments=None):
         """The part of an iteration that does not touch the density parameters: loss normalisers and sample depths for `rays`
-        (optimizer.py:437-470 up to the network call).  -> dict(counts, counts_work, z, seed, far0)"""
+        (optimizer.py:437-470 up to the network call).  -> dict(counts, front_work, z, seed, far0).  shard_segments (sharded loop):
+        (compacted segment starts on the device, window position of every segment) of this rank's batch."""
         draws = draws if draws is not None else self._draws
         render = self._model_config.model.render
         S, perturb = render.N_samples_train, render.perturb
@@ -616,23 +621,30 @@ class Optimizer:
                 u1 = draws.jitter(n, S // 2 if ogm else S).to(dev)
             if ogm:
                 u2 = draws.pdf(n, S // 2).to(dev)
-        # Sharded: the reference compares every ground-truth depth with far[0], the first ray of the WHOLE batch
-        # (optimizer.py:460-461) = rank 0's first ray (it owns the first active keyframe); one float broadcast.
-        far0 = self._dist.broadcast_far0(rays, first_key=first_key) if self._dist is not None else None
-        # loss normalisers first: in the sharded mode their (2-int) all-reduce is pure latency and runs behind the sampler and
-        # the density forward; it is waited for right before the loss kernel, its first consumer
-        counts = ops.count_opaque(rays, depths, n_rays_dev=n_rays_dev, far0=far0)
-        counts_work = self._dist.all_reduce_counts(counts, async_op=True) if self._dist is not None else None
+        # Sharded: the loss divides by the GLOBAL counts and compares every ground-truth depth with far[0], the first ray of the WHOLE
+        # batch (optimizer.py:460-461,488-489,569-578).  One all-gather of the ranks' front records {first-ray key, live count, depths}
+        # delivers all three (mapping/sharding.py); it is pure latency and runs behind the sampler and the density forward - awaited
+        # right before the loss kernel, its first consumer.
+        counts = far0 = front_work = None
+        if self._dist is not None:
+            if shard_segments is not None:
+                seg_start, seg_order, cap = shard_segments[0], shard_segments[1], self._front_cap
+            else:       # a caller outside the training loop (compute_loss): the batch is one segment at this rank's position
+                seg_start, seg_order = torch.tensor([0, n], device=dev, dtype=torch.int32), [self._dist.rank]
+                cap = self._dist.max_over_ranks(n)
+            front_work = self._dist.gather_front(ops.shard_front_pack(rays, seg_start, seg_order, depths, n_rays_dev, cap))
+        else:
+            counts = ops.count_opaque(rays, depths, n_rays_dev=n_rays_dev)
         if ogm:
             z = ops.sample_rays_occ(rays, self._occupancy_grid.detach(), S, perturb, u_jitter=u1, u_pdf=u2, seed=seed,
                                     n_rays_dev=n_rays_dev)
         else:
             z = ops.sample_rays_uniform(rays, S, perturb, u_jitter=u1, seed=seed, n_rays_dev=n_rays_dev)
-        return dict(counts=counts, counts_work=counts_work, z=z, seed=seed, far0=far0)
+        return dict(counts=counts, front_work=front_work, z=z, seed=seed, far0=far0)
 
     def _loss_and_grads(self, rays, depths, params, iteration_idx, want_ray_grads, want_param_grads, n_rays_dev=None,
                         loss_out=None, accumulate_into_param_grad=False, draws=None, want_stats=True, defer_grad_wait=False,
-                        poison=None, front=None, input_grad_event=None, defer_weight_fold=False, first_key=None):
+                        poison=None, front=None, input_grad_event=None, defer_weight_fold=False, shard_segments=None):
         """sample -> density -> fused render+loss(+backward) -> density backward.  rays [N,13], depths [N] on device.
         front: the result of _sample_front for these rays when the caller already ran it (the pipelined training loop);
         input_grad_event: recorded by the density backward as soon as d_rays is complete (ops.density_backward)."""
@@ -643,16 +655,16 @@ class Optimizer:
         dev = self._device
         n = rays.shape[0]
         if front is None:
-            front = self._sample_front(rays, depths, n_rays_dev, draws, first_key=first_key)
-        counts, counts_work, z, seed, far0 = front["counts"], front["counts_work"], front["z"], front["seed"], front["far0"]
+            front = self._sample_front(rays, depths, n_rays_dev, draws, shard_segments=shard_segments)
+        counts, front_work, z, seed, far0 = front["counts"], front["front_work"], front["z"], front["seed"], front["far0"]
         noise = None
         if draws is not None and noise_std > 0:
             noise = (draws.noise(n, S) * noise_std).to(dev)
         p = params.detach()
         self._flush_density_step()            # the previous iteration's (deferred) density Adam step lands here
         sigma = ops.density_forward(spec, p, rays=rays, z=z, n_rays_dev=n_rays_dev)
-        if counts_work is not None:
-            counts_work.wait()
+        if front_work is not None:
+            counts, far0 = front_work.wait()
         loss, d_sigma, d_rays, stats, _ = ops.los_loss_fused(sigma, z, rays, depths, self._scale_f, self._loss_config(iteration_idx),
                                                             counts, noise=noise, noise_std=noise_std, seed=seed + 1,
                                                             n_rays_dev=n_rays_dev, want_stats=want_stats, loss_out=loss_out, far0=far0,
@@ -679,8 +691,9 @@ class Optimizer:
             if self._dist is not None and want_param_grads:
                 # only the training loop (defer_grad_wait) steps a slice and gathers the parameters; every other caller
                 # (compute_loss -> autograd -> an optimiser of its own) gets the whole sum whatever the exchange form
-                grad_work = self._dist.exchange_grads(grad_params, int(spec.n_mlp_params), async_op=True,
-                                                      force_all_reduce=not defer_grad_wait)
+                # (overwrite mode: the next backward stores every float of the gradient - the chunks of other ranks need no zeroing)
+                grad_work = self._dist.exchange_grads(grad_params, async_op=True, force_all_reduce=not defer_grad_wait,
+                                                      zero_rest=not overwrite)
                 if not defer_grad_wait:
                     grad_work.wait()
                     grad_work = None
@@ -695,19 +708,20 @@ class Optimizer:
         (far[0] broadcast, loss normalisers, density gradient) with zero contributions, in the order _loss_and_grads issues
         them, so that the other ranks neither block nor see different sums."""
         dev = self._device
-        self._dist.broadcast_far0(None, device=dev)
-        counts = torch.zeros(2, device=dev, dtype=torch.int32)
-        counts_work = self._dist.all_reduce_counts(counts, async_op=True)
+        front_work = self._dist.gather_front(ops.shard_front_pack(None, None, (), None, None, self._front_cap, device=dev))
         self._flush_density_step()
-        counts_work.wait()
+        front_work.wait()
         grad_work = None
         if want_param_grads and params is not None:
             if params.grad is None:
                 params.grad = torch.zeros_like(params)
             elif self._overwrite_grads:
-                params.grad.zero_()          # no backward of this rank overwrites the previous iteration's (reduced) gradient: contribute zeros
-            spec = self._model.nerf_model._model_sigma.spec
-            grad_work = self._dist.exchange_grads(params.grad, int(spec.n_mlp_params), async_op=True)
+                # no backward of this rank overwrites what the previous exchange left in the buffer: contribute zeros again.  The
+                # all-reduce form leaves the sum in the whole vector; the reduce-scatter form only reads the buffer and writes this
+                # rank's chunk (and the phase starts from an all-zero gradient: _do_iterate_optimizer's phase end).
+                sl = self._dist.owned_range(params.grad.numel())
+                (params.grad if sl is None else params.grad.view(-1)[sl[0]:sl[1]]).zero_()
+            grad_work = self._dist.exchange_grads(params.grad.view(-1), async_op=True, zero_rest=not self._overwrite_grads)
         self._results_lidar = None
         return dict(loss=None, d_rays=None, grad_params=params.grad if (want_param_grads and params is not None) else None,
                     stats=None, z=None, grad_work=grad_work)
@@ -723,20 +737,18 @@ class Optimizer:
 
     def _step_density(self, work, group):
         """Adam step of the density parameters once their gradient exchange (if any) has finished.  Sharded with the
-        "reduce_scatter" exchange a rank steps the MLP matrices and ITS slice of the hash tables, then the slices are gathered."""
+        "reduce_scatter" exchange a rank steps ITS chunk of the flat parameter vector, then the chunks are gathered."""
         if work is not None:
             work.wait()
         ranges = None
         if self._dist is not None:
-            params = self._model.nerf_model._model_sigma.params
-            n_mlp = int(self._model.nerf_model._model_sigma.spec.n_mlp_params)
-            sl = self._dist.table_slice(n_mlp, params.numel())
+            sl = self._dist.owned_range(self._model.nerf_model._model_sigma.params.numel())
             if sl is not None:
-                ranges = [(0, n_mlp), sl]
+                ranges = [sl]
         # (overwrite mode: the next backward stores its gradient over this one - nothing to zero)
         self._optimizer.step(zero_grad=not self._overwrite_grads, groups=(group,), ranges=ranges)
         if ranges is not None:
-            self._dist.gather_params(self._model.nerf_model._model_sigma.params.data.view(-1), n_mlp)
+            self._dist.gather_params(self._model.nerf_model._model_sigma.params.data.view(-1))
 
     def compute_loss(self, camera_samples: Tuple[torch.Tensor, torch.Tensor], lidar_samples: Tuple[torch.Tensor, torch.Tensor],
                      iteration_idx: int, override_enables: bool = False, tracking=False) -> torch.Tensor:
@@ -754,6 +766,48 @@ class Optimizer:
         stats = self._results_lidar["stats"]
         self._results_lidar.update(depth_fine=stats[:, 0], opacity_fine=stats[:, 1], variance=stats[:, 2])
         self._depth_eps = float(stats[:, 6].mean().item())
+        assert not torch.isnan(loss), "NaN Loss Encountered"
+        return loss
+
+    def compute_loss_api(self, lidar_samples: Tuple[torch.Tensor, torch.Tensor], iteration_idx: int) -> torch.Tensor:
+        """API-parity mode of compute_loss: the loss evaluated the way the reference evaluates it (optimizer.py:437-595) -
+        Model.forward -> the result dictionary with its [N,S] weights / samples and [N,S,3] points materialised in HBM (model_tcnn.py:70-105)
+        -> torch ops on that dictionary -> torch autograd back through render_rays.  Same value and gradients as compute_loss, which
+        computes all of it in one fused kernel pass without the dictionary; this is the form a caller gets who keeps the reference's own
+        loss code on top of this package's Model, and the one bench.py times as `api_parity_mode`."""
+        lc = self._model_config.loss
+        rays, depths = lidar_samples
+        rays = rays.reshape(-1, rays.shape[-1])
+        rays = rays if rays.device == self._device else rays.to(self._device)
+        scale = self._scale_f
+        g = depths.reshape(-1, 1).to(self._device).float() * scale                          # ground-truth depths, metres
+        # the reference's (N,1) > (N,) broadcast followed by [..., 0]: every depth is compared with far of the FIRST ray (:460-461)
+        transparent = depths.reshape(-1).to(self._device) > rays[0, 12].detach()
+        opaque = (depths.reshape(-1).to(self._device) > 0) & ~transparent
+        res = self._model(rays, self._ray_sampler, self._scale_factor, camera=False, return_variance=True)
+        s = res["samples_fine"] * scale                                                      # sample depths, metres
+        w = res["weights_fine"]
+        w_sum = w.sum(1) + 1e-10
+        mean = (s * w).sum(1) / w_sum
+        var = ((s - mean[:, None]) ** 2 * w).sum(1) / w_sum + 1e-10
+        std = var.sqrt()
+        js = self.calculate_JS_divergence(g, lc.min_depth_eps / 3., mean[:, None], std[:, None]).reshape(-1)
+        loss = lc.depthloss_lambda * torch.nn.functional.mse_loss((res["depth_fine"] * scale)[opaque], g[opaque, 0])
+        cfg = self._loss_config(iteration_idx)
+        if lc.loss_selection in ("L1_JS", "L2_JS"):
+            js = torch.where(js < lc.JS_loss.min_js_score, torch.zeros_like(js), js).clamp(max=lc.JS_loss.max_js_score)
+            eps = (lc.min_depth_eps * (1 + lc.JS_loss.alpha * js))[:, None].detach()
+            self._depth_eps = float(eps.mean().item())
+        else:
+            eps = cfg.fixed_eps
+            self._depth_eps = eps
+        from ..models.losses import get_weights_gt
+        w_gt = get_weights_gt(s.detach(), g, eps)
+        w_gt = w_gt * opaque[:, None]
+        los = (w - w_gt).abs().mean() if lc.loss_selection in ("L1_JS", "L1_LOS") else ((w - w_gt) ** 2).mean()
+        loss = loss + cfg.los_lambda * los + (res["opacity_fine"][opaque] - 1).abs().mean()
+        res.update(rays=rays.detach(), depths=depths.reshape(-1).to(self._device).float(), n_rays_dev=None, stats=None)
+        self._results_lidar = res
         assert not torch.isnan(loss), "NaN Loss Encountered"
         return loss
 

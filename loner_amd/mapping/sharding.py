@@ -2,38 +2,39 @@
 
 The reference has no multi-GPU mapping; rays of different keyframes are independent through
 forward, loss sums and backward, pose gradients are private to a keyframe, so the window shards
-by keyframe with ONE exchange step per iteration:
+by keyframe with the density-parameter gradient as the one exchanged quantity:
 
   * rank r owns keyframes {i : i mod G == r} of the <= 8-keyframe window;
-  * every rank holds a full replica of the density parameters, Adam state and occupancy grid;
-  * before the loss is scaled, the two normalisers (#rays, #opaque rays) are all-reduced (2 ints),
-    because the reference divides by GLOBAL counts (optimizer.py:488-489,569-570,577-578);
-  * after backward, the density-parameter gradient is all-reduced (sum) - RCCL over xGMI via
-    torch.distributed backend "nccl"; every rank then applies the identical Adam step, so replicas
-    stay bit-equal (the reduced buffer is used as produced by the collective on every rank);
-  * the loss compares every ground-truth depth with `far` of the first ray of the batch (the far[0] quirk,
-    optimizer.py:460-461): the ranks agree on that ray with one 8-byte MIN all-reduce (window order of each rank's
-    first kept ray | its far), so the sharded loss equals the single-GPU one also when a keyframe lost all its rays;
-  * every N_iters_acc-th step the occupancy-grid pseudo-gradient (V^3 floats) is all-reduced the
+  * every rank holds a full replica of the density parameters and the occupancy grid;
+  * per iteration there is ONE small collective in front of the loss and ONE gradient exchange behind the backward:
+
+    front    the loss divides by GLOBAL counts (#rays, #opaque rays: optimizer.py:488-489,569-570,577-578) and compares every
+             ground-truth depth with `far` of the first ray of the WHOLE batch (the far[0] quirk, optimizer.py:460-461) - and "opaque"
+             itself depends on far[0].  Every rank contributes one "front record" = {first-ray key = window order of its first kept
+             ray | that ray's far, live-ray count, the ground-truth depths of its kept rays} (2 KB for 512 rays); the records are
+             all-gathered and every rank derives far[0] and both counts from all depths locally (lnr_shard_front_reduce): one
+             latency-bound collective, issued right after the ray compaction and awaited right before the loss kernel, so it hides
+             behind the sampler and the density forward.  (Rounds 2-4 used a MIN all-reduce of the key followed by an all-reduce
+             of the counts: two dependent collectives.)
+    gradient "all_reduce": one all-reduce(sum) of the flat gradient [MLP matrices | tables] (29.7 MB); every rank runs the whole Adam
+             step (237 MB of HBM traffic, ~25-35 us).  "reduce_scatter": the flat gradient is reduce-scattered in G equal contiguous
+             chunks (rank r receives the sum of chunk r; the 3072 MLP weights simply lie in chunk 0), every rank runs Adam on ITS
+             chunk only (parameters and Adam moments of a chunk live where it is stepped: 1/G of the Adam traffic per rank), then
+             the stepped chunks are all-gathered - ONE reduce-scatter + ONE all-gather (rounds 2-4: a separate all-reduce for the MLP
+             weights as well).  Same bytes on the wire as a ring all-reduce (it IS its two halves), but only the first half can hide
+             behind the pose tail - the all-gather sits directly in front of the next density forward.  Worth it when the dense
+             Adam step is a visible part of a rank's iteration (large tables, many ranks): the default from 4 ranks on.  Either form
+             is issued asynchronously and awaited at the deferred density step, i.e. it overlaps the pose tail, the occupancy step
+             and the next batch's ray build.
+             payload="bf16": either form can put the gradient on the wire as bf16 (half the bytes; the sum over ranks is then
+             rounded to 8 mantissa bits - replicas stay bit-identical because every rank receives the same sum).
+  * every N_iters_acc-th step the occupancy-grid pseudo-gradient (V^3 64-bit fixed-point accumulators) is all-reduced the
     same way so that the samplers do not diverge.
 
-Two forms of the gradient exchange (DistContext(exchange=...)):
+Replicas stay bit-equal because every rank uses the reduced buffer as produced by the collective.
 
-  "all_reduce"      one all-reduce(sum) of the flat gradient [MLP matrices | tables] (29.7 MB); every rank runs the whole
-                    Adam step (237 MB of HBM traffic, ~25-35 us).  Issued asynchronously and awaited at the deferred
-                    density step, i.e. it overlaps the pose tail, the occupancy step and the next batch's ray build.
-  "reduce_scatter"  the table gradient is reduce-scattered by contiguous slice (rank r receives the sum of slice r), every
-                    rank runs Adam on ITS slice of the table only (parameters and Adam moments of a slice live where the
-                    slice is stepped: 1/G of the Adam traffic per rank), then the stepped parameter slices are all-gathered;
-                    the 3072 MLP weights are all-reduced separately and stepped everywhere.  Same bytes on the wire as a
-                    ring all-reduce (it IS its two halves), but only the first half can hide behind the pose tail - the
-                    all-gather sits directly in front of the next density forward.  Worth it when the dense Adam step is
-                    a visible part of a rank's iteration (large tables, many ranks): the default from 4 ranks on.
-  payload="bf16"    either form can put the gradient on the wire as bf16 (half the bytes; the sum over ranks is then
-                    rounded to 8 mantissa bits - replicas stay bit-identical because every rank receives the same sum).
-
-This module is backend-agnostic (it only calls torch.distributed), which is what lets the
-world_size-2 `gloo` tests exercise it on CPU.
+This module is backend-agnostic (it only calls torch.distributed; the two record helpers have a plain-torch form for CPU
+tensors next to the HIP kernels), which is what lets the world_size-2 `gloo` tests exercise it on CPU.
 """
 from typing import List, Sequence
 
@@ -60,30 +61,70 @@ def first_ray_key(rays: torch.Tensor, seg_start: torch.Tensor, seg_order: Sequen
     return torch.where(live.any().reshape(1), key, torch.full_like(key, NO_RAY_KEY))
 
 
+FRONT_HEADER = 4                     # float32 words in front of a record's depths (include/loner_hip.h: LNR_FRONT_HEADER)
+
+
+def front_record(rays, seg_start, seg_order: Sequence[int], depths, n_live, cap: int, device=None) -> torch.Tensor:
+    """A rank's front record, float32 [FRONT_HEADER + cap]: words 0-1 the first-ray key (int64 bits), word 2 the live-ray count (int32
+    bits), word 3 zero, then the ground-truth depths of its kept rays (zeros beyond the count).  rays None: a rank without keyframes.
+    n_live: int or int32 tensor [1].  Plain torch ops on any device - on the MI355X the optimiser uses ops.shard_front_pack, one launch."""
+    if rays is None:
+        dev = torch.device(device if device is not None else "cpu")
+        key = torch.full((1,), NO_RAY_KEY, dtype=torch.int64, device=dev)
+        n = torch.zeros(1, dtype=torch.int32, device=dev)
+        body = torch.zeros(int(cap), dtype=torch.float32, device=dev)
+    else:
+        dev = rays.device
+        key = first_ray_key(rays, seg_start, seg_order)
+        n = torch.as_tensor(n_live, dtype=torch.int32, device=dev).reshape(1).clamp(max=int(cap))
+        d = depths.reshape(-1).float()[:int(cap)]
+        body = torch.zeros(int(cap), dtype=torch.float32, device=dev)
+        body[:d.shape[0]] = torch.where(torch.arange(d.shape[0], device=dev) < n, d, torch.zeros_like(d))
+    return torch.cat([key.view(torch.float32), n.view(torch.float32), torch.zeros(1, dtype=torch.float32, device=dev), body])
+
+
+def reduce_front_records(records: torch.Tensor, world: int, stride: int):
+    """all-gathered front records [world * stride] -> (counts int32 [2] = {#rays, #opaque rays} of the whole batch, far0 float32 [1]):
+    far[0] = the `far` under the smallest key; opaque = depth > 0 and not depth > far[0] (optimizer.py:460-463).  Plain torch ops -
+    on the MI355X DistContext uses ops.shard_front_reduce, one launch."""
+    recs = records.reshape(world, stride)
+    keys = recs[:, 0:2].contiguous().view(torch.int64).reshape(world)
+    kmin = keys.min().reshape(1)
+    far0 = kmin.view(torch.float32)[0:1].clone()                      # little endian: the low word
+    n = recs[:, 2].contiguous().view(torch.int32).clamp(0, stride - FRONT_HEADER)
+    d = recs[:, FRONT_HEADER:]
+    live = torch.arange(stride - FRONT_HEADER, device=records.device)[None, :] < n[:, None]
+    opaque = live & (d > 0) & ~(d > far0)
+    return torch.stack([n.sum(), opaque.sum()]).to(torch.int32), far0
+
+
 def shard_window(n_keyframes: int, world_size: int, rank: int) -> List[int]:
     """Indices of the window's keyframes owned by `rank` (round-robin)."""
     return [i for i in range(n_keyframes) if i % world_size == rank]
 
 
 class _Pending:
-    """handle of an asynchronous gradient exchange: wait() blocks (the stream, for RCCL) and finishes the bookkeeping"""
+    """handle of an asynchronous collective: wait() blocks (the stream, for RCCL) and finishes the bookkeeping; its value is what
+    `finish` returns"""
 
     def __init__(self, works, finish=None):
-        self._works, self._finish = [w for w in works if w is not None], finish
+        self._works, self._finish, self._value = [w for w in works if w is not None], finish, None
 
     def wait(self):
         for w in self._works:
             w.wait()
+        self._works = []
         if self._finish is not None:
-            self._finish()
+            self._value = self._finish()
             self._finish = None
+        return self._value
 
 
 class DistContext:
     def __init__(self, group=None, exchange: str = None, payload: str = "fp32"):
         """exchange None: "reduce_scatter" from 4 ranks on, "all_reduce" below - with four or more ranks a rank's share of the window is
         one or two keyframes (an iteration of ~0.4 ms), of which the dense Adam step over all 7.4 M parameters is ~9 %; stepping a
-        1/G slice of the tables removes (G-1)/G of that, at the price of the all-gather in front of the next density forward."""
+        1/G chunk removes (G-1)/G of that, at the price of the all-gather in front of the next density forward."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
@@ -95,62 +136,75 @@ class DistContext:
             raise ValueError(f"unknown gradient exchange {exchange!r} / payload {payload!r}")
         self.exchange, self.payload = exchange, payload
 
-    # ---- density gradient --------------------------------------------------------------------------------------------
-    def table_slice(self, n_mlp: int, n_total: int):
-        """(lo, hi) of this rank's slice of the flat parameter vector in the "reduce_scatter" form, or None when the whole
-        vector is all-reduced (form "all_reduce", or a table that does not split into 16-byte aligned equal slices)."""
-        n_table = n_total - n_mlp
-        if self.exchange != "reduce_scatter" or n_table <= 0 or n_table % (4 * self.world_size) or n_mlp % 4:
-            return None
-        chunk = n_table // self.world_size
-        return n_mlp + self.rank * chunk, n_mlp + (self.rank + 1) * chunk
+    # ---- the front of an iteration: far[0] and the loss normalisers -----------------------------------------------------
+    def front_capacity(self, n_keyframes: int, rays_per_keyframe: int) -> int:
+        """depth slots of a front record: the candidate rays of the rank that owns the most keyframes of an n_keyframes window (the same
+        number on every rank: an all-gather wants equal contributions)"""
+        return -(-int(n_keyframes) // self.world_size) * int(rays_per_keyframe)
 
-    def exchange_grads(self, flat: torch.Tensor, n_mlp: int, async_op: bool = True, force_all_reduce: bool = False):
+    def gather_front(self, record: torch.Tensor) -> _Pending:
+        """All-gather the ranks' front records (front_record / ops.shard_front_pack), asynchronously.  .wait() -> (counts int32 [2] =
+        {#rays, #opaque rays} of the WHOLE batch, far0 float32 [1] = far of the batch's first ray), derived locally from the gathered
+        depths; identical on every rank."""
+        world, stride = self.world_size, record.numel()
+        gathered = torch.empty(world * stride, dtype=torch.float32, device=record.device)
+        work = dist.all_gather_into_tensor(gathered, record, group=self.group, async_op=True)
+
+        def finish():
+            if gathered.is_cuda:
+                from .. import ops
+                return ops.shard_front_reduce(gathered, world, stride)
+            return reduce_front_records(gathered, world, stride)
+        return _Pending([work], finish)
+
+    # ---- density gradient --------------------------------------------------------------------------------------------
+    def owned_range(self, n_total: int):
+        """(lo, hi) of this rank's chunk of the flat parameter vector in the "reduce_scatter" form, or None when the whole vector is
+        all-reduced (form "all_reduce", or a vector that does not split into 16-byte aligned equal chunks)."""
+        if self.exchange != "reduce_scatter" or n_total <= 0 or n_total % (4 * self.world_size):
+            return None
+        chunk = n_total // self.world_size
+        return self.rank * chunk, (self.rank + 1) * chunk
+
+    def exchange_grads(self, flat: torch.Tensor, async_op: bool = True, force_all_reduce: bool = False, zero_rest: bool = True):
         """Sum the flat density gradient [MLP | tables] over the ranks.  After .wait(): form "all_reduce" - `flat` holds the sum
-        everywhere; form "reduce_scatter" - flat[:n_mlp] and flat[lo:hi] (table_slice) hold the sums, the rest of the table
-        gradient is zeroed (it belongs to other ranks).  force_all_reduce: the whole sum everywhere whatever the configured
-        form - for callers that hand the gradient to an optimiser of their own (Optimizer.compute_loss through autograd): only
-        the training loop knows how to step a slice and gather the parameters afterwards."""
+        everywhere; form "reduce_scatter" - flat[lo:hi] (owned_range) holds the sum of this rank's chunk; the rest of the vector
+        belongs to other ranks and is zeroed when zero_rest (a caller whose next backward STORES the whole gradient - the training
+        loop's overwrite mode - passes False and saves two fills of the table per iteration).  force_all_reduce: the whole sum everywhere
+        whatever the configured form - for callers that hand the gradient to an optimiser of their own (Optimizer.compute_loss through
+        autograd): only the training loop knows how to step a chunk and gather the parameters afterwards."""
         bf16 = self.payload == "bf16"
-        sl = None if force_all_reduce else self.table_slice(n_mlp, flat.numel())
+        sl = None if force_all_reduce else self.owned_range(flat.numel())
         if sl is None:
             buf = flat.to(torch.bfloat16) if bf16 else flat
             work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             pending = _Pending([work], (lambda: flat.copy_(buf)) if bf16 else None)
         else:
             lo, hi = sl
-            w_mlp = dist.all_reduce(flat[:n_mlp], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            table = flat[n_mlp:]
-            src = table.to(torch.bfloat16) if bf16 else table
+            src = flat.to(torch.bfloat16) if bf16 else flat
             out = torch.empty(hi - lo, device=flat.device, dtype=src.dtype)
-            w_tab = dist.reduce_scatter_tensor(out, src, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            work = dist.reduce_scatter_tensor(out, src, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
             def finish():
-                flat[n_mlp:lo].zero_()
-                flat[hi:].zero_()
+                if zero_rest:
+                    flat[:lo].zero_()
+                    flat[hi:].zero_()
                 flat[lo:hi].copy_(out)
-            pending = _Pending([w_mlp, w_tab], finish)
+            pending = _Pending([work], finish)
         if not async_op:
             pending.wait()
         return pending
 
-    def gather_params(self, flat_params: torch.Tensor, n_mlp: int):
-        """form "reduce_scatter": every rank has stepped its slice of the table; collect the slices (in place)."""
-        sl = self.table_slice(n_mlp, flat_params.numel())
+    def gather_params(self, flat_params: torch.Tensor):
+        """form "reduce_scatter": every rank has stepped its chunk of the parameters; collect the chunks (in place)."""
+        sl = self.owned_range(flat_params.numel())
         if sl is None:
             return
         mine = flat_params[sl[0]:sl[1]].clone()
-        dist.all_gather_into_tensor(flat_params[n_mlp:], mine, group=self.group)
+        dist.all_gather_into_tensor(flat_params, mine, group=self.group)
 
     def owned(self, window: Sequence) -> list:
         return [window[i] for i in shard_window(len(window), self.world_size, self.rank)]
-
-    def all_reduce_counts(self, counts: torch.Tensor, async_op: bool = False):
-        """counts int32 [2] = {#rays, #opaque} of this rank -> global, in place.  With async_op=True the collective's
-        handle is returned instead and the caller `.wait()`s right before the first use: the tiny all-reduce is pure
-        latency and hides behind the sampler and the density forward."""
-        work = dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
-        return work if async_op else counts
 
     def all_reduce_grads(self, flat: torch.Tensor, async_op: bool = False):
         """Sum a flat buffer over ranks, in place (the occupancy pseudo-gradient: 64-bit fixed-point accumulators, exact)."""
@@ -171,20 +225,13 @@ class DistContext:
     def owned_indices(self, n_keyframes: int) -> List[int]:
         return shard_window(n_keyframes, self.world_size, self.rank)
 
-    def broadcast_far0(self, rays, device=None, first_key=None) -> torch.Tensor:
-        """The reference's `depth > far[0]` test (optimizer.py:460-461) uses the first ray of the whole batch: the first kept ray of the
-        first keyframe, in window order, that kept any (the cube test may drop every candidate of a keyframe, ray_utils.py:322).
-        Every rank contributes `first_key` (first_ray_key below / ops.first_ray_key: window order << 32 | bits of its own first ray's
-        far, INT64_MAX without a ray) and one MIN all-reduce leaves the key of the batch's first ray everywhere; its low word is far[0],
-        returned as a device float [1] for lnr_count_opaque / lnr_los_loss_fused.  Without first_key the rank's position stands in for
-        the window order and `rays` (None: no ray) is taken as a batch of kept rays - right whenever rank order is keyframe order."""
-        if first_key is None:
-            if rays is None or rays.shape[0] == 0:
-                first_key = torch.full((1,), NO_RAY_KEY, dtype=torch.int64, device=rays.device if rays is not None else device)
-            else:
-                first_key = first_ray_key(rays, torch.tensor([0, rays.shape[0]], device=rays.device, dtype=torch.int32), [self.rank])
-        dist.all_reduce(first_key, op=dist.ReduceOp.MIN, group=self.group)
-        return first_key.view(torch.float32)[0:1]          # little endian: the low word
+    def max_over_ranks(self, value: int) -> int:
+        """the largest of the ranks' integers (a host value on every rank: one blocking all-reduce; used off the training loop only)"""
+        t = torch.tensor([int(value)], dtype=torch.int64)
+        if dist.get_backend(self.group) == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())
 
     def broadcast_(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
         dist.broadcast(t, src=src, group=self.group)

@@ -88,9 +88,13 @@ class Model(nn.Module):
         ahead = pre is None and rays.is_cuda and n > step
         if ahead:
             main = torch.cuda.current_stream(rays.device)
-            if getattr(self, "_sampler_stream", None) is None:
-                self._sampler_stream = torch.cuda.Stream(rays.device)
-            side = self._sampler_stream
+            # one side stream per device (a stream belongs to the device it was created on).  The sampler reads the occupancy grid the
+            # ray_sampler holds: nothing updates it while a render is in flight - the optimiser's occupancy step and this route are
+            # both issued by the one mapper thread, and the side stream has joined the main stream again when this call returns.
+            streams = self.__dict__.setdefault("_sampler_streams", {})
+            side = streams.get(rays.device)
+            if side is None:
+                side = streams[rays.device] = torch.cuda.Stream(rays.device)
             side.wait_stream(main)                   # the rays (and the occupancy grid) come from the main stream
 
             def sample_ahead(lo):

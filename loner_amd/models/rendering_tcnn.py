@@ -12,18 +12,45 @@ import torch
 from .. import ops
 
 
+class _Raw2Outputs(torch.autograd.Function):
+    """(sigma [N,S], rays_d [N,3], far [N]) -> (depth, weights, opacity, variance): compositing by lnr_render_forward, its analytic
+    backward by lnr_render_backward.  z_vals and the noise are constants (the reference's z_vals leave get_samples detached)."""
+
+    @staticmethod
+    def forward(ctx, sigma, rays_d, far, z, noise, noise_std, seed):
+        n = z.shape[0]
+        rays = torch.zeros(n, 13, device=z.device)
+        rays[:, 3:6] = rays_d.detach()
+        rays[:, 12] = far.detach().reshape(-1)
+        sigma_c = sigma.detach().float().contiguous()
+        depth, weights, opacity, variance = ops.render_forward(sigma_c, z, rays, noise=noise, noise_std=noise_std, seed=seed)
+        ctx.save_for_backward(sigma_c, z, rays, noise if noise is not None else torch.empty(0))
+        ctx.noise_std, ctx.seed, ctx.has_noise, ctx.far_shape = noise_std, seed, noise is not None, far.shape
+        return depth, weights, opacity, variance
+
+    @staticmethod
+    def backward(ctx, g_depth, g_weights, g_opacity, g_variance):
+        sigma, z, rays, noise = ctx.saved_tensors
+        d_sigma, d_rays = ops.render_backward(sigma, z, rays, g_depth, g_weights, g_opacity, g_variance,
+                                              noise=noise if ctx.has_noise else None, noise_std=ctx.noise_std, seed=ctx.seed)
+        return (d_sigma if ctx.needs_input_grad[0] else None, d_rays[:, 3:6] if ctx.needs_input_grad[1] else None,
+                d_rays[:, 12].reshape(ctx.far_shape) if ctx.needs_input_grad[2] else None, None, None, None, None)
+
+
 def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, sigma_only=True, num_colors=3,
                 softplus=False, far=None, ret_var=False, noise=None):
-    """rendering_tcnn.py:71-147 for the lidar configuration (sigma_only, far given).  Forward only."""
+    """rendering_tcnn.py:71-147 for the lidar configuration (sigma_only, far given).  Differentiable like the reference's (plain
+    autograd there): gradients reach `raw` (the densities), `rays_d` (through |d| in the interval lengths, :100) and `far` (through
+    the depth's background term, :126-130).  `z_vals` are constants here - in the reference's pipeline they leave get_samples
+    detached (ray_sampling.py:75-90) - so a z_vals that requires a gradient is refused rather than silently ignored."""
     if not sigma_only or softplus or far is None:
         raise NotImplementedError("raw2outputs: only the lidar configuration (sigma_only=True, far given) is supported")
-    n = z_vals.shape[0]
-    rays = torch.zeros(n, 13, device=z_vals.device)
-    rays[:, 3:6] = rays_d
-    rays[:, 12] = far.reshape(-1)
+    if torch.is_grad_enabled() and z_vals.requires_grad:
+        raise NotImplementedError("raw2outputs: a gradient with respect to z_vals is not implemented (the reference's samplers return "
+                                  "detached depths); pass z_vals.detach()")
     seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (noise is None and raw_noise_std > 0) else 0
-    depth, weights, opacity, variance = ops.render_forward(raw[..., 0], z_vals, rays, noise=noise,
-                                                           noise_std=raw_noise_std, seed=seed)
+    depth, weights, opacity, variance = _Raw2Outputs.apply(raw[..., 0], rays_d, far, z_vals.detach().float().contiguous(),
+                                                           noise, float(raw_noise_std), seed)
     return torch.tensor([-1.]), depth, weights, opacity, (variance if ret_var else None)
 
 

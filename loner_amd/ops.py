@@ -284,6 +284,32 @@ def first_ray_key(rays, out_seg_start, seg_order):
     return key
 
 
+def shard_front_pack(rays, out_seg_start, seg_order, depths, n_rays_dev, cap, device=None):
+    """A rank's "front record" for the sharded loop's one all-gather (include/loner_hip.h: lnr_shard_front_pack): float32
+    [FRONT_HEADER + cap] = first-ray key | live-ray count | ground-truth depths.  rays None: a rank without keyframes."""
+    dev = rays.device if rays is not None else torch.device(device)
+    rec = torch.empty(hip.FRONT_HEADER + int(cap), device=dev, dtype=torch.float32)
+    if rays is None:
+        check(load().lnr_shard_front_pack(None, None, None, 0, None, 0, None, int(cap), _ptr(rec), _stream()), "lnr_shard_front_pack")
+        return rec
+    require_device(rays, out_seg_start, depths, n_rays_dev)
+    n_seg = len(seg_order)
+    order = (C.c_int32 * n_seg)(*[int(v) for v in seg_order])
+    check(load().lnr_shard_front_pack(_ptr(rays), _ptr(out_seg_start), order, n_seg, _ptr(_f32c(depths)), rays.shape[0], _ptr(n_rays_dev),
+                                      int(cap), _ptr(rec), _stream()), "lnr_shard_front_pack")
+    return rec
+
+
+def shard_front_reduce(records, world, stride):
+    """gathered front records [world * stride] -> (counts int32 [2] = {#rays, #opaque rays} of the WHOLE batch, far0 float [1])"""
+    require_device(records)
+    assert records.dtype == torch.float32 and records.numel() == world * stride
+    counts = torch.empty(2, device=records.device, dtype=torch.int32)
+    far0 = torch.empty(1, device=records.device, dtype=torch.float32)
+    check(load().lnr_shard_front_reduce(_ptr(records), int(world), int(stride), _ptr(counts), _ptr(far0), _stream()), "lnr_shard_front_reduce")
+    return counts, far0
+
+
 def lidar_rays_backward(d_rays, rays, src_index, seg_start_dev, directions_list, transforms, scale):
     """-> d_transform [n_seg, 12]"""
     require_device(d_rays, rays, src_index, seg_start_dev, transforms)

@@ -178,6 +178,7 @@ class OracleMapper:
         for kf in free:
             tensors.append(kf.pose6); lrs.append(cfg.lr_pose)
         adam = AdamState(tensors, lrs)
+        self.last_adam = adam            # (tests read the moments of the phase that just ran)
         n_valid = 0
         for it in range(n_iters):
             rays_all, depth_all = [], []

@@ -126,8 +126,14 @@ def test_occ_sampler_trained_grid_bit_identical_to_oracle(ops, golden, S):
     assert np.array_equal(z.cpu().numpy(), zo)
     # and against the reference itself: identical wherever its float32 exp happened to round correctly
     ref_same = (st["probs"] == g[f"trained_probs{S}"]).all(axis=1)
-    assert ref_same.mean() > 0.5
-    assert np.array_equal(z.cpu().numpy()[ref_same], g[f"trained_z{S}"][ref_same])
+    zk, zr = z.cpu().numpy(), g[f"trained_z{S}"]
+    frac_rows, frac_z_rows, frac_z = float(ref_same.mean()), float((zk == zr).all(axis=1).mean()), float((zk == zr).mean())
+    print(f"trained grid, S={S}: rays whose pdf equals the reference's bit for bit {frac_rows:.4f}; rays with all sample depths identical "
+          f"{frac_z_rows:.4f}; sample depths identical {frac_z:.6f} (torch's float32 exp is not correctly rounded: SURVEY B.5)")
+    # the observed fractions of this fixture (64 rays; 99.88 % / 99.84 % of the pdf VALUES are identical): a regression moves them
+    floor_rows, floor_z_rows, floor_z = {128: (0.9375, 0.96875, 0.9954), 512: (0.65625, 0.75, 0.9979)}[S]
+    assert frac_rows >= floor_rows and frac_z_rows >= floor_z_rows and frac_z >= floor_z
+    assert np.array_equal(zk[ref_same], zr[ref_same])
 
 
 def test_occ_sampler_large_and_ragged_sample_counts(ops, golden):
@@ -400,6 +406,27 @@ def test_render_forward_backward_matches_golden(ops, golden):
     assert rel(d_sigma, g["dsigma"]) < 1e-4
     assert rel(d_rays[:, 3:6], g["ddirs"]) < 1e-4
     assert rel(d_rays[:, 12], g["dfar"][:, 0]) < 1e-4
+
+
+def test_raw2outputs_is_differentiable_like_the_reference(ops, golden):
+    """models.rendering_tcnn.raw2outputs (rendering_tcnn.py:71-147, plain autograd in the reference): called with the reference's
+    signature, its outputs AND the gradients torch autograd delivers to raw, rays_d and far equal the reference's (G5); a z_vals that
+    requires a gradient is refused (the kernels treat sample depths as constants, as the reference's detached samplers make them)."""
+    from loner_amd.models.rendering_tcnn import raw2outputs
+    g = golden("g5_render")
+    raw = dv(g["sigma"])[..., None].clone().requires_grad_(True)
+    dirs, far = dv(g["dirs"]).clone().requires_grad_(True), dv(g["far"]).clone().requires_grad_(True)
+    _, depth, weights, opacity, variance = raw2outputs(raw, dv(g["z"]), dirs, raw_noise_std=1.0, sigma_only=True, far=far, ret_var=True,
+                                                       noise=dv(g["noise"]))
+    assert rel(depth, g["depth"]) < 1e-5 and rel(weights, g["weights"]) < 1e-5 and rel(variance, g["variance"]) < 1e-4
+    ((depth * dv(g["cot_depth"])).sum() + (weights * dv(g["cot_weights"])).sum() + (opacity * dv(g["cot_opacity"])).sum() +
+     (variance * dv(g["cot_variance"])).sum()).backward()
+    assert rel(raw.grad[..., 0], g["dsigma"]) < 1e-4 and rel(dirs.grad, g["ddirs"]) < 1e-4 and rel(far.grad, g["dfar"]) < 1e-4
+    with pytest.raises(NotImplementedError):
+        raw2outputs(raw.detach(), dv(g["z"]).requires_grad_(True), dirs.detach(), sigma_only=True, far=far.detach())
+    with torch.no_grad():          # and without a graph it is the plain forward
+        out = raw2outputs(raw, dv(g["z"]), dirs, raw_noise_std=1.0, sigma_only=True, far=far, noise=dv(g["noise"]))
+    assert out[4] is None and not out[1].requires_grad and rel(out[1], g["depth"]) < 1e-5
 
 
 def test_render_ragged_and_long_rays_match_oracle(ops):

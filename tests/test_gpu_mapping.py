@@ -166,6 +166,38 @@ def test_optimizer_loop_reproduces_reference_trajectory(golden):
     assert sd["state"][0]["step"] == 12 and set(sd["state"][0]) >= {"exp_avg", "exp_avg_sq"}
 
 
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_optimizer_first_iterations_match_reference_state_by_state(golden, k):
+    """G14: the state after k = 1, 2, 3 iterations of the reference's loop on G9's configuration and draws - density parameters,
+    both Adam moments of the density group and of the pose group, the free pose, the grid - asserted TIGHTLY (the 12-iteration
+    end state above is Adam-amplified and loose: a wrong bias correction or moment update would move every element by ~lr here).
+    The parameters are a quantile statement: a handful of table entries whose gradient is of the size of Adam's eps (1e-8) take a
+    different-sized step on any rounding difference (the CPU oracle shows the same: tests/test_oracle_golden.py)."""
+    from loner_amd.mapping.optimizer import OptimizationSettings, Optimizer
+    g, h = golden("g9_loop"), golden("g14_loop_first_steps")
+    opt = Optimizer(small_settings(48, 64), None, world_cube(), 0, False, True, False)
+    with torch.no_grad():
+        opt._model.nerf_model._model_sigma.params.copy_(torch.from_numpy(g["params0"]))
+    kfs = make_keyframes([torch.from_numpy(g["pose_init0"]), torch.from_numpy(g["pose_init1"])])
+    kfs[0].is_anchored = True
+    opt.set_draws(_Replay(g))
+    opt._do_iterate_optimizer(kfs, [None], optimizer_settings=OptimizationSettings(k, False, False, False, True))
+    sd = opt._optimizer.state_dict()
+    st_sigma, st_pose = sd["state"][sd["param_groups"][0]["params"][0]], sd["state"][sd["param_groups"][1]["params"][0]]
+    assert int(st_sigma["step"]) == int(h[f"step_{k}"]) == k
+    e = dict(m=rel(st_sigma["exp_avg"], h[f"exp_avg_{k}"]), v=rel(st_sigma["exp_avg_sq"], h[f"exp_avg_sq_{k}"]),
+             pm=rel(st_pose["exp_avg"][1], h[f"pose_exp_avg_{k}"]), pv=rel(st_pose["exp_avg_sq"][1], h[f"pose_exp_avg_sq_{k}"]))
+    dp = np.abs(opt._model.nerf_model._model_sigma.params.detach().cpu().numpy() - h[f"params_{k}"])
+    pose1 = kfs[1].get_lidar_pose().get_pose_tensor().detach().cpu().numpy()
+    e.update(p99=float(np.quantile(dp, 0.99)), frac_1e4=float((dp > 1e-4).mean()), pmax=float(dp.max()),
+             pose=float(np.abs(pose1 - h[f"pose1_{k}"]).max()), grid=rel(opt._occupancy_grid_model.occupancy_grid[0, 0], h[f"grid_{k}"]))
+    print(f"G14 k={k}:", {a: f"{b:.2e}" for a, b in e.items()})
+    assert e["m"] < 1e-4 and e["v"] < 2e-4, e                           # Adam moments of the density parameters
+    assert e["pm"] < 5e-4 and e["pv"] < 1e-3, e                         # ... of the free pose (its gradient is asserted to 5e-4 elsewhere)
+    assert e["p99"] < 1e-5 and e["frac_1e4"] < 2e-3 and e["pmax"] <= 2.001 * 1e-2 * k, e
+    assert e["pose"] < 2e-6 and e["grid"] < 1e-5, e
+
+
 def test_optimizer_schedule_default_config_properties():
     """Default network (16-level hash grid, 64-wide MLP), 2 keyframes, in-kernel RNG: the schedule runs, the
     anchored keyframe does not move, the free one does, the loss goes down, nothing is NaN."""
@@ -219,6 +251,59 @@ def test_compute_loss_is_differentiable_like_the_reference(golden):
         assert gp is not None and torch.isfinite(gp).all() and gp.abs().sum() > 0
     opt._step_occupancy_grid()
     assert float(opt._occupancy_grid_model.occupancy_grid.abs().max()) > 0
+
+
+def test_api_parity_mode_reproduces_the_reference_and_the_fused_loss(golden):
+    """Optimizer.compute_loss_api - Model.forward -> result dictionary -> torch ops -> autograd, the route of the reference's own
+    compute_loss (optimizer.py:437-595; SURVEY 8d "API-parity mode") - on the G8 fixture: the loss, the dynamic margin and the
+    gradients with respect to the density parameters and the ray records equal the REFERENCE's, and they equal what the fused-loss
+    route (compute_loss: one kernel pass, no dictionary) returns for the same draws."""
+    from loner_amd.mapping.optimizer import OptimizationSettings, Optimizer
+    g = golden("g8_compute_loss")
+    opt = Optimizer(small_settings(96, 128), None, world_cube(), 0, False, True, False)
+    sig = opt._model.nerf_model._model_sigma.params
+    with torch.no_grad():
+        sig.copy_(torch.from_numpy(g["params"]))
+        opt._occupancy_grid_model.occupancy_grid.copy_(torch.from_numpy(g["grid"])[None, None])
+    opt._occupancy_grid = opt._occupancy_grid_model()
+    opt._ray_sampler.update_occ_grid(opt._occupancy_grid.detach())
+    opt._optimization_settings = OptimizationSettings(1, False, False, False, True)
+    opt._model.freeze_sigma_head(False)
+
+    class Draws:
+        def jitter(self, n, h): return torch.from_numpy(g["u1"])
+        def pdf(self, n, h): return torch.from_numpy(g["u2"])
+        def noise(self, n, s_): return torch.from_numpy(g["noise"])
+    depths = torch.from_numpy(g["depths"]).to(DEV)
+    out = {}
+    for mode in ("api", "fused"):
+        rays = torch.from_numpy(g["rays"]).to(DEV).requires_grad_(True)
+        sig.grad = None
+        if mode == "api":
+            opt._ray_sampler.set_draws(Draws())
+            loss = opt.compute_loss_api((rays, depths), 0)
+            opt._ray_sampler.set_draws(None)
+            res = opt._results_lidar
+            assert res["weights_fine"].shape == (192, 128) and res["points_fine"].shape == (192, 128, 3)
+            assert np.array_equal(res["samples_fine"].detach().cpu().numpy(), g["z"])          # bit-identical sample depths
+            assert rel(res["weights_fine"], g["weights"]) < 1e-4 and rel(res["depth_fine"], g["depth"]) < 1e-4
+            grid_before = opt._occupancy_grid_model.occupancy_grid.detach().clone()
+            opt._step_occupancy_grid()       # the occupancy step reads the API mode's result dictionary too (optimizer.py:598-609)
+            assert not torch.equal(grid_before, opt._occupancy_grid_model.occupancy_grid.detach())
+            with torch.no_grad():
+                opt._occupancy_grid_model.occupancy_grid.copy_(grid_before)
+            opt._ray_sampler.update_occ_grid(opt._occupancy_grid_model().detach())
+        else:
+            opt.set_draws(Draws())
+            loss = opt.compute_loss(None, (rays, depths), 0)
+            opt.set_draws(None)
+        loss.backward()
+        out[mode] = (float(loss), sig.grad.clone(), rays.grad.clone(), float(opt._depth_eps))
+        assert abs(float(loss) - float(g["loss"])) / float(g["loss"]) < 1e-4, mode
+        assert rel(sig.grad, g["dparams"]) < 2e-4 and rel(rays.grad, g["drays"]) < 2e-4, mode
+        assert abs(float(opt._depth_eps) - float(g["depth_eps"])) < 1e-4 * float(g["depth_eps"]), mode
+    assert abs(out["api"][0] - out["fused"][0]) < 2e-5 * abs(out["fused"][0])
+    assert rel(out["api"][1], out["fused"][1]) < 1e-4 and rel(out["api"][2], out["fused"][2]) < 1e-4
 
 
 def test_training_reduces_l1_depth_matched_quality_gate():

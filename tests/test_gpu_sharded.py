@@ -1,9 +1,12 @@
 """The keyframe-sharded optimisation loop (loner_amd/mapping/sharding.py + Optimizer.set_distributed) with the real HIP
 kernels on the one GPU of the test box.
 
-* RCCL (`backend="nccl"`) at world_size 1: the collectives of the sharded loop (far[0] broadcast, loss normalisers, density
-  gradient, occupancy pseudo-gradient) execute on the device through RCCL and the run is bit-identical to the
-  non-distributed one.
+* RCCL (`backend="nccl"`) at world_size 1: the collectives of the sharded loop (the front-record all-gather that carries far[0]
+  and the loss normalisers, the density gradient exchange, the occupancy pseudo-gradient) execute on the device through RCCL
+  and the run is bit-identical to the non-distributed one.
+* EIGHT processes sharing the GPU over gloo on the DEFAULT network (2^18-entry tables, 7.4 M parameters): the BASELINE configs[3]
+  shape - an 8-keyframe window, one keyframe per rank, the default `reduce_scatter` exchange (8 chunks, ranged Adam, all-gather) -
+  and a 5-keyframe window with three idle ranks.
 * two / three processes sharing the GPU over gloo (RCCL refuses several ranks on one device; the torch.distributed calls
   are the same): replicas end bit-identical, only a rank's own non-anchored keyframes move, a rank that owns no keyframe
   (window smaller than the world size) still joins every collective, and - on identical, keyframe-keyed random draws -
@@ -21,6 +24,7 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 N_RAYS, N_SAMPLES = 128, 64
+BIG_RAYS, BIG_SAMPLES = 512, 128          # the 8-rank runs on the default network
 
 
 class KeyedDraws:
@@ -62,11 +66,17 @@ def _poses(n_kf):
     return poses
 
 
-def _setup(world_window, seed=0):
+def _setup(world_window, seed=0, default_net=False):
     from tests.test_gpu_mapping import make_keyframes, small_settings, world_cube
     from loner_amd.mapping.optimizer import Optimizer
     torch.cuda.set_device(0)
-    s = small_settings(N_RAYS, N_SAMPLES)
+    if default_net:
+        from loner_amd.common.settings import default_optimizer_settings
+        s = default_optimizer_settings()
+        s["num_samples"]["lidar"], s["num_samples"]["sky"] = BIG_RAYS, 0
+        s["model_config"]["model"]["render"]["N_samples_train"] = BIG_SAMPLES
+    else:
+        s = small_settings(N_RAYS, N_SAMPLES)
     torch.manual_seed(seed)                                 # identical initial parameters on every rank
     opt = Optimizer(s, None, world_cube(), 0, False, True, False)
     window = make_keyframes(_poses(world_window))
@@ -80,7 +90,7 @@ def _blobs(opt):
     return [params.detach(), st["exp_avg"], st["exp_avg_sq"], opt._occupancy_grid_model.occupancy_grid.detach().reshape(-1)]
 
 
-def _worker(rank, world, port, ret, backend, n_kf, n_it, keyed, exchange="all_reduce", payload="fp32"):
+def _worker(rank, world, port, ret, backend, n_kf, n_it, keyed, exchange="all_reduce", payload="fp32", default_net=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     if backend == "nccl":
@@ -89,13 +99,13 @@ def _worker(rank, world, port, ret, backend, n_kf, n_it, keyed, exchange="all_re
         dist.init_process_group("gloo", rank=rank, world_size=world)
     from loner_amd.mapping.optimizer import OptimizationSettings
     from loner_amd.mapping.sharding import DistContext, shard_window
-    opt, window = _setup(n_kf)
+    opt, window = _setup(n_kf, default_net=default_net)
     ctx = DistContext(exchange=exchange, payload=payload)
     opt.set_distributed(ctx)
     owned_ids = shard_window(n_kf, world, rank)
     if keyed:
         if owned_ids:
-            opt.set_draws(KeyedDraws(owned_ids))
+            opt.set_draws(KeyedDraws(owned_ids, n_rays=BIG_RAYS if default_net else N_RAYS))
     else:
         torch.manual_seed(100 + rank)                       # different ray draws per rank
     before = [kf.get_lidar_pose().get_pose_tensor().detach().clone() for kf in window]
@@ -112,31 +122,38 @@ def _worker(rank, world, port, ret, backend, n_kf, n_it, keyed, exchange="all_re
     dist.all_reduce(loss)
     moved = [float((kf.get_lidar_pose().get_pose_tensor().detach() - b).abs().max()) for kf, b in zip(window, before)]
     ret[rank] = dict(sums=[g.cpu().tolist() for g in gathered], loss=loss.cpu().numpy(), finite=bool(torch.isfinite(blobs[0]).all()),
-                     moved=moved, owned=owned_ids, step=opt._global_step, params=blobs[0].cpu().numpy(),
+                     moved=moved, owned=owned_ids, step=opt._global_step,
+                     # (default network: 30 MB per rank through the manager - the first and the last rank hand theirs over, the
+                     # replicas are compared by the gathered sums)
+                     params=blobs[0].cpu().numpy() if (not default_net or rank in (0, world - 1)) else None,
                      grid=blobs[3].cpu().numpy(), poses=[kf.get_lidar_pose().get_pose_tensor().detach().cpu().numpy() for kf in window],
-                     n_valid=opt.last_stats["n_valid_rays"], adam_steps=opt._optimizer.state[opt._model.nerf_model._model_sigma.params]["step"])
+                     n_valid=opt.last_stats["n_valid_rays"], adam_steps=opt._optimizer.state[opt._model.nerf_model._model_sigma.params]["step"],
+                     exchange=ctx.exchange, owned_range=ctx.owned_range(blobs[0].numel()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run(world, backend, n_kf, n_it, keyed, exchange="all_reduce", payload="fp32"):
+def _run(world, backend, n_kf, n_it, keyed, exchange="all_reduce", payload="fp32", default_net=False, timeout=300):
     port = 29600 + (os.getpid() * 7 + world * 13 + n_kf) % 300
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, ret, backend, n_kf, n_it, keyed, exchange, payload)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret, backend, n_kf, n_it, keyed, exchange, payload, default_net)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(300)
+        p.join(timeout)
+        if p.exitcode is None:
+            for q in procs:
+                q.kill()
         assert p.exitcode == 0, "a rank of the sharded run failed (or deadlocked)"
     return [ret[r] for r in range(world)]
 
 
-def _single(n_kf, n_it, keyed):
+def _single(n_kf, n_it, keyed, default_net=False):
     from loner_amd.mapping.optimizer import OptimizationSettings
-    opt, window = _setup(n_kf)
+    opt, window = _setup(n_kf, default_net=default_net)
     if keyed:
-        opt.set_draws(KeyedDraws(list(range(n_kf))))
+        opt.set_draws(KeyedDraws(list(range(n_kf)), n_rays=BIG_RAYS if default_net else N_RAYS))
     opt._do_iterate_optimizer(window, [None], optimizer_settings=OptimizationSettings(n_it, False, False, False, True))
     torch.cuda.synchronize()
     blobs = _blobs(opt)
@@ -176,15 +193,15 @@ def test_sharded_run_equals_single_gpu_on_identical_draws():
 
 
 def test_reduce_scatter_exchange_and_bf16_payload():
-    """The sharded-Adam form of the exchange (reduce-scatter of the table gradient, Adam on a rank's own slice, all-gather of
-    the stepped slices; MLP weights all-reduced) gives the bits of the all-reduce form - with two ranks a sum has one order -
+    """The sharded-Adam form of the exchange (reduce-scatter of the flat gradient in equal chunks, Adam on a rank's own chunk,
+    all-gather of the stepped chunks) gives the bits of the all-reduce form - with two ranks a sum has one order -
     and its replicas stay identical.  The bf16 payload halves the bytes on the wire: replicas identical among themselves, the
     map within bf16 rounding of the fp32 run's."""
     n_it = 12
     ar = _run(2, "gloo", 4, n_it, keyed=True)
     rs = _run(2, "gloo", 4, n_it, keyed=True, exchange="reduce_scatter")
     same_map = lambda sums: all([s_[i] for i in (0, 3, 4, 7)] == [sums[0][i] for i in (0, 3, 4, 7)] for s_ in sums)   # parameters and grid
-    assert same_map(rs[0]["sums"])                  # (the Adam moments of a table slice live on the rank that steps it)
+    assert same_map(rs[0]["sums"])                  # (the Adam moments of a chunk live on the rank that steps it)
     assert np.array_equal(rs[0]["params"], ar[0]["params"]) and np.array_equal(rs[1]["params"], ar[1]["params"])
     assert np.array_equal(rs[0]["loss"], ar[0]["loss"]) and np.array_equal(rs[0]["grid"], ar[0]["grid"])
     for mode in ("all_reduce", "reduce_scatter"):
@@ -207,11 +224,89 @@ def test_rank_without_keyframes_joins_every_collective():
     assert all(r["step"] == n_it and r["adam_steps"] == n_it for r in rs)
     assert np.abs(rs[2]["params"] - single["params"]).max() < 2e-4 * np.abs(single["params"]).max()
     assert np.abs(rs[0]["loss"] - single["loss"]).max() < 2e-4 * np.abs(single["loss"]).max()
-    # the same with the reduce-scatter exchange: 8192-float tables of the small net do not split three ways -> it must fall
-    # back to the all-reduce form rather than fail
+    # the same with the reduce-scatter exchange: the small net's 26624 parameters do not split into three aligned chunks -> it must
+    # fall back to the all-reduce form rather than fail
     rs3 = _run(3, "gloo", 2, n_it, keyed=True, exchange="reduce_scatter")
     assert rs3[0]["sums"][0] == rs3[0]["sums"][1] == rs3[0]["sums"][2]                      # (fallback: moments replicated too)
     assert np.array_equal(rs3[0]["params"], rs[0]["params"])
+
+
+def test_front_record_kernels_equal_their_torch_forms():
+    """lnr_shard_front_pack / lnr_shard_front_reduce (the sharded loop's one small collective: far[0] and both loss normalisers from an
+    all-gather of {first-ray key, live count, depths}) against the plain-torch forms the CPU gloo tests run, bit for bit: ragged
+    segments, an empty first segment, a rank without keyframes, a live count below the buffer size, transparent rays on both sides."""
+    from loner_amd import ops
+    from loner_amd.mapping import sharding as SH
+    gen = torch.Generator().manual_seed(4)
+    cap, recs_k, recs_t = 700, [], []
+    for r, (seg, order, n_live) in enumerate([([0, 0, 300, 640], [1, 4, 6], 600), ([0, 512], [2], 512), (None, None, 0), ([0, 5, 5], [0, 9], 5)]):
+        if seg is None:
+            recs_k.append(ops.shard_front_pack(None, None, (), None, None, cap, device="cuda"))
+            recs_t.append(SH.front_record(None, None, (), None, 0, cap, device="cuda"))
+            continue
+        n = seg[-1]
+        rays = torch.randn(n, 13, generator=gen)
+        rays[:, 12] = 0.3 + 0.05 * r + 0.2 * torch.rand(n, generator=gen)
+        depths = torch.rand(n, generator=gen) * 0.8 - 0.05                    # some non-positive, some beyond far
+        seg_dev = torch.tensor(seg, dtype=torch.int32, device="cuda")
+        n_dev = torch.tensor([n_live], dtype=torch.int32, device="cuda")
+        recs_k.append(ops.shard_front_pack(rays.cuda(), seg_dev, order, depths.cuda(), n_dev, cap))
+        recs_t.append(SH.front_record(rays.cuda(), seg_dev, order, depths.cuda(), n_dev, cap))
+    for a, b in zip(recs_k, recs_t):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    allk = torch.cat(recs_k)
+    counts_k, far0_k = ops.shard_front_reduce(allk, 4, 4 + cap)
+    counts_t, far0_t = SH.reduce_front_records(allk, 4, 4 + cap)
+    assert counts_k.tolist() == counts_t.tolist() and torch.equal(far0_k.view(torch.int32), far0_t.view(torch.int32))
+    assert counts_k[0].item() == 600 + 512 + 0 + 5 and 0 < counts_k[1].item() < counts_k[0].item()
+    # the batch's first ray is rank 3's (window position 0): every depth is compared with ITS far
+    assert float(far0_k) == float(recs_k[3][0:1].view(torch.float32)) and float(far0_k) != float(recs_k[0][0:1].view(torch.float32))
+    nobody = torch.cat([recs_k[2], recs_k[2]])
+    c0, f0 = ops.shard_front_reduce(nobody, 2, 4 + cap)
+    assert c0.tolist() == [0, 0] and bool(torch.isnan(f0).all())
+
+
+def test_eight_ranks_default_network_reduce_scatter_equals_single_gpu():
+    """BASELINE configs[3] as far as one GPU can execute it: an 8-keyframe window sharded one keyframe per rank over EIGHT processes
+    (gloo between them; every rank runs the HIP kernels on the shared MI355X), default network (16 x 2^18-entry levels, 7.4 M
+    parameters), the exchange left at its default - `reduce_scatter` from 4 ranks: eight 927 104-float chunks, ranged Adam, all-gather -
+    7 iterations incl. the occupancy step at global step 0.  On keyframe-keyed draws the window's loss trace, the final parameters,
+    the grid and the poses equal the single-GPU run; the replicas are identical; every rank stepped exactly its chunk."""
+    n_it = 7
+    single = _single(8, n_it, keyed=True, default_net=True)
+    rs = _run(8, "gloo", 8, n_it, keyed=True, exchange=None, default_net=True, timeout=900)
+    assert [r["owned"] for r in rs] == [[k] for k in range(8)] and all(r["exchange"] == "reduce_scatter" for r in rs)
+    n_par = single["params"].size
+    assert n_par == 7416832 and [r["owned_range"] for r in rs] == [(k * n_par // 8, (k + 1) * n_par // 8) for k in range(8)]
+    assert single["n_valid"] == n_it * 8 * BIG_RAYS and sum(r["n_valid"] for r in rs) == single["n_valid"]       # no ray dropped: draws line up
+    same_map = lambda sums: all([s_[i] for i in (0, 3, 4, 7)] == [sums[0][i] for i in (0, 3, 4, 7)] for s_ in sums)   # parameters and grid
+    assert all(same_map(r["sums"]) for r in rs) and np.array_equal(rs[7]["params"], rs[0]["params"])
+    assert all(r["finite"] and r["step"] == n_it and r["adam_steps"] == n_it for r in rs)
+    loss, ref = rs[0]["loss"], single["loss"]
+    rel_loss = np.abs(loss - ref).max(axis=0) / np.abs(ref).max(axis=0)
+    rel_par = np.abs(rs[0]["params"] - single["params"]).max() / np.abs(single["params"]).max()
+    print("8 ranks vs single GPU: loss terms rel", rel_loss, " params rel", rel_par)
+    assert np.abs(loss[0] - ref[0]).max() <= 2e-6 * np.abs(ref[0]).max()            # first iteration: same parameters, same draws
+    assert rel_loss.max() < 5e-4 and rel_par < 5e-4
+    assert np.abs(rs[0]["grid"] - single["grid"]).max() < 1e-3 * max(np.abs(single["grid"]).max(), 1e-12)
+    for k in range(8):
+        assert np.abs(rs[k]["poses"][k] - single["poses"][k]).max() < 2e-5
+        assert all((rs[k]["moved"][j] > 0) == (j == k and k != 0) for j in range(8))       # only a rank's own non-anchored keyframe moves
+
+
+def test_eight_ranks_five_keyframes_three_idle_ranks():
+    """A 5-keyframe window on 8 ranks (the first keyframes of every run): ranks 5-7 own nothing, join every collective with an empty
+    front record and a zero gradient, step their chunk of the parameters like everyone else and end with the same replica."""
+    n_it = 4
+    single = _single(5, n_it, keyed=True, default_net=True)
+    rs = _run(8, "gloo", 5, n_it, keyed=True, exchange=None, default_net=True, timeout=900)
+    assert [r["owned"] for r in rs] == [[0], [1], [2], [3], [4], [], [], []]
+    same_map = lambda sums: all([s_[i] for i in (0, 3, 4, 7)] == [sums[0][i] for i in (0, 3, 4, 7)] for s_ in sums)   # parameters and grid
+    assert all(same_map(r["sums"]) for r in rs) and np.array_equal(rs[7]["params"], rs[0]["params"])
+    assert all(np.array_equal(r["grid"], rs[0]["grid"]) for r in rs)
+    assert all(r["step"] == n_it and r["adam_steps"] == n_it and r["finite"] for r in rs)
+    assert np.abs(rs[0]["loss"] - single["loss"]).max() < 5e-4 * np.abs(single["loss"]).max()
+    assert np.abs(rs[7]["params"] - single["params"]).max() < 5e-4 * np.abs(single["params"]).max()
 
 
 def test_rccl_world_size_one_is_bit_identical_to_non_distributed():

@@ -134,6 +134,23 @@ def test_missing_library_is_an_error(lib_path, tmp_path):
     assert "RAISED" in out.stdout
 
 
+def test_product_initialiser_equals_the_oracles(lib_path):
+    """SigmaNetwork(seed=s) - the product's own initialiser (Xavier-uniform matrices, uniform(-1e-4, 1e-4) tables, tinycudann's
+    layout) - reproduces oracle.network.init_params(spec, s) bit for bit, for the default and for a frequency-encoded network: the
+    HIP legs of bench.py start from the product's initialiser, the oracle legs from the oracle's, and they are the same tensor."""
+    from loner_amd.common.settings import default_nerf_config
+    from loner_amd.models.nerf_tcnn import SigmaNetwork
+    from oracle import network as NW
+    nc = default_nerf_config()
+    cases = [(nc["pos_encoding_sigma"], nc["sigma_network"]),
+             (dict(otype="Frequency", n_frequencies=12), dict(activation="ReLU", n_neurons=128, n_hidden_layers=2))]
+    for enc, net in cases:
+        for seed in (0, 7):
+            a = SigmaNetwork(3, 1, enc, net, seed=seed).params.detach()
+            b = NW.init_params(NW.NetworkSpec.from_config(dict(enc), dict(net)), seed)
+            assert a.dtype == b.dtype and torch.equal(a, b)
+
+
 def test_pose_maths_matches_oracle_and_scipy():
     from scipy.spatial.transform import Rotation
     from loner_amd.common.pose_utils import axis_angle_to_matrix, matrix_to_axis_angle, tensor_to_transform

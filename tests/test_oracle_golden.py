@@ -251,6 +251,48 @@ def test_g9_optimisation_loop(golden):
     assert rel_err(m.params.detach().numpy(), g["params1"]) < 2e-2
 
 
+# ---------------------------------------------------------------- G14: the first iterations of the G9 loop, state by state
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_g14_first_iterations_parameters_and_adam_moments(golden, k):
+    """After k = 1, 2, 3 iterations of the reference's loop (G9's configuration and draws): density parameters, both Adam moments of
+    the density and the pose group, the free pose and the grid.  Tight where G9's 12-iteration end state (Adam-amplified) is loose:
+    a wrong bias correction or moment update moves every element by ~lr here.  k = 1 is bit-exact; from k = 2 the reference's own
+    scatter order varies its gradient in the last bits and a handful of table entries whose gradient is ~1e-8 (Adam's eps) take a
+    different-sized step - hence a quantile statement on the parameters next to the tight one on the moments."""
+    g, h = golden("g9_loop"), golden("g14_loop_first_steps")
+    from loner_amd.utils import synthetic as SY
+    spec = NW.NetworkSpec.from_config(
+        dict(otype="HashGrid", n_levels=4, log2_hashmap_size=12, base_resolution=8, n_features_per_level=2),
+        dict(activation="ReLU", n_neurons=32, n_hidden_layers=1))
+    m = MS.OracleMapper(spec, t(g["params0"]), float(g["scale"].reshape(-1)[0]), g["shift"], MS.MapperConfig(n_rays=48, n_samples=64), grid_size=32)
+    dirs, _ = SY.lidar_pattern()
+    base = SY.trajectory_pose6(8)
+    kfs = [MS.OracleKeyframe(dirs, SY.scene_ranges(dirs, P.transform_from_pose6(base[i])), t(g[f"pose_init{i}"]).clone(), anchored=(i == 0))
+           for i in range(2)]
+    keys = sorted(n for n in g if n.startswith("draw"))
+
+    class Replay:
+        i = 0
+        def _next(self):
+            v = t(g[keys[self.i]]); self.i += 1
+            return v
+        def ray_index(self, n, c): return self._next()
+        def jitter(self, n, hh): return self._next()
+        def pdf(self, n, hh): return self._next()
+        def noise(self, n, s): return self._next()
+    m.iterate(kfs, k, draws=Replay())
+    adam = m.last_adam
+    assert adam.t == int(h[f"step_{k}"]) == k
+    assert rel_err(adam.m[0].numpy(), h[f"exp_avg_{k}"]) < 1e-4 and rel_err(adam.v[0].numpy(), h[f"exp_avg_sq_{k}"]) < 1e-4
+    assert rel_err(adam.m[1].numpy(), h[f"pose_exp_avg_{k}"]) < 2e-4 and rel_err(adam.v[1].numpy(), h[f"pose_exp_avg_sq_{k}"]) < 2e-4
+    dp = np.abs(m.params.numpy() - h[f"params_{k}"])
+    assert np.quantile(dp, 0.99) < 2e-6 and (dp > 1e-4).mean() < 1e-3 and dp.max() <= 2.001 * 1e-2 * k
+    assert np.abs(kfs[1].pose6.detach().numpy() - h[f"pose1_{k}"]).max() < 1e-6
+    assert rel_err(m.grid[0, 0].numpy(), h[f"grid_{k}"]) < 1e-6
+    if k == 1:
+        assert dp.max() == 0 and np.array_equal(adam.m[0].numpy(), h["exp_avg_1"])
+
+
 # ---------------------------------------------------------------- G10 pose
 def _g11_replay(g):
     from tests.test_gpu_mapping import _Replay

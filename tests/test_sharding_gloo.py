@@ -61,7 +61,7 @@ def _worker(rank, world, port, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import loss as OL
     from oracle import network as NW
-    from loner_amd.mapping.sharding import DistContext, shard_window
+    from loner_amd.mapping.sharding import DistContext, front_record, shard_window
     ctx = DistContext()
     window, scale = _window()
     spec = NW.NetworkSpec.from_config(dict(otype="HashGrid", n_levels=4, n_features_per_level=2, log2_hashmap_size=10, base_resolution=4),
@@ -70,15 +70,21 @@ def _worker(rank, world, port, ret):
     params[spec.n_mlp_params:] *= 3000
     mine = ctx.owned(window)
     assert [i for i, w in enumerate(window) if any(w is m for m in mine)] == shard_window(len(window), world, rank)
-    # local counts -> global counts (the kernels' lnr_count_opaque + all_reduce_counts)
+    # far[0] of the whole batch and the global counts: ONE all-gather of the ranks' front records (the kernels' lnr_shard_front_pack /
+    # lnr_shard_front_reduce; here their plain-torch forms)
     rays = torch.cat([i[0] for i in mine]); depths = torch.cat([i[1] for i in mine])
-    far0 = ctx.broadcast_far0(rays)[0]                               # rank 0's first ray = first ray of the whole batch
-    assert float(far0) == float(window[0][0][0, 12])
+    idx = ctx.owned_indices(len(window))
+    seg_start = torch.tensor([0] + list(np.cumsum([i[0].shape[0] for i in mine])), dtype=torch.int32)
+    cap = ctx.front_capacity(len(window), max(i[0].shape[0] for i in window))
+    assert cap >= rays.shape[0]
+    counts, far0 = ctx.gather_front(front_record(rays, seg_start, [2 * i for i in idx], depths, rays.shape[0], cap)).wait()
+    far0 = far0[0]
+    assert float(far0) == float(window[0][0][0, 12])                 # rank 0's first ray = first ray of the whole batch
     if rank != 0:
         assert float(rays[0, 12]) != float(far0)                     # a rank's own first ray would give a different mask
         assert int((depths > rays[0, 12]).sum()) != int((depths > far0).sum())
-    local = torch.tensor([rays.shape[0], int(((depths > 0) & ~(depths > far0)).sum())], dtype=torch.int32)
-    counts = ctx.all_reduce_counts(local.clone())
+    all_d = torch.cat([i[1] for i in window])
+    assert counts.tolist() == [all_d.shape[0], int(((all_d > 0) & ~(all_d > far0)).sum())]
     p = params.clone().requires_grad_(True)
     loss_r, _ = _rank_loss(spec, p, mine, scale, (int(counts[0]), int(counts[1])), far0=far0)
     loss_r.backward()
@@ -129,18 +135,25 @@ def _exchange_worker(rank, world, port, ret):
         for payload in ("fp32", "bf16"):
             ctx = DistContext(exchange=exchange, payload=payload)
             flat = local.clone()
-            ctx.exchange_grads(flat, n_mlp, async_op=True).wait()
-            sl = ctx.table_slice(n_mlp, flat.numel())
+            ctx.exchange_grads(flat, async_op=True).wait()
+            sl = ctx.owned_range(flat.numel())
             assert (sl is None) == (exchange == "all_reduce")
             # a fake "step": every rank writes rank-independent values derived from the reduced gradient into the part it owns
             params = torch.zeros_like(flat)
             if sl is None:
                 params.copy_(flat * 0.5)
             else:
-                params[:n_mlp] = flat[:n_mlp] * 0.5
+                assert sl == (rank * (n_mlp + n_table) // world, (rank + 1) * (n_mlp + n_table) // world)   # equal chunks of the WHOLE vector
                 params[sl[0]:sl[1]] = flat[sl[0]:sl[1]] * 0.5
-                assert float(flat[n_mlp:sl[0]].abs().sum()) == 0.0 and float(flat[sl[1]:].abs().sum()) == 0.0   # other ranks' slices: zeroed
-                ctx.gather_params(params, n_mlp)
+                assert float(flat[:sl[0]].abs().sum()) == 0.0 and float(flat[sl[1]:].abs().sum()) == 0.0   # other ranks' chunks: zeroed
+                ctx.gather_params(params)
+                # zero_rest=False (the training loop's overwrite mode): the other chunks keep the rank's own contribution, the
+                # rank's chunk still receives the sum
+                keep = local.clone()
+                ctx.exchange_grads(keep, async_op=True, zero_rest=False).wait()
+                assert torch.equal(keep[sl[0]:sl[1]], flat[sl[0]:sl[1]])
+                assert torch.equal(keep[:sl[0]], local[:sl[0]]) and torch.equal(keep[sl[1]:], local[sl[1]:])
+                assert ctx.owned_range(n_mlp + n_table + 2) is None              # does not split into aligned equal chunks: all-reduce form
             out[(exchange, payload)] = params
     ret[rank] = {k: v.numpy() for k, v in out.items()}
     ret[f"local{rank}"] = local.numpy()
@@ -162,8 +175,6 @@ def test_gradient_exchange_forms_agree():
         want = total.clone()
         if payload == "bf16":
             want = total_bf.clone()
-            if exchange == "reduce_scatter":
-                want[:48] = total[:48]                                     # the MLP part always travels in fp32
         assert np.array_equal(v0, (want * 0.5).numpy()), key
 
 
@@ -185,10 +196,11 @@ def _far0_window():
 def _far0_worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from loner_amd.mapping.sharding import NO_RAY_KEY, DistContext, first_ray_key
+    from loner_amd.mapping.sharding import NO_RAY_KEY, DistContext, first_ray_key, front_record
     ctx = DistContext()
     window = _far0_window()
-    out = {}
+    cap = ctx.front_capacity(len(window), max(w[0].shape[0] for w in window))
+    out, out_counts = {}, {}
     # which keyframes lost every candidate ray to the cube test (ray_utils.py:322): none / the first / both of rank 0 / all
     for name, empty in (("none", ()), ("kf0", (0,)), ("kf0_kf2", (0, 2)), ("kf0_kf1", (0, 1)), ("all", (0, 1, 2, 3))):
         idx = ctx.owned_indices(len(window))
@@ -198,11 +210,18 @@ def _far0_worker(rank, world, port, ret):
         key = first_ray_key(rays, seg_start, [2 * i for i in idx])
         if all(i in empty for i in idx):
             assert int(key) == NO_RAY_KEY
-        far0 = ctx.broadcast_far0(rays, first_key=key)
-        assert far0.shape == (1,) and far0.dtype == torch.float32
+        depths = torch.cat([window[i][1] if i not in empty else window[i][1][:0] for i in idx])
+        rec = front_record(rays, seg_start, [2 * i for i in idx], depths, rays.shape[0], cap)
+        assert rec.shape == (4 + cap,) and int(rec[0:2].view(torch.int64)) == int(key) and int(rec[2:3].view(torch.int32)) == rays.shape[0]
+        counts, far0 = ctx.gather_front(rec).wait()
+        assert far0.shape == (1,) and far0.dtype == torch.float32 and counts.dtype == torch.int32
         out[name] = float(far0)
-        # a rank that owns no keyframe at all joins with rays = None (Optimizer._join_without_rays)
-    assert float(ctx.broadcast_far0(None, device="cpu") if rank == 1 else ctx.broadcast_far0(window[0][0])) == float(window[0][0][0, 12])
+        out_counts[name] = counts.tolist()
+    # a rank that owns no keyframe at all joins with rays = None (Optimizer._join_without_rays)
+    rec = front_record(None, None, (), None, 0, cap) if rank == 1 else \
+        front_record(window[0][0], torch.tensor([0, window[0][0].shape[0]], dtype=torch.int32), [0], window[0][1], window[0][0].shape[0], cap)
+    counts, far0 = ctx.gather_front(rec).wait()
+    assert float(far0) == float(window[0][0][0, 12]) and int(counts[0]) == window[0][0].shape[0]
     # the failure word at the end of a sharded phase: the earliest failing iteration wins, code and iteration stay a pair
     word = lambda c, i: torch.tensor([c, i], dtype=torch.int32)
     assert ctx.earliest_failure(word(0, 0)).tolist() == [0, 0]
@@ -210,12 +229,14 @@ def _far0_worker(rank, world, port, ret):
     assert ctx.earliest_failure(word(0, 0) if rank == 0 else word(3, 9)).tolist() == [3, 9]
     assert ctx.earliest_failure(word(2, 5) if rank == 0 else word(1, 5)).tolist() == [1, 5]
     ret[rank] = out
+    ret[f"counts{rank}"] = out_counts
     dist.destroy_process_group()
 
 
 def test_far0_is_the_first_kept_ray_of_the_window_whoever_owns_it():
     """optimizer.py:460-461 compares every depth with far[0] of the WHOLE batch.  When the cube test drops every ray of the first
-    keyframe(s), that ray belongs to a later keyframe - possibly another rank's: one MIN all-reduce of (window order | far bits)."""
+    keyframe(s), that ray belongs to a later keyframe - possibly another rank's: the smallest (window order | far bits) key among the
+    all-gathered front records; the global counts are derived from the same records."""
     port = 30900 + (os.getpid() % 1000)
     mgr = mp.Manager()
     ret = mgr.dict()
@@ -226,3 +247,10 @@ def test_far0_is_the_first_kept_ray_of_the_window_whoever_owns_it():
     for r in (0, 1):
         assert ret[r]["none"] == first(0) and ret[r]["kf0"] == first(1) and ret[r]["kf0_kf2"] == first(1) and ret[r]["kf0_kf1"] == first(2)
         assert np.isnan(ret[r]["all"])                                   # nobody has a ray: the value is never used
+    # the global normalisers that came with it: #rays and #opaque (depth > 0 and not depth > far[0]) over the keyframes that kept rays
+    assert ret["counts0"] == ret["counts1"]
+    for name, empty in (("none", ()), ("kf0", (0,)), ("kf0_kf2", (0, 2)), ("kf0_kf1", (0, 1)), ("all", (0, 1, 2, 3))):
+        d = torch.cat([window[k][1] for k in range(4) if k not in empty] + [torch.zeros(0)])
+        far0 = ret[0][name]
+        want = [int(d.shape[0]), int(((d > 0) & ~(d > far0)).sum()) if d.shape[0] else 0]
+        assert ret["counts0"][name] == want, (name, ret["counts0"][name], want)
