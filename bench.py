@@ -34,9 +34,10 @@ def parse():
     ap.add_argument("--keyframes", type=int, default=8)
     ap.add_argument("--rays", type=int, default=512)
     ap.add_argument("--samples", type=int, default=512)
-    ap.add_argument("--dtype", choices=["f32", "f16"], default="f32",
-                    help="arithmetic of the density network: f32 (default, stricter than the reference) or f16 "
-                         "(the reference's storage types: fp16 features and weights on MFMA, fp32 accumulation)")
+    ap.add_argument("--dtype", choices=["f32", "f16", "f32_chain"], default="f32",
+                    help="arithmetic of the density network: f32 (default, stricter than the reference; the MLP's products as three-term "
+                         "bf16 splits on the bf16 matrix pipe), f16 (the reference's storage types: fp16 features and weights on MFMA, fp32 "
+                         "accumulation) or f32_chain (fp32 with exact fma chains on v_mfma_f32_16x16x4_f32: the pre-round-5 kernels, for A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--quick", action="store_true",
                     help="development: only the timed region and its kernel table (no other-dtype leg, no north-star network leg, no render leg, "
@@ -382,7 +383,7 @@ def make_bench_optimizer(rays, samples, dtype="f32", device_index=0, rank=0, par
     settings["num_samples"]["lidar"] = rays
     settings["num_samples"]["sky"] = 0
     settings["model_config"]["model"]["render"]["N_samples_train"] = samples
-    settings["model_config"]["model"]["nerf_config"]["sigma_network"]["precision"] = "fp16" if dtype == "f16" else "fp32"
+    settings["model_config"]["model"]["nerf_config"]["sigma_network"]["precision"] = {"f16": "fp16", "f32_chain": "fp32_chain"}.get(dtype, "fp32")
     torch.manual_seed(0)                               # identical initial parameters on every rank
     o = Optimizer(settings, None, WorldCube(torch.tensor(scale), torch.from_numpy(shift)), device_index, False, True, False)
     if params0 is not None:
@@ -688,7 +689,9 @@ def main():
     h, ind, nh = spec.n_neurons, spec.in_dim, spec.n_hidden
     mac = h * ind + (nh - 1) * h * h
     plane_b = 2.0 if args.dtype == "f16" else 4.0                      # bytes of one feature-plane element
-    mfma_peak = 2500.0e12 if args.dtype == "f16" else 157.3e12         # dense MFMA peak of the MLP kernels' arithmetic type
+    # dense MFMA peak of the MLP kernels' arithmetic type: the fp32 mode runs 6 bf16 products per fp32 product on the bf16 pipe, i.e. at
+    # best 2500 / 6 = 417 TFLOP/s of fp32-equivalent work (its yardstick); the exact-chain kernels are held to the fp32 MFMA peak
+    mfma_peak = 2500.0e12 if args.dtype == "f16" else (157.3e12 if args.dtype == "f32_chain" else 2500.0e12 / 6.0)
     # Algorithmic work per launch:
     #   encode_backward: d_feature planes in, z and the ray records once, 6 ray-gradient floats out, the table gradient once
     #   mlp_backward:    forward recompute + input gradient + weight gradient GEMMs of the fp32 MLP

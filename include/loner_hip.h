@@ -47,11 +47,16 @@ typedef enum LnrEncoding { LNR_ENC_HASHGRID = 0, LNR_ENC_FREQUENCY = 1 } LnrEnco
 
 /* Arithmetic of the density network.  The reference runs tinycudann in half precision (fp16 parameters copy, fp16 encoded
  * features, FullyFusedMLP on tensor cores: cfg/nerf_config/default_nerf_hash.yaml:20-31, src/models/nerf_tcnn.py:35-38).
- *   LNR_PREC_F32: everything in fp32 (fp32 MFMA = exact fma chains); stricter than the reference, the default.
+ *   LNR_PREC_F32: everything in fp32; stricter than the reference, the default.  Matrix products of the reference's default shape
+ *                 class (32 encoded features -> <= 64 ReLU neurons -> 1) run on the bf16 matrix pipe with every fp32 operand split
+ *                 into three bf16 terms (x = x0 + x1 + x2 exactly) and the six largest partial products accumulated in fp32:
+ *                 error per product below 2^-24 relative (the order of fp32's own rounding; exact for operands of <= 16 significant
+ *                 bits), ~2.5x the speed of the fp32 MFMA.  Every other network: v_mfma_f32_16x16x4_f32 (exact fp32 fma chains).
+ *   LNR_PREC_F32_CHAIN: fp32 with exact fma chains (v_mfma_f32_16x16x4_f32) for every network, the default class included.
  *   LNR_PREC_F16: the reference's storage types - encoded features and MLP weights rounded to fp16, matrix products on
  *                 v_mfma_f32_16x16x32_f16 with fp32 accumulation (the reference accumulates in fp16), fp32 master
  *                 parameters and fp32 gradients (the reference: fp16 atomics with a loss scale of 128). */
-typedef enum LnrPrecision { LNR_PREC_F32 = 0, LNR_PREC_F16 = 1 } LnrPrecision;
+typedef enum LnrPrecision { LNR_PREC_F32 = 0, LNR_PREC_F16 = 1, LNR_PREC_F32_CHAIN = 2 } LnrPrecision;
 
 /* Grid position of the hash-grid lookup, pos = x*scale + 0.5:  LNR_POS_FMA rounds once (tiny-cuda-nn's fmaf, the
  * default), LNR_POS_MUL_ADD rounds the product and the sum separately (what un-contracted code would do).  The two
@@ -164,7 +169,14 @@ size_t lnr_density_workspace_forward(const LnrNetSpec* spec /*host*/, int64_t n_
                                           Between two density calls on a workspace its content belongs to the library: a caller that writes
                                           into it - or hands it to another network / batch size - is fine (that is detected by layout), one
                                           that scribbles over it from outside must call lnr_density_workspace_init again. */
+/* REQUIRED once for every allocation that is used as a workspace - also for a new allocation that happens to get the address of a
+ * released one: the library keeps a small host-side note per workspace ADDRESS (layout signature, call stamp, "overflow accumulators
+ * known zero"), which lnr_density_workspace_init resets.  Without it a recycled address would be believed to hold zeroed accumulators.
+ * lnr_density_workspace_release drops the note when a workspace is freed (optional but tidy: the notes are bounded - beyond 64 of them
+ * every note is dropped, which only costs the next backward on each workspace one clear).  One workspace serves one stream at a time:
+ * forward and backward of a call pair, and successive calls, are ordered by the stream they are issued on. */
 int lnr_density_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
+int lnr_density_workspace_release(void* workspace);
 
 /* sigma = MLP(enc((xyz+1)/2))[0]           replaces tinycudann forward at nerf_tcnn.py:63-72
  * Points are given either explicitly (pts != NULL, [n_points,3] in the world cube [-1,1]) or
@@ -387,9 +399,11 @@ int lnr_occ_grid_apply(float* grid, int64_t* grad_acc, int64_t count, float lr, 
                        void* stream);
 
 /* ---- self test ------------------------------------------------------------------------------------------ */
-/* Checks the MFMA fragment layouts the density kernels rely on (v_mfma_f32_16x16x4_f32 and v_mfma_f32_16x16x32_f16,
- * asymmetric operands); out[0] = max abs error of the fp32 form, out[1] = of the fp16 form. */
-int lnr_selftest_mfma(float* out /*[2]*/, void* stream);
+/* Checks the MFMA fragment layouts the density kernels rely on (v_mfma_f32_16x16x4_f32, v_mfma_f32_16x16x32_f16 and the split-bf16
+ * product on v_mfma_f32_16x16x32_bf16; asymmetric operands); out[0] = max abs error of the fp32 form, out[1] = of the fp16 form,
+ * out[2] = of the three-term bf16 split (operands chosen so that the kept partial products are the exact product: must be 0, and
+ * the split itself must give back its input). */
+int lnr_selftest_mfma(float* out /*[3]*/, void* stream);
 
 #ifdef __cplusplus
 }

@@ -105,7 +105,7 @@ extern "C" int lnr_net_spec_finalize(LnrNetSpec* s) {
                 "n_neurons must be 16, 32, 64, 128 or 256, got %d", s->n_neurons);
     LNR_REQUIRE(s->n_hidden >= 1 && s->n_hidden <= 8, "n_hidden_layers must be in [1,8], got %d", s->n_hidden);
     LNR_REQUIRE(s->activation >= LNR_ACT_NONE && s->activation <= LNR_ACT_TANH, "unknown activation %d", s->activation);
-    LNR_REQUIRE(s->precision == LNR_PREC_F32 || s->precision == LNR_PREC_F16, "unknown precision %d", s->precision);
+    LNR_REQUIRE(s->precision == LNR_PREC_F32 || s->precision == LNR_PREC_F16 || s->precision == LNR_PREC_F32_CHAIN, "unknown precision %d", s->precision);
     LNR_REQUIRE(s->pos_rounding == LNR_POS_FMA || s->pos_rounding == LNR_POS_MUL_ADD, "unknown pos_rounding %d", s->pos_rounding);
     if (s->encoding == LNR_ENC_HASHGRID) {
         LNR_REQUIRE(s->n_levels >= 1 && s->n_levels <= LNR_MAX_LEVELS, "n_levels must be in [1,%d]", LNR_MAX_LEVELS);

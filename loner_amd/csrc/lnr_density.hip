@@ -39,8 +39,12 @@ uint64_t layout_signature(const LnrNetSpec* spec, int64_t cap) {
     return h;
 }
 // a density call with this layout touches the workspace: a different layout than the note's leaves the accumulators unknown
+// (bounded: a caller that never releases its workspaces cannot grow the map without limit - dropping every note is always safe, the
+// next backward on each workspace then clears its accumulators once)
+void ws_bound_locked() { if (g_ws_notes.size() > 64) g_ws_notes.clear(); }
 void ws_touch(const void* ws, uint64_t layout) {
     std::lock_guard<std::mutex> lock(g_ws_mutex);
+    ws_bound_locked();
     auto it = g_ws_notes.find(ws);
     if (it == g_ws_notes.end()) g_ws_notes[ws] = WsNote{layout, 0u, false};
     else if (it->second.layout != layout) { it->second.layout = layout; it->second.ovf_zero = false; }
@@ -49,6 +53,7 @@ void ws_touch(const void* ws, uint64_t layout) {
 // until ws_backward_done
 void ws_backward_begin(const void* ws, uint64_t layout, int* epoch, bool* clear) {
     std::lock_guard<std::mutex> lock(g_ws_mutex);
+    ws_bound_locked();
     WsNote& n = g_ws_notes[ws];
     if (n.layout != layout) { n.layout = layout; n.ovf_zero = false; }
     *clear = !n.ovf_zero;
@@ -686,6 +691,12 @@ extern "C" int lnr_density_workspace_init(void* workspace, size_t workspace_byte
     return LNR_OK;
 }
 
+extern "C" int lnr_density_workspace_release(void* workspace) {
+    LNR_REQUIRE(workspace != nullptr, "lnr_density_workspace_release: null workspace");
+    ws_forget(workspace);
+    return LNR_OK;
+}
+
 extern "C" int lnr_density_forward(const LnrNetSpec* spec, const float* params, const float* pts, int64_t n_points,
                                    const float* rays, const float* z, int32_t n_rays, int32_t n_samples,
                                    const int32_t* n_rays_dev, float* sigma, void* workspace, size_t workspace_bytes, void* stream) {
@@ -726,6 +737,12 @@ extern "C" int lnr_density_forward(const LnrNetSpec* spec, const float* params, 
         rc = lnr_mlp_fwd_f16(spec, params, feat, L.m_pad, &mp, sigma, st);
         if (rc) return rc;
         LNR_CHECK_LAUNCH("lnr_density_forward(mlp f16)");
+        return LNR_OK;
+    }
+    if (lnr_bf3_class(spec, cap)) {
+        rc = lnr_mlp_fwd_bf3(spec, params, feat, L.m_pad, &mp, sigma, st);
+        if (rc) return rc;
+        LNR_CHECK_LAUNCH("lnr_density_forward(mlp bf16x3)");
         return LNR_OK;
     }
     switch (spec->n_neurons / 16) {
@@ -815,6 +832,7 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     {
     LnrProfScope prof("mlp_backward", st);
     if (f16) rc = lnr_mlp_bwd_f16(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &n_slabs, st);
+    else if (lnr_bf3_class(spec, cap)) rc = lnr_mlp_bwd_bf3(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &n_slabs, st);
     else if (plan.regs) rc = mlp_bwd_regs(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &plan, st);
     else switch (spec->n_neurons / 16) {
         case 1: rc = lnr_mlp_bwd_ht1(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &plan, st); break;
@@ -912,6 +930,7 @@ extern "C" int lnr_density_fold_weight_grads(const LnrNetSpec* spec, int64_t n_p
     LNR_REQUIRE(workspace_bytes >= L.total, "lnr_density_fold_weight_grads: workspace too small");
     int n_slabs;
     if (spec->precision == LNR_PREC_F16) n_slabs = lnr_f16_bwd_slabs(spec, n_points);
+    else if (lnr_bf3_class(spec, n_points)) n_slabs = lnr_bf3_bwd_slabs(spec, n_points);
     else {
         DensityPlan plan;
         rc = plan_launch(spec, n_points, true, &plan, "lnr_density_fold_weight_grads");
@@ -955,6 +974,7 @@ extern "C" int lnr_selftest_mfma(float* out, void* stream) {
     LNR_REQUIRE(out != nullptr, "lnr_selftest_mfma: null out");
     hipLaunchKernelGGL(selftest_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out);
     lnr_selftest_mfma_f16(out, (hipStream_t)stream);
+    lnr_selftest_mfma_bf3(out, (hipStream_t)stream);
     LNR_CHECK_LAUNCH("lnr_selftest_mfma");
     return LNR_OK;
 }

@@ -213,6 +213,13 @@ int lnr_mlp_bwd_f16(const LnrNetSpec* spec, const float* params, const void* fea
                     float* dfeat, float* slabs, int want_dfeat, int* n_slabs, hipStream_t st);
 int lnr_f16_bwd_slabs(const LnrNetSpec* spec, int64_t n_points);
 int lnr_selftest_mfma_f16(float* out, hipStream_t st);
+// fp32 mode, default shape class, on the bf16 matrix pipe with three-term operand splits (lnr_density_bf3.hip)
+bool lnr_bf3_class(const LnrNetSpec* spec, int64_t n_points);
+int lnr_mlp_fwd_bf3(const LnrNetSpec* spec, const float* params, const float* feat, int64_t m_pad, const MlpPoints* pt, float* sigma, hipStream_t st);
+int lnr_mlp_bwd_bf3(const LnrNetSpec* spec, const float* params, const float* feat, int64_t m_pad, const MlpPoints* pt, const float* d_sigma,
+                    float* dfeat, float* slabs, int want_dfeat, int* n_slabs, hipStream_t st);
+int lnr_bf3_bwd_slabs(const LnrNetSpec* spec, int64_t n_points);
+int lnr_selftest_mfma_bf3(float* out, hipStream_t st);
 int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, const float* dfeat,
                         float* dxl, int64_t m_pad, float* grad_table, void* regions, const RegionPlan* plan, int* counts, int bpg,
                         int maxo, int shift, long long* ovf, int* ovf_flag, int epoch, float* d_pts, float* d_rays_acc, long long* ray_acc, bool bins_w8, int parts,

@@ -237,22 +237,27 @@ __device__ __forceinline__ void forward_level_loop(LevelInfo L, const float* __r
             // Dense levels, two features: the x-neighbour of corner 2r is the NEXT entry (e + 1: 16 contiguous bytes), so the eight
             // corners are four 16-byte gathers - what a coarse level waits for is the CU's address path, ~16 clocks per vector-memory
             // instruction however well it coalesces, 11 instructions per step before (8 gathers, the depth, 2 stores), 7 now.  Lanes
-            // whose indices reach the table size (points outside the unit cube: the reference's modulo applies) re-fetch the odd
+            // whose indices reach the table size (points outside the unit cube: the reference's modulo applies) re-fetch their
             // corners one by one.
             const uint32_t any = e[0] | e[1] | e[2] | e[3] | e[4] | e[5] | e[6] | e[7];
             const bool wrapped = any >= L.size;
             wrap_entries<LK, 8>(L, e);
             typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
+            // (a wrapped index may be the level's LAST entry: the 16-byte gather starts one entry earlier at most, so that it never
+            // reads past the level - past the parameter buffer, when the level is the last of an all-dense network - and a wrapped
+            // lane re-fetches all eight corners)
+            const uint32_t last_pair = L.size - 2u;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const f4u q = *reinterpret_cast<const f4u*>(reinterpret_cast<const char*>(table) + (size_t)(e[2 * r] * 8u));
+                const uint32_t ea = e[2 * r] < last_pair ? e[2 * r] : last_pair;
+                const f4u q = *reinterpret_cast<const f4u*>(reinterpret_cast<const char*>(table) + (size_t)(ea * 8u));
                 tv[2 * r][0] = q.x; tv[2 * r][1] = q.y; tv[2 * r + 1][0] = q.z; tv[2 * r + 1][1] = q.w;
             }
             if (wrapped) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float2 t2 = ld32<float2>(table, e[2 * r + 1] * 8u);
-                    tv[2 * r + 1][0] = t2.x; tv[2 * r + 1][1] = t2.y;
+                for (int k = 0; k < 8; ++k) {
+                    const float2 t2 = ld32<float2>(table, e[k] * 8u);
+                    tv[k][0] = t2.x; tv[k][1] = t2.y;
                 }
             }
         } else {
@@ -318,8 +323,8 @@ encode_forward_kernel(const LnrNetSpec spec, const float* __restrict__ table, co
     const int lv = nth_level(level_mask, slot);
     const LevelInfo L = level_info(spec, lv);
     const uint32_t M = (uint32_t)live_points(src);
-    // the MLP kernels read whole tiles of 16 (fp32) / 32 (fp16) samples: zero the ragged tail
-    const uint32_t Mt = H16 ? (M + 31u) / 32u * 32u : (M + 15u) / 16u * 16u;
+    // the MLP kernels read whole tiles of 16 (exact-chain fp32) / 32 (split-bf16 fp32 backward, fp16) samples: zero the ragged tail
+    const uint32_t Mt = (M + 31u) / 32u * 32u;
     float* planes = feat + (size_t)(H16 ? lv * (F / 2) : lv * F) * m_pad;
     const uint32_t plane_bytes = (uint32_t)m_pad * 4u;
     forward_level<F, H16>(L, table, src, planes, plane_bytes, M, Mt, chunk, bpg);

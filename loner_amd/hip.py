@@ -25,7 +25,7 @@ ENCODINGS = {"HashGrid": 0, "Grid": 0, "Frequency": 1}
 ACTIVATIONS = {"None": 0, "ReLU": 1, "Sine": 2, "LeakyReLU": 3, "Exponential": 4, "Sigmoid": 5,
                "Squareplus": 6, "Softplus": 7, "Tanh": 8}
 LOSS_SELECTIONS = {"L1_JS": 0, "L2_JS": 1, "L1_LOS": 2, "L2_LOS": 3}
-PRECISIONS = {"fp32": 0, "float32": 0, "fp16": 1, "half": 1, "float16": 1}
+PRECISIONS = {"fp32": 0, "float32": 0, "fp16": 1, "half": 1, "float16": 1, "fp32_chain": 2}
 POS_ROUNDINGS = {"fma": 0, "mul_add": 1}
 BWD_TABLE_ATOMICS = 1        # LNR_BWD_TABLE_ATOMICS
 BWD_REPORT_REGIONS = 2       # LNR_BWD_REPORT_REGIONS
@@ -66,6 +66,7 @@ _SIGNATURES = {
     "lnr_density_workspace": (C.c_size_t, [C.POINTER(NetSpec), C.c_int64]),
     "lnr_density_workspace_forward": (C.c_size_t, [C.POINTER(NetSpec), C.c_int64]),
     "lnr_density_workspace_init": (C.c_int, [P, C.c_size_t, P]),
+    "lnr_density_workspace_release": (C.c_int, [P]),
     "lnr_density_forward": (C.c_int, [C.POINTER(NetSpec), P, P, C.c_int64, P, P, C.c_int32, C.c_int32, P, P, P, C.c_size_t, P]),
     "lnr_density_backward": (C.c_int, [C.POINTER(NetSpec), P, P, C.c_int64, P, P, C.c_int32, C.c_int32, P, P, P, P, P,
                                        C.c_int32, C.c_int32, P, C.c_size_t, P, P]),

@@ -68,6 +68,8 @@ def _workspace(spec, device, n_points, forward_only=False):
     ent = _workspaces.get(key)
     if ent is None or ent["buf"].numel() * 4 < need:
         clipped = 0 if ent is None else ent["clipped_before"] + int(ent["buf"][:1].view(torch.int32).item())
+        if ent is not None:                         # the library's note about the old buffer goes with it (include/loner_hip.h)
+            check(load().lnr_density_workspace_release(_ptr(ent["buf"])), "lnr_density_workspace_release")
         _workspaces.pop(key, None)
         ent = None                                  # release the old buffer before the larger one is allocated
         ent = {"buf": torch.empty((need + 3) // 4, device=device, dtype=torch.float32), "features_of": None, "clipped_before": clipped}
@@ -500,7 +502,8 @@ def rng_draws(which, seed, n_rays, n_per_ray, device="cuda"):
 
 
 def selftest_mfma(device="cuda"):
-    """max abs error of the two MFMA fragment-layout checks (fp32 16x16x4 and fp16 16x16x32); 0.0 when both layouts hold."""
-    out = torch.full((2,), -1.0, device=device)
+    """max abs error of the three MFMA fragment-layout checks (fp32 16x16x4, fp16 16x16x32, the three-term bf16 split on 16x16x32);
+    0.0 when all layouts hold (and the split product of the test operands is exact)."""
+    out = torch.full((3,), -1.0, device=device)
     check(load().lnr_selftest_mfma(_ptr(out), _stream()), "lnr_selftest_mfma")
     return float(out.abs().max().item()) if bool((out >= 0).all()) else -1.0

@@ -97,7 +97,8 @@ class NetworkSpec:
         s.activation = str(net.get("activation", "ReLU"))
         s.n_neurons = int(net.get("n_neurons", 64))
         s.n_hidden = int(net.get("n_hidden_layers", 1))
-        s.precision = {"fp32": "fp32", "float32": "fp32", "fp16": "fp16", "half": "fp16", "float16": "fp16"}[str(net.get("precision", "fp32"))]
+        # ("fp32_chain": the kernels' exact-fma-chain variant of fp32 - the same arithmetic definition here)
+        s.precision = {"fp32": "fp32", "float32": "fp32", "fp32_chain": "fp32", "fp16": "fp16", "half": "fp16", "float16": "fp16"}[str(net.get("precision", "fp32"))]
         s._build_levels()
         return s
 

@@ -170,6 +170,16 @@ def test_samplers_internal_rng_properties(ops, golden):
 NETS = {
     "default": (dict(otype="HashGrid", n_levels=16, n_features_per_level=2, log2_hashmap_size=18, base_resolution=16),
                 dict(activation="ReLU", n_neurons=64, n_hidden_layers=1)),
+    # the default shape class (32 encoded features -> <= 64 ReLU neurons -> 1): "fp32" runs its matrix products on the bf16 pipe with
+    # three-term operand splits (lnr_density_bf3.hip), "fp32_chain" on v_mfma_f32_16x16x4_f32 (exact fma chains, lnr_density_impl.h)
+    "default_chain": (dict(otype="HashGrid", n_levels=16, n_features_per_level=2, log2_hashmap_size=18, base_resolution=16),
+                      dict(activation="ReLU", n_neurons=64, n_hidden_layers=1, precision="fp32_chain")),
+    "default_n32": (dict(otype="HashGrid", n_levels=16, n_features_per_level=2, log2_hashmap_size=14, base_resolution=8),
+                    dict(activation="ReLU", n_neurons=32, n_hidden_layers=1)),
+    "default_n16": (dict(otype="HashGrid", n_levels=16, n_features_per_level=2, log2_hashmap_size=13, base_resolution=4),
+                    dict(activation="ReLU", n_neurons=16, n_hidden_layers=1)),
+    "default_n32_chain": (dict(otype="HashGrid", n_levels=16, n_features_per_level=2, log2_hashmap_size=14, base_resolution=8),
+                          dict(activation="ReLU", n_neurons=32, n_hidden_layers=1, precision="fp32_chain")),
     "small_hash": (dict(otype="HashGrid", n_levels=4, n_features_per_level=2, log2_hashmap_size=12, base_resolution=8),
                    dict(activation="ReLU", n_neurons=32, n_hidden_layers=1)),
     "hash_f4_2hidden": (dict(otype="HashGrid", n_levels=6, n_features_per_level=4, log2_hashmap_size=14, base_resolution=4, per_level_scale=1.5),
@@ -220,6 +230,43 @@ def test_density_forward_matches_oracle(ops, name):
     err32 = float((ref32.double() - ref64).abs().max()) / scale
     print(f"{name}: |sigma|max={scale:.3g}  hip-vs-oracle(fp32) {err:.2e}  hip-vs-fp64 {err64:.2e}  oracle-fp32-vs-fp64 {err32:.2e}")
     assert err < 1e-5
+
+
+def test_all_dense_network_at_and_beyond_the_cube_boundary(ops):
+    """An all-dense network (both levels index their grid directly: no hashed level behind them in the parameter buffer) evaluated ON
+    and OUTSIDE the unit-cube boundary, where grid indices reach the level size and the reference's modulo wraps them - the wrapped
+    index can be the level's last entry, and the dense levels' 16-byte pair gathers must not read past it (the last level's
+    end is the end of the parameter buffer).  Forward and both gradients equal the oracle, and the guard bytes behind the buffer stay
+    untouched by the backward."""
+    from loner_amd import hip
+    enc = dict(otype="HashGrid", n_levels=2, n_features_per_level=2, log2_hashmap_size=19, base_resolution=4, per_level_scale=2.0)
+    net = dict(activation="ReLU", n_neurons=32, n_hidden_layers=1)
+    spec_o, spec_h = NW.NetworkSpec.from_config(enc, net), hip.make_net_spec(enc, net)
+    assert all(not lv.hashed for lv in spec_o.levels)
+    params = NW.init_params(spec_o, 5)
+    params[spec_o.n_mlp_params:] *= 3000.0
+    gen = torch.Generator().manual_seed(11)
+    corners = torch.tensor([[sx, sy, sz] for sx in (-1.0, 1.0) for sy in (-1.0, 1.0) for sz in (-1.0, 1.0)])
+    faces = torch.rand(64, 3, generator=gen) * 2 - 1
+    faces[torch.arange(64), torch.randint(0, 3, (64,), generator=gen)] = 1.0          # one coordinate exactly on the far face
+    outside = torch.rand(64, 3, generator=gen) * 0.4 + 0.95                           # up to 35 % beyond it
+    inside = torch.rand(120, 3, generator=gen) * 1.98 - 0.99
+    pts = torch.cat([corners, faces, outside, inside])
+    # the parameters sit at the very END of an allocation with a poisoned guard behind them
+    n = int(spec_h.n_params)
+    buf = torch.full((n + 64,), float("nan"), device=DEV)
+    buf[:n] = dv(params)
+    sig = ops.density_forward(spec_h, buf[:n], pts=dv(pts))
+    ref = NW.density(spec_o, params, pts)
+    assert torch.isfinite(sig).all()
+    assert float((sig.cpu() - ref).abs().max()) / float(ref.abs().max()) < 1e-5
+    d_sigma = torch.randn(pts.shape[0], generator=gen)
+    gbuf = torch.zeros(n + 64, device=DEV)
+    d_pts = ops.density_backward(spec_h, buf[:n], dv(d_sigma), gbuf[:n], pts=dv(pts), want_d_pts=True)
+    p32, x32 = params.clone().requires_grad_(True), pts.clone().requires_grad_(True)
+    (NW.density(spec_o, p32, x32) * d_sigma).sum().backward()
+    assert rel(gbuf[:n], p32.grad) < 2e-5 and float(gbuf[n:].abs().sum()) == 0.0
+    assert rel(d_pts, x32.grad) < 1e-4
 
 
 @pytest.mark.parametrize("name", list(NETS))
