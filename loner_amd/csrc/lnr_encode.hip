@@ -246,7 +246,7 @@ __device__ __forceinline__ void forward_level_loop(LevelInfo L, const float* __r
             // (a wrapped index may be the level's LAST entry: the 16-byte gather starts one entry earlier at most, so that it never
             // reads past the level - past the parameter buffer, when the level is the last of an all-dense network - and a wrapped
             // lane re-fetches all eight corners)
-            const uint32_t last_pair = L.size - 2u;
+            const uint32_t last_pair = L.offset + L.size - 2u;       // (wrap_entries made the indices absolute: + L.offset)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const uint32_t ea = e[2 * r] < last_pair ? e[2 * r] : last_pair;
