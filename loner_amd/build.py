@@ -38,7 +38,7 @@ SOURCES = [("lnr_density_ht.hip", f"lnr_density_ht{ht}.o", [f"-DLNR_HT={ht}"]) f
           [("lnr_density_f16_bwd.hip", f"lnr_density_f16_bwd{part}.o", [f"-DLNR_BWD_PART={part}"]) for part in (0, 1, 2)] + \
           [("lnr_density_f16_fwd.hip", f"lnr_density_f16_fwd{part}.o", [f"-DLNR_FWD_PART={part}"]) for part in (0, 1)] + \
           [(s, s.replace(".hip", ".o"), EXTRA.get(s, [])) for s in
-           ("lnr_core.hip", "lnr_density.hip", "lnr_density_f16.hip", "lnr_density_bf3.hip", "lnr_encode.hip", "lnr_sampler.hip", "lnr_render.hip", "lnr_rays.hip", "lnr_optim.hip", "lnr_pose.hip")]
+           ("lnr_core.hip", "lnr_density.hip", "lnr_density_f16.hip", "lnr_density_bf3.hip", "lnr_density_wide.hip", "lnr_encode.hip", "lnr_sampler.hip", "lnr_render.hip", "lnr_rays.hip", "lnr_optim.hip", "lnr_pose.hip")]
 
 
 def _hipcc():

@@ -404,7 +404,7 @@ struct Layout {
     int64_t m_pad;
     int n_groups, bpg, maxo, shift, nown, n_split;
     RegionPlan plan;
-    size_t off_status, off_feat, off_dfeat, off_dxl, off_dpts, off_rayacc, off_slabs, off_ovf, off_counts, off_regions, total;
+    size_t off_status, off_feat, off_wide, off_dfeat, off_dxl, off_dpts, off_rayacc, off_slabs, off_ovf, off_counts, off_regions, total;
 };
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -476,6 +476,7 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
     size_t off = 0;
     L.off_status = off; off += LNR_WORKSPACE_STATUS_BYTES;          // status words (include/loner_hip.h), same place for every n_points
     L.off_feat = off; off += align256((size_t)spec->enc_dim * L.m_pad * sizeof(float));
+    L.off_wide = off; off += align256(lnr_wide_workspace(spec));     // chunk planes of the 256 x 2..3 route (0 bytes for every other network); the forward uses them too
     L.off_dfeat = off; off += align256((size_t)spec->enc_dim * L.m_pad * sizeof(float));
     L.off_dxl = off; off += align256((size_t)L.n_groups * 3 * L.m_pad * sizeof(float));
     L.off_dpts = off; off += align256((size_t)3 * L.m_pad * sizeof(float));      // d_pts scratch of the general d_rays route
@@ -528,10 +529,10 @@ static int check_spec(const LnrNetSpec* spec, const char* who) {
 
 // LNR_PREC_F16 is implemented for the reference's sigma network shape class; anything else must say so, not fall back
 static int check_f16(const LnrNetSpec* spec, const char* who) {
-    if (spec->precision != LNR_PREC_F16 || lnr_f16_supported(spec)) return LNR_OK;
-    lnr_set_error("%s: precision fp16 covers networks with an even number of encoded features per level, 16/32/64/128 neurons (256 with one "
-                  "hidden layer), at most 3 hidden layers and at most 128 (padded) inputs whose weights fit the LDS; use precision fp32 for "
-                  "this network", who);
+    if (spec->precision != LNR_PREC_F16 || lnr_f16_supported(spec) || lnr_wide_class(spec)) return LNR_OK;
+    lnr_set_error("%s: precision fp16 covers networks with an even number of encoded features per level, 16/32/64/128/256 neurons, "
+                  "at most 3 hidden layers and - below 256 neurons - at most 128 (padded) inputs whose weights fit the LDS; use precision "
+                  "fp32 for this network", who);
     return LNR_ERR_UNSUPPORTED;
 }
 
@@ -548,6 +549,10 @@ static size_t bwd_lds(const LnrNetSpec* s, int w_lds, int waves, int dw64) {
 // of a CDNA4 CU.
 static int plan_launch(const LnrNetSpec* spec, int64_t n_points, bool backward, DensityPlan* plan, const char* who) {
     const int64_t tiles = (n_points + 15) / 16;
+    if (lnr_wide_class(spec)) {          // 256 x 2..3: the layer-by-layer route plans its own launches (lnr_density_wide.hip)
+        plan->fast32 = 0; plan->w_lds = 0; plan->waves = 4; plan->dw64 = 0; plan->regs = 0; plan->lds = 0; plan->grid = 1; plan->n_slabs = 1;
+        return LNR_OK;
+    }
     // (the register-resident kernels address the planes with 32-bit byte offsets up to 17 planes: n_points <= 2^25)
     if (spec->activation == LNR_ACT_RELU && spec->n_hidden == 1 && spec->in_dim == 32 && spec->enc_dim == 32 && spec->n_neurons <= 64 &&
         n_points <= (1ll << 25)) {
@@ -733,6 +738,12 @@ extern "C" int lnr_density_forward(const LnrNetSpec* spec, const float* params, 
     if (rc) return rc;
     LNR_CHECK_LAUNCH("lnr_density_forward(encode)");
     LnrProfScope prof_mlp("mlp_forward", st);
+    if (lnr_wide_class(spec)) {
+        rc = lnr_mlp_fwd_wide(spec, params, feat, L.m_pad, &mp, sigma, (char*)workspace + L.off_wide, st);
+        if (rc) return rc;
+        LNR_CHECK_LAUNCH("lnr_density_forward(mlp 256 x n)");
+        return LNR_OK;
+    }
     if (f16) {
         rc = lnr_mlp_fwd_f16(spec, params, feat, L.m_pad, &mp, sigma, st);
         if (rc) return rc;
@@ -831,7 +842,8 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     int n_slabs = plan.n_slabs;
     {
     LnrProfScope prof("mlp_backward", st);
-    if (f16) rc = lnr_mlp_bwd_f16(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &n_slabs, st);
+    if (lnr_wide_class(spec)) rc = lnr_mlp_bwd_wide(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, want_grad ? 1 : 0, &n_slabs, ws + L.off_wide, st);
+    else if (f16) rc = lnr_mlp_bwd_f16(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &n_slabs, st);
     else if (lnr_bf3_class(spec, cap)) rc = lnr_mlp_bwd_bf3(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &n_slabs, st);
     else if (plan.regs) rc = mlp_bwd_regs(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &plan, st);
     else switch (spec->n_neurons / 16) {
@@ -929,7 +941,8 @@ extern "C" int lnr_density_fold_weight_grads(const LnrNetSpec* spec, int64_t n_p
     const Layout L = make_layout(spec, n_points);
     LNR_REQUIRE(workspace_bytes >= L.total, "lnr_density_fold_weight_grads: workspace too small");
     int n_slabs;
-    if (spec->precision == LNR_PREC_F16) n_slabs = lnr_f16_bwd_slabs(spec, n_points);
+    if (lnr_wide_class(spec)) n_slabs = 1;
+    else if (spec->precision == LNR_PREC_F16) n_slabs = lnr_f16_bwd_slabs(spec, n_points);
     else if (lnr_bf3_class(spec, n_points)) n_slabs = lnr_bf3_bwd_slabs(spec, n_points);
     else {
         DensityPlan plan;

@@ -220,6 +220,14 @@ int lnr_mlp_bwd_bf3(const LnrNetSpec* spec, const float* params, const float* fe
                     float* dfeat, float* slabs, int want_dfeat, int* n_slabs, hipStream_t st);
 int lnr_bf3_bwd_slabs(const LnrNetSpec* spec, int64_t n_points);
 int lnr_selftest_mfma_bf3(float* out, hipStream_t st);
+// 256 neurons x 2..3 hidden layers, both precisions: layer by layer through chunk planes in the workspace (lnr_density_wide.hip)
+bool lnr_wide_class(const LnrNetSpec* spec);
+size_t lnr_wide_workspace(const LnrNetSpec* spec);
+int lnr_wide_slabs(void);
+int lnr_mlp_fwd_wide(const LnrNetSpec* spec, const float* params, const float* feat, int64_t m_pad, const MlpPoints* pt, float* sigma,
+                     void* planes, hipStream_t st);
+int lnr_mlp_bwd_wide(const LnrNetSpec* spec, const float* params, const float* feat, int64_t m_pad, const MlpPoints* pt, const float* d_sigma,
+                     float* dfeat, float* slabs, int want_dfeat, int want_dw, int* n_slabs, void* planes, hipStream_t st);
 int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const PointSrc* src, int64_t cap_points, const float* dfeat,
                         float* dxl, int64_t m_pad, float* grad_table, void* regions, const RegionPlan* plan, int* counts, int bpg,
                         int maxo, int shift, long long* ovf, int* ovf_flag, int epoch, float* d_pts, float* d_rays_acc, long long* ray_acc, bool bins_w8, int parts,

@@ -63,10 +63,17 @@ __device__ __forceinline__ f32x4 bf3_mfma6(const Frag3& a, const Frag3& b, f32x4
     return acc;
 }
 
-// the lane's eight first-layer inputs of sample m: features 8g .. 8g+7 (fb = plane 8g)
-__device__ __forceinline__ void bf3_load_x(const float* __restrict__ fb, uint32_t plane_bytes, uint32_t m, float x[8]) {
+// Sample order inside a 32-sample step: column c of column tile t stands for sample 2c + t.  A lane's first-layer inputs of BOTH
+// tiles - features 8g .. 8g+7 (fb = plane 8g) of samples base + 2c and base + 2c + 1 - are then eight 8-byte loads whose 16 lanes cover
+// one whole 128-byte line per plane (one sample per lane and instruction asked for half a line: the planes streamed at 3.5 TB/s);
+// sigma, d_sigma and the d_feature planes move as pairs the same way.  The planes are zero-filled up to the next multiple of 32
+// samples (encode_forward_kernel), so a ragged last step needs no clamping.
+__device__ __forceinline__ void bf3_load_x2(const float* __restrict__ fb, uint32_t plane_bytes, uint32_t m_even, float x[2][8]) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] = ld32<float>(fb, (uint32_t)i * plane_bytes + m * 4u);
+    for (int i = 0; i < 8; ++i) {
+        const float2 v = ld32<float2>(fb, (uint32_t)i * plane_bytes + m_even * 4u);
+        x[0][i] = v.x; x[1][i] = v.y;
+    }
 }
 
 template <int HT>
@@ -87,43 +94,49 @@ mlp_forward_bf3_kernel(const float* __restrict__ params, const float* __restrict
         for (int r = 0; r < 4; ++r) wo[jt][r] = params[H * 32 + 16 * jt + 4 * g + r];
     }
     const int64_t M = live_samples(n_points, n_rays_dev, n_rays, n_samples);
-    const int64_t n_tiles = M > 0 ? (M + 15) / 16 : 0;
+    const int64_t n_tiles = M > 0 ? (M + 31) / 32 : 0;            // a step = 32 samples = two 16-column tiles
     const int64_t stride = (int64_t)gridDim.x * nw;
     int64_t tile = (int64_t)blockIdx.x * nw + wave;
     if (tile >= n_tiles) return;
     const float* fb = feat + (size_t)(8 * g) * m_pad;
     const uint32_t plane_bytes = (uint32_t)m_pad * 4u;
-    auto sample_of = [&](int64_t tl) -> uint32_t { const int64_t m = tl * 16 + c; return (uint32_t)(m < M ? m : M - 1); };
-    // the inputs are requested TWO tiles ahead (as mlp_forward_relu32_kernel: one tile ahead left the planes streaming at 2.6 TB/s)
-    float cur[8], nxt[8];
-    bf3_load_x(fb, plane_bytes, sample_of(tile), cur);
-    bf3_load_x(fb, plane_bytes, sample_of(tile + stride < n_tiles ? tile + stride : tile), nxt);
+    // the inputs are requested TWO steps ahead (as mlp_forward_relu32_kernel: one ahead left the planes streaming at 2.6 TB/s)
+    float cur[2][8], nxt[2][8];
+    bf3_load_x2(fb, plane_bytes, (uint32_t)(tile * 32 + 2 * c), cur);
+    bf3_load_x2(fb, plane_bytes, (uint32_t)((tile + stride < n_tiles ? tile + stride : tile) * 32 + 2 * c), nxt);
     while (tile < n_tiles) {
         const int64_t nt = tile + stride, nt2 = nt + stride;
-        float nx2[8];                           // (unconditional prefetch: a static number of loads in flight)
-        bf3_load_x(fb, plane_bytes, sample_of(nt2 < n_tiles ? nt2 : tile), nx2);
+        float nx2[2][8];                        // (unconditional prefetch: a static number of loads in flight)
+        bf3_load_x2(fb, plane_bytes, (uint32_t)((nt2 < n_tiles ? nt2 : tile) * 32 + 2 * c), nx2);
         __builtin_amdgcn_sched_barrier(0);      // (the scheduler must not sink the prefetch below the products)
-        Frag3 xb;
-        bf3_split8(cur, xb);
-        f32x4 Z[HT];
+        Frag3 xb0, xb1;
+        bf3_split8(cur[0], xb0);
+        bf3_split8(cur[1], xb1);
+        f32x4 Z0[HT], Z1[HT];
 #pragma unroll
-        for (int jt = 0; jt < HT; ++jt) Z[jt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        // term by term across the HT independent accumulators: a dependent MFMA never follows its producer directly
+        for (int jt = 0; jt < HT; ++jt) { Z0[jt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; Z1[jt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+        // term by term across the 2 HT independent accumulators: a dependent MFMA never follows its producer directly
 #define BF3_X(IA, IB)                                                                          \
-    _Pragma("unroll") for (int jt = 0; jt < HT; ++jt) Z[jt] = BF3_M(wa[jt].t[IA], xb.t[IB], Z[jt]);
+    _Pragma("unroll") for (int jt = 0; jt < HT; ++jt) { Z0[jt] = BF3_M(wa[jt].t[IA], xb0.t[IB], Z0[jt]); Z1[jt] = BF3_M(wa[jt].t[IA], xb1.t[IB], Z1[jt]); }
         BF3_FOR_TERMS(BF3_X)
 #undef BF3_X
-        float part = 0.0f;
+        float p0 = 0.0f, p1 = 0.0f;
 #pragma unroll
         for (int jt = 0; jt < HT; ++jt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) part += wo[jt][r] * fmaxf(Z[jt][r], 0.0f);
-        part += __shfl_xor(part, 16, 64);
-        part += __shfl_xor(part, 32, 64);
-        const int64_t m = tile * 16 + c;
-        if (g == 0 && m < M) sigma[m] = finite_or_clipped<false>(part, clip_flag);
+            for (int r = 0; r < 4; ++r) { p0 += wo[jt][r] * fmaxf(Z0[jt][r], 0.0f); p1 += wo[jt][r] * fmaxf(Z1[jt][r], 0.0f); }
+        p0 += __shfl_xor(p0, 16, 64); p1 += __shfl_xor(p1, 16, 64);
+        p0 += __shfl_xor(p0, 32, 64); p1 += __shfl_xor(p1, 32, 64);
+        const int64_t m = tile * 32 + 2 * c;
+        if (g == 0 && m < M) {
+            p0 = finite_or_clipped<false>(p0, clip_flag);
+            if (m + 1 < M) { p1 = finite_or_clipped<false>(p1, clip_flag); *reinterpret_cast<float2*>(sigma + m) = make_float2(p0, p1); }
+            else sigma[m] = p0;
+        }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { cur[i] = nxt[i]; nxt[i] = nx2[i]; }
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { cur[t][i] = nxt[t][i]; nxt[t][i] = nx2[t][i]; }
         tile = nt;
     }
 }
@@ -204,17 +217,14 @@ mlp_backward_bf3_kernel(const float* __restrict__ params, int n_mlp, const float
     const float* fc = feat + (size_t)c * m_pad;                    // weight-gradient B operand: plane 16it + c
     float* db = dfeat + (size_t)(4 * g) * m_pad;                   // d_feature rows 16it + 4g + r
     int64_t tile = (int64_t)blockIdx.x * nw + wave;
-    auto sample_of = [&](int64_t tl, int t) -> uint32_t { const int64_t m = tl * 32 + 16 * t + c; return (uint32_t)(m < M ? m : M - 1); };
     float xcur[2][8], dcur[2];
+    // column c of tile t = sample 2c + t of the step (see bf3_load_x2); d_sigma is not padded: its pair is read element by element
     auto load_front = [&](int64_t tl, float (&x)[2][8], float (&ds)[2]) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int64_t m = tl * 32 + 16 * t + c;
-            const uint32_t mc = (uint32_t)(m < M ? m : M - 1);
-            bf3_load_x(fb, plane_bytes, mc, x[t]);
-            const float v = d_sigma[mc];
-            ds[t] = m < M ? v : 0.0f;
-        }
+        const int64_t m = tl * 32 + 2 * c;
+        bf3_load_x2(fb, plane_bytes, (uint32_t)m, x);
+        const float v0 = d_sigma[m < M ? m : M - 1], v1 = d_sigma[m + 1 < M ? m + 1 : M - 1];
+        ds[0] = m < M ? v0 : 0.0f;
+        ds[1] = m + 1 < M ? v1 : 0.0f;
     };
     if (tile < n_tiles) load_front(tile, xcur, dcur);
     while (tile < n_tiles) {
@@ -223,16 +233,10 @@ mlp_backward_bf3_kernel(const float* __restrict__ params, int n_mlp, const float
         load_front(nt < n_tiles ? nt : tile, xnxt, dnxt);          // unconditional prefetch of the next step's layer-1 operands
         const bool any = (dcur[0] != 0.0f) | (dcur[1] != 0.0f);
         if (__ballot(any) == 0ull) {                               // nothing flows back into this step
-            if (want_dfeat) {
+            if (want_dfeat) {           // (the d_feature planes are padded like the feature planes: whole pairs are stored)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int64_t m = tile * 32 + 16 * t + c;
-                    if (m < M) {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k)
-                            st32<float>(db, (uint32_t)(16 * (k >> 2) + (k & 3)) * plane_bytes + (uint32_t)m * 4u, 0.0f);
-                    }
-                }
+                for (int k = 0; k < 8; ++k)
+                    st32<float2>(db, (uint32_t)(16 * (k >> 2) + (k & 3)) * plane_bytes + (uint32_t)(tile * 32 + 2 * c) * 4u, make_float2(0.0f, 0.0f));
             }
         } else {
             // this step's weight-gradient B operand: samples tile*32 + 8g .. +7 of plane 16it + c (the planes are zero-filled up to the
@@ -265,15 +269,15 @@ mlp_backward_bf3_kernel(const float* __restrict__ params, int n_mlp, const float
                     dWo_acc[jt][r] += dcur[0] * fmaxf(Z0[r], 0.0f) + dcur[1] * fmaxf(Z1[r], 0.0f);
                     dz[jt][0][r] = Z0[r] > 0.0f ? dcur[0] * wo[jt][r] : 0.0f;
                     dz[jt][1][r] = Z1[r] > 0.0f ? dcur[1] * wo[jt][r] : 0.0f;
-                    T[(16 * jt + 4 * g + r) * BF3_TS + c] = dz[jt][0][r];
-                    T[(16 * jt + 4 * g + r) * BF3_TS + 16 + c] = dz[jt][1][r];
+                    *reinterpret_cast<float2*>(T + (16 * jt + 4 * g + r) * BF3_TS + 2 * c) = make_float2(dz[jt][0][r], dz[jt][1][r]);   // samples 2c, 2c + 1
                 }
             }
             // dX = W1^T dZ: the lane's own dZ values are the B operand under the K permutation (slots 0-3: row tile 2kb, 4-7: 2kb+1)
             if (want_dfeat) {
+                f32x4 D[2][2];                                // [t][it]
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    f32x4 D[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+                    D[t][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; D[t][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                     for (int kb = 0; kb < KB; ++kb) {
                         constexpr bool odd = (HT & 1) != 0;                      // HT == 1: the upper half of the K block is padding
@@ -290,18 +294,17 @@ mlp_backward_bf3_kernel(const float* __restrict__ params, int n_mlp, const float
                             Frag3 a;
 #pragma unroll
                             for (int t3 = 0; t3 < 3; ++t3) a.t[t3] = WT[((t3 * 2 + it) * KB + kb) * 64 + wl];
-                            D[it] = bf3_mfma6(a, b, D[it]);
+                            D[t][it] = bf3_mfma6(a, b, D[t][it]);
                         }
                     }
-                    const int64_t m = tile * 32 + 16 * t + c;
-                    if (m < M) {
-#pragma unroll
-                        for (int it = 0; it < 2; ++it)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                st32<float>(db, (uint32_t)(16 * it + r) * plane_bytes + (uint32_t)m * 4u, D[it][r]);
-                    }
                 }
+                // rows 16it + 4g + r of the d_feature planes, samples 2c and 2c + 1 of the step as one 8-byte store (samples past the end
+                // carry dZ = 0 and land in the planes' padding)
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        st32<float2>(db, (uint32_t)(16 * it + r) * plane_bytes + (uint32_t)(tile * 32 + 2 * c) * 4u, make_float2(D[0][it][r], D[1][it][r]));
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -366,7 +369,7 @@ bool lnr_bf3_class(const LnrNetSpec* spec, int64_t n_points) {
 }
 
 int lnr_mlp_fwd_bf3(const LnrNetSpec* spec, const float* params, const float* feat, int64_t m_pad, const MlpPoints* pt, float* sigma, hipStream_t st) {
-    const int64_t tiles = (pt->n_points + 15) / 16;
+    const int64_t tiles = (pt->n_points + 31) / 32;
     int64_t blocks = (tiles + 3) / 4;
     if (blocks > LNR_DENSITY_MAX_BLOCKS) blocks = LNR_DENSITY_MAX_BLOCKS;
     if (blocks < 1) blocks = 1;

@@ -1,0 +1,330 @@
+// Wide density networks - 256 neurons x 2..3 hidden layers - in both precisions (gfx950, v_mfma_f32_16x16x4_f32).
+//
+// The reference hands n_neurons / n_hidden_layers straight to tinycudann (src/models/nerf_tcnn.py:29-38, schema
+// cfg/nerf_config/default_nerf_hash.yaml:20-31); the fused kernels of this library keep a network's weights and its whole weight
+// gradient on chip (LDS / accumulator registers of ONE workgroup), which ends at one 256 x 256 matrix: 256 KB in fp32, more than the
+// LDS and more than a workgroup's registers.  This file is the route for that shape class, LAYER BY LAYER through HBM:
+//   * the samples are processed in chunks of LNR_WIDE_CHUNK; a chunk's pre-activations Z_l [256][chunk] of every hidden layer and its
+//     dZ planes live in the workspace (0.5 - 0.7 GB), so the batch size does not bound the memory;
+//   * forward of a layer: a wave owns 16 samples, all 256 rows; weights stream from L2 (wide_layer_fwd_kernel);
+//   * the WEIGHT GRADIENT dW_l = dZ_l a_{l-1}^T is split over samples ACROSS workgroups (split-K): a workgroup owns a 64 x 64 tile of
+//     dW and one of S sample ranges of the chunk, both operands are read straight from the [row][sample] planes as 16-byte loads
+//     (4 consecutive samples = the K dimension of one MFMA: no transposition anywhere), accumulators in registers, one partial slab
+//     per sample range, folded in a fixed order (wide_dw_kernel / wide_fold_kernel: deterministic, no atomics);
+//   * back-propagation dA_{l-1} = W_l^T dZ_l per 16-sample tile with the activation derivative applied on the way out.
+// Precision: LNR_PREC_F32 / LNR_PREC_F32_CHAIN - exact fp32 fma chains; LNR_PREC_F16 (HALF) - the reference's storage model of
+// oracle/network.py: weights and every layer's inputs rounded to fp16 where they are consumed, products and sums in fp32 (a product of
+// two fp16 values is exact in fp32, so the fp32 MFMA computes what the f16 MFMA with fp32 accumulation computes), gradients straight
+// through the rounding, in fp32.  Semantics = oracle/network.py.  Built for coverage of the configuration schema, not for speed: the
+// planes cross HBM once per layer and direction (see DESIGN.md 4.6 for the measured times).
+#include "lnr_f16_common.h"
+
+#define LNR_WIDE_CHUNK 131072          // samples per chunk (a multiple of 64): 128 MB per [256][chunk] fp32 plane set
+#define LNR_WIDE_SPLITS 32             // sample ranges of a chunk in the weight-gradient kernel (partial slabs 1 .. S)
+#define LNR_WIDE_H 256
+
+enum { WIDE_IN_FEAT = 0, WIDE_IN_PAIR = 1, WIDE_IN_Z = 2 };
+
+struct WideSamples {                   // which samples a launch works on
+    int64_t lo, n;                     // chunk = samples [lo, lo + n) of the batch
+    int64_t n_points; const int32_t* n_rays_dev; int32_t n_rays, n_samples;      // the batch's live sample count (live_samples)
+};
+__device__ __forceinline__ int64_t wide_live(const WideSamples& s) {
+    const int64_t M = live_samples(s.n_points, s.n_rays_dev, s.n_rays, s.n_samples) - s.lo;     // live samples of this chunk
+    return M < 0 ? 0 : (M < s.n ? M : s.n);
+}
+
+template <bool HALF> __device__ __forceinline__ float wide_w(float v) { return HALF ? round_f16(v) : v; }
+
+// one input value of a layer: input k of batch sample m (chunk-local sample ml)
+template <bool HALF, int IN>
+__device__ __forceinline__ float wide_input(const float* __restrict__ in, int64_t stride, int k, int enc_dim, int64_t m, int64_t ml, int act) {
+    if (IN == WIDE_IN_FEAT) return k < enc_dim ? in[(size_t)k * stride + m] : 1.0f;
+    if (IN == WIDE_IN_PAIR) {
+        if (k >= enc_dim) return 1.0f;
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 p = __builtin_bit_cast(h2, reinterpret_cast<const uint32_t*>(in)[(size_t)(k >> 1) * stride + m]);
+        return (float)((k & 1) ? p.y : p.x);
+    }
+    const float a = act_fwd(in[(size_t)k * stride + ml], act);
+    return HALF ? round_f16(a) : a;
+}
+
+// Z_out[j][ml] = sum_k W[j][k] in_k(ml): a wave owns a 16-sample tile, all 256 rows (64 accumulator registers)
+template <bool HALF, int IN>
+__global__ void __launch_bounds__(256)
+wide_layer_fwd_kernel(const float* __restrict__ W, int K, const float* __restrict__ in, int64_t in_stride, int enc_dim, int act,
+                      WideSamples smp, float* __restrict__ z_out, int64_t chp) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int64_t M = wide_live(smp);
+    const int64_t n_tiles = (M + 15) / 16;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        int64_t ml = tile * 16 + c;
+        if (ml >= M) ml = M - 1;                                  // (finite operands for the padding columns; their rows are never read as live)
+        const int64_t m = smp.lo + ml;
+        f32x4 Z[16];
+#pragma unroll
+        for (int jt = 0; jt < 16; ++jt) Z[jt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int kt = 0; kt < K / 16; ++kt) {
+            float x[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = wide_input<HALF, IN>(in, in_stride, 16 * kt + 4 * g + r, enc_dim, m, ml, act);
+                x[r] = (HALF && IN == WIDE_IN_FEAT) ? round_f16(v) : v;
+            }
+#pragma unroll
+            for (int jt = 0; jt < 16; ++jt) {
+                float4 wa = *reinterpret_cast<const float4*>(W + (size_t)(16 * jt + c) * K + 16 * kt + 4 * g);
+                if (HALF) { wa.x = round_f16(wa.x); wa.y = round_f16(wa.y); wa.z = round_f16(wa.z); wa.w = round_f16(wa.w); }
+                MFMA4(Z[jt], wa, x[0], x[1], x[2], x[3]);
+            }
+        }
+        const int64_t col = tile * 16 + c;                        // (chunk planes are padded to whole tiles: store unconditionally)
+#pragma unroll
+        for (int jt = 0; jt < 16; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z_out[(size_t)(16 * jt + 4 * g + r) * chp + col] = Z[jt][r];
+    }
+}
+
+// sigma = w_out . act(Z_L) (the last hidden activation is NOT rounded in the storage model: oracle/network.py density_unit)
+template <bool HALF>
+__global__ void __launch_bounds__(256)
+wide_out_kernel(const float* __restrict__ wo, int act, const float* __restrict__ z, int64_t chp, WideSamples smp, float* __restrict__ sigma,
+                int32_t* __restrict__ clip_flag) {
+    __shared__ float w_s[LNR_WIDE_H];
+    for (int i = threadIdx.x; i < LNR_WIDE_H; i += blockDim.x) w_s[i] = wide_w<HALF>(wo[i]);
+    __syncthreads();
+    const int64_t M = wide_live(smp);
+    for (int64_t ml = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ml < M; ml += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.0f;
+        for (int j = 0; j < LNR_WIDE_H; ++j) s = __builtin_fmaf(w_s[j], act_fwd(z[(size_t)j * chp + ml], act), s);
+        sigma[smp.lo + ml] = HALF ? finite_or_clipped<true>(s, clip_flag) : finite_or_clipped<false>(s, clip_flag);
+    }
+}
+
+// dZ_L[j][ml] = d_sigma[m] w_out[j] act'(Z_L[j][ml]); columns past the live count (up to the next multiple of 16) are zeroed: the
+// weight-gradient kernel reads whole 16-sample tiles
+template <bool HALF>
+__global__ void __launch_bounds__(256)
+wide_dz_out_kernel(const float* __restrict__ wo, int act, const float* __restrict__ z, int64_t chp, WideSamples smp,
+                   const float* __restrict__ d_sigma, float* __restrict__ dz) {
+    __shared__ float w_s[LNR_WIDE_H];
+    for (int i = threadIdx.x; i < LNR_WIDE_H; i += blockDim.x) w_s[i] = wide_w<HALF>(wo[i]);
+    __syncthreads();
+    const int64_t M = wide_live(smp);
+    const int64_t M16 = (M + 15) / 16 * 16;
+    for (int64_t ml = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ml < M16; ml += (int64_t)gridDim.x * blockDim.x) {
+        const float ds = ml < M ? d_sigma[smp.lo + ml] : 0.0f;
+        for (int j = 0; j < LNR_WIDE_H; ++j)
+            dz[(size_t)j * chp + ml] = ml < M ? ds * w_s[j] * act_bwd(z[(size_t)j * chp + ml], act) : 0.0f;
+    }
+}
+
+// d w_out[j] += sum over the chunk of d_sigma[m] act(Z_L[j][ml]): one workgroup per row j (the same one in every chunk: the
+// accumulation order is fixed)
+__global__ void __launch_bounds__(256)
+wide_dwo_kernel(int act, const float* __restrict__ z, int64_t chp, WideSamples smp, const float* __restrict__ d_sigma, float* __restrict__ dwo) {
+    __shared__ float part[4];
+    const int j = blockIdx.x;
+    const int64_t M = wide_live(smp);
+    float s = 0.0f;
+    for (int64_t ml = threadIdx.x; ml < M; ml += blockDim.x) s = __builtin_fmaf(d_sigma[smp.lo + ml], act_fwd(z[(size_t)j * chp + ml], act), s);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) dwo[j] += (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+// partial[split][j][k] = sum over the split's sample tiles of dZ[j][s] in_k[s]: workgroup = (64-row block, 64-column block, split),
+// wave w = row tile 4 rb + w, up to four 16-column tiles; both operands are 16-byte loads of 4 consecutive samples of one row
+template <bool HALF, int IN>
+__global__ void __launch_bounds__(256)
+wide_dw_kernel(const float* __restrict__ dz, int64_t chp, const float* __restrict__ in, int64_t in_stride, int enc_dim, int K, int act,
+               WideSamples smp, float* __restrict__ partial, int64_t n_mlp, int64_t layer_off) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int n_cb = (K + 63) / 64;
+    const int rb = blockIdx.x % 4, cb = (blockIdx.x / 4) % n_cb, split = blockIdx.x / (4 * n_cb);
+    const int jt = 4 * rb + wave;
+    const int64_t M = wide_live(smp);
+    const int64_t n_tiles = (M + 15) / 16;
+    f32x4 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int64_t tile = split; tile < n_tiles; tile += LNR_WIDE_SPLITS) {
+        const int64_t s0 = tile * 16 + 4 * g;                                 // the lane's four samples (chunk-local)
+        const float4 a4 = *reinterpret_cast<const float4*>(dz + (size_t)(16 * jt + c) * chp + s0);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            const int k = 64 * cb + 16 * ct + c;
+            if (64 * cb + 16 * ct >= K) continue;                              // (wave-uniform: a ragged last column block)
+            float b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int64_t ml = s0 + i;
+                if (ml >= M) ml = M - 1;                                       // (dZ of a padding sample is 0: any finite value will do)
+                const float v = wide_input<HALF, IN>(in, in_stride, k, enc_dim, smp.lo + ml, ml, act);
+                b[i] = (HALF && IN == WIDE_IN_FEAT) ? round_f16(v) : v;
+            }
+            MFMA4(acc[ct], a4, b[0], b[1], b[2], b[3]);
+        }
+    }
+    float* out = partial + (size_t)(1 + split) * n_mlp + layer_off;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        if (64 * cb + 16 * ct >= K) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(size_t)(16 * jt + 4 * g + r) * K + 64 * cb + 16 * ct + c] = acc[ct][r];
+    }
+}
+
+// total[off + i] += sum over the splits of partial[1 + s][off + i], s ascending (fixed order)
+__global__ void __launch_bounds__(256)
+wide_fold_kernel(float* __restrict__ slabs, int64_t n_mlp, int64_t off, int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float s = 0.0f;
+    for (int sp = 0; sp < LNR_WIDE_SPLITS; ++sp) s += slabs[(size_t)(1 + sp) * n_mlp + off + i];
+    slabs[off + i] += s;
+}
+
+// out_k[ml] = sum_j W[j][k] dZ[j][ml]: a wave owns a 16-sample tile (its dZ column: 64 registers), W^T operands stream from L2.
+// TO_FEAT: the result is the d_feature planes (rows < enc_dim, live samples); else it is multiplied by act'(Z_prev[k][ml]) and
+// becomes the previous layer's dZ (padding columns zero)
+template <bool HALF, bool TO_FEAT>
+__global__ void __launch_bounds__(256)
+wide_dx_kernel(const float* __restrict__ W, int K, const float* __restrict__ dz, int64_t chp, int act, WideSamples smp,
+               const float* __restrict__ z_prev, float* __restrict__ out, int64_t out_stride, int enc_dim) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int64_t M = wide_live(smp);
+    const int64_t n_tiles = (M + 15) / 16;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t ml = tile * 16 + c;
+        const bool valid = ml < M;
+        float d[16][4];
+#pragma unroll
+        for (int jt = 0; jt < 16; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d[jt][r] = dz[(size_t)(16 * jt + 4 * g + r) * chp + ml];          // (whole tiles exist: padding columns are 0)
+        for (int kt = 0; kt < K / 16; ++kt) {
+            f32x4 D = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int jt = 0; jt < 16; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    D = __builtin_amdgcn_mfma_f32_16x16x4f32(wide_w<HALF>(W[(size_t)(16 * jt + 4 * g + r) * K + 16 * kt + c]), d[jt][r], D, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 16 * kt + 4 * g + r;
+                if (TO_FEAT) { if (valid && k < enc_dim) out[(size_t)k * out_stride + smp.lo + ml] = D[r]; }
+                else out[(size_t)k * out_stride + ml] = valid ? D[r] * act_bwd(z_prev[(size_t)k * chp + ml], act) : 0.0f;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+bool lnr_wide_class(const LnrNetSpec* spec) {
+    return spec->n_neurons == LNR_WIDE_H && spec->n_hidden >= 2 && spec->n_hidden <= 3 && spec->in_dim % 16 == 0 &&
+           (spec->precision != LNR_PREC_F16 || ((spec->enc_dim & 1) == 0 && !(spec->encoding == LNR_ENC_HASHGRID && (spec->n_features & 1))));
+}
+
+// bytes of chunk planes behind the other workspace regions: Z of every hidden layer + two dZ buffers, [256][LNR_WIDE_CHUNK] each
+size_t lnr_wide_workspace(const LnrNetSpec* spec) {
+    if (!lnr_wide_class(spec)) return 0;
+    return (size_t)(spec->n_hidden + 2) * LNR_WIDE_H * LNR_WIDE_CHUNK * sizeof(float);
+}
+int lnr_wide_slabs(void) { return 1 + LNR_WIDE_SPLITS; }
+
+namespace {
+struct WideCtx {
+    const LnrNetSpec* spec; const float* params; const float* feat; int64_t m_pad; const MlpPoints* pt; float* planes; hipStream_t st;
+    bool half; int H, NH, K1, act;
+    float* z(int l) const { return planes + (size_t)l * LNR_WIDE_H * LNR_WIDE_CHUNK; }            // pre-activations of hidden layer l (0-based)
+    float* dzbuf(int i) const { return planes + (size_t)(NH + i) * LNR_WIDE_H * LNR_WIDE_CHUNK; }
+    const float* W(int l) const { return l == 0 ? params : params + (size_t)H * K1 + (size_t)(l - 1) * H * H; }
+    const float* Wo() const { return params + (size_t)H * K1 + (size_t)(NH - 1) * H * H; }
+    WideSamples samples(int64_t lo, int64_t n) const { return WideSamples{lo, n, pt->n_points, pt->n_rays_dev, pt->n_rays, pt->n_samples}; }
+};
+
+template <bool HALF>
+static void wide_forward_chunk(const WideCtx& c, const WideSamples& s) {
+    const dim3 block(256);
+    const int64_t tiles = (s.n + 15) / 16;
+    const dim3 grid((unsigned)((tiles + 3) / 4 > 2048 ? 2048 : (tiles + 3) / 4));
+    if (HALF) hipLaunchKernelGGL((wide_layer_fwd_kernel<HALF, WIDE_IN_PAIR>), grid, block, 0, c.st, c.W(0), c.K1, c.feat, c.m_pad, c.spec->enc_dim, c.act, s, c.z(0), (int64_t)LNR_WIDE_CHUNK);
+    else hipLaunchKernelGGL((wide_layer_fwd_kernel<HALF, WIDE_IN_FEAT>), grid, block, 0, c.st, c.W(0), c.K1, c.feat, c.m_pad, c.spec->enc_dim, c.act, s, c.z(0), (int64_t)LNR_WIDE_CHUNK);
+    for (int l = 1; l < c.NH; ++l)
+        hipLaunchKernelGGL((wide_layer_fwd_kernel<HALF, WIDE_IN_Z>), grid, block, 0, c.st, c.W(l), c.H, c.z(l - 1), (int64_t)LNR_WIDE_CHUNK, c.H, c.act, s, c.z(l), (int64_t)LNR_WIDE_CHUNK);
+}
+
+template <bool HALF>
+static int wide_forward(const WideCtx& c, float* sigma) {
+    for (int64_t lo = 0; lo < c.pt->n_points; lo += LNR_WIDE_CHUNK) {
+        const int64_t n = c.pt->n_points - lo < LNR_WIDE_CHUNK ? c.pt->n_points - lo : LNR_WIDE_CHUNK;
+        const WideSamples s = c.samples(lo, n);
+        wide_forward_chunk<HALF>(c, s);
+        hipLaunchKernelGGL(wide_out_kernel<HALF>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.st, c.Wo(), c.act, c.z(c.NH - 1), (int64_t)LNR_WIDE_CHUNK, s, sigma, c.pt->clip_flag);
+    }
+    return LNR_OK;
+}
+
+template <bool HALF>
+static int wide_backward(const WideCtx& c, const float* d_sigma, float* dfeat, float* slabs, int want_dfeat, int want_dw) {
+    const int64_t n_mlp = c.spec->n_mlp_params;
+    if (hipMemsetAsync(slabs, 0, (size_t)n_mlp * sizeof(float), c.st) != hipSuccess) { lnr_set_error("lnr_density_backward: hipMemsetAsync failed"); return LNR_ERR_LAUNCH; }
+    const dim3 block(256);
+    const int64_t off_o = (int64_t)c.H * c.K1 + (int64_t)(c.NH - 1) * c.H * c.H;
+    for (int64_t lo = 0; lo < c.pt->n_points; lo += LNR_WIDE_CHUNK) {
+        const int64_t n = c.pt->n_points - lo < LNR_WIDE_CHUNK ? c.pt->n_points - lo : LNR_WIDE_CHUNK;
+        const WideSamples s = c.samples(lo, n);
+        const int64_t tiles = (n + 15) / 16;
+        const dim3 grid_t((unsigned)((tiles + 3) / 4 > 2048 ? 2048 : (tiles + 3) / 4));
+        const dim3 grid_s((unsigned)((n + 255) / 256));
+        wide_forward_chunk<HALF>(c, s);
+        float* dz = c.dzbuf(0);
+        float* dz_other = c.dzbuf(1);
+        hipLaunchKernelGGL(wide_dz_out_kernel<HALF>, grid_s, block, 0, c.st, c.Wo(), c.act, c.z(c.NH - 1), (int64_t)LNR_WIDE_CHUNK, s, d_sigma, dz);
+        if (want_dw) hipLaunchKernelGGL(wide_dwo_kernel, dim3(LNR_WIDE_H), block, 0, c.st, c.act, c.z(c.NH - 1), (int64_t)LNR_WIDE_CHUNK, s, d_sigma, slabs + off_o);
+        for (int l = c.NH - 1; l >= 0; --l) {
+            const int K = l == 0 ? c.K1 : c.H;
+            const int64_t layer_off = l == 0 ? 0 : (int64_t)c.H * c.K1 + (int64_t)(l - 1) * c.H * c.H;
+            const dim3 grid_w((unsigned)(4 * ((K + 63) / 64) * LNR_WIDE_SPLITS));
+            if (!want_dw) {}                                       // frozen parameters (tracking phase): the input gradient only
+            else if (l > 0) hipLaunchKernelGGL((wide_dw_kernel<HALF, WIDE_IN_Z>), grid_w, block, 0, c.st, dz, (int64_t)LNR_WIDE_CHUNK, c.z(l - 1), (int64_t)LNR_WIDE_CHUNK, c.H, K, c.act, s, slabs, n_mlp, layer_off);
+            else if (HALF) hipLaunchKernelGGL((wide_dw_kernel<HALF, WIDE_IN_PAIR>), grid_w, block, 0, c.st, dz, (int64_t)LNR_WIDE_CHUNK, c.feat, c.m_pad, c.spec->enc_dim, K, c.act, s, slabs, n_mlp, layer_off);
+            else hipLaunchKernelGGL((wide_dw_kernel<HALF, WIDE_IN_FEAT>), grid_w, block, 0, c.st, dz, (int64_t)LNR_WIDE_CHUNK, c.feat, c.m_pad, c.spec->enc_dim, K, c.act, s, slabs, n_mlp, layer_off);
+            const int64_t count = (int64_t)c.H * K;
+            if (want_dw) hipLaunchKernelGGL(wide_fold_kernel, dim3((unsigned)((count + 255) / 256)), block, 0, c.st, slabs, n_mlp, layer_off, count);
+            if (l > 0) {
+                hipLaunchKernelGGL((wide_dx_kernel<HALF, false>), grid_t, block, 0, c.st, c.W(l), K, dz, (int64_t)LNR_WIDE_CHUNK, c.act, s, c.z(l - 1), dz_other, (int64_t)LNR_WIDE_CHUNK, K);
+                float* t = dz; dz = dz_other; dz_other = t;
+            } else if (want_dfeat) {
+                hipLaunchKernelGGL((wide_dx_kernel<HALF, true>), grid_t, block, 0, c.st, c.W(0), K, dz, (int64_t)LNR_WIDE_CHUNK, c.act, s, (const float*)nullptr, dfeat, c.m_pad, c.spec->enc_dim);
+            }
+        }
+    }
+    return LNR_OK;
+}
+
+static WideCtx wide_ctx(const LnrNetSpec* spec, const float* params, const float* feat, int64_t m_pad, const MlpPoints* pt, void* planes, hipStream_t st) {
+    return WideCtx{spec, params, feat, m_pad, pt, (float*)planes, st, spec->precision == LNR_PREC_F16, spec->n_neurons, spec->n_hidden, spec->in_dim, spec->activation};
+}
+}  // namespace
+
+int lnr_mlp_fwd_wide(const LnrNetSpec* spec, const float* params, const float* feat, int64_t m_pad, const MlpPoints* pt, float* sigma,
+                     void* planes, hipStream_t st) {
+    const WideCtx c = wide_ctx(spec, params, feat, m_pad, pt, planes, st);
+    return c.half ? wide_forward<true>(c, sigma) : wide_forward<false>(c, sigma);
+}
+
+// the weight gradient lands in slab 0 (slabs 1 .. LNR_WIDE_SPLITS are the weight-gradient kernel's partial sums): *n_slabs = 1
+int lnr_mlp_bwd_wide(const LnrNetSpec* spec, const float* params, const float* feat, int64_t m_pad, const MlpPoints* pt, const float* d_sigma,
+                     float* dfeat, float* slabs, int want_dfeat, int want_dw, int* n_slabs, void* planes, hipStream_t st) {
+    const WideCtx c = wide_ctx(spec, params, feat, m_pad, pt, planes, st);
+    *n_slabs = 1;
+    return c.half ? wide_backward<true>(c, d_sigma, dfeat, slabs, want_dfeat, want_dw) : wide_backward<false>(c, d_sigma, dfeat, slabs, want_dfeat, want_dw);
+}

@@ -198,6 +198,11 @@ NETS = {
     "freq16_h16": (dict(otype="Frequency", n_frequencies=16), dict(activation="Softplus", n_neurons=16, n_hidden_layers=1)),
     "freq_tanh128": (dict(otype="Frequency", n_frequencies=5), dict(activation="Tanh", n_neurons=128, n_hidden_layers=2)),
     "freq_relu128x3": (dict(otype="Frequency", n_frequencies=12), dict(activation="ReLU", n_neurons=128, n_hidden_layers=3)),
+    # 256 neurons x 2..3 hidden layers: the layer-by-layer route with the split-K weight gradient (lnr_density_wide.hip)
+    "freq_wide256x2": (dict(otype="Frequency", n_frequencies=6), dict(activation="ReLU", n_neurons=256, n_hidden_layers=2)),
+    "hash_wide256x3": (dict(otype="HashGrid", n_levels=8, n_features_per_level=2, log2_hashmap_size=12, base_resolution=8),
+                       dict(activation="LeakyReLU", n_neurons=256, n_hidden_layers=3)),
+    "freq_sine256x2": (dict(otype="Frequency", n_frequencies=12), dict(activation="Sine", n_neurons=256, n_hidden_layers=2)),
 }
 
 
@@ -297,9 +302,11 @@ def test_density_backward_matches_oracle_autograd(ops, name):
     assert rel(grad2, grad) < 1e-6
 
 
-@pytest.mark.parametrize("name", ["freq_relu128", "freq_relu128x3", "freq_wide256", "freq_siren", "hash_f4_2hidden"])
+@pytest.mark.parametrize("name", ["freq_relu128", "freq_relu128x3", "freq_wide256", "freq_siren", "hash_f4_2hidden", "freq_wide256x2", "hash_wide256x3"])
 def test_general_fp32_backward_over_many_steps(ops, name):
-    """mlp_backward_regs_kernel (lnr_density_regs.h) beyond one step per workgroup: 256 workgroups x 64 samples per step, so 40 013 points
+    """(the two 256 x n networks: the layer-by-layer route, lnr_density_wide.hip - 40 013 points are a partly filled chunk whose weight
+    gradient is split over 32 sample ranges; test_wide_networks_across_chunks covers several chunks)
+    mlp_backward_regs_kernel (lnr_density_regs.h) beyond one step per workgroup: 256 workgroups x 64 samples per step, so 40 013 points
     are three steps with a ragged last tile, the inputs of step i + 1 requested during step i; a stretch of 20 000 points without gradient
     makes whole steps take the workgroup-uniform skip (their d_feature rows must still come out zero), single points without gradient sit
     inside live tiles.  The five networks cover the three homes of the weights (all in LDS, hidden matrices only, none), 4 / 8 / 16 row
@@ -323,6 +330,52 @@ def test_general_fp32_backward_over_many_steps(ops, name):
     grad2 = torch.zeros_like(grad)
     assert ops.density_backward(spec_h, dv(params), dv(d_sigma), grad2, pts=dv(pts), want_d_pts=False) is None
     assert rel(grad2, grad) < 1e-6
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_wide_networks_across_chunks(ops, prec):
+    """256 x 2 through the layer-by-layer route over MORE than two chunks of 131 072 samples (rays form, a device-side live count that
+    ends inside the last chunk): sigma of a subset and the full gradient against the oracle - evaluated chunk by chunk on the CPU with
+    the same arithmetic model - and the padding rays beyond the live count untouched."""
+    from loner_amd import hip
+    enc, net = NETS["freq_wide256x2"]
+    net = dict(net, precision=prec)
+    spec_o, spec_h = NW.NetworkSpec.from_config(enc, net), hip.make_net_spec(enc, net)
+    params = NW.init_params(spec_o, 4)
+    gen = torch.Generator().manual_seed(21)
+    n_rays, S, live = 2200, 128, 2100                      # 281 600 sample slots, 268 800 live: two full chunks + 6 656 samples
+    rays = torch.zeros(n_rays, 13)
+    rays[:, 0:3] = torch.rand(n_rays, 3, generator=gen) * 0.6 - 0.3
+    rays[:, 3:6] = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=gen), dim=1)
+    z = torch.sort(torch.rand(n_rays, S, generator=gen) * 0.6, dim=1).values
+    d_sigma = torch.randn(n_rays, S, generator=gen)
+    d_sigma[torch.rand(n_rays, S, generator=gen) < 0.5] = 0.0
+    n_dev = torch.tensor([live], dtype=torch.int32, device=DEV)
+    R, Z = dv(rays), dv(z)
+    sig = ops.density_forward(spec_h, dv(params), rays=R, z=Z, n_rays_dev=n_dev)
+    grad = torch.zeros(int(spec_h.n_params), device=DEV)
+    d_rays = torch.zeros(n_rays, 13, device=DEV)
+    ops.density_backward(spec_h, dv(params), dv(d_sigma), grad, rays=R, z=Z, n_rays_dev=n_dev, reuse_features=True, d_rays=d_rays)
+    p = params.clone().requires_grad_(True)
+    ref_rows = torch.cat([torch.arange(0, 3), torch.arange(1022, 1026), torch.arange(2046, 2050), torch.arange(live - 3, live)])   # around the chunk seams (1024, 2048) and the end
+    total = torch.zeros(())
+    sig_ref = {}
+    for lo in range(0, live, 300):                                       # the oracle in pieces (memory), the gradient accumulates
+        hi = min(lo + 300, live)
+        pts = (rays[lo:hi, None, 0:3] + rays[lo:hi, None, 3:6] * z[lo:hi, :, None]).reshape(-1, 3)
+        s_ = NW.density(spec_o, p, pts).reshape(hi - lo, S)
+        (s_ * d_sigma[lo:hi]).sum().backward()
+        for r in ref_rows.tolist():
+            if lo <= r < hi:
+                sig_ref[r] = s_[r - lo].detach()
+    tol_s, tol_g = (1e-5, 3e-5) if prec == "fp32" else (2e-3, 3e-3)
+    scale = max(float(v.abs().max()) for v in sig_ref.values())
+    for r, v in sig_ref.items():
+        assert float((sig[r].cpu() - v).abs().max()) / scale < tol_s, r
+    e_g = rel(grad, p.grad)
+    print(f"256 x 2 over three chunks ({prec}): dparams rel {e_g:.2e}")
+    assert e_g < tol_g
+    assert float(d_rays[live:].abs().max()) == 0.0 and float(d_rays[:live, 0:6].abs().max()) > 0.0
 
 
 @pytest.mark.parametrize("name", ["default", "freq_siren"])
@@ -822,7 +875,7 @@ def test_fp16_mode_config5_4096x256(ops):
 
 
 @pytest.mark.parametrize("name", ["hash_f4_2hidden", "hash_f8", "freq_siren", "freq_relu128", "small_hash", "freq_wide256", "freq_relu3",
-                                  "freq_tanh2", "freq_sine16", "freq12_small", "freq16_h16", "freq_tanh128"])
+                                  "freq_tanh2", "freq_sine16", "freq12_small", "freq16_h16", "freq_tanh128", "freq_wide256x2", "hash_wide256x3"])
 def test_fp16_mode_general_networks(ops, name):
     """precision fp16 beyond the reference's default shape: frequency encoding + SIREN / wide ReLU MLPs, several hidden layers,
     4 or 8 features per level - forward and every gradient against the oracle with the same storage rounding (fp16 features,
@@ -864,8 +917,8 @@ def test_fp16_mode_general_networks(ops, name):
 
 def test_fp16_mode_refuses_what_it_does_not_cover(ops):
     from loner_amd import hip
-    wide2 = (NETS["freq_wide256"][0], dict(NETS["freq_wide256"][1], n_hidden_layers=2))
-    for enc, net in (NETS["hash_f1"], wide2):                     # odd feature count per level; a 256 x 256 hidden matrix
+    many_inputs = (dict(otype="Frequency", n_frequencies=24), dict(activation="ReLU", n_neurons=128, n_hidden_layers=2))
+    for enc, net in (NETS["hash_f1"], many_inputs):               # odd feature count per level; 144 inputs into a 128-wide network
         bad = hip.make_net_spec(enc, dict(net, precision="fp16"))
         with pytest.raises(RuntimeError, match="fp16"):
             ops.density_forward(bad, torch.zeros(int(bad.n_params), device=DEV), pts=torch.zeros(64, 3, device=DEV))
