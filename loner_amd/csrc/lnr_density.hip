@@ -417,6 +417,13 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
     Layout L;
     L.m_pad = (n_points + 63) / 64 * 64;
     if (L.m_pad < 64) L.m_pad = 64;
+    // Plane skew: the MLP kernels read / write all 32 feature (d_feature) planes of the same samples at once, and the bench window's
+    // planes are 2^21 samples = 8 MiB apart - a power-of-two stride puts the 32 concurrent streams on the same HBM channel / cache set
+    // bits.  A plane stride that is a multiple of 64 KiB gets 17 x 256 bytes on top (LNR_PLANE_SKEW floats; 0 switches it off: A/B).
+#ifndef LNR_PLANE_SKEW
+#define LNR_PLANE_SKEW 1088
+#endif
+    if (LNR_PLANE_SKEW > 0 && (L.m_pad * (int64_t)sizeof(float)) % 65536 == 0) L.m_pad += LNR_PLANE_SKEW;
     const bool hash = spec->encoding == LNR_ENC_HASHGRID;
     L.n_groups = hash ? spec->n_levels : 1;
     L.shift = LNR_SLICE_SHIFT;

@@ -228,8 +228,12 @@ wide_dx_kernel(const float* __restrict__ W, int K, const float* __restrict__ dz,
 
 // ------------------------------------------------------------------------------------------------ host side
 bool lnr_wide_class(const LnrNetSpec* spec) {
-    return spec->n_neurons == LNR_WIDE_H && spec->n_hidden >= 2 && spec->n_hidden <= 3 && spec->in_dim % 16 == 0 &&
-           (spec->precision != LNR_PREC_F16 || ((spec->enc_dim & 1) == 0 && !(spec->encoding == LNR_ENC_HASHGRID && (spec->n_features & 1))));
+    if (spec->n_neurons != LNR_WIDE_H || spec->n_hidden < 1 || spec->n_hidden > 3 || spec->in_dim % 16 != 0) return false;
+    const bool f16 = spec->precision == LNR_PREC_F16;
+    if (f16 && ((spec->enc_dim & 1) || (spec->encoding == LNR_ENC_HASHGRID && (spec->n_features & 1)))) return false;    // pair planes
+    // one hidden layer: the fused kernels (fp32: lnr_density_regs.h; fp16: lnr_f16_*_kernel.h unless its LDS budget says no, e.g. 80
+    // inputs); two and three: always here
+    return spec->n_hidden >= 2 || (f16 && !lnr_f16_supported(spec));
 }
 
 // bytes of chunk planes behind the other workspace regions: Z of every hidden layer + two dZ buffers, [256][LNR_WIDE_CHUNK] each

@@ -138,6 +138,22 @@ def _worker(rank, world, port, ret, backend, n_kf, n_it, keyed, exchange="all_re
                      grid=blobs[3].cpu().numpy(), poses=[kf.get_lidar_pose().get_pose_tensor().detach().cpu().numpy() for kf in window],
                      n_valid=opt.last_stats["n_valid_rays"], adam_steps=opt._optimizer.state[opt._model.nerf_model._model_sigma.params]["step"],
                      exchange=ctx.exchange, owned_range=ctx.owned_range(blobs[0].numel()))
+    if default_net:
+        # the exchange itself at this world size on the device tensors of the default network, against a closed form: rank r contributes
+        # (r + 1) everywhere and i mod 7 on top; zero_rest=False is the training loop's form (the rest keeps the rank's own values)
+        n = blobs[0].numel()
+        ramp = (torch.arange(n, device="cuda") % 7).float()
+        flat = ramp + float(rank + 1)
+        ctx.exchange_grads(flat, async_op=True, zero_rest=False).wait()
+        total = world * ramp + float(world * (world + 1) // 2)
+        sl = ctx.owned_range(n)
+        if sl is None:
+            ok = bool(torch.equal(flat, total))
+        else:
+            ok = bool(torch.equal(flat[sl[0]:sl[1]], total[sl[0]:sl[1]])) and bool(torch.equal(flat[:sl[0]], (ramp + float(rank + 1))[:sl[0]]))
+            ctx.gather_params(flat)
+            ok = ok and bool(torch.equal(flat, total))
+        ret[rank] = dict(ret[rank], exchange_exact=ok)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -279,9 +295,12 @@ def test_eight_ranks_default_network_reduce_scatter_equals_single_gpu():
     """BASELINE configs[3] as far as one GPU can execute it: an 8-keyframe window sharded one keyframe per rank over EIGHT processes
     (gloo between them; every rank runs the HIP kernels on the shared MI355X), default network (16 x 2^18-entry levels, 7.4 M
     parameters), the exchange left at its default - `reduce_scatter` from 4 ranks: eight 927 104-float chunks, ranged Adam, all-gather -
-    6 iterations incl. the occupancy step at global step 0.  On keyframe-keyed draws the window's loss trace, the final parameters,
+    3 iterations incl. the occupancy step at global step 0 (the L1 line-of-sight loss has a sign() in its gradient and Adam's steps are
+    sign-sized: two CORRECT runs that differ in summation order drift apart by a factor ~5 per iteration - 0.7 % of the entries are off
+    by > 1e-3 after 4 iterations, 32 % after 6, measured - so the comparison is made early, and the exchange is ALSO checked directly
+    against a closed form on the same 8 ranks and device tensors).  On keyframe-keyed draws the window's loss trace, the final parameters,
     the grid and the poses equal the single-GPU run; the replicas are identical; every rank stepped exactly its chunk."""
-    n_it = 6
+    n_it = 3
     single = _single(8, n_it, keyed=True, default_net=True)
     rs = _run(8, "gloo", 8, n_it, keyed=True, exchange=None, default_net=True, timeout=900)
     assert [r["owned"] for r in rs] == [[k] for k in range(8)] and all(r["exchange"] == "reduce_scatter" for r in rs)
@@ -300,7 +319,8 @@ def test_eight_ranks_default_network_reduce_scatter_equals_single_gpu():
     dp = np.abs(rs[0]["params"] - single["params"])
     print("8 ranks vs single GPU: loss terms rel", rel_loss, " params: max", dp.max(), "99.9 % quantile", np.quantile(dp, 0.999), "fraction > 1e-3", (dp > 1e-3).mean())
     assert np.abs(loss[0] - ref[0]).max() <= 2e-6 * np.abs(ref[0]).max()            # first iteration: same parameters, same draws
-    assert rel_loss.max() < 3e-3 and np.quantile(dp, 0.999) < 2e-3 and (dp > 1e-3).mean() < 1e-2 and dp.max() <= 2.001e-2 * n_it
+    assert rel_loss.max() < 2e-3 and np.quantile(dp, 0.99) < 1e-4 and (dp > 3e-4).mean() < 2e-2 and dp.max() <= 2.001e-2 * n_it
+    assert all(r["exchange_exact"] for r in rs)                  # reduce-scatter + all-gather of 8 x 927 104 floats: the exact sums
     assert np.abs(rs[0]["grid"] - single["grid"]).max() < 1e-3 * max(np.abs(single["grid"]).max(), 1e-12)
     for k in range(8):
         assert np.abs(rs[k]["poses"][k] - single["poses"][k]).max() < 2e-5
@@ -310,7 +330,7 @@ def test_eight_ranks_default_network_reduce_scatter_equals_single_gpu():
 def test_eight_ranks_five_keyframes_three_idle_ranks():
     """A 5-keyframe window on 8 ranks (the first keyframes of every run): ranks 5-7 own nothing, join every collective with an empty
     front record and a zero gradient, step their chunk of the parameters like everyone else and end with the same replica."""
-    n_it = 4
+    n_it = 3
     single = _single(5, n_it, keyed=True, default_net=True)
     rs = _run(8, "gloo", 5, n_it, keyed=True, exchange=None, default_net=True, timeout=900)
     assert [r["owned"] for r in rs] == [[0], [1], [2], [3], [4], [], [], []]
@@ -318,10 +338,10 @@ def test_eight_ranks_five_keyframes_three_idle_ranks():
     assert all(same_map(r["sums"]) for r in rs) and np.array_equal(rs[7]["params"], rs[0]["params"])
     assert all(np.array_equal(r["grid"], rs[0]["grid"]) for r in rs)
     assert all(r["step"] == n_it and r["adam_steps"] == n_it and r["finite"] for r in rs)
-    assert np.abs(rs[0]["loss"] - single["loss"]).max() < 3e-3 * np.abs(single["loss"]).max()
+    assert np.abs(rs[0]["loss"] - single["loss"]).max() < 2e-3 * np.abs(single["loss"]).max() and all(r["exchange_exact"] for r in rs)
     dp = np.abs(rs[7]["params"] - single["params"])                   # (a quantile statement: see the 8-keyframe test)
     print("5 keyframes on 8 ranks vs single GPU: params max", dp.max(), "99.9 % quantile", np.quantile(dp, 0.999), "fraction > 1e-3", (dp > 1e-3).mean())
-    assert np.quantile(dp, 0.999) < 2e-3 and (dp > 1e-3).mean() < 1e-2 and dp.max() <= 2.001e-2 * n_it
+    assert np.quantile(dp, 0.99) < 1e-4 and (dp > 3e-4).mean() < 2e-2 and dp.max() <= 2.001e-2 * n_it
 
 
 def test_rccl_world_size_one_is_bit_identical_to_non_distributed():
