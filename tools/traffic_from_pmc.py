@@ -16,6 +16,7 @@ ALIAS = {"encode_backward_kernel": "encode_backward", "encode_forward_kernel<2, 
          "encode_forward_pair_kernel<2, true>": "encode_forward_f16", "encode_forward_kernel<2, true>": "encode_forward_f16", "table_grad_reduce2_kernel": "table_grad_reduce",
          "table_grad_reduce_split_kernel": "table_grad_reduce_split",
          "mlp_backward_relu32_kernel": "mlp_backward", "mlp_forward_relu32_kernel": "mlp_forward",
+         "mlp_backward_bf3_kernel": "mlp_backward", "mlp_forward_bf3_kernel": "mlp_forward",
          "sum_dx_planes_kernel": "sum_dx_planes", "adam_kernel": "adam", "los_loss_fused_kernel": "los_loss_fused"}
 fetch, write = per_kernel("FETCH_SIZE"), per_kernel("WRITE_SIZE")
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace), bench.py --quick --steps 8 --warmup 4 (tools/gpu_run.sh pmc:FETCH_SIZE pmc:WRITE_SIZE), 1x MI355X",
