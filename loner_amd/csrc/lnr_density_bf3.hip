@@ -28,6 +28,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 #define BF3_TS 36            // floats per neuron row of the dZ transpose buffer (32 samples + pad: 144-byte rows, 16-byte aligned)
+// A/B knobs (tagged development builds): workgroups of the forward per CU (160 registers allow three: 12 waves per CU keep more plane
+// lines in flight), steps the backward requests its layer-1 operands ahead (2: 248 registers, still two waves per SIMD)
+#ifndef LNR_BF3_FWD_OCC
+#define LNR_BF3_FWD_OCC 3
+#endif
+#ifndef LNR_BF3_BWD_AHEAD
+#define LNR_BF3_BWD_AHEAD 2
+#endif
 
 struct Frag3 { u32x4 t[3]; };        // the three bf16x8 terms of one MFMA operand fragment, as dwords
 
@@ -77,7 +85,7 @@ __device__ __forceinline__ void bf3_load_x2(const float* __restrict__ fb, uint32
 }
 
 template <int HT>
-__global__ void __launch_bounds__(LNR_DENSITY_BLOCK, 2)
+__global__ void __launch_bounds__(LNR_DENSITY_BLOCK, LNR_BF3_FWD_OCC)
 mlp_forward_bf3_kernel(const float* __restrict__ params, const float* __restrict__ feat, int64_t m_pad, int64_t n_points,
                        const int32_t* __restrict__ n_rays_dev, int n_rays, int n_samples, float* __restrict__ sigma, int32_t* __restrict__ clip_flag) {
     constexpr int H = 16 * HT;
@@ -226,11 +234,22 @@ mlp_backward_bf3_kernel(const float* __restrict__ params, int n_mlp, const float
         ds[0] = m < M ? v0 : 0.0f;
         ds[1] = m + 1 < M ? v1 : 0.0f;
     };
+#if LNR_BF3_BWD_AHEAD >= 2
+    float xnxt[2][8], dnxt[2];
+    if (tile < n_tiles) { load_front(tile, xcur, dcur); load_front(tile + stride < n_tiles ? tile + stride : tile, xnxt, dnxt); }
+#else
     if (tile < n_tiles) load_front(tile, xcur, dcur);
+#endif
     while (tile < n_tiles) {
         const int64_t nt = tile + stride;
+#if LNR_BF3_BWD_AHEAD >= 2
+        const int64_t nt2 = nt + stride;
+        float xnx2[2][8], dnx2[2];
+        load_front(nt2 < n_tiles ? nt2 : tile, xnx2, dnx2);        // unconditional prefetch of the layer-1 operands, two steps ahead
+#else
         float xnxt[2][8], dnxt[2];
         load_front(nt < n_tiles ? nt : tile, xnxt, dnxt);          // unconditional prefetch of the next step's layer-1 operands
+#endif
         const bool any = (dcur[0] != 0.0f) | (dcur[1] != 0.0f);
         if (__ballot(any) == 0ull) {                               // nothing flows back into this step
             if (want_dfeat) {           // (the d_feature planes are padded like the feature planes: whole pairs are stored)
@@ -329,9 +348,15 @@ mlp_backward_bf3_kernel(const float* __restrict__ params, int n_mlp, const float
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
+#if LNR_BF3_BWD_AHEAD >= 2
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { xcur[t][i] = xnxt[t][i]; xnxt[t][i] = xnx2[t][i]; }
+            dcur[t] = dnxt[t]; dnxt[t] = dnx2[t];
+#else
 #pragma unroll
             for (int i = 0; i < 8; ++i) xcur[t][i] = xnxt[t][i];
             dcur[t] = dnxt[t];
+#endif
         }
         tile = nt;
     }
