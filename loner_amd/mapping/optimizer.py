@@ -65,6 +65,14 @@ class HipAdam(torch.optim.Optimizer):
         """groups: indices of the parameter groups to step (default: all).  ranges: [(lo, hi), ...] element ranges of the
         (flat) parameters to step instead of all of them - the sharded form in which a rank owns a slice of the hash tables
         (mapping/sharding.py); moments outside the ranges are left alone, the step count advances once."""
+        return self.step_now(zero_grad, groups, ranges)
+
+    @torch.no_grad()
+    def step_now(self, zero_grad=True, groups=None, ranges=None):
+        """step() without torch.optim.Optimizer's per-call wrapper (profiler record, pre / post hooks: ~15 us of host time per call, two
+        calls per iteration - a tenth of a one-keyframe rank's host budget).  The training loop calls this; `step` is the public form."""
+        if groups is not None and len(groups) == 0:
+            return
         for gi, group in enumerate(self.param_groups):
             if groups is not None and gi not in groups:
                 continue
@@ -121,6 +129,7 @@ class Optimizer:
         self._data_prep_device = 'cpu' if settings.data_prep_on_cpu else self._device
         self._world_cube = world_cube.to(self._data_prep_device)
         self._ray_range = torch.Tensor(list(self._model_config.model.ray_range)).to(self._data_prep_device)
+        self._ray_range_f = [float(v) for v in self._ray_range.reshape(-1).cpu()]       # (host floats: read in every iteration)
         self._scale_f = float(world_cube.scale_factor)
         self._shift_f = [float(v) for v in torch.as_tensor(world_cube.shift).reshape(-1).cpu()]
 
@@ -158,12 +167,39 @@ class Optimizer:
         self._grad_event = None
         self._poison = None          # failure guard of the running phase (device int32[2]), None outside a phase
         self.last_failure = None
+        self._pc = None               # per-phase cache of the configuration values read in every iteration (_consts)
         self._pending_density = None  # (all-reduce handle or None, group index, lr): density Adam step deferred by the training loop
         self._defer_density_step = True   # False: step right away (same arithmetic; the tests compare the two)
         self._overwrite_grads = True      # False: the density gradient is accumulated and zeroed by Adam (same results; the tests compare the two)
         self.last_stats = {}
 
     # -------------------------------------------------------------------------------------------
+    def _consts(self):
+        """Configuration values the loop reads in EVERY iteration, looked up once per optimisation phase (the settings object wraps
+        every nested dictionary anew on each attribute access: ~35 lookups per iteration were 20 us of a one-keyframe rank's 350 us of
+        host time, which is what bounds that rank once two collectives are enqueued - DESIGN.md section 5).  Dropped at the start of
+        every phase and by anyone who edits the configuration between calls (self._pc = None)."""
+        pc = self._pc
+        if pc is None:
+            render, lc = self._model_config.model.render, self._model_config.loss
+            if lc.loss_selection not in hip.LOSS_SELECTIONS:
+                raise ValueError(f"Can't use unknown Loss {lc.loss_selection}")
+            ogm = self._settings.samples_selection.strategy == 'OGM'
+            pc = self._pc = dict(
+                S=render.N_samples_train, perturb=render.perturb, noise_std=float(render.raw_noise_std), ogm=ogm,
+                occ_every=int(self._model_config.model.occ_model.N_iters_acc) if ogm else 0,
+                strategy=self._settings.rays_selection.strategy,
+                loss=dict(selection=hip.LOSS_SELECTIONS[lc.loss_selection], min_js=lc.JS_loss.min_js_score, max_js=lc.JS_loss.max_js_score,
+                          js_alpha=lc.JS_loss.alpha, depth_lambda=lc.depthloss_lambda, min_eps=lc.min_depth_eps,
+                          decay_los=bool(lc.decay_los_lambda), los_lambda=lc.los_lambda,
+                          los_rate=lc.los_lambda_decay_rate if lc.decay_los_lambda else None,
+                          los_steps=lc.los_lambda_decay_steps if lc.decay_los_lambda else None,
+                          min_los=lc.min_los_lambda if lc.decay_los_lambda else None,
+                          decay_eps=bool(lc.decay_depth_eps), depth_eps=lc.depth_eps,
+                          eps_rate=lc.depth_eps_decay_rate if lc.decay_depth_eps else None,
+                          eps_steps=lc.depth_eps_decay_steps if lc.decay_depth_eps else None))
+        return pc
+
     def set_draws(self, draws):
         """Inject host random draws (objects with ray_index/sky_index/jitter/pdf/noise, see oracle.mapping_step)."""
         self._draws = draws
@@ -241,6 +277,8 @@ class Optimizer:
                 self._optimization_settings = optimizer_settings
             os_ = self._optimization_settings
             os_.freeze_poses = os_.freeze_poses or self._settings.freeze_poses or self._use_gt_poses
+            self._pc = None
+            pc = self._consts()
 
             if self._settings.samples_selection.strategy == 'OGM':
                 self._ray_sampler.update_occ_grid(self._occupancy_grid.detach())
@@ -362,11 +400,10 @@ class Optimizer:
                                 g['lr'] = lr0 * (gamma ** it_idx)
                             dg = density_group if density_group is not None else \
                                 (0 if (sigma_params and not tracking and not os_.freeze_sigma_mlp) else None)
-                            self._optimizer.step(zero_grad=True, groups=tuple(i for i in range(len(groups)) if i != dg))
+                            self._optimizer.step_now(zero_grad=True, groups=tuple(i for i in range(len(groups)) if i != dg))
                         else:
                             dg = None
-                        if self._settings.samples_selection.strategy == 'OGM' and \
-                                self._global_step % self._model_config.model.occ_model.N_iters_acc == 0:
+                        if pc["ogm"] and self._global_step % pc["occ_every"] == 0:
                             self._step_occupancy_grid()
                         if it_idx + 1 < n_it:
                             batch = front_end(it_idx + 1)
@@ -392,7 +429,7 @@ class Optimizer:
                                                self._model.nerf_model._model_sigma.params, it_idx, want_ray_grads=any_free,
                                                want_param_grads=not os_.freeze_sigma_mlp, n_rays_dev=batch["n_dev"],
                                                loss_out=loss_log[it_idx], accumulate_into_param_grad=True, want_stats=False,
-                                               defer_grad_wait=True, poison=poison, shard_segments=(batch["seg_start"], tab.seg_order))
+                                               defer_grad_wait=True, poison=poison, shard_segments=(batch["seg_start"], tab.seg_order_c))
                 else:
                     out = self._join_without_rays(sigma_params[0] if sigma_params else None, want_param_grads=not os_.freeze_sigma_mlp)
                 if any_free:
@@ -402,7 +439,7 @@ class Optimizer:
                         g['lr'] = lr0 * (gamma ** it_idx)
                     if density_group is None:
                         dg = 0 if (sigma_params and not tracking and not os_.freeze_sigma_mlp) else None     # stepped right away
-                        self._optimizer.step(zero_grad=True, groups=tuple(i for i in range(len(groups)) if i != dg))
+                        self._optimizer.step_now(zero_grad=True, groups=tuple(i for i in range(len(groups)) if i != dg))
                         if dg is not None:
                             self._step_density(out["grad_work"], dg)
                     else:
@@ -410,10 +447,9 @@ class Optimizer:
                         # between reads the density parameters - pose gradient and pose step, occupancy step, the next batch's ray
                         # build, compaction, counts and sampling - so in the sharded mode all of that runs beside the gradient
                         # all-reduce instead of behind it.  Same arithmetic, same order per parameter group.
-                        self._optimizer.step(zero_grad=True, groups=tuple(i for i in range(len(groups)) if i != density_group))
+                        self._optimizer.step_now(zero_grad=True, groups=tuple(i for i in range(len(groups)) if i != density_group))
                         self._pending_density = (out["grad_work"], density_group, self._optimizer.param_groups[density_group]['lr'])
-                if self.should_enable_lidar() and self._settings.samples_selection.strategy == 'OGM' and \
-                        self._global_step % self._model_config.model.occ_model.N_iters_acc == 0:
+                if self.should_enable_lidar() and pc["ogm"] and self._global_step % pc["occ_every"] == 0:
                     self._step_occupancy_grid()
                 self._global_step += 1
                 if profiler is not None:
@@ -523,6 +559,8 @@ class Optimizer:
         # window position of every segment (lidar before sky inside a keyframe): the order of the single-GPU batch
         order_of = getattr(self, "_active_order", None) or list(range(len(active)))
         tab.seg_order = [2 * order_of[k] + (1 if sky_ else 0) for k, sky_ in zip(poses, is_sky)]
+        import ctypes as _C
+        tab.seg_order_c = (_C.c_int32 * len(tab.seg_order))(*tab.seg_order)      # (for lnr_shard_front_pack, every iteration)
         tab.fixed_T12 = None           # set per phase: the matrices of the poses that are not optimised (_do_iterate_optimizer)
         tab.seg_kf_dev = torch.tensor(poses, device=dev)
         tab.lidar_seg_mask = torch.tensor([0.0 if s else 1.0 for s in is_sky], device=dev)[:, None]
@@ -531,7 +569,7 @@ class Optimizer:
 
     def _draw_window_indices(self, active, tab):
         """Host-injected draws (parity tests) or non-RANDOM strategies; None -> drawn inside the build kernel."""
-        strat = self._settings.rays_selection.strategy
+        strat = self._consts()["strategy"]
         if strat == 'RANDOM' and self._draws is None:
             return None
         out = []
@@ -562,11 +600,11 @@ class Optimizer:
             T12 = ops.pose_forward(pose_dev)
             if tab.fixed_T12 is not None:                  # poses that are not optimised in this phase: the matrix their Pose hands out
                 T12 = torch.where(tab.free_col, T12, tab.fixed_T12)
-        rr = [float(self._ray_range[0]), float(self._ray_range[1])]
+        rr = self._ray_range_f
         index = self._draw_window_indices(active, tab)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if index is None else 0
         rays_c, depths_c, keep, src_c = ops.build_window_rays(tab, T12, rr, self._scale_f, self._shift_f, index=index, seed=seed)
-        rays, depths, src, out_seg, n_dev = ops.compact_rays(rays_c, depths_c, keep, src_c, tab.seg_start_list, n_out=n_out)
+        rays, depths, src, out_seg, n_dev = ops.compact_rays(rays_c, depths_c, keep, src_c, tab.seg_start, n_out=n_out)   # (the table's ctypes array: built once per phase)
         return dict(rays=rays, depths=depths, src=src, seg_start=out_seg, n_dev=n_dev, T12=T12, tab=tab)
 
     def _pose_backward(self, batch, d_rays, pose_dev, free_mask_u8, poison=None, poison_tag=0):
@@ -585,23 +623,20 @@ class Optimizer:
 
     # -------------------------------------------------------------------------------------------
     def _loss_config(self, iteration_idx) -> hip.LossConfig:
-        lc = self._model_config.loss
+        lc = self._consts()["loss"]
         cfg = hip.LossConfig()
-        if lc.loss_selection not in hip.LOSS_SELECTIONS:
-            raise ValueError(f"Can't use unknown Loss {lc.loss_selection}")
-        cfg.selection = hip.LOSS_SELECTIONS[lc.loss_selection]
-        cfg.min_js, cfg.max_js, cfg.js_alpha = lc.JS_loss.min_js_score, lc.JS_loss.max_js_score, lc.JS_loss.alpha
-        if lc.decay_los_lambda:
-            cfg.los_lambda = max(lc.los_lambda * (lc.los_lambda_decay_rate ** ((self._global_step + 1) / lc.los_lambda_decay_steps)),
-                                 lc.min_los_lambda)
+        cfg.selection = lc["selection"]
+        cfg.min_js, cfg.max_js, cfg.js_alpha = lc["min_js"], lc["max_js"], lc["js_alpha"]
+        if lc["decay_los"]:
+            cfg.los_lambda = max(lc["los_lambda"] * (lc["los_rate"] ** ((self._global_step + 1) / lc["los_steps"])), lc["min_los"])
         else:
-            cfg.los_lambda = lc.los_lambda
-        cfg.depth_lambda = lc.depthloss_lambda
-        cfg.min_eps = lc.min_depth_eps
-        if lc.decay_depth_eps:
-            cfg.fixed_eps = max(lc.depth_eps * (lc.depth_eps_decay_rate ** (iteration_idx / lc.depth_eps_decay_steps)), lc.min_depth_eps)
+            cfg.los_lambda = lc["los_lambda"]
+        cfg.depth_lambda = lc["depth_lambda"]
+        cfg.min_eps = lc["min_eps"]
+        if lc["decay_eps"]:
+            cfg.fixed_eps = max(lc["depth_eps"] * (lc["eps_rate"] ** (iteration_idx / lc["eps_steps"])), lc["min_eps"])
         else:
-            cfg.fixed_eps = lc.depth_eps
+            cfg.fixed_eps = lc["depth_eps"]
         return cfg
 
     def _sample_front(self, rays, depths, n_rays_dev, draws=None, shard_segments=None):
@@ -609,13 +644,12 @@ class Optimizer:
         (optimizer.py:437-470 up to the network call).  -> dict(counts, front_work, z, seed, far0).  shard_segments (sharded loop):
         (compacted segment starts on the device, window position of every segment) of this rank's batch."""
         draws = draws if draws is not None else self._draws
-        render = self._model_config.model.render
-        S, perturb = render.N_samples_train, render.perturb
+        pc = self._consts()
+        S, perturb, ogm = pc["S"], pc["perturb"], pc["ogm"]
         dev = self._device
         n = rays.shape[0]
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if draws is None else 0
         u1 = u2 = None
-        ogm = self._settings.samples_selection.strategy == 'OGM'
         if draws is not None:
             if perturb > 0:
                 u1 = draws.jitter(n, S // 2 if ogm else S).to(dev)
@@ -649,8 +683,8 @@ class Optimizer:
         front: the result of _sample_front for these rays when the caller already ran it (the pipelined training loop);
         input_grad_event: recorded by the density backward as soon as d_rays is complete (ops.density_backward)."""
         draws = draws if draws is not None else self._draws
-        render = self._model_config.model.render
-        S, noise_std = render.N_samples_train, float(render.raw_noise_std)
+        pc = self._consts()
+        S, noise_std = pc["S"], pc["noise_std"]
         spec = self._model.nerf_model._model_sigma.spec
         dev = self._device
         n = rays.shape[0]
@@ -746,7 +780,7 @@ class Optimizer:
             if sl is not None:
                 ranges = [sl]
         # (overwrite mode: the next backward stores its gradient over this one - nothing to zero)
-        self._optimizer.step(zero_grad=not self._overwrite_grads, groups=(group,), ranges=ranges)
+        self._optimizer.step_now(zero_grad=not self._overwrite_grads, groups=(group,), ranges=ranges)
         if ranges is not None:
             self._dist.gather_params(self._model.nerf_model._model_sigma.params.data.view(-1))
 
@@ -760,6 +794,7 @@ class Optimizer:
         rays, depths = lidar_samples
         rays = rays.reshape(-1, rays.shape[-1])
         depths = depths.reshape(-1).to(self._device).float().contiguous()
+        self._pc = None                  # a public entry point: re-read the configuration (the training loop caches it per phase)
         params = self._model.nerf_model._model_sigma.params
         rays_dev = rays if rays.device == self._device else rays.to(self._device)
         loss = _LidarLossFn.apply(rays_dev, params, self, depths, iteration_idx)
@@ -776,6 +811,7 @@ class Optimizer:
         computes all of it in one fused kernel pass without the dictionary; this is the form a caller gets who keeps the reference's own
         loss code on top of this package's Model, and the one bench.py times as `api_parity_mode`."""
         lc = self._model_config.loss
+        self._pc = None
         rays, depths = lidar_samples
         rays = rays.reshape(-1, rays.shape[-1])
         rays = rays if rays.device == self._device else rays.to(self._device)

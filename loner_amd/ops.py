@@ -251,7 +251,7 @@ def pose_backward(pose6, d_transforms, mask=None, out=None, accumulate=False, po
 
 
 def compact_rays(rays, depths, keep, src_index, seg_start, n_out=None):
-    """seg_start: python list [n_seg+1].  -> (rays_out [cap,13], depths_out, src_out, out_seg_start dev int32
+    """seg_start: python list [n_seg+1] (or the ctypes int32 array of a WindowTables).  -> (rays_out [cap,13], depths_out, src_out, out_seg_start dev int32
     [n_seg+1], n_out dev int32 [1]); only the first n_out rows are meaningful.  n_out (optional): an int32 [1] device tensor the
     live count is written into (the training loop hands in a row of its per-iteration log instead of copying into it afterwards)."""
     require_device(rays, depths, keep, src_index)
@@ -268,7 +268,7 @@ def compact_rays(rays, depths, keep, src_index, seg_start, n_out=None):
     else:
         require_device(n_out)
         assert n_out.dtype == torch.int32 and n_out.numel() == 1 and n_out.is_contiguous()
-    seg = (C.c_int32 * (n_seg + 1))(*[int(v) for v in seg_start])
+    seg = seg_start if isinstance(seg_start, C.Array) else (C.c_int32 * (n_seg + 1))(*[int(v) for v in seg_start])
     check(load().lnr_compact_rays(_ptr(rays), _ptr(depths), _ptr(keep), _ptr(src_index), n_in, seg, n_seg,
                                   _ptr(rays_out), _ptr(depths_out), _ptr(src_out), _ptr(out_seg), _ptr(n_out), _stream()),
           "lnr_compact_rays")
@@ -296,7 +296,7 @@ def shard_front_pack(rays, out_seg_start, seg_order, depths, n_rays_dev, cap, de
         return rec
     require_device(rays, out_seg_start, depths, n_rays_dev)
     n_seg = len(seg_order)
-    order = (C.c_int32 * n_seg)(*[int(v) for v in seg_order])
+    order = seg_order if isinstance(seg_order, C.Array) else (C.c_int32 * n_seg)(*[int(v) for v in seg_order])
     check(load().lnr_shard_front_pack(_ptr(rays), _ptr(out_seg_start), order, n_seg, _ptr(_f32c(depths)), rays.shape[0], _ptr(n_rays_dev),
                                       int(cap), _ptr(rec), _stream()), "lnr_shard_front_pack")
     return rec
