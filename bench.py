@@ -692,7 +692,7 @@ def main():
     # dense MFMA peak of the MLP kernels' arithmetic type: the fp32 mode runs 6 bf16 products per fp32 product on the bf16 pipe, i.e. at
     # best 2500 / 6 = 417 TFLOP/s of fp32-equivalent work (its yardstick); the exact-chain kernels are held to the fp32 MFMA peak
     mfma_peak = 2500.0e12 if args.dtype == "f16" else (157.3e12 if args.dtype == "f32_chain" else 2500.0e12 / 6.0)
-    # Algorithmic work per launch (DESIGN.md section 4):
+    # Algorithmic work per launch (DESIGN.md section 3):
     #   encode_backward: d_feature planes in, z and the ray records once, 6 ray-gradient floats out, the table gradient once
     #   mlp_backward:    forward recompute + input gradient + weight gradient GEMMs of the fp32 MLP
     alg = {
@@ -743,7 +743,7 @@ def main():
                             "(the VALU 72 % / 50 % busy), half of a wave's cycles parked in s_waitcnt / barriers - whose in-LDS radix partition of the "
                             "gradient records, hashing, and the d/dx term's table re-gather (47 M L2 line reads = 6 GB over the L2 -> L1 path, "
                             "profiles/r04_pmc_tcp_tcc_encode.txt) overlap only partly; four structural variants were measured in round 4 "
-                            "(DESIGN.md 4.3, 8)",
+                            "(DESIGN.md 3.4; docs/HISTORY.md 4.3, 8)",
                     "secondary": {k: v for k, v in kernels.items() if k != dom and k in ("encode_backward", "encode_dx", "mlp_backward", "mlp_forward", "encode_forward", "table_grad_reduce")}}
     line = {
         "metric": "training rays/sec", "value": total_rays / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
@@ -771,7 +771,7 @@ def main():
         "disclosures": {
             "table_gradient_records": "hash-table gradient contributions travel as 8-byte records whose two values are rounded to 26 bits "
                                       "(sign, 8 exponent, 17 mantissa bits; relative error <= 2^-18) before an exact 64-bit fixed-point sum - a "
-                                      "sub-fp32 step inside the f32 mode (DESIGN.md 4.3; parity vs the fp32 oracle 2e-5)",
+                                      "sub-fp32 step inside the f32 mode (DESIGN.md 3.4; parity vs the fp32 oracle 2e-5)",
             "grid_position": "fma(x, scale, 0.5) as tiny-cuda-nn (one rounding); spec switch pos_rounding=mul_add for the other convention",
             "timed_region": "inputs resident in HBM (scans uploaded once per keyframe before the loop); no host sync inside the loop",
         },

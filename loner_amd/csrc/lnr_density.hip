@@ -110,7 +110,7 @@ reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs, int n_mlp, flo
 // read-modify-writes (it is the only writer of that slice).  PAIR: packed pair records (n_features >= 2) or {idx, v}
 // records - see lnr_density_api.h.
 //
-// The kernel is bound by instruction issue and latency, not by bytes (ablations in DESIGN.md): a region holds ~30-60 records,
+// The kernel is bound by instruction issue and latency, not by bytes (ablations in docs/HISTORY.md 4.3): a region holds ~30-60 records,
 // so every wave instruction serves one short region.  Hence the shape of the loop: a wave takes a contiguous run of its owner's
 // regions, lane r holds region r's record count, and everything that depends only on the region - its count (v_readlane), its
 // address (scalar arithmetic), the trip count - stays on the scalar unit; the first piece (64 x-pair records or 128 8-byte
@@ -457,7 +457,7 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
                 if (xp) r *= 0.5;                                           // one record per x-neighbour pair
                 else if (spec->level_scale[l] < LNR_COMBINE_SCALE_MAX) r *= LNR_COMBINE_FILL;   // run-length combined along the rays
                 // twice the expectation + 64 records, in 256-byte units: a record beyond the capacity costs four (two) 64-bit global atomics,
-                // so the capacity is generous (sweep in DESIGN.md; the reduce does not care how full a region is)
+                // so the capacity is generous (sweep in DESIGN.md 2; the reduce does not care how full a region is)
                 const double recs = (r * (xp ? LNR_REGION_HEADROOM_XP : LNR_REGION_HEADROOM) + LNR_REGION_SLACK) * shrink;
                 uint64_t bytes = (uint64_t)(recs * (xp ? 12.0 : 8.0));
                 // Binned partition (lnr_encode.hip): hashed levels, whose records spread evenly over the owners - a batch (one sample per

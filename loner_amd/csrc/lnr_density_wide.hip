@@ -16,7 +16,7 @@
 // oracle/network.py: weights and every layer's inputs rounded to fp16 where they are consumed, products and sums in fp32 (a product of
 // two fp16 values is exact in fp32, so the fp32 MFMA computes what the f16 MFMA with fp32 accumulation computes), gradients straight
 // through the rounding, in fp32.  Semantics = oracle/network.py.  Built for coverage of the configuration schema, not for speed: the
-// planes cross HBM once per layer and direction (see DESIGN.md 4.6 for the measured times).
+// planes cross HBM once per layer and direction (DESIGN.md 4 has the measured times).
 #include "lnr_f16_common.h"
 
 #define LNR_WIDE_CHUNK 131072          // samples per chunk (a multiple of 64): 128 MB per [256][chunk] fp32 plane set

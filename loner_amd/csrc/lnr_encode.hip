@@ -356,7 +356,7 @@ freq_forward_kernel(const LnrNetSpec spec, const PointSrc src, float* __restrict
 //   k = rint(ph 2/pi), r = ph - k pi/2 (three-term Cody-Waite with fma), minimax sin / cos of r on [-pi/4, pi/4], quadrant from k & 3
 // gives sin(ph), cos(ph) to ~1e-7, and the second feature is cos(ph + d) = cos(ph) - d sin(ph), d = (fl(pi/2) - pi/2) - e, where e is
 // the rounding error of the fp32 addition ph + fl(pi/2) recovered exactly (TwoSum): 1.2e-7 from sin of the rounded sum (numpy check
-// in DESIGN 4.6), i.e. the same fp16 value except within 1e-7 of a rounding boundary (0.004 % of the features).
+// in docs/HISTORY.md 4.6), i.e. the same fp16 value except within 1e-7 of a rounding boundary (0.004 % of the features).
 __device__ __forceinline__ void sincos_f32(float ph, float* s_out, float* c_out) {
     const float k = __builtin_rintf(ph * 0.636619772367581343f);
     float r = __builtin_fmaf(-k, 1.57079637050628662109375f, ph);

@@ -1,4 +1,4 @@
-"""Forward / backward of lnr_density_* in fp16 mode for the general network shapes of DESIGN 4.6, at 4096 rays x 512 samples
+"""Forward / backward of lnr_density_* in fp16 mode for the general network shapes of docs/HISTORY.md 4.6, at 4096 rays x 512 samples
 (backward incl. the encoding's backward, features reused from the forward: the training loop's route)."""
 import argparse, sys, json
 sys.path.insert(0, '.')
