@@ -121,7 +121,7 @@ class _Pending:
 
 
 class DistContext:
-    def __init__(self, group=None, exchange: str = None, payload: str = "fp32"):
+    def __init__(self, group=None, exchange: str = None, payload: str = "fp32", front: str = "inline"):
         """exchange None: "reduce_scatter" from 4 ranks on, "all_reduce" below - with four or more ranks a rank's share of the window is
         one or two keyframes (an iteration of ~0.4 ms), of which the dense Adam step over all 7.4 M parameters is ~9 %; stepping a
         1/G chunk removes (G-1)/G of that, at the price of the all-gather in front of the next density forward."""
@@ -132,9 +132,9 @@ class DistContext:
         self.rank = dist.get_rank(group)
         if exchange is None:
             exchange = "reduce_scatter" if self.world_size >= 4 else "all_reduce"
-        if exchange not in ("all_reduce", "reduce_scatter") or payload not in ("fp32", "bf16"):
-            raise ValueError(f"unknown gradient exchange {exchange!r} / payload {payload!r}")
-        self.exchange, self.payload = exchange, payload
+        if exchange not in ("all_reduce", "reduce_scatter") or payload not in ("fp32", "bf16") or front not in ("inline", "async"):
+            raise ValueError(f"unknown gradient exchange {exchange!r} / payload {payload!r} / front {front!r}")
+        self.exchange, self.payload, self.front = exchange, payload, front
 
     # ---- the front of an iteration: far[0] and the loss normalisers -----------------------------------------------------
     def front_capacity(self, n_keyframes: int, rays_per_keyframe: int) -> int:
@@ -148,7 +148,11 @@ class DistContext:
         depths; identical on every rank."""
         world, stride = self.world_size, record.numel()
         gathered = torch.empty(world * stride, dtype=torch.float32, device=record.device)
-        work = dist.all_gather_into_tensor(gathered, record, group=self.group, async_op=True)
+        # front "inline" (default): a synchronous collective - ProcessGroupNCCL enqueues it on the CURRENT stream, between the pack kernel
+        # and whatever follows, so its latency (a 16 KB all-gather) is in line but nothing crosses queues; "async": on the backend's own
+        # stream, hidden behind the sampler and the density forward at the price of two cross-queue hand-overs, which on this stack cost
+        # about what the in-line latency does (a one-keyframe rank at RCCL world size 1: DESIGN.md section 5)
+        work = dist.all_gather_into_tensor(gathered, record, group=self.group, async_op=self.front == "async")
 
         def finish():
             if gathered.is_cuda:
