@@ -50,7 +50,8 @@ __device__ __forceinline__ float wide_input(const float* __restrict__ in, int64_
     return HALF ? round_f16(a) : a;
 }
 
-// Z_out[j][ml] = sum_k W[j][k] in_k(ml): a wave owns a 16-sample tile, all 256 rows (64 accumulator registers)
+// Z_out[j][ml] = sum_k W[j][k] in_k(ml): a wave owns TWO 16-sample tiles and all 256 rows (128 accumulator registers): every weight
+// fragment streamed from L2 feeds eight MFMAs instead of four (one tile per wave: 14.5 ms per 2.1 M samples for 256 x 2, weight-traffic bound)
 template <bool HALF, int IN>
 __global__ void __launch_bounds__(256)
 wide_layer_fwd_kernel(const float* __restrict__ W, int K, const float* __restrict__ in, int64_t in_stride, int enc_dim, int act,
@@ -59,32 +60,46 @@ wide_layer_fwd_kernel(const float* __restrict__ W, int K, const float* __restric
     const int c = lane & 15, g = lane >> 4;
     const int64_t M = wide_live(smp);
     const int64_t n_tiles = (M + 15) / 16;
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
-        int64_t ml = tile * 16 + c;
-        if (ml >= M) ml = M - 1;                                  // (finite operands for the padding columns; their rows are never read as live)
-        const int64_t m = smp.lo + ml;
-        f32x4 Z[16];
+    const int64_t n_pairs = (n_tiles + 1) / 2;
+    for (int64_t pair = (int64_t)blockIdx.x * 4 + wave; pair < n_pairs; pair += (int64_t)gridDim.x * 4) {
+        int64_t ml[2], m[2];
 #pragma unroll
-        for (int jt = 0; jt < 16; ++jt) Z[jt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int t = 0; t < 2; ++t) {
+            ml[t] = (2 * pair + t) * 16 + c;
+            if (ml[t] >= M) ml[t] = M - 1;                        // (finite operands for padding columns and for a missing second tile)
+            m[t] = smp.lo + ml[t];
+        }
+        f32x4 Z[2][16];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int jt = 0; jt < 16; ++jt) Z[t][jt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         for (int kt = 0; kt < K / 16; ++kt) {
-            float x[4];
+            float x[2][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = wide_input<HALF, IN>(in, in_stride, 16 * kt + 4 * g + r, enc_dim, m, ml, act);
-                x[r] = (HALF && IN == WIDE_IN_FEAT) ? round_f16(v) : v;
-            }
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = wide_input<HALF, IN>(in, in_stride, 16 * kt + 4 * g + r, enc_dim, m[t], ml[t], act);
+                    x[t][r] = (HALF && IN == WIDE_IN_FEAT) ? round_f16(v) : v;
+                }
 #pragma unroll
             for (int jt = 0; jt < 16; ++jt) {
                 float4 wa = *reinterpret_cast<const float4*>(W + (size_t)(16 * jt + c) * K + 16 * kt + 4 * g);
                 if (HALF) { wa.x = round_f16(wa.x); wa.y = round_f16(wa.y); wa.z = round_f16(wa.z); wa.w = round_f16(wa.w); }
-                MFMA4(Z[jt], wa, x[0], x[1], x[2], x[3]);
+                MFMA4(Z[0][jt], wa, x[0][0], x[0][1], x[0][2], x[0][3]);
+                MFMA4(Z[1][jt], wa, x[1][0], x[1][1], x[1][2], x[1][3]);
             }
         }
-        const int64_t col = tile * 16 + c;                        // (chunk planes are padded to whole tiles: store unconditionally)
 #pragma unroll
-        for (int jt = 0; jt < 16; ++jt)
+        for (int t = 0; t < 2; ++t) {
+            if (2 * pair + t >= n_tiles) continue;                // (whole tiles of the chunk planes are written, padding columns included)
+            const int64_t col = (2 * pair + t) * 16 + c;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) z_out[(size_t)(16 * jt + 4 * g + r) * chp + col] = Z[jt][r];
+            for (int jt = 0; jt < 16; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z_out[(size_t)(16 * jt + 4 * g + r) * chp + col] = Z[t][jt][r];
+        }
     }
 }
 
@@ -160,13 +175,26 @@ wide_dw_kernel(const float* __restrict__ dz, int64_t chp, const float* __restric
         for (int ct = 0; ct < 4; ++ct) {
             const int k = 64 * cb + 16 * ct + c;
             if (64 * cb + 16 * ct >= K) continue;                              // (wave-uniform: a ragged last column block)
+            // four consecutive samples of input k as ONE 16-byte load (the planes hold whole 16-sample tiles - zero-filled features,
+            // finite Z columns - and dZ of a padding sample is 0, so nothing is clamped)
             float b[4];
+            if (IN == WIDE_IN_FEAT) {
+                if (k < enc_dim) {
+                    const float4 v = *reinterpret_cast<const float4*>(in + (size_t)k * in_stride + smp.lo + s0);
+                    b[0] = v.x; b[1] = v.y; b[2] = v.z; b[3] = v.w;
+                } else { b[0] = b[1] = b[2] = b[3] = 1.0f; }
+                if (HALF) { b[0] = round_f16(b[0]); b[1] = round_f16(b[1]); b[2] = round_f16(b[2]); b[3] = round_f16(b[3]); }
+            } else if (IN == WIDE_IN_PAIR) {
+                if (k < enc_dim) {
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint32_t*>(in) + (size_t)(k >> 1) * in_stride + smp.lo + s0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int64_t ml = s0 + i;
-                if (ml >= M) ml = M - 1;                                       // (dZ of a padding sample is 0: any finite value will do)
-                const float v = wide_input<HALF, IN>(in, in_stride, k, enc_dim, smp.lo + ml, ml, act);
-                b[i] = (HALF && IN == WIDE_IN_FEAT) ? round_f16(v) : v;
+                    for (int i = 0; i < 4; ++i) { const h2 p = __builtin_bit_cast(h2, v[i]); b[i] = (float)((k & 1) ? p.y : p.x); }
+                } else { b[0] = b[1] = b[2] = b[3] = 1.0f; }
+            } else {
+                const float4 v = *reinterpret_cast<const float4*>(in + (size_t)k * in_stride + s0);
+                b[0] = act_fwd(v.x, act); b[1] = act_fwd(v.y, act); b[2] = act_fwd(v.z, act); b[3] = act_fwd(v.w, act);
+                if (HALF) { b[0] = round_f16(b[0]); b[1] = round_f16(b[1]); b[2] = round_f16(b[2]); b[3] = round_f16(b[3]); }
             }
             MFMA4(acc[ct], a4, b[0], b[1], b[2], b[3]);
         }
@@ -257,8 +285,8 @@ struct WideCtx {
 template <bool HALF>
 static void wide_forward_chunk(const WideCtx& c, const WideSamples& s) {
     const dim3 block(256);
-    const int64_t tiles = (s.n + 15) / 16;
-    const dim3 grid((unsigned)((tiles + 3) / 4 > 2048 ? 2048 : (tiles + 3) / 4));
+    const int64_t pairs = ((s.n + 15) / 16 + 1) / 2;                 // a wave owns two 16-sample tiles
+    const dim3 grid((unsigned)((pairs + 3) / 4 > 2048 ? 2048 : (pairs + 3) / 4));
     if (HALF) hipLaunchKernelGGL((wide_layer_fwd_kernel<HALF, WIDE_IN_PAIR>), grid, block, 0, c.st, c.W(0), c.K1, c.feat, c.m_pad, c.spec->enc_dim, c.act, s, c.z(0), (int64_t)LNR_WIDE_CHUNK);
     else hipLaunchKernelGGL((wide_layer_fwd_kernel<HALF, WIDE_IN_FEAT>), grid, block, 0, c.st, c.W(0), c.K1, c.feat, c.m_pad, c.spec->enc_dim, c.act, s, c.z(0), (int64_t)LNR_WIDE_CHUNK);
     for (int l = 1; l < c.NH; ++l)
@@ -285,7 +313,7 @@ static int wide_backward(const WideCtx& c, const float* d_sigma, float* dfeat, f
     for (int64_t lo = 0; lo < c.pt->n_points; lo += LNR_WIDE_CHUNK) {
         const int64_t n = c.pt->n_points - lo < LNR_WIDE_CHUNK ? c.pt->n_points - lo : LNR_WIDE_CHUNK;
         const WideSamples s = c.samples(lo, n);
-        const int64_t tiles = (n + 15) / 16;
+        const int64_t tiles = (n + 15) / 16;                         // (wide_dx_kernel: one tile per wave - two would need 512 registers and spill)
         const dim3 grid_t((unsigned)((tiles + 3) / 4 > 2048 ? 2048 : (tiles + 3) / 4));
         const dim3 grid_s((unsigned)((n + 255) / 256));
         wide_forward_chunk<HALF>(c, s);

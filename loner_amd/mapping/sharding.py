@@ -121,7 +121,7 @@ class _Pending:
 
 
 class DistContext:
-    def __init__(self, group=None, exchange: str = None, payload: str = "fp32", front: str = "inline"):
+    def __init__(self, group=None, exchange: str = None, payload: str = "fp32", front: str = None):
         """exchange None: "reduce_scatter" from 4 ranks on, "all_reduce" below - with four or more ranks a rank's share of the window is
         one or two keyframes (an iteration of ~0.4 ms), of which the dense Adam step over all 7.4 M parameters is ~9 %; stepping a
         1/G chunk removes (G-1)/G of that, at the price of the all-gather in front of the next density forward."""
@@ -132,6 +132,11 @@ class DistContext:
         self.rank = dist.get_rank(group)
         if exchange is None:
             exchange = "reduce_scatter" if self.world_size >= 4 else "all_reduce"
+        # front None: "inline" with the all-reduce exchange, "async" with the reduce-scatter exchange - what a one-keyframe rank measured at
+        # RCCL world size 1 (tools/probe_sharded_overhead.py: 0.380 / 0.396 ms per iteration inline / async with all_reduce, 0.685 / 0.443
+        # with reduce_scatter, whose synchronous parameter all-gather shares the compute stream with the in-line collective)
+        if front is None:
+            front = "inline" if exchange == "all_reduce" else "async"
         if exchange not in ("all_reduce", "reduce_scatter") or payload not in ("fp32", "bf16") or front not in ("inline", "async"):
             raise ValueError(f"unknown gradient exchange {exchange!r} / payload {payload!r} / front {front!r}")
         self.exchange, self.payload, self.front = exchange, payload, front
@@ -148,10 +153,9 @@ class DistContext:
         depths; identical on every rank."""
         world, stride = self.world_size, record.numel()
         gathered = torch.empty(world * stride, dtype=torch.float32, device=record.device)
-        # front "inline" (default): a synchronous collective - ProcessGroupNCCL enqueues it on the CURRENT stream, between the pack kernel
-        # and whatever follows, so its latency (a 16 KB all-gather) is in line but nothing crosses queues; "async": on the backend's own
-        # stream, hidden behind the sampler and the density forward at the price of two cross-queue hand-overs, which on this stack cost
-        # about what the in-line latency does (a one-keyframe rank at RCCL world size 1: DESIGN.md section 5)
+        # front "inline": a synchronous collective - ProcessGroupNCCL enqueues it on the CURRENT stream, between the pack kernel and
+        # whatever follows, so its latency (a 16 KB all-gather) is in line but nothing crosses queues; "async": on the backend's own
+        # stream, hidden behind the sampler and the density forward at the price of two cross-queue hand-overs (DESIGN.md section 5)
         work = dist.all_gather_into_tensor(gathered, record, group=self.group, async_op=self.front == "async")
 
         def finish():

@@ -13,6 +13,8 @@ from loner_amd import hip, ops   # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--rays", type=int, default=4096)
 ap.add_argument("--samples", type=int, default=512)
+ap.add_argument("--only", default="", help="substring of the network names to run (e.g. '256 x 2'); default: all")
+ap.add_argument("--prec", default="fp32,fp16")
 a = ap.parse_args()
 g = torch.Generator().manual_seed(5)
 n_rays, S = a.rays, a.samples
@@ -40,7 +42,9 @@ for name, enc, net in (("freq12 -> 128 x 2", freq12, dict(activation="ReLU", n_n
                        ("freq12 -> 256 x 3", freq12, dict(activation="ReLU", n_neurons=256, n_hidden_layers=3)),
                        ("hash16x2 -> 256 x 2", dict(otype="HashGrid", n_levels=16, n_features_per_level=2, log2_hashmap_size=18, base_resolution=16),
                         dict(activation="ReLU", n_neurons=256, n_hidden_layers=2))):
-    for prec in ("fp32", "fp16"):
+    if a.only and a.only not in name:
+        continue
+    for prec in a.prec.split(","):
         spec = hip.make_net_spec(enc, dict(net, precision=prec))
         p = (torch.rand(int(spec.n_params), generator=g) - 0.5).cuda(); grad = torch.zeros_like(p)
         fwd = timed(lambda: ops.density_forward(spec, p, rays=rays, z=z))
