@@ -218,6 +218,61 @@ wide_fold_kernel(float* __restrict__ slabs, int64_t n_mlp, int64_t off, int64_t 
     slabs[off + i] += s;
 }
 
+// WT[k][j] = W[j][k] for one 256 x 256 hidden matrix (64 KB tiles through LDS would be overkill: 65 536 elements, once per backward call)
+__global__ void __launch_bounds__(256)
+wide_transpose_kernel(const float* __restrict__ W, float* __restrict__ WT) {
+    __shared__ float tile[16][17];
+    const int bx = blockIdx.x % 16, by = blockIdx.x / 16, tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    tile[ty][tx] = W[(size_t)(16 * by + ty) * LNR_WIDE_H + 16 * bx + tx];
+    __syncthreads();
+    WT[(size_t)(16 * bx + ty) * LNR_WIDE_H + 16 * by + tx] = tile[tx][ty];
+}
+
+// Back-propagation through a HIDDEN matrix, dZ_prev[k][ml] = act'(Z_prev[k][ml]) sum_j W[j][k] dZ[j][ml], as a forward layer with the
+// TRANSPOSED weights: with WT [k][j] row-major the A fragments are 16-byte loads and the lane's dZ values are the B operands, i.e. the
+// loop of wide_layer_fwd_kernel (two tiles per wave).  The first version read W itself - one 4-byte load per MFMA, 64 of them hoisted per K
+// block: 488 registers, 1.85 ms per chunk = 9 TFLOP/s, 40 % of a 256 x 2 backward (profiles/r05_wide_networks.txt).
+template <bool HALF>
+__global__ void __launch_bounds__(256)
+wide_dx_hidden_kernel(const float* __restrict__ WT, const float* __restrict__ dz, int64_t chp, int act, WideSamples smp,
+                      const float* __restrict__ z_prev, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int64_t M = wide_live(smp);
+    const int64_t n_tiles = (M + 15) / 16;
+    const int64_t n_pairs = (n_tiles + 1) / 2;
+    for (int64_t pair = (int64_t)blockIdx.x * 4 + wave; pair < n_pairs; pair += (int64_t)gridDim.x * 4) {
+        const bool have1 = 2 * pair + 1 < n_tiles;
+        const int64_t ml0 = (2 * pair) * 16 + c, ml1 = have1 ? ml0 + 16 : ml0;           // (a missing second tile: the first one again, result dropped)
+        float d[2][16][4];                                        // dZ rows 16jt + 4g + r of the lane's two samples: the B operands of every K block
+#pragma unroll
+        for (int jt = 0; jt < 16; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                         // (whole tiles exist: padding columns are 0)
+                d[0][jt][r] = dz[(size_t)(16 * jt + 4 * g + r) * chp + ml0];
+                d[1][jt][r] = dz[(size_t)(16 * jt + 4 * g + r) * chp + ml1];
+            }
+#pragma unroll 1
+        for (int kt = 0; kt < 16; ++kt) {                        // (rolled: one output row tile at a time keeps the epilogue's operands few)
+            f32x4 D0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, D1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            const float* wrow = WT + (size_t)(16 * kt + c) * LNR_WIDE_H + 4 * g;
+#pragma unroll
+            for (int jt = 0; jt < 16; ++jt) {
+                float4 wa = *reinterpret_cast<const float4*>(wrow + 16 * jt);
+                if (HALF) { wa.x = round_f16(wa.x); wa.y = round_f16(wa.y); wa.z = round_f16(wa.z); wa.w = round_f16(wa.w); }
+                MFMA4(D0, wa, d[0][jt][0], d[0][jt][1], d[0][jt][2], d[0][jt][3]);
+                MFMA4(D1, wa, d[1][jt][0], d[1][jt][1], d[1][jt][2], d[1][jt][3]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const size_t row = (size_t)(16 * kt + 4 * g + r) * chp;
+                out[row + ml0] = ml0 < M ? D0[r] * act_bwd(z_prev[row + ml0], act) : 0.0f;
+                if (have1) out[row + ml1] = ml1 < M ? D1[r] * act_bwd(z_prev[row + ml1], act) : 0.0f;
+            }
+        }
+    }
+}
+
 // out_k[ml] = sum_j W[j][k] dZ[j][ml]: a wave owns a 16-sample tile (its dZ column: 64 registers), W^T operands stream from L2.
 // TO_FEAT: the result is the d_feature planes (rows < enc_dim, live samples); else it is multiplied by act'(Z_prev[k][ml]) and
 // becomes the previous layer's dZ (padding columns zero)
@@ -269,7 +324,7 @@ size_t lnr_wide_workspace(const LnrNetSpec* spec) {
     if (!lnr_wide_class(spec)) return 0;
     return (size_t)(spec->n_hidden + 2) * LNR_WIDE_H * LNR_WIDE_CHUNK * sizeof(float);
 }
-int lnr_wide_slabs(void) { return 1 + LNR_WIDE_SPLITS; }
+int lnr_wide_slabs(void) { return 3 + LNR_WIDE_SPLITS; }      // slab 0, the partial slabs, the transposed hidden matrices
 
 namespace {
 struct WideCtx {
@@ -310,11 +365,17 @@ static int wide_backward(const WideCtx& c, const float* d_sigma, float* dfeat, f
     if (hipMemsetAsync(slabs, 0, (size_t)n_mlp * sizeof(float), c.st) != hipSuccess) { lnr_set_error("lnr_density_backward: hipMemsetAsync failed"); return LNR_ERR_LAUNCH; }
     const dim3 block(256);
     const int64_t off_o = (int64_t)c.H * c.K1 + (int64_t)(c.NH - 1) * c.H * c.H;
+    // transposed copies of the hidden matrices (back-propagation reads them as A fragments): behind the partial slabs
+    float* wt = slabs + (size_t)(2 + LNR_WIDE_SPLITS) * n_mlp;
+    for (int l = 1; l < c.NH; ++l)
+        hipLaunchKernelGGL(wide_transpose_kernel, dim3(256), block, 0, c.st, c.W(l), wt + (size_t)(l - 1) * c.H * c.H);
     for (int64_t lo = 0; lo < c.pt->n_points; lo += LNR_WIDE_CHUNK) {
         const int64_t n = c.pt->n_points - lo < LNR_WIDE_CHUNK ? c.pt->n_points - lo : LNR_WIDE_CHUNK;
         const WideSamples s = c.samples(lo, n);
-        const int64_t tiles = (n + 15) / 16;                         // (wide_dx_kernel: one tile per wave - two would need 512 registers and spill)
+        const int64_t tiles = (n + 15) / 16;                         // (wide_dx_kernel, first layer: one tile per wave)
         const dim3 grid_t((unsigned)((tiles + 3) / 4 > 2048 ? 2048 : (tiles + 3) / 4));
+        const int64_t pairs = (tiles + 1) / 2;                       // (wide_dx_hidden_kernel: two tiles per wave)
+        const dim3 grid_p((unsigned)((pairs + 3) / 4 > 2048 ? 2048 : (pairs + 3) / 4));
         const dim3 grid_s((unsigned)((n + 255) / 256));
         wide_forward_chunk<HALF>(c, s);
         float* dz = c.dzbuf(0);
@@ -332,7 +393,7 @@ static int wide_backward(const WideCtx& c, const float* d_sigma, float* dfeat, f
             const int64_t count = (int64_t)c.H * K;
             if (want_dw) hipLaunchKernelGGL(wide_fold_kernel, dim3((unsigned)((count + 255) / 256)), block, 0, c.st, slabs, n_mlp, layer_off, count);
             if (l > 0) {
-                hipLaunchKernelGGL((wide_dx_kernel<HALF, false>), grid_t, block, 0, c.st, c.W(l), K, dz, (int64_t)LNR_WIDE_CHUNK, c.act, s, c.z(l - 1), dz_other, (int64_t)LNR_WIDE_CHUNK, K);
+                hipLaunchKernelGGL(wide_dx_hidden_kernel<HALF>, grid_p, block, 0, c.st, wt + (size_t)(l - 1) * c.H * c.H, dz, (int64_t)LNR_WIDE_CHUNK, c.act, s, c.z(l - 1), dz_other);
                 float* t = dz; dz = dz_other; dz_other = t;
             } else if (want_dfeat) {
                 hipLaunchKernelGGL((wide_dx_kernel<HALF, true>), grid_t, block, 0, c.st, c.W(0), K, dz, (int64_t)LNR_WIDE_CHUNK, c.act, s, (const float*)nullptr, dfeat, c.m_pad, c.spec->enc_dim);
