@@ -189,7 +189,11 @@ wide_dw_kernel(const float* __restrict__ dz, int64_t chp, const float* __restric
                     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
                     const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint32_t*>(in) + (size_t)(k >> 1) * in_stride + smp.lo + s0);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { const h2 p = __builtin_bit_cast(h2, v[i]); b[i] = (float)((k & 1) ? p.y : p.x); }
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t w = v[i];           // (a copy: __builtin_bit_cast applied to the vector ELEMENT v[i] reads element 0 for every i)
+                        const h2 p = __builtin_bit_cast(h2, w);
+                        b[i] = (float)((k & 1) ? p.y : p.x);
+                    }
                 } else { b[0] = b[1] = b[2] = b[3] = 1.0f; }
             } else {
                 const float4 v = *reinterpret_cast<const float4*>(in + (size_t)k * in_stride + s0);
