@@ -6,7 +6,8 @@
 // LDS and more than a workgroup's registers.  This file is the route for that shape class, LAYER BY LAYER through HBM:
 //   * the samples are processed in chunks of LNR_WIDE_CHUNK; a chunk's pre-activations Z_l [256][chunk] of every hidden layer and its
 //     dZ planes live in the workspace (0.5 - 0.7 GB), so the batch size does not bound the memory;
-//   * forward of a layer: a wave owns 16 samples, all 256 rows; weights stream from L2 (wide_layer_fwd_kernel);
+//   * forward of a layer: a wave owns two 16-sample tiles and all 256 rows; the workgroup stages the layer's weights through LDS one
+//     16-input block at a time, double-buffered (wide_layer_fwd_kernel);
 //   * the WEIGHT GRADIENT dW_l = dZ_l a_{l-1}^T is split over samples ACROSS workgroups (split-K): a workgroup owns a 64 x 64 tile of
 //     dW and one of S sample ranges of the chunk, both operands are read straight from the [row][sample] planes as 16-byte loads
 //     (4 consecutive samples = the K dimension of one MFMA: no transposition anywhere), accumulators in registers, one partial slab
@@ -20,8 +21,13 @@
 #include "lnr_f16_common.h"
 
 #define LNR_WIDE_CHUNK 131072          // samples per chunk (a multiple of 64): 128 MB per [256][chunk] fp32 plane set
-#define LNR_WIDE_SPLITS 32             // sample ranges of a chunk in the weight-gradient kernel (partial slabs 1 .. S)
+// sample ranges of a chunk in the weight-gradient kernel (partial slabs 1 .. S).  A workgroup walks its range tile by tile - one 16-byte
+// load per operand, 16 MFMAs, repeat: latency-bound - so the parallelism has to come from the number of ranges: with 32 of them (512
+// workgroups for a 256 x 256 matrix, 2 waves per SIMD) the kernel took 0.84 ms per chunk, 7 TFLOP/s (profiles/r05_wide_networks.txt)
+#define LNR_WIDE_SPLITS 128
 #define LNR_WIDE_H 256
+#define WIDE_LDS_ROW 20                // floats per staged weight row of the forward: 16 + 4 padding (the 16 lanes of a 16-byte LDS read hit 16 distinct bank quads)
+#define WIDE_LDS_TROW 260              // floats per staged row of a transposed matrix (back-propagation): 256 + 4 padding, same reason
 
 enum { WIDE_IN_FEAT = 0, WIDE_IN_PAIR = 1, WIDE_IN_Z = 2 };
 
@@ -35,6 +41,10 @@ __device__ __forceinline__ int64_t wide_live(const WideSamples& s) {
 }
 
 template <bool HALF> __device__ __forceinline__ float wide_w(float v) { return HALF ? round_f16(v) : v; }
+template <bool HALF> __device__ __forceinline__ float4 wide_w4(float4 v) {
+    if (HALF) { v.x = round_f16(v.x); v.y = round_f16(v.y); v.z = round_f16(v.z); v.w = round_f16(v.w); }
+    return v;
+}
 
 // one input value of a layer: input k of batch sample m (chunk-local sample ml)
 template <bool HALF, int IN>
@@ -50,23 +60,64 @@ __device__ __forceinline__ float wide_input(const float* __restrict__ in, int64_
     return HALF ? round_f16(a) : a;
 }
 
-// Z_out[j][ml] = sum_k W[j][k] in_k(ml): a wave owns TWO 16-sample tiles and all 256 rows (128 accumulator registers): every weight
-// fragment streamed from L2 feeds eight MFMAs instead of four (one tile per wave: 14.5 ms per 2.1 M samples for 256 x 2, weight-traffic bound)
+// Order of the 16 LDS fragment reads and 128 MFMAs of one K block: fragment jt + 1 is requested before the eight MFMAs of fragment jt
+// are issued (left alone the scheduler puts every read directly in front of its MFMAs, into the same registers: ~100 idle cycles of the
+// matrix pipe per 256 busy ones with one wave per SIMD).  Mask 0x100 = LDS read, 0x008 = MFMA.
+#define WIDE_PIPELINE_LDS_MFMA()                                   \
+    do {                                                          \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 14; ++i_) {       \
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);    \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    \
+        }                                                         \
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);       \
+    } while (0)
+
+// wide_input in two halves for software prefetch: the load (issued a K block ahead) and what is computed from the loaded word
+template <bool HALF, int IN>
+__device__ __forceinline__ float wide_input_load(const float* __restrict__ in, int64_t stride, int k, int enc_dim, int64_t m, int64_t ml) {
+    if (IN == WIDE_IN_FEAT) return k < enc_dim ? in[(size_t)k * stride + m] : 1.0f;
+    if (IN == WIDE_IN_PAIR) return k < enc_dim ? in[(size_t)(k >> 1) * stride + m] : 0.0f;      // (the half2 pair as a bit pattern)
+    return in[(size_t)k * stride + ml];
+}
+template <bool HALF, int IN>
+__device__ __forceinline__ float wide_input_finish(float raw, int k, int enc_dim, int act) {
+    if (IN == WIDE_IN_FEAT) return HALF ? round_f16(raw) : raw;
+    if (IN == WIDE_IN_PAIR) {
+        if (k >= enc_dim) return 1.0f;
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const uint32_t bits = __builtin_bit_cast(uint32_t, raw);
+        const h2 p = __builtin_bit_cast(h2, bits);
+        return (float)((k & 1) ? p.y : p.x);
+    }
+    const float a = act_fwd(raw, act);
+    return HALF ? round_f16(a) : a;
+}
+
+// Z_out[j][ml] = sum_k W[j][k] in_k(ml): a wave owns TWO 16-sample tiles and all 256 rows (128 accumulator registers); the workgroup
+// stages W[:, 16 kt .. 16 kt + 15] (16 KB) through LDS, double-buffered - block kt + 1 is in flight from L2 while block kt feeds the MFMAs,
+// and the four waves share one copy.  (One tile per wave, fragments from L2: 14.5 ms per 2.1 M samples for 256 x 2; two tiles per wave:
+// 11.4 ms, 0.47 ms per chunk and hidden layer = 4.3 x the MFMA time - every wave pulled the whole 256 KB matrix through L2 -> L1 itself.)
+// The loop over tile pairs is workgroup-uniform (barriers inside): a wave beyond the last pair computes on clamped columns and stores nothing.
 template <bool HALF, int IN>
 __global__ void __launch_bounds__(256)
 wide_layer_fwd_kernel(const float* __restrict__ W, int K, const float* __restrict__ in, int64_t in_stride, int enc_dim, int act,
                       WideSamples smp, float* __restrict__ z_out, int64_t chp) {
+    __shared__ __attribute__((aligned(16))) float w_s[2][LNR_WIDE_H * WIDE_LDS_ROW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int64_t M = wide_live(smp);
     const int64_t n_tiles = (M + 15) / 16;
     const int64_t n_pairs = (n_tiles + 1) / 2;
-    for (int64_t pair = (int64_t)blockIdx.x * 4 + wave; pair < n_pairs; pair += (int64_t)gridDim.x * 4) {
+    const int n_kt = K / 16;
+    const float* wsrc = W + (size_t)threadIdx.x * K;               // staging: thread j copies row j's 16 floats of a block
+    for (int64_t base = (int64_t)blockIdx.x * 4; base < n_pairs; base += (int64_t)gridDim.x * 4) {
+        const int64_t pair = base + wave;
         int64_t ml[2], m[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             ml[t] = (2 * pair + t) * 16 + c;
-            if (ml[t] >= M) ml[t] = M - 1;                        // (finite operands for padding columns and for a missing second tile)
+            if (ml[t] >= M) ml[t] = M - 1;                        // (finite operands for padding columns, a missing second tile, an idle wave)
             m[t] = smp.lo + ml[t];
         }
         f32x4 Z[2][16];
@@ -74,22 +125,52 @@ wide_layer_fwd_kernel(const float* __restrict__ W, int K, const float* __restric
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int jt = 0; jt < 16; ++jt) Z[t][jt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        for (int kt = 0; kt < K / 16; ++kt) {
-            float x[2][4];
+        float4 s0 = *reinterpret_cast<const float4*>(wsrc), s1 = *reinterpret_cast<const float4*>(wsrc + 4),
+               s2 = *reinterpret_cast<const float4*>(wsrc + 8), s3 = *reinterpret_cast<const float4*>(wsrc + 12);
+        {                                                         // (every reader of buffer 0 is behind the barrier that ended its K block)
+            float4* dst = reinterpret_cast<float4*>(&w_s[0][threadIdx.x * WIDE_LDS_ROW]);
+            dst[0] = wide_w4<HALF>(s0); dst[1] = wide_w4<HALF>(s1); dst[2] = wide_w4<HALF>(s2); dst[3] = wide_w4<HALF>(s3);
+        }
+        float x[2][4], xr[2][4];                                  // this K block's inputs; the next block's, as loaded
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = wide_input<HALF, IN>(in, in_stride, 16 * kt + 4 * g + r, enc_dim, m[t], ml[t], act);
-                    x[t][r] = (HALF && IN == WIDE_IN_FEAT) ? round_f16(v) : v;
-                }
+            for (int r = 0; r < 4; ++r) xr[t][r] = wide_input_load<HALF, IN>(in, in_stride, 4 * g + r, enc_dim, m[t], ml[t]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[t][r] = wide_input_finish<HALF, IN>(xr[t][r], 4 * g + r, enc_dim, act);
+        __syncthreads();
+        for (int kt = 0; kt < n_kt; ++kt) {
+            const bool more = kt + 1 < n_kt;
+            if (more) {                                           // requests for block kt + 1 go out before this block's MFMAs
+                const float* nx = wsrc + 16 * (kt + 1);
+                s0 = *reinterpret_cast<const float4*>(nx); s1 = *reinterpret_cast<const float4*>(nx + 4);
+                s2 = *reinterpret_cast<const float4*>(nx + 8); s3 = *reinterpret_cast<const float4*>(nx + 12);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xr[t][r] = wide_input_load<HALF, IN>(in, in_stride, 16 * (kt + 1) + 4 * g + r, enc_dim, m[t], ml[t]);
+            }
+            const float* wb = &w_s[kt & 1][c * WIDE_LDS_ROW + 4 * g];
+            float4 wa = *reinterpret_cast<const float4*>(wb);     // W[16 jt + c][16 kt + 4 g ..] (rounded at staging in the fp16 mode), one fragment ahead
 #pragma unroll
             for (int jt = 0; jt < 16; ++jt) {
-                float4 wa = *reinterpret_cast<const float4*>(W + (size_t)(16 * jt + c) * K + 16 * kt + 4 * g);
-                if (HALF) { wa.x = round_f16(wa.x); wa.y = round_f16(wa.y); wa.z = round_f16(wa.z); wa.w = round_f16(wa.w); }
+                const float4 wn = *reinterpret_cast<const float4*>(wb + 16 * (jt < 15 ? jt + 1 : 15) * WIDE_LDS_ROW);
                 MFMA4(Z[0][jt], wa, x[0][0], x[0][1], x[0][2], x[0][3]);
                 MFMA4(Z[1][jt], wa, x[1][0], x[1][1], x[1][2], x[1][3]);
+                wa = wn;
             }
+            WIDE_PIPELINE_LDS_MFMA();
+            if (more) {
+                float4* dst = reinterpret_cast<float4*>(&w_s[(kt + 1) & 1][threadIdx.x * WIDE_LDS_ROW]);
+                dst[0] = wide_w4<HALF>(s0); dst[1] = wide_w4<HALF>(s1); dst[2] = wide_w4<HALF>(s2); dst[3] = wide_w4<HALF>(s3);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[t][r] = wide_input_finish<HALF, IN>(xr[t][r], 16 * (kt + 1) + 4 * g + r, enc_dim, act);
+            }
+            __syncthreads();                                      // block kt + 1 is visible; nobody reads block kt any more
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -139,9 +220,9 @@ wide_dz_out_kernel(const float* __restrict__ wo, int act, const float* __restric
 
 // d w_out[j] += sum over the chunk of d_sigma[m] act(Z_L[j][ml]): one workgroup per row j (the same one in every chunk: the
 // accumulation order is fixed)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 wide_dwo_kernel(int act, const float* __restrict__ z, int64_t chp, WideSamples smp, const float* __restrict__ d_sigma, float* __restrict__ dwo) {
-    __shared__ float part[4];
+    __shared__ float part[16];                                    // (1024 threads: 256 workgroups of 4 waves left three quarters of the wave slots empty)
     const int j = blockIdx.x;
     const int64_t M = wide_live(smp);
     float s = 0.0f;
@@ -149,7 +230,11 @@ wide_dwo_kernel(int act, const float* __restrict__ z, int64_t chp, WideSamples s
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) dwo[j] += (part[0] + part[1]) + (part[2] + part[3]);
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+        for (int w = 0; w < 16; ++w) t += part[w];                // fixed order
+        dwo[j] += t;
+    }
 }
 
 // partial[split][j][k] = sum over the split's sample tiles of dZ[j][s] in_k[s]: workgroup = (64-row block, 64-column block, split),
@@ -240,12 +325,18 @@ template <bool HALF>
 __global__ void __launch_bounds__(256)
 wide_dx_hidden_kernel(const float* __restrict__ WT, const float* __restrict__ dz, int64_t chp, int act, WideSamples smp,
                       const float* __restrict__ z_prev, float* __restrict__ out) {
+    // WT rows 16 kt .. 16 kt + 15 (16 KB, contiguous) staged through LDS, double-buffered and shared by the four waves, as in
+    // wide_layer_fwd_kernel; the loop over tile pairs is workgroup-uniform for the barriers
+    __shared__ __attribute__((aligned(16))) float wt_s[2][16 * WIDE_LDS_TROW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int64_t M = wide_live(smp);
     const int64_t n_tiles = (M + 15) / 16;
     const int64_t n_pairs = (n_tiles + 1) / 2;
-    for (int64_t pair = (int64_t)blockIdx.x * 4 + wave; pair < n_pairs; pair += (int64_t)gridDim.x * 4) {
+    const int st_row = threadIdx.x >> 6, st_col = (4 * threadIdx.x) & 255;       // staging: element 1024 q + 4 tid of a block = row 4 q + tid / 64
+    for (int64_t base = (int64_t)blockIdx.x * 4; base < n_pairs; base += (int64_t)gridDim.x * 4) {
+        const bool active = base + wave < n_pairs;
+        const int64_t pair = active ? base + wave : n_pairs - 1;                 // (an idle wave: the last pair again, result dropped)
         const bool have1 = 2 * pair + 1 < n_tiles;
         const int64_t ml0 = (2 * pair) * 16 + c, ml1 = have1 ? ml0 + 16 : ml0;           // (a missing second tile: the first one again, result dropped)
         float d[2][16][4];                                        // dZ rows 16jt + 4g + r of the lane's two samples: the B operands of every K block
@@ -256,23 +347,54 @@ wide_dx_hidden_kernel(const float* __restrict__ WT, const float* __restrict__ dz
                 d[0][jt][r] = dz[(size_t)(16 * jt + 4 * g + r) * chp + ml0];
                 d[1][jt][r] = dz[(size_t)(16 * jt + 4 * g + r) * chp + ml1];
             }
+        const float* wsrc = WT + 4 * threadIdx.x;
+        float4 s0 = *reinterpret_cast<const float4*>(wsrc), s1 = *reinterpret_cast<const float4*>(wsrc + 1024),
+               s2 = *reinterpret_cast<const float4*>(wsrc + 2048), s3 = *reinterpret_cast<const float4*>(wsrc + 3072);
+        {
+            float* dst = &wt_s[0][st_row * WIDE_LDS_TROW + st_col];
+            *reinterpret_cast<float4*>(dst) = wide_w4<HALF>(s0); *reinterpret_cast<float4*>(dst + 4 * WIDE_LDS_TROW) = wide_w4<HALF>(s1);
+            *reinterpret_cast<float4*>(dst + 8 * WIDE_LDS_TROW) = wide_w4<HALF>(s2); *reinterpret_cast<float4*>(dst + 12 * WIDE_LDS_TROW) = wide_w4<HALF>(s3);
+        }
+        __syncthreads();
 #pragma unroll 1
         for (int kt = 0; kt < 16; ++kt) {                        // (rolled: one output row tile at a time keeps the epilogue's operands few)
-            f32x4 D0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, D1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            const float* wrow = WT + (size_t)(16 * kt + c) * LNR_WIDE_H + 4 * g;
-#pragma unroll
-            for (int jt = 0; jt < 16; ++jt) {
-                float4 wa = *reinterpret_cast<const float4*>(wrow + 16 * jt);
-                if (HALF) { wa.x = round_f16(wa.x); wa.y = round_f16(wa.y); wa.z = round_f16(wa.z); wa.w = round_f16(wa.w); }
-                MFMA4(D0, wa, d[0][jt][0], d[0][jt][1], d[0][jt][2], d[0][jt][3]);
-                MFMA4(D1, wa, d[1][jt][0], d[1][jt][1], d[1][jt][2], d[1][jt][3]);
+            const bool more = kt + 1 < 16;
+            if (more) {
+                const float* nx = wsrc + (size_t)(kt + 1) * 4096;
+                s0 = *reinterpret_cast<const float4*>(nx); s1 = *reinterpret_cast<const float4*>(nx + 1024);
+                s2 = *reinterpret_cast<const float4*>(nx + 2048); s3 = *reinterpret_cast<const float4*>(nx + 3072);
             }
+            float zp[2][4];                                       // Z_prev of this block's output rows: requested before the MFMAs, used behind them
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const size_t row = (size_t)(16 * kt + 4 * g + r) * chp;
-                out[row + ml0] = ml0 < M ? D0[r] * act_bwd(z_prev[row + ml0], act) : 0.0f;
-                if (have1) out[row + ml1] = ml1 < M ? D1[r] * act_bwd(z_prev[row + ml1], act) : 0.0f;
+                zp[0][r] = z_prev[row + ml0]; zp[1][r] = z_prev[row + ml1];
             }
+            f32x4 D0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, D1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            const float* wb = &wt_s[kt & 1][c * WIDE_LDS_TROW + 4 * g];
+            float4 wa = *reinterpret_cast<const float4*>(wb);     // WT[16 kt + c][16 jt + 4 g ..], one fragment ahead
+#pragma unroll
+            for (int jt = 0; jt < 16; ++jt) {
+                const float4 wn = *reinterpret_cast<const float4*>(wb + 16 * (jt < 15 ? jt + 1 : 15));
+                MFMA4(D0, wa, d[0][jt][0], d[0][jt][1], d[0][jt][2], d[0][jt][3]);
+                MFMA4(D1, wa, d[1][jt][0], d[1][jt][1], d[1][jt][2], d[1][jt][3]);
+                wa = wn;
+            }
+            WIDE_PIPELINE_LDS_MFMA();
+            if (active) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const size_t row = (size_t)(16 * kt + 4 * g + r) * chp;
+                    out[row + ml0] = ml0 < M ? D0[r] * act_bwd(zp[0][r], act) : 0.0f;
+                    if (have1) out[row + ml1] = ml1 < M ? D1[r] * act_bwd(zp[1][r], act) : 0.0f;
+                }
+            }
+            if (more) {
+                float* dst = &wt_s[(kt + 1) & 1][st_row * WIDE_LDS_TROW + st_col];
+                *reinterpret_cast<float4*>(dst) = wide_w4<HALF>(s0); *reinterpret_cast<float4*>(dst + 4 * WIDE_LDS_TROW) = wide_w4<HALF>(s1);
+                *reinterpret_cast<float4*>(dst + 8 * WIDE_LDS_TROW) = wide_w4<HALF>(s2); *reinterpret_cast<float4*>(dst + 12 * WIDE_LDS_TROW) = wide_w4<HALF>(s3);
+            }
+            __syncthreads();
         }
     }
 }
@@ -385,7 +507,7 @@ static int wide_backward(const WideCtx& c, const float* d_sigma, float* dfeat, f
         float* dz = c.dzbuf(0);
         float* dz_other = c.dzbuf(1);
         hipLaunchKernelGGL(wide_dz_out_kernel<HALF>, grid_s, block, 0, c.st, c.Wo(), c.act, c.z(c.NH - 1), (int64_t)LNR_WIDE_CHUNK, s, d_sigma, dz);
-        if (want_dw) hipLaunchKernelGGL(wide_dwo_kernel, dim3(LNR_WIDE_H), block, 0, c.st, c.act, c.z(c.NH - 1), (int64_t)LNR_WIDE_CHUNK, s, d_sigma, slabs + off_o);
+        if (want_dw) hipLaunchKernelGGL(wide_dwo_kernel, dim3(LNR_WIDE_H), dim3(1024), 0, c.st, c.act, c.z(c.NH - 1), (int64_t)LNR_WIDE_CHUNK, s, d_sigma, slabs + off_o);
         for (int l = c.NH - 1; l >= 0; --l) {
             const int K = l == 0 ? c.K1 : c.H;
             const int64_t layer_off = l == 0 ? 0 : (int64_t)c.H * c.K1 + (int64_t)(l - 1) * c.H * c.H;
