@@ -211,9 +211,10 @@ wide_dz_out_kernel(const float* __restrict__ wo, int act, const float* __restric
     __syncthreads();
     const int64_t M = wide_live(smp);
     const int64_t M16 = (M + 15) / 16 * 16;
+    const int j0 = blockIdx.y * (LNR_WIDE_H / gridDim.y), j1 = j0 + LNR_WIDE_H / gridDim.y;     // (a thread walks a quarter of the rows: 4 x the loads in flight)
     for (int64_t ml = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ml < M16; ml += (int64_t)gridDim.x * blockDim.x) {
         const float ds = ml < M ? d_sigma[smp.lo + ml] : 0.0f;
-        for (int j = 0; j < LNR_WIDE_H; ++j)
+        for (int j = j0; j < j1; ++j)
             dz[(size_t)j * chp + ml] = ml < M ? ds * w_s[j] * act_bwd(z[(size_t)j * chp + ml], act) : 0.0f;
     }
 }
@@ -238,55 +239,79 @@ wide_dwo_kernel(int act, const float* __restrict__ z, int64_t chp, WideSamples s
 }
 
 // partial[split][j][k] = sum over the split's sample tiles of dZ[j][s] in_k[s]: workgroup = (64-row block, 64-column block, split),
-// wave w = row tile 4 rb + w, up to four 16-column tiles; both operands are 16-byte loads of 4 consecutive samples of one row
+// wave w = row tile 4 rb + w, up to four 16-column tiles; both operands are 16-byte loads of 4 consecutive samples of one row, requested
+// one tile ahead of the MFMAs that consume them.  The 4 n_cb workgroups of a split read the same dZ rows and input rows: the block
+// index is decoded so that they share an XCD (workgroup i runs on XCD i mod 8), i.e. one L2 - with the plain (rb, cb, split) order a
+// split's workgroups sat on all eight and every plane crossed the fabric 2 - 4 times.
 template <bool HALF, int IN>
 __global__ void __launch_bounds__(256)
 wide_dw_kernel(const float* __restrict__ dz, int64_t chp, const float* __restrict__ in, int64_t in_stride, int enc_dim, int K, int act,
                WideSamples smp, float* __restrict__ partial, int64_t n_mlp, int64_t layer_off) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
-    const int n_cb = (K + 63) / 64;
-    const int rb = blockIdx.x % 4, cb = (blockIdx.x / 4) % n_cb, split = blockIdx.x / (4 * n_cb);
+    const int n_cb = (K + 63) / 64, n_inner = 4 * n_cb;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;           // (LNR_WIDE_SPLITS is a multiple of 8)
+    const int inner = q % n_inner, split = (q / n_inner) * 8 + xcd;
+    const int rb = inner & 3, cb = inner >> 2;
     const int jt = 4 * rb + wave;
     const int64_t M = wide_live(smp);
     const int64_t n_tiles = (M + 15) / 16;
+    const float* dz_row = dz + (size_t)(16 * jt + c) * chp + 4 * g;
     f32x4 acc[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    for (int64_t tile = split; tile < n_tiles; tile += LNR_WIDE_SPLITS) {
-        const int64_t s0 = tile * 16 + 4 * g;                                 // the lane's four samples (chunk-local)
-        const float4 a4 = *reinterpret_cast<const float4*>(dz + (size_t)(16 * jt + c) * chp + s0);
+    // four consecutive samples of input k as ONE 16-byte load (the planes hold whole 16-sample tiles - zero-filled features, finite Z
+    // columns - and dZ of a padding sample is 0, so nothing is clamped); pair planes travel as bit patterns
+    auto load_tile = [&](int64_t tile, float4& a4, float4 (&raw)[4]) {
+        const int64_t s0 = tile * 16;
+        a4 = *reinterpret_cast<const float4*>(dz_row + s0);
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
             const int k = 64 * cb + 16 * ct + c;
+            raw[ct] = float4{0.0f, 0.0f, 0.0f, 0.0f};
             if (64 * cb + 16 * ct >= K) continue;                              // (wave-uniform: a ragged last column block)
-            // four consecutive samples of input k as ONE 16-byte load (the planes hold whole 16-sample tiles - zero-filled features,
-            // finite Z columns - and dZ of a padding sample is 0, so nothing is clamped)
-            float b[4];
-            if (IN == WIDE_IN_FEAT) {
-                if (k < enc_dim) {
-                    const float4 v = *reinterpret_cast<const float4*>(in + (size_t)k * in_stride + smp.lo + s0);
-                    b[0] = v.x; b[1] = v.y; b[2] = v.z; b[3] = v.w;
-                } else { b[0] = b[1] = b[2] = b[3] = 1.0f; }
-                if (HALF) { b[0] = round_f16(b[0]); b[1] = round_f16(b[1]); b[2] = round_f16(b[2]); b[3] = round_f16(b[3]); }
-            } else if (IN == WIDE_IN_PAIR) {
-                if (k < enc_dim) {
-                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint32_t*>(in) + (size_t)(k >> 1) * in_stride + smp.lo + s0);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const uint32_t w = v[i];           // (a copy: __builtin_bit_cast applied to the vector ELEMENT v[i] reads element 0 for every i)
-                        const h2 p = __builtin_bit_cast(h2, w);
-                        b[i] = (float)((k & 1) ? p.y : p.x);
-                    }
-                } else { b[0] = b[1] = b[2] = b[3] = 1.0f; }
-            } else {
-                const float4 v = *reinterpret_cast<const float4*>(in + (size_t)k * in_stride + s0);
-                b[0] = act_fwd(v.x, act); b[1] = act_fwd(v.y, act); b[2] = act_fwd(v.z, act); b[3] = act_fwd(v.w, act);
-                if (HALF) { b[0] = round_f16(b[0]); b[1] = round_f16(b[1]); b[2] = round_f16(b[2]); b[3] = round_f16(b[3]); }
-            }
-            MFMA4(acc[ct], a4, b[0], b[1], b[2], b[3]);
+            if (IN == WIDE_IN_Z) raw[ct] = *reinterpret_cast<const float4*>(in + (size_t)k * in_stride + s0 + 4 * g);
+            else if (k < enc_dim) raw[ct] = *reinterpret_cast<const float4*>(in + (size_t)(IN == WIDE_IN_PAIR ? (k >> 1) : k) * in_stride + smp.lo + s0 + 4 * g);
         }
+    };
+    // what the MFMAs consume, computed from the loaded words (the activation's switch sits here, behind the MFMAs of the tile before:
+    // in front of them its s_waitcnt would also wait for the requests just issued for the next tile)
+    auto finish = [&](const float4 (&raw)[4], float (&b)[4][4]) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            const int k = 64 * cb + 16 * ct + c;
+            b[ct][0] = raw[ct].x; b[ct][1] = raw[ct].y; b[ct][2] = raw[ct].z; b[ct][3] = raw[ct].w;
+            if (64 * cb + 16 * ct >= K) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (IN == WIDE_IN_FEAT) {
+                    if (k >= enc_dim) b[ct][i] = 1.0f;
+                    if (HALF) b[ct][i] = round_f16(b[ct][i]);
+                } else if (IN == WIDE_IN_PAIR) {
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    const uint32_t w = __builtin_bit_cast(uint32_t, b[ct][i]);
+                    const h2 p = __builtin_bit_cast(h2, w);
+                    b[ct][i] = k < enc_dim ? (float)((k & 1) ? p.y : p.x) : 1.0f;
+                } else {
+                    b[ct][i] = act_fwd(b[ct][i], act);
+                    if (HALF) b[ct][i] = round_f16(b[ct][i]);
+                }
+            }
+        }
+    };
+    float4 a_c = float4{0.0f, 0.0f, 0.0f, 0.0f}, a_n = a_c, r_n[4];
+    float b_c[4][4];
+    int64_t tile = split;
+    if (tile < n_tiles) { load_tile(tile, a_c, r_n); finish(r_n, b_c); }
+    for (; tile < n_tiles; tile += LNR_WIDE_SPLITS) {
+        const bool more = tile + LNR_WIDE_SPLITS < n_tiles;
+        if (more) load_tile(tile + LNR_WIDE_SPLITS, a_n, r_n);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            if (64 * cb + 16 * ct >= K) continue;
+            MFMA4(acc[ct], a_c, b_c[ct][0], b_c[ct][1], b_c[ct][2], b_c[ct][3]);
+        }
+        if (more) { a_c = a_n; finish(r_n, b_c); }
     }
     float* out = partial + (size_t)(1 + split) * n_mlp + layer_off;
 #pragma unroll
@@ -307,12 +332,13 @@ wide_fold_kernel(float* __restrict__ slabs, int64_t n_mlp, int64_t off, int64_t 
     slabs[off + i] += s;
 }
 
-// WT[k][j] = W[j][k] for one 256 x 256 hidden matrix (64 KB tiles through LDS would be overkill: 65 536 elements, once per backward call)
+// WT[k][j] = W[j][k] for one 256 x K matrix (K a multiple of 16; K / 16 x 16 workgroups, one 16 x 16 tile each; once per backward call)
 __global__ void __launch_bounds__(256)
-wide_transpose_kernel(const float* __restrict__ W, float* __restrict__ WT) {
+wide_transpose_kernel(const float* __restrict__ W, int K, float* __restrict__ WT) {
     __shared__ float tile[16][17];
-    const int bx = blockIdx.x % 16, by = blockIdx.x / 16, tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    tile[ty][tx] = W[(size_t)(16 * by + ty) * LNR_WIDE_H + 16 * bx + tx];
+    const int n_bx = K / 16;
+    const int bx = blockIdx.x % n_bx, by = blockIdx.x / n_bx, tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    tile[ty][tx] = W[(size_t)(16 * by + ty) * K + 16 * bx + tx];
     __syncthreads();
     WT[(size_t)(16 * bx + ty) * LNR_WIDE_H + 16 * by + tx] = tile[tx][ty];
 }
@@ -321,10 +347,12 @@ wide_transpose_kernel(const float* __restrict__ W, float* __restrict__ WT) {
 // TRANSPOSED weights: with WT [k][j] row-major the A fragments are 16-byte loads and the lane's dZ values are the B operands, i.e. the
 // loop of wide_layer_fwd_kernel (two tiles per wave).  The first version read W itself - one 4-byte load per MFMA, 64 of them hoisted per K
 // block: 488 registers, 1.85 ms per chunk = 9 TFLOP/s, 40 % of a 256 x 2 backward (profiles/r05_wide_networks.txt).
-template <bool HALF>
+// TO_FEAT (the first layer, WT = W_1^T [in_dim][256]): the result is the d_feature planes - rows < enc_dim, live samples, no activation
+// derivative.  (Its first version read W_1 untransposed, one tile per wave: 0.34 ms per chunk for 80 inputs, more than the hidden layer.)
+template <bool HALF, bool TO_FEAT>
 __global__ void __launch_bounds__(256)
-wide_dx_hidden_kernel(const float* __restrict__ WT, const float* __restrict__ dz, int64_t chp, int act, WideSamples smp,
-                      const float* __restrict__ z_prev, float* __restrict__ out) {
+wide_dx_kernel(const float* __restrict__ WT, int n_kt, const float* __restrict__ dz, int64_t chp, int act, WideSamples smp,
+               const float* __restrict__ z_prev, float* __restrict__ out, int64_t out_stride, int enc_dim) {
     // WT rows 16 kt .. 16 kt + 15 (16 KB, contiguous) staged through LDS, double-buffered and shared by the four waves, as in
     // wide_layer_fwd_kernel; the loop over tile pairs is workgroup-uniform for the barriers
     __shared__ __attribute__((aligned(16))) float wt_s[2][16 * WIDE_LDS_TROW];
@@ -357,8 +385,8 @@ wide_dx_hidden_kernel(const float* __restrict__ WT, const float* __restrict__ dz
         }
         __syncthreads();
 #pragma unroll 1
-        for (int kt = 0; kt < 16; ++kt) {                        // (rolled: one output row tile at a time keeps the epilogue's operands few)
-            const bool more = kt + 1 < 16;
+        for (int kt = 0; kt < n_kt; ++kt) {                      // (rolled: one output row tile at a time keeps the epilogue's operands few)
+            const bool more = kt + 1 < n_kt;
             if (more) {
                 const float* nx = wsrc + (size_t)(kt + 1) * 4096;
                 s0 = *reinterpret_cast<const float4*>(nx); s1 = *reinterpret_cast<const float4*>(nx + 1024);
@@ -368,7 +396,7 @@ wide_dx_hidden_kernel(const float* __restrict__ WT, const float* __restrict__ dz
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const size_t row = (size_t)(16 * kt + 4 * g + r) * chp;
-                zp[0][r] = z_prev[row + ml0]; zp[1][r] = z_prev[row + ml1];
+                zp[0][r] = TO_FEAT ? 0.0f : z_prev[row + ml0]; zp[1][r] = TO_FEAT ? 0.0f : z_prev[row + ml1];
             }
             f32x4 D0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, D1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             const float* wb = &wt_s[kt & 1][c * WIDE_LDS_TROW + 4 * g];
@@ -384,9 +412,15 @@ wide_dx_hidden_kernel(const float* __restrict__ WT, const float* __restrict__ dz
             if (active) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const size_t row = (size_t)(16 * kt + 4 * g + r) * chp;
-                    out[row + ml0] = ml0 < M ? D0[r] * act_bwd(zp[0][r], act) : 0.0f;
-                    if (have1) out[row + ml1] = ml1 < M ? D1[r] * act_bwd(zp[1][r], act) : 0.0f;
+                    const int k = 16 * kt + 4 * g + r;
+                    if (TO_FEAT) {
+                        if (k < enc_dim && ml0 < M) out[(size_t)k * out_stride + smp.lo + ml0] = D0[r];
+                        if (k < enc_dim && have1 && ml1 < M) out[(size_t)k * out_stride + smp.lo + ml1] = D1[r];
+                    } else {
+                        const size_t row = (size_t)k * chp;
+                        out[row + ml0] = ml0 < M ? D0[r] * act_bwd(zp[0][r], act) : 0.0f;
+                        if (have1) out[row + ml1] = ml1 < M ? D1[r] * act_bwd(zp[1][r], act) : 0.0f;
+                    }
                 }
             }
             if (more) {
@@ -395,42 +429,6 @@ wide_dx_hidden_kernel(const float* __restrict__ WT, const float* __restrict__ dz
                 *reinterpret_cast<float4*>(dst + 8 * WIDE_LDS_TROW) = wide_w4<HALF>(s2); *reinterpret_cast<float4*>(dst + 12 * WIDE_LDS_TROW) = wide_w4<HALF>(s3);
             }
             __syncthreads();
-        }
-    }
-}
-
-// out_k[ml] = sum_j W[j][k] dZ[j][ml]: a wave owns a 16-sample tile (its dZ column: 64 registers), W^T operands stream from L2.
-// TO_FEAT: the result is the d_feature planes (rows < enc_dim, live samples); else it is multiplied by act'(Z_prev[k][ml]) and
-// becomes the previous layer's dZ (padding columns zero)
-template <bool HALF, bool TO_FEAT>
-__global__ void __launch_bounds__(256)
-wide_dx_kernel(const float* __restrict__ W, int K, const float* __restrict__ dz, int64_t chp, int act, WideSamples smp,
-               const float* __restrict__ z_prev, float* __restrict__ out, int64_t out_stride, int enc_dim) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = lane & 15, g = lane >> 4;
-    const int64_t M = wide_live(smp);
-    const int64_t n_tiles = (M + 15) / 16;
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
-        const int64_t ml = tile * 16 + c;
-        const bool valid = ml < M;
-        float d[16][4];
-#pragma unroll
-        for (int jt = 0; jt < 16; ++jt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) d[jt][r] = dz[(size_t)(16 * jt + 4 * g + r) * chp + ml];          // (whole tiles exist: padding columns are 0)
-        for (int kt = 0; kt < K / 16; ++kt) {
-            f32x4 D = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int jt = 0; jt < 16; ++jt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    D = __builtin_amdgcn_mfma_f32_16x16x4f32(wide_w<HALF>(W[(size_t)(16 * jt + 4 * g + r) * K + 16 * kt + c]), d[jt][r], D, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = 16 * kt + 4 * g + r;
-                if (TO_FEAT) { if (valid && k < enc_dim) out[(size_t)k * out_stride + smp.lo + ml] = D[r]; }
-                else out[(size_t)k * out_stride + ml] = valid ? D[r] * act_bwd(z_prev[(size_t)k * chp + ml], act) : 0.0f;
-            }
         }
     }
 }
@@ -494,19 +492,20 @@ static int wide_backward(const WideCtx& c, const float* d_sigma, float* dfeat, f
     // transposed copies of the hidden matrices (back-propagation reads them as A fragments): behind the partial slabs
     float* wt = slabs + (size_t)(2 + LNR_WIDE_SPLITS) * n_mlp;
     for (int l = 1; l < c.NH; ++l)
-        hipLaunchKernelGGL(wide_transpose_kernel, dim3(256), block, 0, c.st, c.W(l), wt + (size_t)(l - 1) * c.H * c.H);
+        hipLaunchKernelGGL(wide_transpose_kernel, dim3(256), block, 0, c.st, c.W(l), c.H, wt + (size_t)(l - 1) * c.H * c.H);
+    float* wt_first = wt + (size_t)(c.NH - 1) * c.H * c.H;         // W_1^T [in_dim][256], for the d_feature planes
+    if (want_dfeat) hipLaunchKernelGGL(wide_transpose_kernel, dim3((unsigned)(c.K1 / 16 * 16)), block, 0, c.st, c.W(0), c.K1, wt_first);
     for (int64_t lo = 0; lo < c.pt->n_points; lo += LNR_WIDE_CHUNK) {
         const int64_t n = c.pt->n_points - lo < LNR_WIDE_CHUNK ? c.pt->n_points - lo : LNR_WIDE_CHUNK;
         const WideSamples s = c.samples(lo, n);
-        const int64_t tiles = (n + 15) / 16;                         // (wide_dx_kernel, first layer: one tile per wave)
-        const dim3 grid_t((unsigned)((tiles + 3) / 4 > 2048 ? 2048 : (tiles + 3) / 4));
-        const int64_t pairs = (tiles + 1) / 2;                       // (wide_dx_hidden_kernel: two tiles per wave)
+        const int64_t tiles = (n + 15) / 16;
+        const int64_t pairs = (tiles + 1) / 2;                       // (wide_dx_kernel: two tiles per wave)
         const dim3 grid_p((unsigned)((pairs + 3) / 4 > 2048 ? 2048 : (pairs + 3) / 4));
         const dim3 grid_s((unsigned)((n + 255) / 256));
         wide_forward_chunk<HALF>(c, s);
         float* dz = c.dzbuf(0);
         float* dz_other = c.dzbuf(1);
-        hipLaunchKernelGGL(wide_dz_out_kernel<HALF>, grid_s, block, 0, c.st, c.Wo(), c.act, c.z(c.NH - 1), (int64_t)LNR_WIDE_CHUNK, s, d_sigma, dz);
+        hipLaunchKernelGGL(wide_dz_out_kernel<HALF>, dim3(grid_s.x, 4), block, 0, c.st, c.Wo(), c.act, c.z(c.NH - 1), (int64_t)LNR_WIDE_CHUNK, s, d_sigma, dz);
         if (want_dw) hipLaunchKernelGGL(wide_dwo_kernel, dim3(LNR_WIDE_H), dim3(1024), 0, c.st, c.act, c.z(c.NH - 1), (int64_t)LNR_WIDE_CHUNK, s, d_sigma, slabs + off_o);
         for (int l = c.NH - 1; l >= 0; --l) {
             const int K = l == 0 ? c.K1 : c.H;
@@ -519,10 +518,12 @@ static int wide_backward(const WideCtx& c, const float* d_sigma, float* dfeat, f
             const int64_t count = (int64_t)c.H * K;
             if (want_dw) hipLaunchKernelGGL(wide_fold_kernel, dim3((unsigned)((count + 255) / 256)), block, 0, c.st, slabs, n_mlp, layer_off, count);
             if (l > 0) {
-                hipLaunchKernelGGL(wide_dx_hidden_kernel<HALF>, grid_p, block, 0, c.st, wt + (size_t)(l - 1) * c.H * c.H, dz, (int64_t)LNR_WIDE_CHUNK, c.act, s, c.z(l - 1), dz_other);
+                hipLaunchKernelGGL((wide_dx_kernel<HALF, false>), grid_p, block, 0, c.st, wt + (size_t)(l - 1) * c.H * c.H, c.H / 16, dz, (int64_t)LNR_WIDE_CHUNK, c.act, s,
+                                   c.z(l - 1), dz_other, (int64_t)LNR_WIDE_CHUNK, 0);
                 float* t = dz; dz = dz_other; dz_other = t;
             } else if (want_dfeat) {
-                hipLaunchKernelGGL((wide_dx_kernel<HALF, true>), grid_t, block, 0, c.st, c.W(0), K, dz, (int64_t)LNR_WIDE_CHUNK, c.act, s, (const float*)nullptr, dfeat, c.m_pad, c.spec->enc_dim);
+                hipLaunchKernelGGL((wide_dx_kernel<HALF, true>), grid_p, block, 0, c.st, wt_first, K / 16, dz, (int64_t)LNR_WIDE_CHUNK, c.act, s, (const float*)nullptr, dfeat,
+                                   c.m_pad, c.spec->enc_dim);
             }
         }
     }
