@@ -30,6 +30,7 @@
 #define WIDE_LDS_TROW 260              // floats per staged row of a transposed matrix (back-propagation): 256 + 4 padding, same reason
 
 enum { WIDE_IN_FEAT = 0, WIDE_IN_PAIR = 1, WIDE_IN_Z = 2 };
+template <int N> struct WideInt { static constexpr int value = N; };
 
 struct WideSamples {                   // which samples a launch works on
     int64_t lo, n;                     // chunk = samples [lo, lo + n) of the batch
@@ -239,14 +240,19 @@ wide_dwo_kernel(int act, const float* __restrict__ z, int64_t chp, WideSamples s
 }
 
 // partial[split][j][k] = sum over the split's sample tiles of dZ[j][s] in_k[s]: workgroup = (64-row block, 64-column block, split),
-// wave w = row tile 4 rb + w, up to four 16-column tiles; both operands are 16-byte loads of 4 consecutive samples of one row, requested
-// one tile ahead of the MFMAs that consume them.  The 4 n_cb workgroups of a split read the same dZ rows and input rows: the block
-// index is decoded so that they share an XCD (workgroup i runs on XCD i mod 8), i.e. one L2 - with the plain (rb, cb, split) order a
-// split's workgroups sat on all eight and every plane crossed the fabric 2 - 4 times.
+// wave w = row tile 4 rb + w, up to four 16-column tiles.  Both operands are 16-byte loads of 4 consecutive samples of one
+// [row][sample] plane (the K dimension of one MFMA: no transposition).  The input operand - the same 64 columns x 16 samples for all four
+// waves - is loaded once per workgroup (one 16-byte load per thread), finished (activation, fp16 rounding, pair extraction: once
+// instead of four times) and shared through LDS, double-buffered, a tile ahead of the MFMAs; the dZ operand is the wave's own.
+// The 4 n_cb workgroups of a split read the same dZ rows and input rows: the block index is decoded so that they share an XCD
+// (workgroup i runs on XCD i mod 8), i.e. one L2 - with the plain (rb, cb, split) order a split's workgroups sat on all eight and
+// every plane crossed the fabric 2 - 4 times.  (0.84 ms per chunk for a hidden matrix with 32 ranges, 0.46 with 128, 0.37 with the XCD
+// order and per-wave operand prefetch.)
 template <bool HALF, int IN>
 __global__ void __launch_bounds__(256)
 wide_dw_kernel(const float* __restrict__ dz, int64_t chp, const float* __restrict__ in, int64_t in_stride, int enc_dim, int K, int act,
                WideSamples smp, float* __restrict__ partial, int64_t n_mlp, int64_t layer_off) {
+    __shared__ __attribute__((aligned(16))) float b_s[2][64 * WIDE_LDS_ROW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int n_cb = (K + 63) / 64, n_inner = 4 * n_cb;
@@ -257,69 +263,69 @@ wide_dw_kernel(const float* __restrict__ dz, int64_t chp, const float* __restric
     const int64_t M = wide_live(smp);
     const int64_t n_tiles = (M + 15) / 16;
     const float* dz_row = dz + (size_t)(16 * jt + c) * chp + 4 * g;
-    f32x4 acc[4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    // four consecutive samples of input k as ONE 16-byte load (the planes hold whole 16-sample tiles - zero-filled features, finite Z
-    // columns - and dZ of a padding sample is 0, so nothing is clamped); pair planes travel as bit patterns
-    auto load_tile = [&](int64_t tile, float4& a4, float4 (&raw)[4]) {
-        const int64_t s0 = tile * 16;
-        a4 = *reinterpret_cast<const float4*>(dz_row + s0);
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            const int k = 64 * cb + 16 * ct + c;
-            raw[ct] = float4{0.0f, 0.0f, 0.0f, 0.0f};
-            if (64 * cb + 16 * ct >= K) continue;                              // (wave-uniform: a ragged last column block)
-            if (IN == WIDE_IN_Z) raw[ct] = *reinterpret_cast<const float4*>(in + (size_t)k * in_stride + s0 + 4 * g);
-            else if (k < enc_dim) raw[ct] = *reinterpret_cast<const float4*>(in + (size_t)(IN == WIDE_IN_PAIR ? (k >> 1) : k) * in_stride + smp.lo + s0 + 4 * g);
+    // the thread's share of the input operand: samples 4 sq .. 4 sq + 3 of column sc of the workgroup's 64
+    const int sc = threadIdx.x >> 2, sq = threadIdx.x & 3;
+    const int sk = 64 * cb + sc;
+    const bool s_load = sk < K && (IN == WIDE_IN_Z || sk < enc_dim);          // (else: a constant-one padding input, or beyond a ragged last block)
+    const float* s_src = in + (size_t)(IN == WIDE_IN_PAIR ? (sk >> 1) : sk) * in_stride + (IN == WIDE_IN_Z ? 0 : smp.lo) + 4 * sq;
+    float* s_dst0 = &b_s[0][sc * WIDE_LDS_ROW + 4 * sq];
+    // (the planes hold whole 16-sample tiles - zero-filled features, finite Z columns - and dZ of a padding sample is 0: nothing is clamped)
+    auto finish1 = [&](float v) -> float {
+        if (IN == WIDE_IN_FEAT) {
+            if (!s_load) v = 1.0f;
+            return HALF ? round_f16(v) : v;
+        } else if (IN == WIDE_IN_PAIR) {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const uint32_t w = __builtin_bit_cast(uint32_t, v);
+            const h2 p = __builtin_bit_cast(h2, w);
+            return s_load ? (float)((sk & 1) ? p.y : p.x) : 1.0f;
         }
+        v = act_fwd(v, act);
+        return HALF ? round_f16(v) : v;
     };
-    // what the MFMAs consume, computed from the loaded words (the activation's switch sits here, behind the MFMAs of the tile before:
-    // in front of them its s_waitcnt would also wait for the requests just issued for the next tile)
-    auto finish = [&](const float4 (&raw)[4], float (&b)[4][4]) {
+    auto finish = [&](float4 raw) -> float4 { return float4{finish1(raw.x), finish1(raw.y), finish1(raw.z), finish1(raw.w)}; };
+    // the loop over the split's tiles, for a workgroup with NCT 16-column tiles (a compile-time count - and a loop body without
+    // branches in front of its MFMAs: with a wave-uniform "skip this column tile" inside, every MFMA group waited for ALL outstanding
+    // loads, the next tile's included).  The last iteration requests its own tile again and stages it into the idle buffer.
+    auto run = [&](auto nct_tag) {
+        constexpr int NCT = decltype(nct_tag)::value;
+        f32x4 acc[NCT];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            const int k = 64 * cb + 16 * ct + c;
-            b[ct][0] = raw[ct].x; b[ct][1] = raw[ct].y; b[ct][2] = raw[ct].z; b[ct][3] = raw[ct].w;
-            if (64 * cb + 16 * ct >= K) continue;
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const float4 zero4 = float4{0.0f, 0.0f, 0.0f, 0.0f};
+        float4 a_c = zero4, a_n = zero4, raw = zero4;
+        int64_t tile = split;
+        if (tile < n_tiles) {
+            if (s_load) raw = *reinterpret_cast<const float4*>(s_src + tile * 16);
+            a_c = *reinterpret_cast<const float4*>(dz_row + tile * 16);
+            *reinterpret_cast<float4*>(s_dst0) = finish(raw);
+        }
+        __syncthreads();
+        for (int it = 0; tile < n_tiles; tile += LNR_WIDE_SPLITS, ++it) {       // (workgroup-uniform trip count: barriers inside)
+            const int64_t nt = tile + LNR_WIDE_SPLITS < n_tiles ? tile + LNR_WIDE_SPLITS : tile;
+            if (s_load) raw = *reinterpret_cast<const float4*>(s_src + nt * 16);
+            a_n = *reinterpret_cast<const float4*>(dz_row + nt * 16);
+            const float* bb = &b_s[it & 1][c * WIDE_LDS_ROW + 4 * g];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (IN == WIDE_IN_FEAT) {
-                    if (k >= enc_dim) b[ct][i] = 1.0f;
-                    if (HALF) b[ct][i] = round_f16(b[ct][i]);
-                } else if (IN == WIDE_IN_PAIR) {
-                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-                    const uint32_t w = __builtin_bit_cast(uint32_t, b[ct][i]);
-                    const h2 p = __builtin_bit_cast(h2, w);
-                    b[ct][i] = k < enc_dim ? (float)((k & 1) ? p.y : p.x) : 1.0f;
-                } else {
-                    b[ct][i] = act_fwd(b[ct][i], act);
-                    if (HALF) b[ct][i] = round_f16(b[ct][i]);
-                }
+            for (int ct = 0; ct < NCT; ++ct) {
+                const float4 b = *reinterpret_cast<const float4*>(bb + 16 * ct * WIDE_LDS_ROW);
+                MFMA4(acc[ct], a_c, b.x, b.y, b.z, b.w);
             }
+            *reinterpret_cast<float4*>(s_dst0 + ((it + 1) & 1) * 64 * WIDE_LDS_ROW) = finish(raw);
+            a_c = a_n;
+            __syncthreads();
         }
+        float* out = partial + (size_t)(1 + split) * n_mlp + layer_off;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(size_t)(16 * jt + 4 * g + r) * K + 64 * cb + 16 * ct + c] = acc[ct][r];
     };
-    float4 a_c = float4{0.0f, 0.0f, 0.0f, 0.0f}, a_n = a_c, r_n[4];
-    float b_c[4][4];
-    int64_t tile = split;
-    if (tile < n_tiles) { load_tile(tile, a_c, r_n); finish(r_n, b_c); }
-    for (; tile < n_tiles; tile += LNR_WIDE_SPLITS) {
-        const bool more = tile + LNR_WIDE_SPLITS < n_tiles;
-        if (more) load_tile(tile + LNR_WIDE_SPLITS, a_n, r_n);
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            if (64 * cb + 16 * ct >= K) continue;
-            MFMA4(acc[ct], a_c, b_c[ct][0], b_c[ct][1], b_c[ct][2], b_c[ct][3]);
-        }
-        if (more) { a_c = a_n; finish(r_n, b_c); }
-    }
-    float* out = partial + (size_t)(1 + split) * n_mlp + layer_off;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-        if (64 * cb + 16 * ct >= K) continue;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) out[(size_t)(16 * jt + 4 * g + r) * K + 64 * cb + 16 * ct + c] = acc[ct][r];
-    }
+    const int n_ct = (K - 64 * cb) / 16;                            // column tiles of this workgroup (a ragged last block has fewer than four)
+    if (n_ct >= 4) run(WideInt<4>{});
+    else if (n_ct == 3) run(WideInt<3>{});
+    else if (n_ct == 2) run(WideInt<2>{});
+    else run(WideInt<1>{});
 }
 
 // total[off + i] += sum over the splits of partial[1 + s][off + i], s ascending (fixed order)
