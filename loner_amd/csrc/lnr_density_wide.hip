@@ -7,17 +7,19 @@
 //   * the samples are processed in chunks of LNR_WIDE_CHUNK; a chunk's pre-activations Z_l [256][chunk] of every hidden layer and its
 //     dZ planes live in the workspace (0.5 - 0.7 GB), so the batch size does not bound the memory;
 //   * forward of a layer: a wave owns two 16-sample tiles and all 256 rows; the workgroup stages the layer's weights through LDS one
-//     16-input block at a time, double-buffered (wide_layer_fwd_kernel);
+//     16-input block at a time, double-buffered, while the inputs of the next block are in flight (wide_layer_fwd_kernel);
 //   * the WEIGHT GRADIENT dW_l = dZ_l a_{l-1}^T is split over samples ACROSS workgroups (split-K): a workgroup owns a 64 x 64 tile of
 //     dW and one of S sample ranges of the chunk, both operands are read straight from the [row][sample] planes as 16-byte loads
-//     (4 consecutive samples = the K dimension of one MFMA: no transposition anywhere), accumulators in registers, one partial slab
-//     per sample range, folded in a fixed order (wide_dw_kernel / wide_fold_kernel: deterministic, no atomics);
-//   * back-propagation dA_{l-1} = W_l^T dZ_l per 16-sample tile with the activation derivative applied on the way out.
+//     (4 consecutive samples = the K dimension of one MFMA: no transposition anywhere), the input operand shared through LDS, the
+//     workgroups of a range on one XCD, accumulators in registers, one partial slab per sample range, folded in a fixed order
+//     (wide_dw_kernel / wide_fold_kernel: deterministic, no atomics);
+//   * back-propagation dA_{l-1} = W_l^T dZ_l as a forward layer with a transposed copy of the weights, made once per call, the
+//     activation derivative applied on the way out (wide_dx_kernel; the first layer writes the d_feature planes).
 // Precision: LNR_PREC_F32 / LNR_PREC_F32_CHAIN - exact fp32 fma chains; LNR_PREC_F16 (HALF) - the reference's storage model of
 // oracle/network.py: weights and every layer's inputs rounded to fp16 where they are consumed, products and sums in fp32 (a product of
 // two fp16 values is exact in fp32, so the fp32 MFMA computes what the f16 MFMA with fp32 accumulation computes), gradients straight
-// through the rounding, in fp32.  Semantics = oracle/network.py.  Built for coverage of the configuration schema, not for speed: the
-// planes cross HBM once per layer and direction (DESIGN.md 4 has the measured times).
+// through the rounding, in fp32.  Semantics = oracle/network.py.  The planes cross HBM once per layer and direction; measured times and
+// the history of the kernels: DESIGN.md 4, profiles/r05_wide_networks.txt (256 x 2 at 2.1 M samples: 6.2 / 17.8 ms, ~60 TFLOP/s).
 #include "lnr_f16_common.h"
 
 #define LNR_WIDE_CHUNK 131072          // samples per chunk (a multiple of 64): 128 MB per [256][chunk] fp32 plane set

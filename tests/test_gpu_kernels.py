@@ -320,7 +320,7 @@ def test_density_backward_matches_oracle_autograd(ops, name):
 @pytest.mark.parametrize("name", ["freq_relu128", "freq_relu128x3", "freq_wide256", "freq_siren", "hash_f4_2hidden", "freq_wide256x2", "freq_tanh256x3"])
 def test_general_fp32_backward_over_many_steps(ops, name):
     """(the two 256 x n networks: the layer-by-layer route, lnr_density_wide.hip - 40 013 points are a partly filled chunk whose weight
-    gradient is split over 32 sample ranges; test_wide_networks_across_chunks covers several chunks.  The three-layer one is smooth
+    gradient is split over 128 sample ranges; test_wide_networks_across_chunks covers several chunks.  The three-layer one is smooth
     (Tanh): with 256 x 3 piecewise-linear units and 40 013 points the fp32 oracle itself is 8e-3 from its fp64 self - pre-activations
     within rounding of a kink change a unit's derivative - so a kinked network of that size cannot be held to 2e-5 by anyone)
     mlp_backward_regs_kernel (lnr_density_regs.h) beyond one step per workgroup: 256 workgroups x 64 samples per step, so 40 013 points
