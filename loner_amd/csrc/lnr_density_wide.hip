@@ -17,7 +17,8 @@
 //     activation derivative applied on the way out (wide_dx_kernel; the first layer writes the d_feature planes).
 // Precision: LNR_PREC_F32 / LNR_PREC_F32_CHAIN - exact fp32 fma chains; LNR_PREC_F16 (HALF) - the reference's storage model of
 // oracle/network.py: weights and every layer's inputs rounded to fp16 where they are consumed, products and sums in fp32 (a product of
-// two fp16 values is exact in fp32, so the fp32 MFMA computes what the f16 MFMA with fp32 accumulation computes), gradients straight
+// two fp16 values is exact in fp32, so the fp32 MFMA computes what the f16 MFMA with fp32 accumulation computes: the forward layers use
+// the f16 pipe - wide_layer_fwd_h_kernel - the backward kernels, whose dZ operand is fp32, the fp32 pipe), gradients straight
 // through the rounding, in fp32.  Semantics = oracle/network.py.  The planes cross HBM once per layer and direction; measured times and
 // the history of the kernels: DESIGN.md 4, profiles/r05_wide_networks.txt (256 x 2 at 2.1 M samples: 6.2 / 17.8 ms, ~60 TFLOP/s).
 #include "lnr_f16_common.h"
@@ -175,6 +176,135 @@ wide_layer_fwd_kernel(const float* __restrict__ W, int K, const float* __restric
             }
             __syncthreads();                                      // block kt + 1 is visible; nobody reads block kt any more
         }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (2 * pair + t >= n_tiles) continue;                // (whole tiles of the chunk planes are written, padding columns included)
+            const int64_t col = (2 * pair + t) * 16 + c;
+#pragma unroll
+            for (int jt = 0; jt < 16; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z_out[(size_t)(16 * jt + 4 * g + r) * chp + col] = Z[t][jt][r];
+        }
+    }
+}
+
+// The forward layer of the fp16 mode on the f16 matrix pipe (v_mfma_f32_16x16x32_f16: one instruction per 32 inputs where the fp32 pipe
+// takes eight - the storage model's values either way: fp16 operands, fp32 accumulation).  Same tiling and staging as
+// wide_layer_fwd_kernel; a K block is 32 inputs, the staged weights are fp16 (80-byte rows), the first layer's B operand is four dwords
+// of the half2 pair planes as they are (lnr_density_f16.hip: K slot 8 g + i of a lane = input 32 kb + 8 g + i), a hidden layer's is
+// act(Z) rounded and packed.  Inputs beyond in_dim (a last block of 16) meet zero weights.  IN: WIDE_IN_PAIR or WIDE_IN_Z.
+#define WIDE_LDS_HROW 40               // halves per staged weight row: 32 + 8 padding
+#define WIDE_PIPELINE_LDS_MFMA_H()                                 \
+    do {                                                          \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 14; ++i_) {       \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    \
+        }                                                         \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);        \
+    } while (0)
+
+template <int IN>
+__global__ void __launch_bounds__(256)
+wide_layer_fwd_h_kernel(const float* __restrict__ W, int K, const float* __restrict__ in, int64_t in_stride, int enc_dim, int act,
+                        WideSamples smp, float* __restrict__ z_out, int64_t chp) {
+    __shared__ __attribute__((aligned(16))) f16 w_h[2][LNR_WIDE_H * WIDE_LDS_HROW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int64_t M = wide_live(smp);
+    const int64_t n_tiles = (M + 15) / 16;
+    const int64_t n_pairs = (n_tiles + 1) / 2;
+    const int n_kb = (K + 31) / 32;
+    const float* wsrc = W + (size_t)threadIdx.x * K;               // staging: thread j converts row j's 32 floats of a block
+    const uint32_t ones2 = pack_h2(1.0f, 1.0f);
+    for (int64_t base = (int64_t)blockIdx.x * 4; base < n_pairs; base += (int64_t)gridDim.x * 4) {
+        const int64_t pair = base + wave;
+        int64_t ml[2], m[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            ml[t] = (2 * pair + t) * 16 + c;
+            if (ml[t] >= M) ml[t] = M - 1;                        // (finite operands for padding columns, a missing second tile, an idle wave)
+            m[t] = smp.lo + ml[t];
+        }
+        f32x4 Z[2][16];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int jt = 0; jt < 16; ++jt) Z[t][jt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        float4 s0, s1, s2, s3, s4, s5, s6, s7;                    // the thread's 32 weights of the block in flight
+        float xr[2][8];                                           // the lane's inputs of the block in flight, as loaded (pair planes: 4 dwords)
+        f16x8 xb[2];
+#define WIDE_H_STAGE_LOAD(kb_)                                                                                              \
+        do {                                                                                                                \
+            const int k0_ = 32 * (kb_);                                                                                     \
+            const bool hi_ = k0_ + 16 < K;                       /* (in_dim is a multiple of 16: a block is whole or half) */ \
+            const float* a_ = wsrc + k0_; const float* b_ = wsrc + (hi_ ? k0_ + 16 : k0_);                                  \
+            s0 = *reinterpret_cast<const float4*>(a_); s1 = *reinterpret_cast<const float4*>(a_ + 4);                       \
+            s2 = *reinterpret_cast<const float4*>(a_ + 8); s3 = *reinterpret_cast<const float4*>(a_ + 12);                  \
+            s4 = *reinterpret_cast<const float4*>(b_); s5 = *reinterpret_cast<const float4*>(b_ + 4);                       \
+            s6 = *reinterpret_cast<const float4*>(b_ + 8); s7 = *reinterpret_cast<const float4*>(b_ + 12);                  \
+        } while (0)
+#define WIDE_H_STAGE_STORE(buf_, kb_)       /* (the second half of a last half block is zeroed here, not at the load: no early wait) */ \
+        do {                                                                                                                \
+            if (!(32 * (kb_) + 16 < K)) { s4 = s5 = s6 = s7 = float4{0.0f, 0.0f, 0.0f, 0.0f}; }                             \
+            u32x4* d_ = reinterpret_cast<u32x4*>(&w_h[buf_][threadIdx.x * WIDE_LDS_HROW]);                                  \
+            d_[0] = u32x4{pack_h2(s0.x, s0.y), pack_h2(s0.z, s0.w), pack_h2(s1.x, s1.y), pack_h2(s1.z, s1.w)};              \
+            d_[1] = u32x4{pack_h2(s2.x, s2.y), pack_h2(s2.z, s2.w), pack_h2(s3.x, s3.y), pack_h2(s3.z, s3.w)};              \
+            d_[2] = u32x4{pack_h2(s4.x, s4.y), pack_h2(s4.z, s4.w), pack_h2(s5.x, s5.y), pack_h2(s5.z, s5.w)};              \
+            d_[3] = u32x4{pack_h2(s6.x, s6.y), pack_h2(s6.z, s6.w), pack_h2(s7.x, s7.y), pack_h2(s7.z, s7.w)};              \
+        } while (0)
+        auto x_load = [&](int kb) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (IN == WIDE_IN_PAIR) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {                 // pair plane 16 kb + 4 g + q = inputs 32 kb + 8 g + 2 q, + 1
+                        const int p = 16 * kb + 4 * g + q;
+                        xr[t][q] = in[(size_t)(2 * p < enc_dim ? p : 0) * in_stride + m[t]];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) xr[t][r] = in[(size_t)(32 * kb + 8 * g + r) * in_stride + ml[t]];
+                }
+            }
+        };
+        auto x_finish = [&](int kb) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (IN == WIDE_IN_PAIR) {
+                    uint32_t d[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) d[q] = 2 * (16 * kb + 4 * g + q) < enc_dim ? __builtin_bit_cast(uint32_t, xr[t][q]) : ones2;     // (padding inputs are the constant 1)
+                    xb[t] = frag_from_dwords(d[0], d[1], d[2], d[3]);
+                } else {
+                    xb[t] = frag_from_dwords(pack_h2(act_fwd(xr[t][0], act), act_fwd(xr[t][1], act)), pack_h2(act_fwd(xr[t][2], act), act_fwd(xr[t][3], act)),
+                                             pack_h2(act_fwd(xr[t][4], act), act_fwd(xr[t][5], act)), pack_h2(act_fwd(xr[t][6], act), act_fwd(xr[t][7], act)));
+                }
+            }
+        };
+        WIDE_H_STAGE_LOAD(0);
+        x_load(0);
+        WIDE_H_STAGE_STORE(0, 0);                                 // (every reader of buffer 0 is behind the barrier that ended its K block)
+        x_finish(0);
+        __syncthreads();
+        for (int kb = 0; kb < n_kb; ++kb) {
+            const bool more = kb + 1 < n_kb;
+            if (more) { WIDE_H_STAGE_LOAD(kb + 1); x_load(kb + 1); }
+            const f16* wb = &w_h[kb & 1][c * WIDE_LDS_HROW + 8 * g];
+            f16x8 wa = *reinterpret_cast<const f16x8*>(wb);       // W[16 jt + c][32 kb + 8 g ..], one fragment ahead
+#pragma unroll
+            for (int jt = 0; jt < 16; ++jt) {
+                const f16x8 wn = *reinterpret_cast<const f16x8*>(wb + 16 * (jt < 15 ? jt + 1 : 15) * WIDE_LDS_HROW);
+                Z[0][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, xb[0], Z[0][jt], 0, 0, 0);
+                Z[1][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, xb[1], Z[1][jt], 0, 0, 0);
+                wa = wn;
+            }
+            WIDE_PIPELINE_LDS_MFMA_H();
+            if (more) { WIDE_H_STAGE_STORE((kb + 1) & 1, kb + 1); x_finish(kb + 1); }
+            __syncthreads();                                      // block kb + 1 is visible; nobody reads block kb any more
+        }
+#undef WIDE_H_STAGE_LOAD
+#undef WIDE_H_STAGE_STORE
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             if (2 * pair + t >= n_tiles) continue;                // (whole tiles of the chunk planes are written, padding columns included)
@@ -474,10 +604,15 @@ static void wide_forward_chunk(const WideCtx& c, const WideSamples& s) {
     const dim3 block(256);
     const int64_t pairs = ((s.n + 15) / 16 + 1) / 2;                 // a wave owns two 16-sample tiles
     const dim3 grid((unsigned)((pairs + 3) / 4 > 2048 ? 2048 : (pairs + 3) / 4));
-    if (HALF) hipLaunchKernelGGL((wide_layer_fwd_kernel<HALF, WIDE_IN_PAIR>), grid, block, 0, c.st, c.W(0), c.K1, c.feat, c.m_pad, c.spec->enc_dim, c.act, s, c.z(0), (int64_t)LNR_WIDE_CHUNK);
-    else hipLaunchKernelGGL((wide_layer_fwd_kernel<HALF, WIDE_IN_FEAT>), grid, block, 0, c.st, c.W(0), c.K1, c.feat, c.m_pad, c.spec->enc_dim, c.act, s, c.z(0), (int64_t)LNR_WIDE_CHUNK);
+    if (HALF) {                                                     // the f16 matrix pipe
+        hipLaunchKernelGGL((wide_layer_fwd_h_kernel<WIDE_IN_PAIR>), grid, block, 0, c.st, c.W(0), c.K1, c.feat, c.m_pad, c.spec->enc_dim, c.act, s, c.z(0), (int64_t)LNR_WIDE_CHUNK);
+        for (int l = 1; l < c.NH; ++l)
+            hipLaunchKernelGGL((wide_layer_fwd_h_kernel<WIDE_IN_Z>), grid, block, 0, c.st, c.W(l), c.H, c.z(l - 1), (int64_t)LNR_WIDE_CHUNK, c.H, c.act, s, c.z(l), (int64_t)LNR_WIDE_CHUNK);
+        return;
+    }
+    hipLaunchKernelGGL((wide_layer_fwd_kernel<false, WIDE_IN_FEAT>), grid, block, 0, c.st, c.W(0), c.K1, c.feat, c.m_pad, c.spec->enc_dim, c.act, s, c.z(0), (int64_t)LNR_WIDE_CHUNK);
     for (int l = 1; l < c.NH; ++l)
-        hipLaunchKernelGGL((wide_layer_fwd_kernel<HALF, WIDE_IN_Z>), grid, block, 0, c.st, c.W(l), c.H, c.z(l - 1), (int64_t)LNR_WIDE_CHUNK, c.H, c.act, s, c.z(l), (int64_t)LNR_WIDE_CHUNK);
+        hipLaunchKernelGGL((wide_layer_fwd_kernel<false, WIDE_IN_Z>), grid, block, 0, c.st, c.W(l), c.H, c.z(l - 1), (int64_t)LNR_WIDE_CHUNK, c.H, c.act, s, c.z(l), (int64_t)LNR_WIDE_CHUNK);
 }
 
 template <bool HALF>
