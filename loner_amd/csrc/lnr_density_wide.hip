@@ -317,19 +317,31 @@ wide_layer_fwd_h_kernel(const float* __restrict__ W, int K, const float* __restr
     }
 }
 
-// sigma = w_out . act(Z_L) (the last hidden activation is NOT rounded in the storage model: oracle/network.py density_unit)
+// sigma = w_out . act(Z_L) (the last hidden activation is NOT rounded in the storage model: oracle/network.py density_unit).  A workgroup
+// owns 64 samples; wave w sums rows 64 w .. 64 w + 63 (an fma chain), the four partial sums are added in a fixed order.  (One thread per
+// sample walking all 256 rows: 79 us per chunk, 512 workgroups with one dependent load chain per thread.)
 template <bool HALF>
 __global__ void __launch_bounds__(256)
 wide_out_kernel(const float* __restrict__ wo, int act, const float* __restrict__ z, int64_t chp, WideSamples smp, float* __restrict__ sigma,
                 int32_t* __restrict__ clip_flag) {
     __shared__ float w_s[LNR_WIDE_H];
+    __shared__ float part[4][64];
     for (int i = threadIdx.x; i < LNR_WIDE_H; i += blockDim.x) w_s[i] = wide_w<HALF>(wo[i]);
     __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t M = wide_live(smp);
-    for (int64_t ml = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ml < M; ml += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < M; base += (int64_t)gridDim.x * 64) {      // (workgroup-uniform: barriers inside)
+        const int64_t ml = base + lane;
         float s = 0.0f;
-        for (int j = 0; j < LNR_WIDE_H; ++j) s = __builtin_fmaf(w_s[j], act_fwd(z[(size_t)j * chp + ml], act), s);
-        sigma[smp.lo + ml] = HALF ? finite_or_clipped<true>(s, clip_flag) : finite_or_clipped<false>(s, clip_flag);
+        if (ml < M)
+            for (int j = 64 * wave; j < 64 * wave + 64; ++j) s = __builtin_fmaf(w_s[j], act_fwd(z[(size_t)j * chp + ml], act), s);
+        part[wave][lane] = s;
+        __syncthreads();
+        if (wave == 0 && ml < M) {
+            const float t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+            sigma[smp.lo + ml] = HALF ? finite_or_clipped<true>(t, clip_flag) : finite_or_clipped<false>(t, clip_flag);
+        }
+        __syncthreads();
     }
 }
 
@@ -621,7 +633,7 @@ static int wide_forward(const WideCtx& c, float* sigma) {
         const int64_t n = c.pt->n_points - lo < LNR_WIDE_CHUNK ? c.pt->n_points - lo : LNR_WIDE_CHUNK;
         const WideSamples s = c.samples(lo, n);
         wide_forward_chunk<HALF>(c, s);
-        hipLaunchKernelGGL(wide_out_kernel<HALF>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.st, c.Wo(), c.act, c.z(c.NH - 1), (int64_t)LNR_WIDE_CHUNK, s, sigma, c.pt->clip_flag);
+        hipLaunchKernelGGL(wide_out_kernel<HALF>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, c.st, c.Wo(), c.act, c.z(c.NH - 1), (int64_t)LNR_WIDE_CHUNK, s, sigma, c.pt->clip_flag);
     }
     return LNR_OK;
 }
