@@ -8,6 +8,7 @@ The library lands in loner_amd/_lib/libloner_hip.so (git-ignored, travels with g
 import hashlib
 import json
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -35,8 +36,8 @@ EXTRA = {"lnr_render.hip": ["-mllvm", "-pragma-unroll-threshold=1000000", "-mllv
 SOURCES = [("lnr_density_ht.hip", f"lnr_density_ht{ht}.o", [f"-DLNR_HT={ht}"]) for ht in (16, 8, 4, 2, 1)] + \
           [("lnr_density_regs.hip", f"lnr_density_regs{ht}_{nh}.o", [f"-DLNR_HT={ht}", f"-DLNR_NH={nh}"])
            for ht in (8, 4, 16) for nh in (3, 2, 1) if not (ht == 16 and nh > 1)] + \
-          [("lnr_density_f16_bwd.hip", f"lnr_density_f16_bwd{part}.o", [f"-DLNR_BWD_PART={part}"]) for part in (0, 1, 2)] + \
-          [("lnr_density_f16_fwd.hip", f"lnr_density_f16_fwd{part}.o", [f"-DLNR_FWD_PART={part}"]) for part in (0, 1)] + \
+          [("lnr_density_f16_bwd.hip", f"lnr_density_f16_bwd{part}_fq{fq}.o", [f"-DLNR_BWD_PART={part}", f"-DLNR_BWD_FQ={fq}"]) for part in (2, 1, 0) for fq in (0, 1)] + \
+          [("lnr_density_f16_fwd.hip", f"lnr_density_f16_fwd{part}_fq{fq}.o", [f"-DLNR_FWD_PART={part}", f"-DLNR_FWD_FQ={fq}"]) for part in (1, 0) for fq in (0, 1)] + \
           [(s, s.replace(".hip", ".o"), EXTRA.get(s, [])) for s in
            ("lnr_core.hip", "lnr_density.hip", "lnr_density_f16.hip", "lnr_density_bf3.hip", "lnr_density_wide.hip", "lnr_encode.hip", "lnr_sampler.hip", "lnr_render.hip", "lnr_rays.hip", "lnr_optim.hip", "lnr_pose.hip")]
 
@@ -48,13 +49,20 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def _headers_digest():
-    h = hashlib.sha256()
-    for d in (CSRC, INCLUDE):
-        for f in sorted(os.listdir(d)):
-            if f.endswith(".h"):
-                h.update(open(os.path.join(d, f), "rb").read())
-    return h.hexdigest()
+_INC = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
+
+
+def _deps_digest(path, seen=None):
+    """Digest of the headers a source includes (transitively, quoted includes only): an edit rebuilds the objects that see it, not all 28."""
+    seen = {} if seen is None else seen
+    text = open(path, "rb").read()
+    for inc in _INC.findall(text.decode("utf-8", "replace")):
+        f = os.path.normpath(os.path.join(os.path.dirname(path), inc))
+        if f not in seen and os.path.exists(f):
+            seen[f] = None
+            seen[f] = hashlib.sha256(open(f, "rb").read()).hexdigest()
+            _deps_digest(f, seen)
+    return hashlib.sha256("".join(f"{os.path.basename(k)}:{v}" for k, v in sorted(seen.items())).encode()).hexdigest()
 
 
 def _load_manifest():
@@ -70,7 +78,7 @@ def _compile(item, force):
     path = os.path.join(CSRC, src)
     flags = list(COMMON) + list(extra) + (["-ffp-contract=off"] if src in EXACT else [])
     # staleness by content hash (file mtimes do not survive the copy to the GPU box)
-    digest = hashlib.sha256(open(path, "rb").read() + _headers_digest().encode() + " ".join(flags).encode()).hexdigest()
+    digest = hashlib.sha256(open(path, "rb").read() + _deps_digest(path).encode() + " ".join(flags).encode()).hexdigest()
     stale = force or not os.path.exists(obj) or _load_manifest().get(objname) != digest
     if stale:
         cmd = [_hipcc()] + flags + ["-c", path, "-o", obj]

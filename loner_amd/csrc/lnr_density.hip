@@ -482,10 +482,12 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
     const int64_t blocks = (int64_t)L.n_groups * L.bpg;
     size_t off = 0;
     L.off_status = off; off += LNR_WORKSPACE_STATUS_BYTES;          // status words (include/loner_hip.h), same place for every n_points
-    L.off_feat = off; off += align256((size_t)spec->enc_dim * L.m_pad * sizeof(float));
+    // (fp16 mode + frequency encoding: the MLP kernels evaluate the encoding and its input gradient themselves - no planes at all)
+    const size_t plane_set = lnr_f16_fused_freq(spec) ? 0 : (size_t)spec->enc_dim * L.m_pad * sizeof(float);
+    L.off_feat = off; off += align256(plane_set);
     L.off_wide = off; off += align256(lnr_wide_workspace(spec));     // chunk planes of the 256 x 2..3 route (0 bytes for every other network); the forward uses them too
-    L.off_dfeat = off; off += align256((size_t)spec->enc_dim * L.m_pad * sizeof(float));
-    L.off_dxl = off; off += align256((size_t)L.n_groups * 3 * L.m_pad * sizeof(float));
+    L.off_dfeat = off; off += align256(plane_set);
+    L.off_dxl = off; off += align256(plane_set == 0 ? 0 : (size_t)L.n_groups * 3 * L.m_pad * sizeof(float));
     L.off_dpts = off; off += align256((size_t)3 * L.m_pad * sizeof(float));      // d_pts scratch of the general d_rays route
     L.off_rayacc = off; off += align256(((size_t)(L.m_pad / 64) * 7 + 2) * sizeof(long long));   // per-ray sums of the d_rays route (n_samples >= 64 there) + a non-finite word per ray
     L.off_slabs = off; off += align256((size_t)LNR_BWD_MAX_BLOCKS * spec->n_mlp_params * sizeof(float));
@@ -738,7 +740,8 @@ extern "C" int lnr_density_forward(const LnrNetSpec* spec, const float* params, 
     ws_touch(workspace, layout_signature(spec, cap));
     float* feat = (float*)((char*)workspace + L.off_feat);
     mp.clip_flag = reinterpret_cast<int32_t*>((char*)workspace + L.off_status) + LNR_STATUS_CLIPPED;
-    {
+    const bool fused_freq = lnr_f16_fused_freq(spec);          // the MLP kernel evaluates the encoding itself: no encode launch, no planes
+    if (!fused_freq) {
         LnrProfScope prof("encode_forward", st);
         rc = lnr_encode_forward(spec, params, &src, cap, feat, L.m_pad, f16, st);
     }
@@ -752,7 +755,7 @@ extern "C" int lnr_density_forward(const LnrNetSpec* spec, const float* params, 
         return LNR_OK;
     }
     if (f16) {
-        rc = lnr_mlp_fwd_f16(spec, params, feat, L.m_pad, &mp, sigma, st);
+        rc = lnr_mlp_fwd_f16(spec, params, feat, L.m_pad, &mp, sigma, &src, st);
         if (rc) return rc;
         LNR_CHECK_LAUNCH("lnr_density_forward(mlp f16)");
         return LNR_OK;
@@ -831,7 +834,8 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     if (rc) return rc;
     const bool want_grad = grad_params != nullptr;
 
-    if (!reuse_features) {
+    const bool fused_freq = lnr_f16_fused_freq(spec);          // encoding and its input gradient inside the MLP backward kernel
+    if (!reuse_features && !fused_freq) {
         LnrProfScope prof("encode_forward", st);
         rc = lnr_encode_forward(spec, params, &src, cap, feat, L.m_pad, f16, st);
         if (rc) return rc;
@@ -850,7 +854,7 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     {
     LnrProfScope prof("mlp_backward", st);
     if (lnr_wide_class(spec)) rc = lnr_mlp_bwd_wide(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, want_grad ? 1 : 0, &n_slabs, ws + L.off_wide, st);
-    else if (f16) rc = lnr_mlp_bwd_f16(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &n_slabs, st);
+    else if (f16) rc = lnr_mlp_bwd_f16(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &n_slabs, &src, d_pts_eff, st);
     else if (lnr_bf3_class(spec, cap)) rc = lnr_mlp_bwd_bf3(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &n_slabs, st);
     else if (plan.regs) rc = mlp_bwd_regs(spec, params, feat, L.m_pad, &mp, d_sigma, dfeat, slabs, want_dfeat, &plan, st);
     else switch (spec->n_neurons / 16) {
@@ -883,7 +887,7 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
                    (flags & LNR_BWD_TABLE_ATOMICS) ? 0 : L.n_split, (flags & LNR_BWD_OVERWRITE_GRAD) ? 1 : 0};
     // hash grids (LNR_SPLIT_DX): the input gradient first, as launches of its own; the table-gradient partition follows behind the event
     const bool split = LNR_SPLIT_DX && hash;
-    if (want_dfeat) {
+    if (want_dfeat && !fused_freq) {
         rc = lnr_encode_backward(spec, params, &src, cap, dfeat, dxl, L.m_pad, grad_table, want_grad ? regions : nullptr, &rplan, counts,
                                  L.bpg, L.maxo, L.shift,
                                  ovf, ovf_flag, epoch, d_pts_eff, ray_accum ? d_rays : nullptr, (long long*)(ws + L.off_rayacc), (flags & LNR_BWD_BINS_W8) != 0,

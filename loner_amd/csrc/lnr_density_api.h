@@ -207,10 +207,13 @@ int lnr_encode_forward(const LnrNetSpec* spec, const float* params, const PointS
 
 // fp16-storage MLP kernels (lnr_density_f16.hip): features arrive as half2 planes [level][m_pad]
 bool lnr_f16_supported(const LnrNetSpec* spec);
+// fp16 mode + frequency encoding (up to 16 frequencies): the encoding is evaluated inside the MLP kernels (lnr_f16_freq.h) - no
+// encode launches, no feature / d_feature planes; the backward writes d_pts itself
+bool lnr_f16_fused_freq(const LnrNetSpec* spec);
 int lnr_mlp_fwd_f16(const LnrNetSpec* spec, const float* params, const void* featp, int64_t m_pad, const MlpPoints* pt, float* sigma,
-                    hipStream_t st);
+                    const PointSrc* src, hipStream_t st);
 int lnr_mlp_bwd_f16(const LnrNetSpec* spec, const float* params, const void* featp, int64_t m_pad, const MlpPoints* pt, const float* d_sigma,
-                    float* dfeat, float* slabs, int want_dfeat, int* n_slabs, hipStream_t st);
+                    float* dfeat, float* slabs, int want_dfeat, int* n_slabs, const PointSrc* src, float* d_pts, hipStream_t st);
 int lnr_f16_bwd_slabs(const LnrNetSpec* spec, int64_t n_points);
 int lnr_selftest_mfma_f16(float* out, hipStream_t st);
 // fp32 mode, default shape class, on the bf16 matrix pipe with three-term operand splits (lnr_density_bf3.hip)

@@ -20,6 +20,7 @@
 // As in the fp32 kernels the C layout of one product is made the B layout of the next by permuting K: K slot 8g+i of a
 // 32-neuron block stands for neuron 4g+i of its first 16-neuron tile (i < 4) or 4g+i-4 of its second (i >= 4).
 #include "lnr_f16_common.h"
+#include "lnr_f16_freq.h"
 
 #define F16_TS 40            // halves per neuron row of the dZ transpose buffer (32 samples + pad: 80-byte rows)
 
@@ -296,6 +297,11 @@ static bool f16_fast_class(const LnrNetSpec* spec) {
            spec->n_hidden == 1 && spec->activation == LNR_ACT_RELU && spec->n_neurons <= 64;
 }
 
+// frequency encodings the fused kernels evaluate themselves (lnr_f16_freq.h: at most 12 (sin, cos) pairs per lane = three K blocks)
+static bool lnr_f16_fused_freq_shape(const LnrNetSpec* spec) {
+    return spec->encoding == LNR_ENC_FREQUENCY && spec->n_frequencies >= 1 && lnr_freq_kt(spec->n_frequencies) != 0;
+}
+
 // what LNR_PREC_F16 covers: half2 pair planes need an even number of features per level; the general kernels hold dW in registers
 // (<= 128 neurons, <= 3 hidden layers) and the weights plus the transposes of four waves in LDS
 bool lnr_f16_supported(const LnrNetSpec* spec) {
@@ -307,8 +313,12 @@ bool lnr_f16_supported(const LnrNetSpec* spec) {
     // hidden matrix neither fits the LDS beside the exchange buffers nor the registers as a gradient
     if (!(H == 16 || H == 32 || H == 64 || H == 128 || (H == 256 && spec->n_hidden == 1))) return false;
     if (spec->n_hidden < 1 || spec->n_hidden > F16_NH_MAX || spec->in_dim > 32 * F16_KB_MAX) return false;
-    const size_t lds = lnr_f16_gen_bwd_lds(spec);
+    const size_t lds = lnr_f16_fused_freq_shape(spec) ? lnr_f16_freq_bwd_lds(spec) : lnr_f16_gen_bwd_lds(spec);
     return lds > 0 && lds <= (size_t)LNR_LDS_LIMIT;
+}
+
+bool lnr_f16_fused_freq(const LnrNetSpec* spec) {
+    return spec->precision == LNR_PREC_F16 && lnr_f16_fused_freq_shape(spec) && !lnr_wide_class(spec) && lnr_f16_supported(spec);
 }
 
 static size_t f16_bwd_lds(const LnrNetSpec* spec) {
@@ -318,7 +328,7 @@ static size_t f16_bwd_lds(const LnrNetSpec* spec) {
 }
 
 int lnr_mlp_fwd_f16(const LnrNetSpec* spec, const float* params, const void* featp, int64_t m_pad, const MlpPoints* pt, float* sigma,
-                    hipStream_t st) {
+                    const PointSrc* src, hipStream_t st) {
     const int64_t tiles = (pt->n_points + 31) / 32;
     int64_t blocks = (tiles + 3) / 4;
     if (blocks > LNR_DENSITY_MAX_BLOCKS) blocks = LNR_DENSITY_MAX_BLOCKS;
@@ -333,7 +343,8 @@ int lnr_mlp_fwd_f16(const LnrNetSpec* spec, const float* params, const void* fea
         }
         return LNR_OK;
     }
-    return lnr_mlp_fwd_f16_gen(spec, params, fp, m_pad, pt, sigma, blocks, st);
+    if (lnr_f16_fused_freq(spec)) return lnr_mlp_fwd_f16_freq(spec, params, fp, m_pad, pt, sigma, blocks, src, st);
+    return lnr_mlp_fwd_f16_gen(spec, params, fp, m_pad, pt, sigma, blocks, src, st);
 }
 
 // weight-gradient slabs lnr_mlp_bwd_f16 writes for up to n_points points (one per workgroup)
@@ -347,7 +358,7 @@ int lnr_f16_bwd_slabs(const LnrNetSpec* spec, int64_t n_points) {
 }
 
 int lnr_mlp_bwd_f16(const LnrNetSpec* spec, const float* params, const void* featp, int64_t m_pad, const MlpPoints* pt, const float* d_sigma,
-                    float* dfeat, float* slabs, int want_dfeat, int* n_slabs, hipStream_t st) {
+                    float* dfeat, float* slabs, int want_dfeat, int* n_slabs, const PointSrc* src, float* d_pts, hipStream_t st) {
     const int64_t tiles = (pt->n_points + 31) / 32;
     int64_t blocks = (tiles + 3) / 4;
     if (blocks > LNR_BWD_MAX_BLOCKS) blocks = LNR_BWD_MAX_BLOCKS;
@@ -375,7 +386,8 @@ int lnr_mlp_bwd_f16(const LnrNetSpec* spec, const float* params, const void* fea
     }
     if (blocks > 256) blocks = 256;                                    // general kernels: one workgroup per CU (LDS), persistent over the steps
     *n_slabs = (int)blocks;
-    return lnr_mlp_bwd_f16_gen(spec, params, fp, m_pad, pt, d_sigma, dfeat, slabs, want_dfeat, (int)blocks, st);
+    if (lnr_f16_fused_freq(spec)) return lnr_mlp_bwd_f16_freq(spec, params, fp, m_pad, pt, d_sigma, dfeat, slabs, want_dfeat, (int)blocks, src, d_pts, st);
+    return lnr_mlp_bwd_f16_gen(spec, params, fp, m_pad, pt, d_sigma, dfeat, slabs, want_dfeat, (int)blocks, src, d_pts, st);
 }
 
 // ------------------------------------------------------------------------------------------------ layout self-test

@@ -249,3 +249,23 @@ __device__ __forceinline__ void freq_features4(const LnrNetSpec& spec, const flo
     }
 }
 
+// sin and cos of one phase from ONE range reduction (the comment at freq_forward_h16_kernel, lnr_encode.hip, derives the pair form):
+//   k = rint(ph 2/pi), r = ph - k pi/2 (three-term Cody-Waite with fma), minimax sin / cos of r on [-pi/4, pi/4], quadrant from k & 3
+__device__ __forceinline__ void sincos_f32(float ph, float* s_out, float* c_out) {
+    const float k = __builtin_rintf(ph * 0.636619772367581343f);
+    float r = __builtin_fmaf(-k, 1.57079637050628662109375f, ph);
+    r = __builtin_fmaf(-k, -4.37113900018624283e-8f, r);
+    r = __builtin_fmaf(-k, -1.7151245100059e-15f, r);
+    const float z = r * r;
+    float sp = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    sp = __builtin_fmaf(z, sp, -1.6666654611e-1f);
+    const float s = __builtin_fmaf(z * r, sp, r);
+    float cp = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    cp = __builtin_fmaf(z, cp, 4.166664568298827e-2f);
+    const float c = __builtin_fmaf(z * z, cp, __builtin_fmaf(z, -0.5f, 1.0f));
+    const int q = (int)k;
+    const float a = (q & 1) ? c : s, b = (q & 1) ? s : c;                 // q = 0: (s, c)  1: (c, -s)  2: (-s, -c)  3: (-c, s)
+    *s_out = (q & 2) ? -a : a;
+    *c_out = ((q + 1) & 2) ? -b : b;
+}
+

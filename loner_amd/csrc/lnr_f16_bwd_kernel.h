@@ -62,11 +62,17 @@ __device__ __forceinline__ uint32_t relu_gate(uint32_t d_pair, uint32_t act_pair
     return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, d_pair) * m));
 }
 
-template <int HT, int ACT, int NH, int KT>
+// FQ: the network's input is the frequency encoding of `src`'s points, evaluated here (lnr_f16_freq.h): no feature planes are read, and
+// instead of d_feature planes the kernel writes the input gradient d_pts [n][3] itself (want_dfeat = d_pts wanted): the product
+// dX = W1^T dZ is taken in a ROW ORDER that hands every lane the gradients of its OWN slots (rows 4g .. 4g+3 of row tile `it` = the
+// (sin, cos) pairs 2 it, 2 it + 1 of lane group g), so the chain rule through sin / cos is lane-local register arithmetic beside the
+// re-evaluation of the features for the weight gradient's input image.
+template <int HT, int ACT, int NH, int KT, bool FQ = false>
 __global__ void __launch_bounds__(LNR_DENSITY_BLOCK, 1)          // one wave per SIMD: the gradient accumulators of all layers live in registers
 mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ params, const uint32_t* __restrict__ featp, int64_t m_pad,
                             int64_t n_points, const int32_t* __restrict__ n_rays_dev, int n_rays, int n_samples,
-                            const float* __restrict__ d_sigma, float* __restrict__ dfeat, float* __restrict__ slabs, int want_dfeat) {
+                            const float* __restrict__ d_sigma, float* __restrict__ dfeat, float* __restrict__ slabs, int want_dfeat,
+                            const PointSrc src, float* __restrict__ d_pts) {
     extern __shared__ __attribute__((aligned(16))) f16 Ws[];
     using L = FwdLds<HT, NH, KT>;
     using B = BwdLds<HT, NH, KT>;
@@ -76,7 +82,7 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
     constexpr bool RELU = ACT == LNR_ACT_RELU;
     static_assert(NH >= 1 && NH <= F16_NH_MAX && KT >= 1 && KT <= F16_KB_MAX, "shape");
     static_assert(KBH <= F16_KB_MAX || NH == 1, "256 neurons: one hidden layer");
-    fwd_fill_weights<HT, NH, KT>(Ws, params, spec.in_dim, spec.enc_dim);
+    fwd_fill_weights<HT, NH, KT, FQ>(Ws, params, spec.in_dim, spec.enc_dim, spec.n_frequencies);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int c = lane & 15, g = lane >> 4;                                       // (re-laundered every step: see the loop head)
     const int act = spec.activation, enc_pairs = spec.enc_dim / 2;
@@ -123,7 +129,30 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
     f32x4 accb[NO];                                                         // first layer, constant-one padding columns: every column = the row sums of dZ
 #pragma unroll
     for (int i = 0; i < NO; ++i) accb[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    const int nt0 = (spec.in_dim + 15) / 16;                                // column tiles of the first layer's gradient
+    const int nt0 = FQ ? 2 * KT : (spec.in_dim + 15) / 16;                  // column tiles of the first layer's gradient
+    // FQ: the lane's slots - per slot 2^f (0: dead) and, on lane group 3, the coordinate it belongs to (wave-uniform)
+    FreqLane fl;
+    float fq_mult[FQ ? 4 * KT : 1];
+    int fq_d3[FQ ? 4 * KT : 1];
+    if constexpr (FQ) {
+        fl.init(spec.n_frequencies, g);
+#pragma unroll
+        for (int sl = 0; sl < 4 * KT; ++sl) {
+            const int d3 = fl.rem > 0 ? sl / fl.rem : 0, f3 = fl.nsl + (fl.rem > 0 ? sl % fl.rem : 0);
+            fq_d3[sl] = __builtin_amdgcn_readfirstlane(d3);
+            const float m012 = sl < fl.nsl ? __uint_as_float((uint32_t)(127 + sl) << 23) : 0.0f;
+            const float m3 = sl < 3 * fl.rem ? __uint_as_float((uint32_t)(127 + f3) << 23) : 0.0f;
+            fq_mult[sl] = fl.g3 ? m3 : m012;
+        }
+    }
+    // unit-cube point of the lane's sample in column tile t of `tile` (clamped to the last live sample)
+    auto unit_point_of_column = [&](int64_t tile, int t, float (&xu)[3]) {
+        int64_t m = tile * 32 + 16 * t + c;
+        if (m >= M) m = M - 1;
+        RawPoint rp;
+        load_raw_point(src, (uint32_t)m, src.pts ? 0u : (uint32_t)m / (uint32_t)src.n_samples, rp);
+        unit_point(src, rp, xu);
+    };
 
     // features (B operands of the first layer; the constant-one padding reads as zero, its weights' gradient is accb below) and
     // d_sigma of a step; a wave without a tile re-reads the last one with d_sigma = 0 (finite operands, zero gradient)
@@ -134,11 +163,31 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
         const uint32_t m0 = (uint32_t)(tc * 32) * 4u;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
+            if constexpr (FQ) {
+                float xu[3];
+                unit_point_of_column(tc, t, xu);
+                const float xg = g == 0 ? xu[0] : (g == 1 ? xu[1] : xu[2]);
+#pragma unroll
+                for (int kb = 0; kb < F16_KB_MAX; ++kb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int sl = 4 * kb + q;
+                        uint32_t v = 0u;
+                        if (kb < KT && sl < fl.nsl) {
+                            const int d3 = fq_d3[kb < KT ? sl : 0];
+                            const float x3 = d3 == 0 ? xu[0] : (d3 == 1 ? xu[1] : xu[2]);
+                            float d0, d1;
+                            v = freq_pair<false>(fl.g3 ? x3 : xg, fq_mult[kb < KT ? sl : 0], d0, d1);
+                        }
+                        x[kb][t][q] = v;
+                    }
+            } else {
 #pragma unroll
             for (int kb = 0; kb < F16_KB_MAX; ++kb)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     x[kb][t][q] = kb < KT ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc[kb < KT ? kb : 0], (int)(qoff[q] + m0) + 64 * t, 0, 0) : 0u;
+            }
             const int64_t m = tc * 32 + 16 * t + c;
             const bool ok = have && m < M;
             const float v = d_sigma[ok ? m : 0];
@@ -300,7 +349,8 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
     };
     auto wt_frag_first = [&](int it, int kb) -> f16x8 {                    // natural K order: input k = 16 it + 4 (c & 3) ..
         const int j0 = 32 * kb + 4 * g + (c >> 2);
-        const int p0 = 16 * it + 4 * (c & 3);
+        // (FQ: row 4u + i of row tile `it` = K position of lane group u's slot 2 it + i / 2, half i % 2 - see the kernel's head)
+        const int p0 = FQ ? 32 * (it >> 1) + 8 * (c & 3) + 4 * (it & 1) : 16 * it + 4 * (c & 3);
         const f16* p = Ws + j0 * L::S0 + fwd_slot<L::SWZ0>(p0, j0);
         return 2 * kb + 1 < HT ? tr_frag(p, 16 * L::S0) : tr_frag_lo(p);
     };
@@ -423,8 +473,59 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
         write_dz_image(dzp);
         // The features are not kept across the hidden layers (32 registers at the point of highest pressure): they are read again
         // here (L2) for the input image, together with the next step's operands (a static number of loads: the last step re-reads itself)
-        load_step(step, x, ds);
+        if constexpr (!FQ) load_step(step, x, ds);
         load_step(step + 1 < n_steps ? step + 1 : step, xn, dsn);
+        if constexpr (FQ) {
+            // the features again (input image of the weight gradient) and, with them, the input gradient: slot pair `it` of every lane
+            float xu[2][3], xg[2], accA[2] = {0.0f, 0.0f}, acc3[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+            const int64_t tcl = have_tile ? tile : n_tiles - 1;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                unit_point_of_column(tcl, t, xu[t]);
+                xg[t] = g == 0 ? xu[t][0] : (g == 1 ? xu[t][1] : xu[t][2]);
+            }
+            const float own = fl.g3 ? 0.0f : 1.0f;
+#pragma unroll
+            for (int kb = 0; kb < F16_KB_MAX; ++kb) { x[kb][0] = u32x4{0u, 0u, 0u, 0u}; x[kb][1] = u32x4{0u, 0u, 0u, 0u}; }
+#pragma unroll
+            for (int it = 0; it < 2 * KT; ++it) {
+                if (2 * it >= fl.nsl) break;                               // (wave-uniform) no live slot from here on
+                f32x4 Dq[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+                if (want_dfeat) {
+#pragma unroll
+                    for (int kb = 0; kb < KBH; ++kb) {
+                        const f16x8 a = wt_frag_first(it, kb);
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) Dq[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, dz_frag(dzp, kb, t), Dq[t], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int sl = 2 * it + j;
+                    if (sl >= fl.nsl) break;
+                    const int d3 = fq_d3[sl];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const float x3 = d3 == 0 ? xu[t][0] : (d3 == 1 ? xu[t][1] : xu[t][2]);
+                        float dsn_, dcs_;
+                        x[it >> 1][t][2 * (it & 1) + j] = freq_pair<true>(fl.g3 ? x3 : xg[t], fq_mult[sl], dsn_, dcs_);
+                        const float v = __builtin_fmaf(Dq[t][2 * j], dsn_, Dq[t][2 * j + 1] * dcs_);
+                        const float va = v * own, vb = v - va;            // lane groups 0..2: their own coordinate; group 3: coordinate d3
+                        accA[t] += va;
+                        if (d3 == 0) acc3[t][0] += vb; else if (d3 == 1) acc3[t][1] += vb; else acc3[t][2] += vb;
+                    }
+                }
+            }
+            if (want_dfeat) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float r0 = __shfl(acc3[t][0], 48 + c, 64), r1 = __shfl(acc3[t][1], 48 + c, 64), r2 = __shfl(acc3[t][2], 48 + c, 64);
+                    const float tot = accA[t] + (g == 0 ? r0 : (g == 1 ? r1 : r2));
+                    const int64_t m = tile * 32 + 16 * t + c;
+                    if (have_tile && m < M && g < 3) d_pts[3 * m + g] = 0.5f * sc_up * tot;          // x = (xyz + 1) / 2
+                }
+            }
+        } else
         if (want_dfeat) {
             for (int it = 0; it < nt0; ++it) {
                 f32x4 Dq[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
@@ -473,6 +574,11 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int col = 16 * kt + c;
+                    if constexpr (FQ) {                                     // K position -> the feature evaluated there; the ones-padding columns once
+                        const int k = lnr_freq_feature_at(col, spec.n_frequencies);
+                        if (k >= 0) slab[(16 * jt + 4 * g + r) * in_dim + k] = unit * acc0[i][kt][r];
+                        if (kt == 0 && spec.enc_dim + c < in_dim) slab[(16 * jt + 4 * g + r) * in_dim + spec.enc_dim + c] = unit * accb[i][r];
+                    } else
                     if (col < in_dim) slab[(16 * jt + 4 * g + r) * in_dim + col] = unit * (col < spec.enc_dim ? acc0[i][kt][r] : accb[i][r]);
                 }
             if constexpr (NHID > 0) {

@@ -46,10 +46,17 @@ static inline int f16_set_lds(K kernel, size_t lds, const char* who) {
 }
 
 
-// the general forward (any supported width / depth / activation), lnr_density_f16_fwd.hip
+// the general forward (any supported width / depth / activation), lnr_density_f16_fwd.hip: features from half2 pair planes (_gen) or the
+// frequency encoding of `src`'s points evaluated inside the kernel (_freq: lnr_f16_freq.h; featp / m_pad unused)
 int lnr_mlp_fwd_f16_gen(const LnrNetSpec* spec, const float* params, const uint32_t* featp, int64_t m_pad, const MlpPoints* pt, float* sigma,
-                        int64_t blocks, hipStream_t st);
-// the general backward, lnr_density_f16_bwd.hip: one launch, `blocks` workgroups = weight-gradient slabs; its LDS need (0: no kernel)
+                        int64_t blocks, const PointSrc* src, hipStream_t st);
+int lnr_mlp_fwd_f16_freq(const LnrNetSpec* spec, const float* params, const uint32_t* featp, int64_t m_pad, const MlpPoints* pt, float* sigma,
+                         int64_t blocks, const PointSrc* src, hipStream_t st);
+// the general backward, lnr_density_f16_bwd.hip: one launch, `blocks` workgroups = weight-gradient slabs; its LDS need (0: no kernel).
+// _freq: no feature planes in, no d_feature planes out - the input gradient goes to d_pts [n][3] (nullable) directly
 int lnr_mlp_bwd_f16_gen(const LnrNetSpec* spec, const float* params, const uint32_t* featp, int64_t m_pad, const MlpPoints* pt, const float* d_sigma,
-                        float* dfeat, float* slabs, int want_dfeat, int blocks, hipStream_t st);
+                        float* dfeat, float* slabs, int want_dfeat, int blocks, const PointSrc* src, float* d_pts, hipStream_t st);
+int lnr_mlp_bwd_f16_freq(const LnrNetSpec* spec, const float* params, const uint32_t* featp, int64_t m_pad, const MlpPoints* pt, const float* d_sigma,
+                         float* dfeat, float* slabs, int want_dfeat, int blocks, const PointSrc* src, float* d_pts, hipStream_t st);
 size_t lnr_f16_gen_bwd_lds(const LnrNetSpec* spec);
+size_t lnr_f16_freq_bwd_lds(const LnrNetSpec* spec);

@@ -25,6 +25,7 @@
 //     activations of row jt - 1 are applied after them, in the shadow of the matrix pipe.
 #pragma once
 #include "lnr_f16_common.h"
+#include "lnr_f16_freq.h"
 
 template <int HT, int NH, int KT>
 struct FwdLds {
@@ -44,8 +45,10 @@ template <bool SWZ> __device__ __forceinline__ int fwd_slot(int col, int row) {
 // fp32 parameters (tinycudann layout: W1 [H][in_dim], hidden [H][H] each, output row [H]) -> the fp16 LDS copy described above.
 // Trip counts are compile-time and the loops unrolled by 8: as `for (i = tid; i < n; i += blockDim.x)` every element was one exposed
 // L2 round trip (128 in a row for the 128 x 2 network: ~20 us in front of the first MFMA of every workgroup).
-template <int HT, int NH, int KT>
-__device__ __forceinline__ void fwd_fill_weights(f16* Ws, const float* __restrict__ params, int in_dim, int enc_dim) {
+// FQ (the frequency encoding computed in the kernel, lnr_f16_freq.h): K position `col` of a first-layer row holds the weight of the
+// feature the fused kernels evaluate there (nf = n_frequencies), padding positions zero.
+template <int HT, int NH, int KT, bool FQ = false>
+__device__ __forceinline__ void fwd_fill_weights(f16* Ws, const float* __restrict__ params, int in_dim, int enc_dim, int nf = 0) {
     using L = FwdLds<HT, NH, KT>;
     constexpr int NT = LNR_DENSITY_BLOCK;
     const int n0 = L::H * in_dim, tid = threadIdx.x;
@@ -53,8 +56,11 @@ __device__ __forceinline__ void fwd_fill_weights(f16* Ws, const float* __restric
 #pragma unroll 8
     for (int it = 0; it < L::H * L::K0 / NT; ++it) {
         const int i = it * NT + tid, row = i / L::K0, col = i % L::K0;
-        const float w = params[row * in_dim + (col < enc_dim ? col : 0)];
-        Ws[row * L::S0 + fwd_slot<L::SWZ0>(col, row)] = col < enc_dim ? (f16)w : (f16)0.0f;
+        int k = col;
+        if constexpr (FQ) k = lnr_freq_feature_at(col, nf);
+        const bool live = FQ ? k >= 0 : col < enc_dim;
+        const float w = params[row * in_dim + (live ? k : 0)];
+        Ws[row * L::S0 + fwd_slot<L::SWZ0>(col, row)] = live ? (f16)w : (f16)0.0f;
     }
     if constexpr (NH > 1) {
         for (int l = 0; l < NH - 1; ++l) {
@@ -152,16 +158,18 @@ __device__ __forceinline__ void fwd_layer(const f16* Wl, const int (&koff)[F16_K
     finish(HT - 1, Z[(HT - 1) & 1]);
 }
 
-template <int HT, int ACT, int NH, int KT, int CT>
+// FQ: the network's input is the frequency encoding of `src`'s points, evaluated here (lnr_f16_freq.h); featp / m_pad unused.
+template <int HT, int ACT, int NH, int KT, int CT, bool FQ = false>
 __global__ void __launch_bounds__(LNR_DENSITY_BLOCK, 2)          // two waves per SIMD: <= 256 registers (two workgroups share a CU's LDS)
 mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ params, const uint32_t* __restrict__ featp, int64_t m_pad,
-                           int64_t n_points, const int32_t* __restrict__ n_rays_dev, int n_rays, int n_samples, float* __restrict__ sigma, int32_t* __restrict__ clip_flag) {
+                           int64_t n_points, const int32_t* __restrict__ n_rays_dev, int n_rays, int n_samples, float* __restrict__ sigma, int32_t* __restrict__ clip_flag,
+                           const PointSrc src) {
     extern __shared__ __attribute__((aligned(16))) f16 Ws[];
     using L = FwdLds<HT, NH, KT>;
     static_assert(NH >= 1 && NH <= F16_NH_MAX && KT >= 1 && KT <= F16_KB_MAX, "shape");
     static_assert(L::KBH <= F16_KB_MAX || NH == 1, "256 neurons: one hidden layer");
     constexpr int TS = 16 * CT;                                           // samples per wave step
-    fwd_fill_weights<HT, NH, KT>(Ws, params, spec.in_dim, spec.enc_dim);
+    fwd_fill_weights<HT, NH, KT, FQ>(Ws, params, spec.in_dim, spec.enc_dim, spec.n_frequencies);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int c = lane & 15, g = lane >> 4;
@@ -184,9 +192,52 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
     for (int jt = 0; jt < HT; ++jt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) wo[jt][r] = (float)Ws[L::OFF_O + 16 * jt + 4 * g + r];
+    // FQ: the lane's slots (lnr_f16_freq.h) - per slot 2^f (0: dead) and, on lane group 3, the coordinate it belongs to
+    FreqLane fl;
+    float fq_mult[FQ ? 4 * KT : 1];
+    int fq_d3[FQ ? 4 * KT : 1];
+    if constexpr (FQ) {
+        fl.init(spec.n_frequencies, g);
+#pragma unroll
+        for (int sl = 0; sl < 4 * KT; ++sl) {
+            const int d3 = fl.rem > 0 ? sl / fl.rem : 0, f3 = fl.nsl + (fl.rem > 0 ? sl % fl.rem : 0);
+            fq_d3[sl] = __builtin_amdgcn_readfirstlane(d3);
+            const float m012 = sl < fl.nsl ? __uint_as_float((uint32_t)(127 + sl) << 23) : 0.0f;
+            const float m3 = sl < 3 * fl.rem ? __uint_as_float((uint32_t)(127 + f3) << 23) : 0.0f;
+            fq_mult[sl] = fl.g3 ? m3 : m012;
+        }
+    }
     // the features of the NEXT step are in flight while this one goes through the layers
     // (samples past M: their planes are padded to m_pad, whatever they hold only reaches columns that are never stored)
     auto load_tile = [&](int64_t tile, u32x4 (&x)[F16_KB_MAX][CT]) __attribute__((always_inline)) {
+        if constexpr (FQ) {
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                int64_t m = tile * TS + 16 * t + c;
+                if (m >= M) m = M - 1;                                     // (columns past the last sample are never stored)
+                RawPoint rp;
+                load_raw_point(src, (uint32_t)m, src.pts ? 0u : (uint32_t)m / (uint32_t)src.n_samples, rp);
+                float xu[3];
+                unit_point(src, rp, xu);
+                const float xg = g == 0 ? xu[0] : (g == 1 ? xu[1] : xu[2]);
+#pragma unroll
+                for (int kb = 0; kb < F16_KB_MAX; ++kb) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int sl = 4 * kb + q;
+                        uint32_t v = 0u;
+                        if (kb < KT && sl < fl.nsl) {                      // (wave-uniform: NSL >= the slots of lane group 3)
+                            const int d3 = fq_d3[kb < KT ? sl : 0];
+                            const float x3 = d3 == 0 ? xu[0] : (d3 == 1 ? xu[1] : xu[2]);
+                            float d0, d1;
+                            v = freq_pair<false>(fl.g3 ? x3 : xg, fq_mult[kb < KT ? sl : 0], d0, d1);
+                        }
+                        x[kb][t][q] = v;
+                    }
+                }
+            }
+            return;
+        }
         const uint32_t m0 = (uint32_t)(tile * TS) * 4u;
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
