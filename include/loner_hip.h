@@ -278,6 +278,28 @@ int lnr_shard_front_pack(const float* rays, const int32_t* out_seg_start /*[n_se
 int lnr_shard_front_reduce(const float* records /*[world][stride] device*/, int32_t world, int32_t stride,
                            int32_t* counts_dev /*[2]*/, float* far0_dev /*[1]*/, void* stream);
 
+/* ---- the sharded loop's collectives: RCCL on the caller's stream (csrc/lnr_comm.hip) -------------------------------------------
+ * The reference has no multi-GPU mapping (its only fan-out is independent trials, examples/run_loner.py:339-424); SURVEY.md 8e
+ * defines the keyframe-sharded window these calls serve.  One communicator per rank and process: rank 0 makes an id
+ * (lnr_comm_unique_id), hands its LNR_COMM_ID_BYTES bytes to the other ranks by any means (the Python layer: the torch.distributed
+ * store), every rank calls lnr_comm_init on its HIP device (collective: returns when all have).  A collective is ONE enqueue on
+ * `stream` - ordered with the kernels before and after it on that stream, no host synchronisation, capturable into a hipGraph.
+ * librccl.so.1 is loaded on first use (dlopen); lnr_comm_available() = 0 when it is not there. */
+#define LNR_COMM_ID_BYTES 128
+typedef enum LnrCommDtype { LNR_COMM_F32 = 0, LNR_COMM_BF16 = 1, LNR_COMM_I64 = 2, LNR_COMM_I32 = 3, LNR_COMM_U8 = 4 } LnrCommDtype;
+typedef enum LnrCommOp { LNR_COMM_SUM = 0, LNR_COMM_MIN = 1, LNR_COMM_MAX = 2 } LnrCommOp;
+int lnr_comm_available(void);
+int lnr_comm_unique_id(void* id /*[LNR_COMM_ID_BYTES] host*/, size_t id_bytes);
+int lnr_comm_init(const void* id, size_t id_bytes, int32_t rank, int32_t world, void** comm_out);
+int lnr_comm_destroy(void* comm);
+/* in place; the gradient all-reduce (optimizer.py:366's loss.backward() summed over the shards), the occupancy pseudo-gradient (I64), the failure word (MIN) */
+int lnr_comm_all_reduce(void* comm, void* buf, size_t count, int32_t dtype /*LnrCommDtype*/, int32_t op /*LnrCommOp*/, void* stream);
+/* recv [recv_count] = sum over ranks of send[rank * recv_count ...]: a rank's chunk of the flat gradient */
+int lnr_comm_reduce_scatter(void* comm, const void* send, void* recv, size_t recv_count, int32_t dtype, void* stream);
+/* recv [world * bytes_per_rank]; send may be the rank's own slot of recv (in place): front records, stepped parameter chunks */
+int lnr_comm_all_gather(void* comm, const void* send, void* recv, size_t bytes_per_rank, void* stream);
+int lnr_comm_broadcast(void* comm, void* buf, size_t bytes, int32_t root, void* stream);
+
 /* Backward of lnr_build_lidar_rays for a window: dL/drays -> dL/d[R|t] per keyframe
  * (the autograd tail ray_utils.py:281-305 <- keyframe.py:80-88).  d_transform [n_seg,12]. */
 int lnr_lidar_rays_backward(const float* d_rays /*[n,13]*/, const float* rays /*[n,13]*/,

@@ -39,7 +39,7 @@ SOURCES = [("lnr_density_ht.hip", f"lnr_density_ht{ht}.o", [f"-DLNR_HT={ht}"]) f
           [("lnr_density_f16_bwd.hip", f"lnr_density_f16_bwd{part}_fq{fq}.o", [f"-DLNR_BWD_PART={part}", f"-DLNR_BWD_FQ={fq}"]) for part in (2, 1, 0) for fq in (0, 1)] + \
           [("lnr_density_f16_fwd.hip", f"lnr_density_f16_fwd{part}_fq{fq}.o", [f"-DLNR_FWD_PART={part}", f"-DLNR_FWD_FQ={fq}"]) for part in (1, 0) for fq in (0, 1)] + \
           [(s, s.replace(".hip", ".o"), EXTRA.get(s, [])) for s in
-           ("lnr_core.hip", "lnr_density.hip", "lnr_density_f16.hip", "lnr_density_bf3.hip", "lnr_density_wide.hip", "lnr_encode.hip", "lnr_sampler.hip", "lnr_render.hip", "lnr_rays.hip", "lnr_optim.hip", "lnr_pose.hip")]
+           ("lnr_core.hip", "lnr_density.hip", "lnr_density_f16.hip", "lnr_density_bf3.hip", "lnr_density_wide.hip", "lnr_encode.hip", "lnr_sampler.hip", "lnr_render.hip", "lnr_rays.hip", "lnr_optim.hip", "lnr_pose.hip", "lnr_comm.hip")]
 
 
 def _hipcc():
@@ -63,6 +63,18 @@ def _deps_digest(path, seen=None):
             seen[f] = hashlib.sha256(open(f, "rb").read()).hexdigest()
             _deps_digest(f, seen)
     return hashlib.sha256("".join(f"{os.path.basename(k)}:{v}" for k, v in sorted(seen.items())).encode()).hexdigest()
+
+
+def sources_digest():
+    """One digest over every kernel source and header (csrc/*.hip, csrc/*.h, include/*.h): what a measurement that outlives the build -
+    profiles/traffic.json's PMC passes - is stamped with, so that bench.py can tell when the kernels have changed since."""
+    h = hashlib.sha256()
+    for d in (CSRC, INCLUDE):
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".hip", ".h")):
+                h.update(f.encode())
+                h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def _load_manifest():

@@ -485,7 +485,7 @@ static Layout make_layout(const LnrNetSpec* spec, int64_t n_points) {
     // (fp16 mode + frequency encoding: the MLP kernels evaluate the encoding and its input gradient themselves - no planes at all)
     const size_t plane_set = lnr_f16_fused_freq(spec) ? 0 : (size_t)spec->enc_dim * L.m_pad * sizeof(float);
     L.off_feat = off; off += align256(plane_set);
-    L.off_wide = off; off += align256(lnr_wide_workspace(spec));     // chunk planes of the 256 x 2..3 route (0 bytes for every other network); the forward uses them too
+    L.off_wide = off; off += align256(lnr_wide_workspace(spec, n_points));     // chunk planes of the 256 x 2..3 route (0 bytes for every other network); the forward uses them too
     L.off_dfeat = off; off += align256(plane_set);
     L.off_dxl = off; off += align256(plane_set == 0 ? 0 : (size_t)L.n_groups * 3 * L.m_pad * sizeof(float));
     L.off_dpts = off; off += align256((size_t)3 * L.m_pad * sizeof(float));      // d_pts scratch of the general d_rays route
@@ -562,9 +562,9 @@ static int plan_launch(const LnrNetSpec* spec, int64_t n_points, bool backward, 
         plan->fast32 = 0; plan->w_lds = 0; plan->waves = 4; plan->dw64 = 0; plan->regs = 0; plan->lds = 0; plan->grid = 1; plan->n_slabs = 1;
         return LNR_OK;
     }
-    // (the register-resident kernels address the planes with 32-bit byte offsets up to 17 planes: n_points <= 2^25)
+    // (the register-resident kernels address up to 32 padded planes with 32-bit byte offsets: m_pad < 2^25, see lnr_bf3_class)
     if (spec->activation == LNR_ACT_RELU && spec->n_hidden == 1 && spec->in_dim == 32 && spec->enc_dim == 32 && spec->n_neurons <= 64 &&
-        n_points <= (1ll << 25)) {
+        n_points <= (1ll << 25) - 2048) {
         plan->fast32 = 1; plan->w_lds = 1; plan->waves = 4; plan->dw64 = 0; plan->regs = 0;
         plan->lds = backward ? (2 * (size_t)spec->n_mlp_params + 4 * (size_t)spec->n_neurons * 20) * sizeof(float)
                              : (size_t)spec->n_mlp_params * sizeof(float);
@@ -723,9 +723,10 @@ extern "C" int lnr_density_forward(const LnrNetSpec* spec, const float* params, 
     const int64_t cap = mp.n_points;
     if (cap == 0) return LNR_OK;
     LNR_REQUIRE(params && sigma && workspace, "lnr_density_forward: null params/sigma/workspace");
-    LNR_REQUIRE(cap * (spec->n_features > 4 ? spec->n_features : 4) < (1ll << 30),
-                "lnr_density_forward: too many points per call for 32-bit plane offsets (n_points * max(n_features, 4) must be < 2^30)");
     const Layout L = make_layout(spec, cap);
+    // (the limit is on the PADDED plane stride - the sample count rounded up to 64, plus the skew: ADVICE r5)
+    LNR_REQUIRE(L.m_pad * (spec->n_features > 4 ? spec->n_features : 4) < (1ll << 30),
+                "lnr_density_forward: too many points per call for 32-bit plane offsets (padded n_points * max(n_features, 4) must be < 2^30)");
     if (workspace_bytes < L.off_dfeat) {
         lnr_set_error("lnr_density_forward: workspace %zu < %zu (lnr_density_workspace_forward)", workspace_bytes, L.off_dfeat);
         return LNR_ERR_WORKSPACE;
@@ -802,9 +803,9 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     if (cap == 0) return empty_batch();
     LNR_REQUIRE(params && d_sigma && workspace, "lnr_density_backward: null argument");
     LNR_REQUIRE(grad_params || d_pts || d_rays, "lnr_density_backward: nothing to compute (no grad_params, d_pts or d_rays)");
-    LNR_REQUIRE(cap * (spec->n_features > 4 ? spec->n_features : 4) < (1ll << 30),
-                "lnr_density_backward: too many points per call for 32-bit plane offsets (n_points * max(n_features, 4) must be < 2^30)");
     const Layout L = make_layout(spec, cap);
+    LNR_REQUIRE(L.m_pad * (spec->n_features > 4 ? spec->n_features : 4) < (1ll << 30),
+                "lnr_density_backward: too many points per call for 32-bit plane offsets (padded n_points * max(n_features, 4) must be < 2^30)");
     if (workspace_bytes < L.total) {
         lnr_set_error("lnr_density_backward: workspace %zu < %zu (lnr_density_workspace)", workspace_bytes, L.total);
         return LNR_ERR_WORKSPACE;

@@ -225,7 +225,7 @@ int lnr_bf3_bwd_slabs(const LnrNetSpec* spec, int64_t n_points);
 int lnr_selftest_mfma_bf3(float* out, hipStream_t st);
 // 256 neurons x 2..3 hidden layers, both precisions: layer by layer through chunk planes in the workspace (lnr_density_wide.hip)
 bool lnr_wide_class(const LnrNetSpec* spec);
-size_t lnr_wide_workspace(const LnrNetSpec* spec);
+size_t lnr_wide_workspace(const LnrNetSpec* spec, int64_t n_points);
 int lnr_wide_slabs(void);
 int lnr_mlp_fwd_wide(const LnrNetSpec* spec, const float* params, const float* feat, int64_t m_pad, const MlpPoints* pt, float* sigma,
                      void* planes, hipStream_t st);

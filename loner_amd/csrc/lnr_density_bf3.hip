@@ -387,10 +387,11 @@ mlp_backward_bf3_kernel(const float* __restrict__ params, int n_mlp, const float
 
 // ------------------------------------------------------------------------------------------------ host side
 bool lnr_bf3_class(const LnrNetSpec* spec, int64_t n_points) {
-    // (32-bit byte offsets inside a group of 8 / 17 planes: n_points <= 2^25, as for the exact-chain kernels)
+    // (32-bit byte offsets from a plane-group base reach plane 16 it + r + ... <= 31 of the PADDED planes: m_pad x 32 planes x 4 bytes must
+    // stay below 2^32, and m_pad is the point count rounded up to 64 plus the 1088-float skew of make_layout - ADVICE r5)
     return spec->precision == LNR_PREC_F32 && spec->encoding == LNR_ENC_HASHGRID && spec->activation == LNR_ACT_RELU && spec->n_hidden == 1 &&
            spec->in_dim == 32 && spec->enc_dim == 32 && spec->n_neurons <= 64 && (spec->n_neurons == 16 || spec->n_neurons == 32 || spec->n_neurons == 64) &&
-           n_points <= (1ll << 25);
+           n_points <= (1ll << 25) - 2048;
 }
 
 int lnr_mlp_fwd_bf3(const LnrNetSpec* spec, const float* params, const float* feat, int64_t m_pad, const MlpPoints* pt, float* sigma, hipStream_t st) {

@@ -593,10 +593,18 @@ bool lnr_wide_class(const LnrNetSpec* spec) {
     return spec->n_hidden >= 2 || (f16 && !lnr_f16_supported(spec));
 }
 
-// bytes of chunk planes behind the other workspace regions: Z of every hidden layer + two dZ buffers, [256][LNR_WIDE_CHUNK] each
-size_t lnr_wide_workspace(const LnrNetSpec* spec) {
+// samples per chunk plane for calls of up to n_points points: a small batch (rendering a few thousand points, tests) gets planes of its own
+// size instead of (n_hidden + 2) x 128 MB; the launches use the same value as their plane stride
+static int64_t wide_chunk_stride(int64_t n_points) {
+    // (a multiple of 256: a workgroup of the layer kernels covers 128 samples, the weight-gradient kernel reads groups of four - whatever
+    // a launch touches beyond the chunk's last sample stays inside the sample's own plane, as it did with full-size planes)
+    const int64_t n = (n_points + 255) / 256 * 256;
+    return n < 256 ? 256 : (n < LNR_WIDE_CHUNK ? n : LNR_WIDE_CHUNK);
+}
+// bytes of chunk planes behind the other workspace regions: Z of every hidden layer + two dZ buffers, [256][chunk stride] each
+size_t lnr_wide_workspace(const LnrNetSpec* spec, int64_t n_points) {
     if (!lnr_wide_class(spec)) return 0;
-    return (size_t)(spec->n_hidden + 2) * LNR_WIDE_H * LNR_WIDE_CHUNK * sizeof(float);
+    return (size_t)(spec->n_hidden + 2) * LNR_WIDE_H * (size_t)wide_chunk_stride(n_points) * sizeof(float);
 }
 int lnr_wide_slabs(void) { return 3 + LNR_WIDE_SPLITS; }      // slab 0, the partial slabs, the transposed hidden matrices
 
@@ -604,8 +612,9 @@ namespace {
 struct WideCtx {
     const LnrNetSpec* spec; const float* params; const float* feat; int64_t m_pad; const MlpPoints* pt; float* planes; hipStream_t st;
     bool half; int H, NH, K1, act;
-    float* z(int l) const { return planes + (size_t)l * LNR_WIDE_H * LNR_WIDE_CHUNK; }            // pre-activations of hidden layer l (0-based)
-    float* dzbuf(int i) const { return planes + (size_t)(NH + i) * LNR_WIDE_H * LNR_WIDE_CHUNK; }
+    int64_t chp;                                                                          // plane stride (samples): wide_chunk_stride of the call's capacity
+    float* z(int l) const { return planes + (size_t)l * LNR_WIDE_H * (size_t)chp; }              // pre-activations of hidden layer l (0-based)
+    float* dzbuf(int i) const { return planes + (size_t)(NH + i) * LNR_WIDE_H * (size_t)chp; }
     const float* W(int l) const { return l == 0 ? params : params + (size_t)H * K1 + (size_t)(l - 1) * H * H; }
     const float* Wo() const { return params + (size_t)H * K1 + (size_t)(NH - 1) * H * H; }
     WideSamples samples(int64_t lo, int64_t n) const { return WideSamples{lo, n, pt->n_points, pt->n_rays_dev, pt->n_rays, pt->n_samples}; }
@@ -617,14 +626,14 @@ static void wide_forward_chunk(const WideCtx& c, const WideSamples& s) {
     const int64_t pairs = ((s.n + 15) / 16 + 1) / 2;                 // a wave owns two 16-sample tiles
     const dim3 grid((unsigned)((pairs + 3) / 4 > 2048 ? 2048 : (pairs + 3) / 4));
     if (HALF) {                                                     // the f16 matrix pipe
-        hipLaunchKernelGGL((wide_layer_fwd_h_kernel<WIDE_IN_PAIR>), grid, block, 0, c.st, c.W(0), c.K1, c.feat, c.m_pad, c.spec->enc_dim, c.act, s, c.z(0), (int64_t)LNR_WIDE_CHUNK);
+        hipLaunchKernelGGL((wide_layer_fwd_h_kernel<WIDE_IN_PAIR>), grid, block, 0, c.st, c.W(0), c.K1, c.feat, c.m_pad, c.spec->enc_dim, c.act, s, c.z(0), c.chp);
         for (int l = 1; l < c.NH; ++l)
-            hipLaunchKernelGGL((wide_layer_fwd_h_kernel<WIDE_IN_Z>), grid, block, 0, c.st, c.W(l), c.H, c.z(l - 1), (int64_t)LNR_WIDE_CHUNK, c.H, c.act, s, c.z(l), (int64_t)LNR_WIDE_CHUNK);
+            hipLaunchKernelGGL((wide_layer_fwd_h_kernel<WIDE_IN_Z>), grid, block, 0, c.st, c.W(l), c.H, c.z(l - 1), c.chp, c.H, c.act, s, c.z(l), c.chp);
         return;
     }
-    hipLaunchKernelGGL((wide_layer_fwd_kernel<false, WIDE_IN_FEAT>), grid, block, 0, c.st, c.W(0), c.K1, c.feat, c.m_pad, c.spec->enc_dim, c.act, s, c.z(0), (int64_t)LNR_WIDE_CHUNK);
+    hipLaunchKernelGGL((wide_layer_fwd_kernel<false, WIDE_IN_FEAT>), grid, block, 0, c.st, c.W(0), c.K1, c.feat, c.m_pad, c.spec->enc_dim, c.act, s, c.z(0), c.chp);
     for (int l = 1; l < c.NH; ++l)
-        hipLaunchKernelGGL((wide_layer_fwd_kernel<false, WIDE_IN_Z>), grid, block, 0, c.st, c.W(l), c.H, c.z(l - 1), (int64_t)LNR_WIDE_CHUNK, c.H, c.act, s, c.z(l), (int64_t)LNR_WIDE_CHUNK);
+        hipLaunchKernelGGL((wide_layer_fwd_kernel<false, WIDE_IN_Z>), grid, block, 0, c.st, c.W(l), c.H, c.z(l - 1), c.chp, c.H, c.act, s, c.z(l), c.chp);
 }
 
 template <bool HALF>
@@ -633,7 +642,7 @@ static int wide_forward(const WideCtx& c, float* sigma) {
         const int64_t n = c.pt->n_points - lo < LNR_WIDE_CHUNK ? c.pt->n_points - lo : LNR_WIDE_CHUNK;
         const WideSamples s = c.samples(lo, n);
         wide_forward_chunk<HALF>(c, s);
-        hipLaunchKernelGGL(wide_out_kernel<HALF>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, c.st, c.Wo(), c.act, c.z(c.NH - 1), (int64_t)LNR_WIDE_CHUNK, s, sigma, c.pt->clip_flag);
+        hipLaunchKernelGGL(wide_out_kernel<HALF>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, c.st, c.Wo(), c.act, c.z(c.NH - 1), c.chp, s, sigma, c.pt->clip_flag);
     }
     return LNR_OK;
 }
@@ -660,24 +669,24 @@ static int wide_backward(const WideCtx& c, const float* d_sigma, float* dfeat, f
         wide_forward_chunk<HALF>(c, s);
         float* dz = c.dzbuf(0);
         float* dz_other = c.dzbuf(1);
-        hipLaunchKernelGGL(wide_dz_out_kernel<HALF>, dim3(grid_s.x, 4), block, 0, c.st, c.Wo(), c.act, c.z(c.NH - 1), (int64_t)LNR_WIDE_CHUNK, s, d_sigma, dz);
-        if (want_dw) hipLaunchKernelGGL(wide_dwo_kernel, dim3(LNR_WIDE_H), dim3(1024), 0, c.st, c.act, c.z(c.NH - 1), (int64_t)LNR_WIDE_CHUNK, s, d_sigma, slabs + off_o);
+        hipLaunchKernelGGL(wide_dz_out_kernel<HALF>, dim3(grid_s.x, 4), block, 0, c.st, c.Wo(), c.act, c.z(c.NH - 1), c.chp, s, d_sigma, dz);
+        if (want_dw) hipLaunchKernelGGL(wide_dwo_kernel, dim3(LNR_WIDE_H), dim3(1024), 0, c.st, c.act, c.z(c.NH - 1), c.chp, s, d_sigma, slabs + off_o);
         for (int l = c.NH - 1; l >= 0; --l) {
             const int K = l == 0 ? c.K1 : c.H;
             const int64_t layer_off = l == 0 ? 0 : (int64_t)c.H * c.K1 + (int64_t)(l - 1) * c.H * c.H;
             const dim3 grid_w((unsigned)(4 * ((K + 63) / 64) * LNR_WIDE_SPLITS));
             if (!want_dw) {}                                       // frozen parameters (tracking phase): the input gradient only
-            else if (l > 0) hipLaunchKernelGGL((wide_dw_kernel<HALF, WIDE_IN_Z>), grid_w, block, 0, c.st, dz, (int64_t)LNR_WIDE_CHUNK, c.z(l - 1), (int64_t)LNR_WIDE_CHUNK, c.H, K, c.act, s, slabs, n_mlp, layer_off);
-            else if (HALF) hipLaunchKernelGGL((wide_dw_kernel<HALF, WIDE_IN_PAIR>), grid_w, block, 0, c.st, dz, (int64_t)LNR_WIDE_CHUNK, c.feat, c.m_pad, c.spec->enc_dim, K, c.act, s, slabs, n_mlp, layer_off);
-            else hipLaunchKernelGGL((wide_dw_kernel<HALF, WIDE_IN_FEAT>), grid_w, block, 0, c.st, dz, (int64_t)LNR_WIDE_CHUNK, c.feat, c.m_pad, c.spec->enc_dim, K, c.act, s, slabs, n_mlp, layer_off);
+            else if (l > 0) hipLaunchKernelGGL((wide_dw_kernel<HALF, WIDE_IN_Z>), grid_w, block, 0, c.st, dz, c.chp, c.z(l - 1), c.chp, c.H, K, c.act, s, slabs, n_mlp, layer_off);
+            else if (HALF) hipLaunchKernelGGL((wide_dw_kernel<HALF, WIDE_IN_PAIR>), grid_w, block, 0, c.st, dz, c.chp, c.feat, c.m_pad, c.spec->enc_dim, K, c.act, s, slabs, n_mlp, layer_off);
+            else hipLaunchKernelGGL((wide_dw_kernel<HALF, WIDE_IN_FEAT>), grid_w, block, 0, c.st, dz, c.chp, c.feat, c.m_pad, c.spec->enc_dim, K, c.act, s, slabs, n_mlp, layer_off);
             const int64_t count = (int64_t)c.H * K;
             if (want_dw) hipLaunchKernelGGL(wide_fold_kernel, dim3((unsigned)((count + 255) / 256)), block, 0, c.st, slabs, n_mlp, layer_off, count);
             if (l > 0) {
-                hipLaunchKernelGGL((wide_dx_kernel<HALF, false>), grid_p, block, 0, c.st, wt + (size_t)(l - 1) * c.H * c.H, c.H / 16, dz, (int64_t)LNR_WIDE_CHUNK, c.act, s,
-                                   c.z(l - 1), dz_other, (int64_t)LNR_WIDE_CHUNK, 0);
+                hipLaunchKernelGGL((wide_dx_kernel<HALF, false>), grid_p, block, 0, c.st, wt + (size_t)(l - 1) * c.H * c.H, c.H / 16, dz, c.chp, c.act, s,
+                                   c.z(l - 1), dz_other, c.chp, 0);
                 float* t = dz; dz = dz_other; dz_other = t;
             } else if (want_dfeat) {
-                hipLaunchKernelGGL((wide_dx_kernel<HALF, true>), grid_p, block, 0, c.st, wt_first, K / 16, dz, (int64_t)LNR_WIDE_CHUNK, c.act, s, (const float*)nullptr, dfeat,
+                hipLaunchKernelGGL((wide_dx_kernel<HALF, true>), grid_p, block, 0, c.st, wt_first, K / 16, dz, c.chp, c.act, s, (const float*)nullptr, dfeat,
                                    c.m_pad, c.spec->enc_dim);
             }
         }
@@ -686,7 +695,7 @@ static int wide_backward(const WideCtx& c, const float* d_sigma, float* dfeat, f
 }
 
 static WideCtx wide_ctx(const LnrNetSpec* spec, const float* params, const float* feat, int64_t m_pad, const MlpPoints* pt, void* planes, hipStream_t st) {
-    return WideCtx{spec, params, feat, m_pad, pt, (float*)planes, st, spec->precision == LNR_PREC_F16, spec->n_neurons, spec->n_hidden, spec->in_dim, spec->activation};
+    return WideCtx{spec, params, feat, m_pad, pt, (float*)planes, st, spec->precision == LNR_PREC_F16, spec->n_neurons, spec->n_hidden, spec->in_dim, spec->activation, wide_chunk_stride(pt->n_points)};
 }
 }  // namespace
 

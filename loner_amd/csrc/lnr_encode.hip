@@ -634,9 +634,6 @@ __device__ __forceinline__ void store_stream_b128(uint64_t global_addr, uint4 v)
 }
 
 #define ENC_BWD_BLOCK LNR_ENC_BWD_BLOCK
-#ifndef LNR_DX_LATE
-#define LNR_DX_LATE 0          /* 1 (A/B builds): the d/dx term behind the copy-out, as in rounds 2-5 */
-#endif
 #define ENC_STAGE_RECORDS (ENC_BWD_BLOCK * 8)
 
 // what the copy-out phase needs to know about one owner of the current batch: one 16-byte LDS read per record
@@ -778,34 +775,6 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
             if (combine) cell_runs(c, lane, head, run);
         }
         PHASE(1);
-        // The d/dx term, consumed right behind the FIRST barrier of the batch (round 6; rounds 2-5: after the copy-out).  gfx9 counts vector
-        // loads, stores and atomics with ONE in-order counter, and behind divergent control flow the compiler can only wait for "all of
-        // them": taken after the copy-out, the wait for the gathers also drained the record stores just issued, and the wait for the next
-        // batch's d_feature values at the loop's back edge drained the per-ray atomics - two exposed HBM round trips per batch
-        // (profiles/r06_encode_backward_phases.txt: "dx" and "load inputs" 36 % / 23 % of a wave's time).  Here the one full wait of a
-        // batch finds only loads in flight (the gathers, issued before the rank atomics, and the prefetch - both older than anything
-        // this batch stores), the next batch's inputs are pinned in registers at the same place, and the stores and atomics of a batch
-        // have until the next batch's wait to land.
-        auto input_gradient = [&]() __attribute__((always_inline)) {
-            if constexpr (WANT_DX) {
-                float dx[3] = {0.0f, 0.0f, 0.0f};
-                if (any && !DBG_SKIP(2)) {
-                    if constexpr (EARLY_DX) dx_from_entries<F>(L, c, g, tv, dx);
-                    else { float tl[8][F]; gather_entries<F>(table, e, tl); dx_from_entries<F>(L, c, g, tl, dx); }
-                }
-                if constexpr (DXM == ENC_DX_RAYS) {
-                    if (wave_any && !DBG_SKIP(1))            // wave-uniform; lane 0 holds the wave's first (live) sample
-                        ray_accumulate_dx(dxl, (uint32_t)__builtin_amdgcn_readfirstlane((int)ray_cur), p_cur.z, dx, lane, src.n_rays);
-                } else if (live) {
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) st32<float>(dxplanes, (uint32_t)d * plane_bytes + m * 4u, dx[d]);
-                }
-            }
-            // the next batch's inputs: in registers from here on (no wait at the back edge)
-#pragma unroll
-            for (int f = 0; f < F; ++f) asm volatile("" : "+v"(g_next[f]));
-            asm volatile("" : "+v"(p_next.z));
-        };
 #pragma unroll
         for (int pass = 0; pass < (emit && !DBG_SKIP(16) ? NPASS : 0); ++pass) {
             // ---- A: this thread's records of the batch; rank within the owner's bucket from an LDS histogram
@@ -861,8 +830,6 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
             PHASE(2);
             __syncthreads();
             PHASE(3);
-            if (pass == 0 && !LNR_DX_LATE) input_gradient();
-            PHASE(10);
             // ---- B: exclusive scan of the histogram; reserve the slots in the regions
             if (wave == 0) {
                 int running = 0;
@@ -973,7 +940,20 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
             // no barrier here: the next histogram only touches cnt[], and its first barrier orders D before the next B/C
             PHASE(8);
         }
-        if (LNR_DX_LATE || !(emit && !DBG_SKIP(16))) input_gradient();          // no partition pass (parameters frozen): the d/dx term is all there is
+        if constexpr (WANT_DX) {
+            float dx[3] = {0.0f, 0.0f, 0.0f};
+            if (any && !DBG_SKIP(2)) {
+                if constexpr (EARLY_DX) dx_from_entries<F>(L, c, g, tv, dx);
+                else { float tl[8][F]; gather_entries<F>(table, e, tl); dx_from_entries<F>(L, c, g, tl, dx); }
+            }
+            if constexpr (DXM == ENC_DX_RAYS) {
+                if (wave_any && !DBG_SKIP(1))            // wave-uniform; lane 0 holds the wave's first (live) sample
+                    ray_accumulate_dx(dxl, (uint32_t)__builtin_amdgcn_readfirstlane((int)ray_cur), p_cur.z, dx, lane, src.n_rays);
+            } else if (live) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) st32<float>(dxplanes, (uint32_t)d * plane_bytes + m * 4u, dx[d]);
+            }
+        }
         PHASE(9);
     }
     PHASE_FLUSH(lnr_phase_cycles, xp ? LNR_N_PHASES : 0);
@@ -1530,7 +1510,7 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
 #ifdef LNR_PHASE_TIMING
             if (getenv("LNR_PHASE_TIMING")) {
                 static const char* names[LNR_N_PHASES] = {"load inputs", "cell/entries/gather/weights", "A rank", "barrier 1", "B scan", "barrier 2",
-                                                          "C stage", "barrier 3", "D copy-out", "-", "dx (behind barrier 1)", "loop"};
+                                                          "C stage", "barrier 3", "D copy-out", "dx", "-", "loop"};
                 unsigned long long h[2 * LNR_N_PHASES];
                 if (lnr_phase_fetch(HIP_SYMBOL(lnr_phase_cycles), h, 2 * LNR_N_PHASES, st)) {
                     lnr_phase_print("encode_backward 8-byte", names, h);

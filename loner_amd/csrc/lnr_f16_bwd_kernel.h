@@ -130,21 +130,9 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
 #pragma unroll
     for (int i = 0; i < NO; ++i) accb[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     const int nt0 = FQ ? 2 * KT : (spec.in_dim + 15) / 16;                  // column tiles of the first layer's gradient
-    // FQ: the lane's slots - per slot 2^f (0: dead) and, on lane group 3, the coordinate it belongs to (wave-uniform)
-    FreqLane fl;
-    float fq_mult[FQ ? 4 * KT : 1];
-    int fq_d3[FQ ? 4 * KT : 1];
-    if constexpr (FQ) {
-        fl.init(spec.n_frequencies, g);
-#pragma unroll
-        for (int sl = 0; sl < 4 * KT; ++sl) {
-            const int d3 = fl.rem > 0 ? sl / fl.rem : 0, f3 = fl.nsl + (fl.rem > 0 ? sl % fl.rem : 0);
-            fq_d3[sl] = __builtin_amdgcn_readfirstlane(d3);
-            const float m012 = sl < fl.nsl ? __uint_as_float((uint32_t)(127 + sl) << 23) : 0.0f;
-            const float m3 = sl < 3 * fl.rem ? __uint_as_float((uint32_t)(127 + f3) << 23) : 0.0f;
-            fq_mult[sl] = fl.g3 ? m3 : m012;
-        }
-    }
+    // FQ (lnr_f16_freq.h): slot sl of this lane = coordinate sl % 3, frequency 4 (sl / 3) + g; a compile-time number of slots
+    constexpr int fq_slots = LNR_FREQ_SLOTS_OF_KT(KT);
+    const float fq_pg = __uint_as_float((uint32_t)(127 + g) << 23);        // 2^g
     // unit-cube point of the lane's sample in column tile t of `tile` (clamped to the last live sample)
     auto unit_point_of_column = [&](int64_t tile, int t, float (&xu)[3]) {
         int64_t m = tile * 32 + 16 * t + c;
@@ -152,6 +140,8 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
         RawPoint rp;
         load_raw_point(src, (uint32_t)m, src.pts ? 0u : (uint32_t)m / (uint32_t)src.n_samples, rp);
         unit_point(src, rp, xu);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) xu[d] *= fq_pg;                        // the lane's share of the frequency (exact)
     };
 
     // features (B operands of the first layer; the constant-one padding reads as zero, its weights' gradient is accb below) and
@@ -166,18 +156,15 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
             if constexpr (FQ) {
                 float xu[3];
                 unit_point_of_column(tc, t, xu);
-                const float xg = g == 0 ? xu[0] : (g == 1 ? xu[1] : xu[2]);
 #pragma unroll
                 for (int kb = 0; kb < F16_KB_MAX; ++kb)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int sl = 4 * kb + q;
                         uint32_t v = 0u;
-                        if (kb < KT && sl < fl.nsl) {
-                            const int d3 = fq_d3[kb < KT ? sl : 0];
-                            const float x3 = d3 == 0 ? xu[0] : (d3 == 1 ? xu[1] : xu[2]);
+                        if (kb < KT && sl < fq_slots) {
                             float d0, d1;
-                            v = freq_pair<false>(fl.g3 ? x3 : xg, fq_mult[kb < KT ? sl : 0], d0, d1);
+                            v = freq_pair<false>(xu[sl % 3] * lnr_freq_slot_scale(sl), 0.0f, d0, d1);
                         }
                         x[kb][t][q] = v;
                     }
@@ -477,19 +464,16 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
         load_step(step + 1 < n_steps ? step + 1 : step, xn, dsn);
         if constexpr (FQ) {
             // the features again (input image of the weight gradient) and, with them, the input gradient: slot pair `it` of every lane
-            float xu[2][3], xg[2], accA[2] = {0.0f, 0.0f}, acc3[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+            float xu[2][3], acc[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
             const int64_t tcl = have_tile ? tile : n_tiles - 1;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                unit_point_of_column(tcl, t, xu[t]);
-                xg[t] = g == 0 ? xu[t][0] : (g == 1 ? xu[t][1] : xu[t][2]);
-            }
-            const float own = fl.g3 ? 0.0f : 1.0f;
+            for (int t = 0; t < 2; ++t) unit_point_of_column(tcl, t, xu[t]);
+            const float dph_g = fq_pg * LNR_PI_F;                          // d(phase)/dx of the lane's share; x 2^(4 (sl / 3)) per slot
 #pragma unroll
             for (int kb = 0; kb < F16_KB_MAX; ++kb) { x[kb][0] = u32x4{0u, 0u, 0u, 0u}; x[kb][1] = u32x4{0u, 0u, 0u, 0u}; }
 #pragma unroll
             for (int it = 0; it < 2 * KT; ++it) {
-                if (2 * it >= fl.nsl) break;                               // (wave-uniform) no live slot from here on
+                if (2 * it >= fq_slots) break;                             // (compile-time) no slot from here on
                 f32x4 Dq[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
                 if (want_dfeat) {
 #pragma unroll
@@ -502,27 +486,33 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int sl = 2 * it + j;
-                    if (sl >= fl.nsl) break;
-                    const int d3 = fq_d3[sl];
+                    if (sl >= fq_slots) break;
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
-                        const float x3 = d3 == 0 ? xu[t][0] : (d3 == 1 ? xu[t][1] : xu[t][2]);
                         float dsn_, dcs_;
-                        x[it >> 1][t][2 * (it & 1) + j] = freq_pair<true>(fl.g3 ? x3 : xg[t], fq_mult[sl], dsn_, dcs_);
-                        const float v = __builtin_fmaf(Dq[t][2 * j], dsn_, Dq[t][2 * j + 1] * dcs_);
-                        const float va = v * own, vb = v - va;            // lane groups 0..2: their own coordinate; group 3: coordinate d3
-                        accA[t] += va;
-                        if (d3 == 0) acc3[t][0] += vb; else if (d3 == 1) acc3[t][1] += vb; else acc3[t][2] += vb;
+                        x[it >> 1][t][2 * (it & 1) + j] = freq_pair<true>(xu[t][sl % 3] * lnr_freq_slot_scale(sl), dph_g * lnr_freq_slot_scale(sl), dsn_, dcs_);
+                        acc[t][sl % 3] += __builtin_fmaf(Dq[t][2 * j], dsn_, Dq[t][2 * j + 1] * dcs_);
                     }
                 }
             }
             if (want_dfeat) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const float r0 = __shfl(acc3[t][0], 48 + c, 64), r1 = __shfl(acc3[t][1], 48 + c, 64), r2 = __shfl(acc3[t][2], 48 + c, 64);
-                    const float tot = accA[t] + (g == 0 ? r0 : (g == 1 ? r1 : r2));
+                    // a sample's gradient = the sum over its four lanes (c, g = 0..3): the two cross-row swaps of CDNA4
+                    float tot[3];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        typedef unsigned u2v __attribute__((ext_vector_type(2)));
+                        const unsigned a0 = __float_as_uint(acc[t][d]);
+                        const u2v r1 = __builtin_amdgcn_permlane16_swap(a0, a0, false, false);      // rows (0,1) and (2,3) meet
+                        const float s1 = __uint_as_float(r1.x) + __uint_as_float(r1.y);
+                        const unsigned b0 = __float_as_uint(s1);
+                        const u2v r2 = __builtin_amdgcn_permlane32_swap(b0, b0, false, false);      // the two halves meet
+                        tot[d] = __uint_as_float(r2.x) + __uint_as_float(r2.y);
+                    }
                     const int64_t m = tile * 32 + 16 * t + c;
-                    if (have_tile && m < M && g < 3) d_pts[3 * m + g] = 0.5f * sc_up * tot;          // x = (xyz + 1) / 2
+                    const float mine = g == 0 ? tot[0] : (g == 1 ? tot[1] : tot[2]);
+                    if (have_tile && m < M && g < 3) d_pts[3 * m + g] = 0.5f * sc_up * mine;          // x = (xyz + 1) / 2
                 }
             }
         } else

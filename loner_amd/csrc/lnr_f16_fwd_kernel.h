@@ -192,21 +192,9 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
     for (int jt = 0; jt < HT; ++jt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) wo[jt][r] = (float)Ws[L::OFF_O + 16 * jt + 4 * g + r];
-    // FQ: the lane's slots (lnr_f16_freq.h) - per slot 2^f (0: dead) and, on lane group 3, the coordinate it belongs to
-    FreqLane fl;
-    float fq_mult[FQ ? 4 * KT : 1];
-    int fq_d3[FQ ? 4 * KT : 1];
-    if constexpr (FQ) {
-        fl.init(spec.n_frequencies, g);
-#pragma unroll
-        for (int sl = 0; sl < 4 * KT; ++sl) {
-            const int d3 = fl.rem > 0 ? sl / fl.rem : 0, f3 = fl.nsl + (fl.rem > 0 ? sl % fl.rem : 0);
-            fq_d3[sl] = __builtin_amdgcn_readfirstlane(d3);
-            const float m012 = sl < fl.nsl ? __uint_as_float((uint32_t)(127 + sl) << 23) : 0.0f;
-            const float m3 = sl < 3 * fl.rem ? __uint_as_float((uint32_t)(127 + f3) << 23) : 0.0f;
-            fq_mult[sl] = fl.g3 ? m3 : m012;
-        }
-    }
+    // FQ (lnr_f16_freq.h): slot sl of this lane = coordinate sl % 3, frequency 4 (sl / 3) + g; a compile-time number of slots
+    constexpr int fq_slots = LNR_FREQ_SLOTS_OF_KT(KT);
+    const float fq_pg = __uint_as_float((uint32_t)(127 + g) << 23);      // 2^g
     // the features of the NEXT step are in flight while this one goes through the layers
     // (samples past M: their planes are padded to m_pad, whatever they hold only reaches columns that are never stored)
     auto load_tile = [&](int64_t tile, u32x4 (&x)[F16_KB_MAX][CT]) __attribute__((always_inline)) {
@@ -219,18 +207,17 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
                 load_raw_point(src, (uint32_t)m, src.pts ? 0u : (uint32_t)m / (uint32_t)src.n_samples, rp);
                 float xu[3];
                 unit_point(src, rp, xu);
-                const float xg = g == 0 ? xu[0] : (g == 1 ? xu[1] : xu[2]);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) xu[d] *= fq_pg;                // the lane's share of the frequency (exact)
 #pragma unroll
                 for (int kb = 0; kb < F16_KB_MAX; ++kb) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int sl = 4 * kb + q;
                         uint32_t v = 0u;
-                        if (kb < KT && sl < fl.nsl) {                      // (wave-uniform: NSL >= the slots of lane group 3)
-                            const int d3 = fq_d3[kb < KT ? sl : 0];
-                            const float x3 = d3 == 0 ? xu[0] : (d3 == 1 ? xu[1] : xu[2]);
+                        if (kb < KT && sl < fq_slots) {                    // (compile-time)
                             float d0, d1;
-                            v = freq_pair<false>(fl.g3 ? x3 : xg, fq_mult[kb < KT ? sl : 0], d0, d1);
+                            v = freq_pair<false>(xu[sl % 3] * lnr_freq_slot_scale(sl), 0.0f, d0, d1);
                         }
                         x[kb][t][q] = v;
                     }

@@ -320,6 +320,10 @@ extern "C" int lnr_shard_front_pack(const float* rays, const int32_t* out_seg_st
                                     const float* depths, int32_t n_rays, const int32_t* n_rays_dev, int32_t cap, float* record, void* stream) {
     LNR_REQUIRE(record && cap >= 0 && n_rays >= 0 && n_seg >= 0 && n_seg <= LNR_MAX_SEG, "lnr_shard_front_pack: bad argument");
     LNR_REQUIRE(n_seg == 0 || (rays && out_seg_start && seg_order && depths), "lnr_shard_front_pack: null argument");
+    // (n_rays is the capacity of the compacted ray buffer: the live count on the device cannot exceed it.  A record with room for fewer
+    // depths would truncate the global #rays / #opaque normalisers silently and scale the loss wrongly - ADVICE r5)
+    LNR_REQUIRE(n_seg == 0 || n_rays <= cap, "lnr_shard_front_pack: a front record of %d depth slots cannot hold the %d rays of this rank "
+                "(every rank must size its record for the fullest rank: DistContext.front_capacity)", cap, n_rays);
     SegOrder ord;
     ord.n = n_seg;
     for (int s = 0; s < n_seg; ++s) {

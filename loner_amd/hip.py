@@ -103,7 +103,18 @@ _SIGNATURES = {
     "lnr_rng_draws": (C.c_int, [C.c_int32, C.c_uint64, C.c_int32, C.c_int32, P, P]),
     "lnr_shard_front_pack": (C.c_int, [P, P, C.POINTER(C.c_int32), C.c_int32, P, C.c_int32, P, C.c_int32, P, P]),
     "lnr_shard_front_reduce": (C.c_int, [P, C.c_int32, C.c_int32, P, P, P]),
+    "lnr_comm_available": (C.c_int, []),
+    "lnr_comm_unique_id": (C.c_int, [P, C.c_size_t]),
+    "lnr_comm_init": (C.c_int, [P, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "lnr_comm_destroy": (C.c_int, [P]),
+    "lnr_comm_all_reduce": (C.c_int, [P, P, C.c_size_t, C.c_int32, C.c_int32, P]),
+    "lnr_comm_reduce_scatter": (C.c_int, [P, P, P, C.c_size_t, C.c_int32, P]),
+    "lnr_comm_all_gather": (C.c_int, [P, P, P, C.c_size_t, P]),
+    "lnr_comm_broadcast": (C.c_int, [P, P, C.c_size_t, C.c_int32, P]),
 }
+COMM_ID_BYTES = 128
+COMM_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.int64: 2, torch.int32: 3, torch.uint8: 4}
+COMM_OPS = {"sum": 0, "min": 1, "max": 2}
 
 _lib = None
 

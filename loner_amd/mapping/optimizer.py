@@ -345,6 +345,7 @@ class Optimizer:
             # step kernel after it does nothing (the reference raises before optimizer.step(), optimizer.py:368-376,590)
             poison = torch.zeros(2, device=self._device, dtype=torch.int32)
             self._poison = poison
+            self._idle_grad_cleared = False              # (_join_without_rays: an idle rank's zero contribution, cleared once per phase)
             self._optimizer = HipAdam(groups if groups else [{'params': []}], poison=poison)
             gamma = float(self._model_config.train.lrate_gamma)
             base_lrs = [g['lr'] for g in groups]
@@ -753,8 +754,15 @@ class Optimizer:
                 # no backward of this rank overwrites what the previous exchange left in the buffer: contribute zeros again.  The
                 # all-reduce form leaves the sum in the whole vector; the reduce-scatter form only reads the buffer and writes this
                 # rank's chunk (and the phase starts from an all-zero gradient: _do_iterate_optimizer's phase end).
+                # The rest of the buffer must be zero as well - it is after a phase that ended normally, but not after an autograd
+                # backward through compute_loss() without a zero_grad, nor after anything else that wrote params.grad in between
+                #  - so the first idle iteration of a phase clears the whole vector: one fill per phase, not per iteration.
                 sl = self._dist.owned_range(params.grad.numel())
-                (params.grad if sl is None else params.grad.view(-1)[sl[0]:sl[1]]).zero_()
+                if sl is None or not self._idle_grad_cleared:
+                    params.grad.zero_()
+                    self._idle_grad_cleared = True
+                else:
+                    params.grad.view(-1)[sl[0]:sl[1]].zero_()
             grad_work = self._dist.exchange_grads(params.grad.view(-1), async_op=True, zero_rest=not self._overwrite_grads)
         self._results_lidar = None
         return dict(loss=None, d_rays=None, grad_params=params.grad if (want_param_grads and params is not None) else None,

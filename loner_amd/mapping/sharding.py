@@ -120,8 +120,110 @@ class _Pending:
         return self._value
 
 
+class NativeComm:
+    """The HIP library's own RCCL communicator (csrc/lnr_comm.hip, include/loner_hip.h `lnr_comm_*`): a collective is ONE enqueue on a HIP
+    stream - torch's current stream, in line with the kernels around it, or this object's side stream when the caller wants it beside
+    other work (`side=True`: one event each way).  torch.distributed is used once, to hand rank 0's communicator id to the other ranks.
+    ProcessGroupNCCL cost a one-keyframe rank ~30 us of host time per collective and two cross-queue waits per asynchronous one
+    (profiles/r05_host_profile_sharded.txt)."""
+
+    def __init__(self, group=None, device=None):
+        import ctypes as C
+        from .. import hip
+        self._hip, self._C = hip, C
+        lib = hip.load()
+        if not lib.lnr_comm_available():
+            raise RuntimeError("librccl.so.1 could not be loaded by the HIP library")
+        self.rank, self.world_size = dist.get_rank(group), dist.get_world_size(group)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        # two communicators: one for the collectives issued in line on the compute stream, one for those on the side stream - RCCL
+        # orders the operations of ONE communicator among themselves, so an in-line front all-gather would otherwise queue behind a
+        # gradient exchange still in flight on the side stream (ADVICE r5).  Every rank issues both sequences in program order.
+        ids = []
+        for _ in range(2):
+            buf = (C.c_char * hip.COMM_ID_BYTES)()
+            if self.rank == 0:
+                hip.check(lib.lnr_comm_unique_id(buf, hip.COMM_ID_BYTES), "lnr_comm_unique_id")
+            ids.append(bytes(buf.raw))
+        box = [ids if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        self._lib, self._comms = lib, []
+        with torch.cuda.device(self.device):
+            for blob in box[0]:
+                comm = C.c_void_p()
+                hip.check(lib.lnr_comm_init(blob, hip.COMM_ID_BYTES, self.rank, self.world_size, C.byref(comm)), "lnr_comm_init")
+                self._comms.append(comm)
+        self._side = None
+
+    def close(self):
+        if self._comms:
+            torch.cuda.synchronize(self.device)
+            for comm in self._comms:
+                self._lib.lnr_comm_destroy(comm)
+            self._comms = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- where a collective runs: torch's current stream, or the side stream behind an event of the current one
+    def _enter(self, side):
+        cur = torch.cuda.current_stream(self.device)
+        if not side:
+            return cur, None
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self._side.wait_event(ev)
+        return self._side, cur
+
+    def _leave(self, stream, cur, keep):
+        """-> work with .wait(): makes the stream current at wait time wait for the collective (None when it ran in line)"""
+        if cur is None:
+            return None
+        done = torch.cuda.Event()
+        done.record(stream)
+        return _NativeWork(done, self.device, keep)
+
+    def all_reduce_(self, t, op="sum", side=False):
+        st, cur = self._enter(side)
+        self._hip.check(self._lib.lnr_comm_all_reduce(self._comms[1 if side else 0], self._hip._ptr(t), t.numel(), self._hip.COMM_DTYPES[t.dtype], self._hip.COMM_OPS[op],
+                                                      self._C.c_void_p(st.cuda_stream)), "lnr_comm_all_reduce")
+        return self._leave(st, cur, (t,))
+
+    def reduce_scatter(self, out, src, side=False):
+        st, cur = self._enter(side)
+        self._hip.check(self._lib.lnr_comm_reduce_scatter(self._comms[1 if side else 0], self._hip._ptr(src), self._hip._ptr(out), out.numel(), self._hip.COMM_DTYPES[src.dtype],
+                                                          self._C.c_void_p(st.cuda_stream)), "lnr_comm_reduce_scatter")
+        return self._leave(st, cur, (out, src))
+
+    def all_gather(self, out, mine, side=False):
+        """out [world * mine.numel()] <- every rank's `mine` (which may be this rank's own slice of out)"""
+        st, cur = self._enter(side)
+        self._hip.check(self._lib.lnr_comm_all_gather(self._comms[1 if side else 0], self._hip._ptr(mine), self._hip._ptr(out), mine.numel() * mine.element_size(),
+                                                      self._C.c_void_p(st.cuda_stream)), "lnr_comm_all_gather")
+        return self._leave(st, cur, (out, mine))
+
+    def broadcast_(self, t, src=0):
+        st, _ = self._enter(False)
+        self._hip.check(self._lib.lnr_comm_broadcast(self._comms[0], self._hip._ptr(t), t.numel() * t.element_size(), int(src),
+                                                     self._C.c_void_p(st.cuda_stream)), "lnr_comm_broadcast")
+
+
+class _NativeWork:
+    def __init__(self, event, device, keep):
+        self._event, self._device, self._keep = event, device, keep          # (the tensors stay referenced until the wait)
+
+    def wait(self):
+        torch.cuda.current_stream(self._device).wait_event(self._event)
+        self._keep = None
+
+
 class DistContext:
-    def __init__(self, group=None, exchange: str = None, payload: str = "fp32", front: str = None):
+    def __init__(self, group=None, exchange: str = None, payload: str = "fp32", front: str = None, native=None):
         """exchange None: "reduce_scatter" from 4 ranks on, "all_reduce" below - with four or more ranks a rank's share of the window is
         one or two keyframes (an iteration of ~0.4 ms), of which the dense Adam step over all 7.4 M parameters is ~9 %; stepping a
         1/G chunk removes (G-1)/G of that, at the price of the all-gather in front of the next density forward."""
@@ -132,14 +234,22 @@ class DistContext:
         self.rank = dist.get_rank(group)
         if exchange is None:
             exchange = "reduce_scatter" if self.world_size >= 4 else "all_reduce"
-        # front None: "inline" with the all-reduce exchange, "async" with the reduce-scatter exchange - what a one-keyframe rank measured at
-        # RCCL world size 1 (tools/probe_sharded_overhead.py: 0.380 / 0.396 ms per iteration inline / async with all_reduce, 0.685 / 0.443
-        # with reduce_scatter, whose synchronous parameter all-gather shares the compute stream with the in-line collective)
+        if native is None:
+            native = dist.get_backend(group) == "nccl" and torch.cuda.is_available()
+        # front None: "inline" with the library's own RCCL binding - one enqueue on the compute stream through a communicator of its own,
+        # so it never queues behind the gradient exchange in flight on the side stream; "async" through torch.distributed, where a
+        # synchronous collective shares ProcessGroupNCCL's one communicator with the asynchronous gradient exchange and would stall the
+        # compute stream until that has finished (measured at world size 1 only: 0.380 / 0.396 ms per iteration in line / async)
         if front is None:
-            front = "inline" if exchange == "all_reduce" else "async"
+            front = "inline" if native else "async"
         if exchange not in ("all_reduce", "reduce_scatter") or payload not in ("fp32", "bf16") or front not in ("inline", "async"):
             raise ValueError(f"unknown gradient exchange {exchange!r} / payload {payload!r} / front {front!r}")
         self.exchange, self.payload, self.front = exchange, payload, front
+        # native None: the HIP library's own RCCL binding whenever the process group is RCCL ("nccl") and the library can load it;
+        # False: torch.distributed for everything (any backend: what the gloo tests on CPU exercise)
+        self.native = None
+        if native:
+            self.native = NativeComm(group)
 
     # ---- the front of an iteration: far[0] and the loss normalisers -----------------------------------------------------
     def front_capacity(self, n_keyframes: int, rays_per_keyframe: int) -> int:
@@ -156,7 +266,10 @@ class DistContext:
         # front "inline": a synchronous collective - ProcessGroupNCCL enqueues it on the CURRENT stream, between the pack kernel and
         # whatever follows, so its latency (a 16 KB all-gather) is in line but nothing crosses queues; "async": on the backend's own
         # stream, hidden behind the sampler and the density forward at the price of two cross-queue hand-overs
-        work = dist.all_gather_into_tensor(gathered, record, group=self.group, async_op=self.front == "async")
+        if self.native is not None and record.is_cuda:
+            work = self.native.all_gather(gathered, record, side=self.front == "async")
+        else:
+            work = dist.all_gather_into_tensor(gathered, record, group=self.group, async_op=self.front == "async")
 
         def finish():
             if gathered.is_cuda:
@@ -185,13 +298,19 @@ class DistContext:
         sl = None if force_all_reduce else self.owned_range(flat.numel())
         if sl is None:
             buf = flat.to(torch.bfloat16) if bf16 else flat
-            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if self.native is not None and flat.is_cuda:
+                work = self.native.all_reduce_(buf, side=async_op)
+            else:
+                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             pending = _Pending([work], (lambda: flat.copy_(buf)) if bf16 else None)
         else:
             lo, hi = sl
             src = flat.to(torch.bfloat16) if bf16 else flat
             out = torch.empty(hi - lo, device=flat.device, dtype=src.dtype)
-            work = dist.reduce_scatter_tensor(out, src, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if self.native is not None and flat.is_cuda:
+                work = self.native.reduce_scatter(out, src, side=async_op)
+            else:
+                work = dist.reduce_scatter_tensor(out, src, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
             def finish():
                 if zero_rest:
@@ -208,6 +327,9 @@ class DistContext:
         sl = self.owned_range(flat_params.numel())
         if sl is None:
             return
+        if self.native is not None and flat_params.is_cuda:
+            self.native.all_gather(flat_params, flat_params[sl[0]:sl[1]])          # in place: the rank's chunk is its slot of the result
+            return
         mine = flat_params[sl[0]:sl[1]].clone()
         dist.all_gather_into_tensor(flat_params, mine, group=self.group)
 
@@ -216,6 +338,9 @@ class DistContext:
 
     def all_reduce_grads(self, flat: torch.Tensor, async_op: bool = False):
         """Sum a flat buffer over ranks, in place (the occupancy pseudo-gradient: 64-bit fixed-point accumulators, exact)."""
+        if self.native is not None and flat.is_cuda and flat.dtype in (torch.float32, torch.int64, torch.int32):
+            work = self.native.all_reduce_(flat, side=async_op)
+            return work if async_op else flat
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         return work if async_op else flat
 
@@ -224,7 +349,10 @@ class DistContext:
         iteration over all ranks (ties: the smallest code), as one packed MIN all-reduce so that the pair stays a pair."""
         none = torch.iinfo(torch.int64).max
         packed = torch.where(poison[0:1] != 0, poison[1:2].long() * 256 + poison[0:1].long(), torch.full((1,), none, dtype=torch.int64, device=poison.device))
-        dist.all_reduce(packed, op=dist.ReduceOp.MIN, group=self.group)
+        if self.native is not None and packed.is_cuda:
+            self.native.all_reduce_(packed, op="min")
+        else:
+            dist.all_reduce(packed, op=dist.ReduceOp.MIN, group=self.group)
         failed = packed != none
         code = torch.where(failed, packed % 256, torch.zeros_like(packed))
         it = torch.where(failed, packed // 256, torch.zeros_like(packed))

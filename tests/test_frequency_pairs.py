@@ -50,6 +50,35 @@ def test_pair_reduction_reproduces_both_features():
     assert differ < 2e-4 * total, (differ, total)                        # fp16 features: the same value except on a rounding boundary
 
 
+def test_hardware_sine_route_reproduces_both_features():
+    """freq_pair with LNR_FREQ_HW_SIN (lnr_f16_freq.h): sin / cos(pi y) from v_sin_f32 / v_cos_f32 of fract(y / 2) (revolutions; modelled
+    here as the exact function + the 1.25e-7 the instructions were measured at, profiles/r06_valu_rate.txt) and the first-order correction
+    for dl = ph - pi y, recovered exactly from one fma - against the reference's sin(ph), sin(rn(ph + pi/2))."""
+    rng = np.random.default_rng(2)
+    x = rng.random(100000).astype(f32)
+    PI, H = f32(np.pi), f32(np.pi / 2)
+    worst_s = worst_c = 0.0
+    for f in range(12):                                                              # (the fused kernels take n_frequencies <= 12)
+        y = (x * f32(2 ** f)).astype(f32)
+        ph = (y * PI).astype(f32)
+        e1 = (np.float64(y) * np.float64(PI) - np.float64(ph)).astype(f32)            # fma(y, PI, -ph): exact
+        assert np.array_equal(np.float64(e1), np.float64(y) * np.float64(PI) - np.float64(ph))
+        dl = fma(y, f32(8.742278000372485e-8), -e1)
+        r = ((y * f32(0.5)) - np.floor(y * f32(0.5))).astype(f32)                       # v_fract_f32: exact
+        noise = rng.uniform(-1.25e-7, 1.25e-7, size=(2, len(x)))
+        S = (np.sin(2 * np.pi * np.float64(r)) + noise[0]).astype(f32)
+        C = (np.cos(2 * np.pi * np.float64(r)) + noise[1]).astype(f32)
+        s, c = fma(C, dl, S), fma(-S, dl, C)
+        h = (ph + H).astype(f32)
+        bb = (h - ph).astype(f32)
+        e = ((ph - (h - bb).astype(f32)).astype(f32) + (H - bb).astype(f32)).astype(f32)
+        d = (f32(4.371139000186243e-8) - e).astype(f32)
+        c2 = fma(-d, s, c)
+        worst_s = max(worst_s, float(np.abs(s - np.sin(ph.astype(np.float64))).max()))
+        worst_c = max(worst_c, float(np.abs(c2 - np.sin(h.astype(np.float64))).max()))
+    assert worst_s < 4e-7 and worst_c < 4e-7, (worst_s, worst_c)
+
+
 def test_sampler_prefix_sums_are_exact_in_float64():
     """sample_occ_kernel's parallel cumsum (lnr_sampler.hip) relies on the float64 prefix sums of the pdf being exact, hence independent of
     the order of the additions: a sequential float64 cumsum (torch.cumsum on the CPU) equals a chunked one bit for bit."""

@@ -26,17 +26,25 @@ os.environ.setdefault("MASTER_PORT", "29713")
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 phase = lambda n: OptimizationSettings(n, False, False, False, True)
-for form, front in ((None, None), ("all_reduce", "inline"), ("all_reduce", "async"), ("reduce_scatter", "inline"), ("reduce_scatter", "async")):
+import gc
+for form, front, native, grad in ((None, None, None, None),
+                                  ("all_reduce", "inline", False, "async"), ("all_reduce", "async", False, "async"),
+                                  ("reduce_scatter", "inline", False, "async"), ("reduce_scatter", "async", False, "async"),
+                                  ("all_reduce", "inline", True, "async"), ("all_reduce", "async", True, "async"),
+                                  ("reduce_scatter", "inline", True, "async"), ("reduce_scatter", "async", True, "async")):
     opt = bench.make_bench_optimizer(512, 512, "f32")
     window = bench.build_window(8)[:1]
     if form is not None:
-        opt.set_distributed(DistContext(exchange=form, front=front))
+        opt.set_distributed(DistContext(exchange=form, front=front, native=native))
     opt._do_iterate_optimizer(window, [None], optimizer_settings=phase(a.warmup))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     opt._do_iterate_optimizer(window, [None], optimizer_settings=phase(a.steps))
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / a.steps
-    print(f"one keyframe x 512 rays x 512 samples, {'non-distributed loop' if form is None else 'sharded loop, world size 1, exchange ' + form + ', front collective ' + front}: "
-          f"{ms:.4f} ms per iteration")
+    what = "non-distributed loop" if form is None else (f"sharded loop, world size 1, {'lnr_comm (own RCCL binding)' if native else 'torch.distributed (ProcessGroupNCCL)'}, "
+                                                        f"exchange {form}, front collective {front}")
+    print(f"one keyframe x 512 rays x 512 samples, {what}: {ms:.4f} ms per iteration", flush=True)
+    del opt
+    gc.collect()
 dist.destroy_process_group()

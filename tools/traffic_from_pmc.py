@@ -1,5 +1,7 @@
 """profiles/traffic.json from the two rocprofv3 PMC passes of tools/pmc.sh (FETCH_SIZE, WRITE_SIZE; per-kernel means)."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, subprocess, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from loner_amd.build import sources_digest
 
 def per_kernel(counter):
     # tools/gpu_run.sh pmc:<counter> writes gpurun_out/pmc_<counter>_<tag>/ (tag "product" by default); tools/pmc.sh gpurun_out/pmc_<counter>/
@@ -23,6 +25,9 @@ out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes
        "units": "counter values are KiB; bytes = value*1024.  bytes_corrected doubles FETCH_SIZE as MI355X_MICROARCH.md prescribes for gfx950 "
                 "(64 B tallied per 128-B request on wide streaming reads; for 8-byte gathers the factor is uncalibrated, so it is an upper bound); "
                 "Infinity-Cache hits are counted, not excluded",
+       # what the passes measured: bench.py compares this with the sources it runs on and flags a stale file
+       "kernel_sources_sha": sources_digest(),
+       "commit": (subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or os.environ.get("LNR_COMMIT", "unknown")),
        "per_launch": {}}
 for k in sorted(set(fetch) | set(write)):
     short = next((v for a, v in ALIAS.items() if a in k), None)

@@ -11,7 +11,7 @@
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 enum { OP_FMA = 0, OP_ADD_U32, OP_XOR, OP_FMA_DPP, OP_SIN, OP_CVT_PK, OP_MUL_LO, OP_FMA64, OP_PK_FMA, OP_CNDMASK,
-       OP_CNDMASK_SET, OP_CNDMASK_SGPR, OP_CNDMASK_3OP, OP_CNDMASK_MIX, OP_CMP, OP_CMP_SGPR, OP_BFI, OP_MOV, OP_MOV_DPP, OP_READLANE, OP_WRITELANE, OP_MAX, OP_CMP_CND, OP_MUL };
+       OP_CNDMASK_SET, OP_CNDMASK_SGPR, OP_CNDMASK_3OP, OP_CNDMASK_MIX, OP_CMP, OP_CMP_SGPR, OP_BFI, OP_MOV, OP_MOV_DPP, OP_READLANE, OP_WRITELANE, OP_MAX, OP_CMP_CND, OP_MUL, OP_CMP_4CND, OP_SCMP_CND, OP_CMP_FMA_CND };
 
 template <int OP>
 __global__ void __launch_bounds__(256) rate_kernel(float* out, unsigned long long* cyc, int iters, float seed) {
@@ -55,6 +55,15 @@ __global__ void __launch_bounds__(256) rate_kernel(float* out, unsigned long lon
                 if (OP == OP_MAX) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
                 if (OP == OP_CMP_CND) { asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %2, vcc" : "+v"(a[i]) : "v"(c), "v"(b) : "vcc"); }
                 if (OP == OP_MUL) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                // one compare, then four selects on its vcc (what a compiler emits for `cond ? a[k] : b` over several values)
+                if (OP == OP_CMP_4CND) { if ((i & 3) == 0) asm volatile("v_cmp_lt_f32 vcc, %4, %5\n\tv_cndmask_b32 %0, %0, %5, vcc\n\tv_cndmask_b32 %1, %1, %5, vcc\n\tv_cndmask_b32 %2, %2, %5, vcc\n\tv_cndmask_b32 %3, %3, %5, vcc"
+                                                                      : "+v"(a[i]), "+v"(a[i + 1]), "+v"(a[i + 2]), "+v"(a[i + 3]) : "v"(c), "v"(b) : "vcc"); }
+                // vcc written by the SCALAR unit (s_mov), then selects
+                if (OP == OP_SCMP_CND) { if ((i & 3) == 0) asm volatile("s_mov_b64 vcc, %4\n\tv_cndmask_b32 %0, %0, %5, vcc\n\tv_cndmask_b32 %1, %1, %5, vcc\n\tv_cndmask_b32 %2, %2, %5, vcc\n\tv_cndmask_b32 %3, %3, %5, vcc"
+                                                                      : "+v"(a[i]), "+v"(a[i + 1]), "+v"(a[i + 2]), "+v"(a[i + 3]) : "s"(msk), "v"(b) : "vcc"); }
+                // compare, three unrelated VALU instructions, then one select
+                if (OP == OP_CMP_FMA_CND) { if ((i & 3) == 0) asm volatile("v_cmp_lt_f32 vcc, %4, %5\n\tv_fma_f32 %1, %1, %5, %4\n\tv_fma_f32 %2, %2, %5, %4\n\tv_fma_f32 %3, %3, %5, %4\n\tv_cndmask_b32 %0, %0, %5, vcc"
+                                                                        : "+v"(a[i]), "+v"(a[i + 1]), "+v"(a[i + 2]), "+v"(a[i + 3]) : "v"(c), "v"(b) : "vcc"); }
             }
         }
     }
@@ -136,6 +145,9 @@ int main() {
         run<OP_WRITELANE>("v_writelane_b32", 32, w);
         run<OP_MAX>("v_max_f32", 32, w);
         run<OP_MUL>("v_mul_f32", 32, w);
+        run<OP_CMP_4CND>("v_cmp, 4 x v_cndmask vcc (5 per group)", 40, w);
+        run<OP_SCMP_CND>("s_mov vcc, 4 x v_cndmask vcc (4 VALU)", 32, w);
+        run<OP_CMP_FMA_CND>("v_cmp, 3 v_fma, v_cndmask vcc (5)", 40, w);
     }
     // accuracy of the hardware sine / cosine (argument in revolutions) over [-1, 1]
     const int n = 1 << 22;
