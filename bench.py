@@ -92,7 +92,12 @@ def build_window(n_kf, device=None):
     return kfs
 
 
-L1_RAYS = 256            # held-out rays of keyframe 0 for the matched-quality probe of the baseline legs
+L1_RAYS = 512            # held-out rays of keyframe 0 for the matched-quality probe of every leg: the subset the reference's curve (G13) was scored on
+
+
+def l1_subset(total=65536):
+    """ray indices of the synthetic 64 x 1024 scan the G13 fixture scored (tests/support.py l1_scan_subset: every 128th ray, offset 7)"""
+    return torch.arange(7, total, total // L1_RAYS)[:L1_RAYS]
 
 
 def window_poses(n_kf):
@@ -133,6 +138,29 @@ QUALITY_ITERS = 100
 QUALITY_SEEDS = 8        # runs per GPU leg (each with its own random draws): the spread of L1 after 100 Adam iterations is part of the answer
 QUALITY_REFERENCE = {"l1_initial_m": 30.02, "l1_after_50_iterations_m": 14.55, "l1_after_100_iterations_m": 10.86,
                      "source": "tests/golden/g13_l1_curve.npz: the reference's Optimizer + compute_l1_depth on this configuration (512 held-out rays, 256 samples)"}
+
+
+def available_cores():
+    """cores this process may actually use: os.cpu_count() is the HOST's (256 on the GPU boxes), the scheduler affinity and the cgroup
+    CPU quota are what a container gets (an oversubscribed torch thread pool - 256 threads on a 16-core quota - runs an oracle iteration
+    many times slower than 16 threads do)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, int(float(quota) / period + 0.5)))
+        except Exception:
+            pass
+    return max(n, 1)
 
 
 def oracle_leg(args, device, budget_s, max_iters, min_iters=2, seed=0, threads=None):
@@ -177,7 +205,7 @@ def oracle_leg(args, device, budget_s, max_iters, min_iters=2, seed=0, threads=N
     m, kfs = make()
 
     def probe():
-        idx = torch.linspace(0, dirs.shape[1] - 1, L1_RAYS).long()
+        idx = l1_subset(dirs.shape[1])
         torch.manual_seed(123)
         return OA.l1_depth(spec, m.params, m.grid[0, 0], dirs[:, idx].to(dev), dist0[idx].to(dev), kfs[0].pose6.detach(), m.scale, m.shift,
                            torch.tensor([1.0, 50.0], device=dev), 256, torch.rand(L1_RAYS, 128).to(dev), (torch.randn(L1_RAYS, 256) * 1.0).to(dev),
@@ -290,6 +318,13 @@ def render_leg(opt, kf, scans=3, dtype="f32"):
         b.record(); torch.cuda.synchronize()
         return a.elapsed_time(b) / reps, out
     ms_depth, depth = timed(lambda: model.render_depth(rays, sampler, opt._scale_f, testing=True), scans)
+    # the opt-in front-to-back route (Model._render_depth_front_to_back): the same scan, the network evaluated only where the transmittance
+    # is still >= 2^-24.  What it skips depends on how far the map has formed (profiles/r06_render_dead.txt)
+    try:
+        ms_ftb, depth_ftb = timed(lambda: model.render_depth(rays, sampler, opt._scale_f, testing=True, front_to_back=True), scans)
+    except Exception as e:                                   # never let the optional route break the line
+        ms_ftb, depth_ftb = None, None
+        ftb_error = str(e)
     with torch.no_grad():
         ms_full, _ = timed(lambda: model(rays, sampler, opt._scale_f, testing=True, camera=False, return_variance=True), 1)
     # per-kernel times of one scan: the library's own events inside lnr_density_forward, torch events around the other two ops
@@ -331,6 +366,13 @@ def render_leg(opt, kf, scans=3, dtype="f32"):
                             "forward of launch i (Model._render_no_grad), so its span is stretched by the sharing and the spans do not add up to "
                             "ms_per_scan; alone it takes 2.3 ms per scan (profiles/r04_render_kernel_stats.csv)",
             "l1_depth_m_of_this_scan": l1,
+            "front_to_back": ({"ms_per_scan": round(ms_ftb, 3), "value": n / (ms_ftb * 1e-3), "unit": "rays/s",
+                               "l1_depth_m_of_this_scan": (float(((depth_ftb * opt._scale_f)[good] - gt[good]).abs().mean()) if bool(good.any()) else None),
+                               "mean_depth_relative_difference_to_default_route": float((depth_ftb.mean() - depth.mean()).abs() / depth.mean().abs()),
+                               "note": "opt-in route (cfg.render.front_to_back / Model.render_depth(front_to_back=True)): blocks of 256 samples along the ray, "
+                                       "a ray leaves once its transmittance is below 2^-24; different launch sizes key different in-kernel random numbers, so "
+                                       "the two routes agree statistically here and to 1e-6 on replayed draws (tests/test_gpu_mapping.py)"}
+                              if ms_ftb is not None else {"error": ftb_error}),
             "roofline": {"kernel": "encode_forward", "bound": "hbm", "achieved": enc_bytes / t_enc / 1e9 if t_enc > 0 else None, "peak": 8000.0,
                          "unit": "GB/s", "frac": enc_bytes / t_enc / 8e12 if t_enc > 0 else None, "algorithmic_bytes_per_scan": enc_bytes,
                          "traffic": None,
@@ -394,11 +436,13 @@ def make_bench_optimizer(rays, samples, dtype="f32", device_index=0, rank=0, par
 
 
 def l1_probe(o, kf0, max_rays):
-    """analysis/compute_l1_depth.py semantics on keyframe kf0 with the optimiser's map"""
+    """analysis/compute_l1_depth.py semantics on keyframe kf0 with the optimiser's map; max_rays == L1_RAYS: exactly G13's subset"""
     from loner_amd.analysis.l1_depth import compute_l1_depth
     from loner_amd.common.ray_utils import LidarRayDirections
-    return compute_l1_depth(kf0.get_lidar_pose(), LidarRayDirections(kf0.get_lidar_scan(), chunk_size=2048), o._model,
-                            o._ray_sampler, o._world_cube, o._ray_range, o._device, max_rays=max_rays)
+    scan = kf0.get_lidar_scan()
+    return compute_l1_depth(kf0.get_lidar_pose(), LidarRayDirections(scan, chunk_size=2048), o._model,
+                            o._ray_sampler, o._world_cube, o._ray_range, o._device, max_rays=max_rays,
+                            indices=l1_subset(len(scan)) if max_rays == L1_RAYS else None)
 
 
 def quality_initial_params():
@@ -792,14 +836,21 @@ def main():
         # BASELINE.md section 3 planned os.cpu_count() threads; torch's CPU ops on [4096,512] tensors do not scale that far on a 256-core
         # host, so the thread count is MEASURED: one iteration each at 16 / 64 / all cores, the fastest count runs the bounded sample
         # and all three timings are reported
-        n_cpu = os.cpu_count() or 1
+        n_cpu = available_cores()
         probe = {}
+        t_probe = time.time()
         for th in sorted({min(16, n_cpu), min(64, n_cpu), n_cpu}):
-            probe[th] = oracle_leg(args, "cpu", budget_s=0.0, max_iters=1, min_iters=1, threads=th)["ms_per_iter"]
+            if probe and time.time() - t_probe > 40.0:      # (the line must finish within minutes whatever the host does)
+                break
+            # (one iteration of a ONE-keyframe window - an eighth of the workload: a badly oversubscribed count costs seconds, not minutes)
+            probe[th] = oracle_leg(_Shape(1, args.rays, args.samples), "cpu", budget_s=0.0, max_iters=1, min_iters=1, threads=th)["ms_per_iter"]
         best = min(probe, key=probe.get)
+        print(f"bench.py: cpu thread probe {probe} ms per one-keyframe iteration in {time.time() - t_probe:.1f} s ({n_cpu} usable cores)", file=sys.stderr, flush=True)
         cpu = oracle_leg(args, "cpu", budget_s=12.0, max_iters=6, threads=best)
         cpu["threads_probe_ms_per_iter"] = {str(k): round(v, 1) for k, v in probe.items()}
-        cpu["sample"] += f"; thread count chosen by a one-iteration probe at {sorted(probe)} threads (fastest: {best})"
+        cpu["available_cores"] = n_cpu
+        cpu["sample"] += (f"; thread count chosen by a one-iteration probe of a one-keyframe window at {sorted(probe)} threads (fastest: {best}; {n_cpu} cores usable "
+                          f"by this process - affinity and cgroup quota - of the host's {os.cpu_count()})")
         try:
             rocm = oracle_leg(args, "cuda", budget_s=4.0, max_iters=max(cpu["iterations"], 3), min_iters=cpu["iterations"])
         except Exception as e:
@@ -866,6 +917,25 @@ def main():
                     "of keyframe 0, the same probe seed) before and after the SAME number of iterations from the same initial parameters; the GPU "
                     f"legs {QUALITY_SEEDS} runs each with different random draws (HIP: the in-kernel generator, tests/test_gpu_rng.py), the CPU leg one run; "
                     "tests/test_gpu_mapping.py::test_l1_depth_curve_matches_the_reference_on_its_own_draws ties the HIP path to the reference's own curve"}
+        # ... and ONE pair of runs at the headline workload itself: 25 iterations of the whole window from the same
+        # initial parameters, the HIP path against the oracle's torch ops on the same MI355X, scored on the same 512 rays.  One run per
+        # leg (the torch leg costs ~0.85 s per iteration): reported, with the 10 % band as a flag, not folded into `matched`.
+        try:
+            t_hw = time.time()
+            hw_it = 25
+            hw_shape = _Shape(args.keyframes, args.rays, args.samples)
+            hw_hip = hip_quality_run(0, iters=hw_it, shape=hw_shape, device_index=local)
+            hw_ref = oracle_leg(hw_shape, "cuda", budget_s=0.0, max_iters=hw_it, min_iters=hw_it, seed=0)
+            hw_rel = hw_hip["l1_depth_m_after"] / hw_ref["l1_depth_m_after"] - 1.0
+            line["matched_quality"]["headline_workload"] = {
+                "config": f"{hw_shape.keyframes} keyframes x {hw_shape.rays} rays x {hw_shape.samples} samples, {hw_it} iterations, one run per leg",
+                "l1_depth_m_before": {"hip_f32": hw_hip["l1_depth_m_before"], "torch_rocm_oracle": hw_ref["l1_depth_m_before"]},
+                "l1_depth_m_after": {"hip_f32": hw_hip["l1_depth_m_after"], "torch_rocm_oracle": hw_ref["l1_depth_m_after"]},
+                "relative_difference": hw_rel, "within_10pct": abs(hw_rel) <= 0.10,
+                "ms_per_iter": {"hip_f32": hw_hip["ms_per_iter"], "torch_rocm_oracle": hw_ref["ms_per_iter"]}}
+            print(f"bench.py: headline-workload quality pair in {time.time() - t_hw:.1f} s", file=sys.stderr, flush=True)
+        except Exception as e:
+            line["matched_quality"]["headline_workload"] = {"error": str(e)}
         # speed-ups: on the full workload only as "same workload" figures with the quality flag beside them; "at matched quality" on the
         # configuration where quality was actually compared
         line["quality_matched"] = matched

@@ -253,6 +253,16 @@ int lnr_compact_rays(const float* rays_in, const float* depths_in, const uint8_t
                      float* rays_out, float* depths_out, int64_t* src_index_out,
                      int32_t* out_seg_start, int32_t* n_out_dev, void* stream);
 
+/* lnr_compact_rays followed, in the same launch, by what the loss needs next from the compacted batch: counts_dev [2] = the normalisers
+ * lnr_count_opaque computes ({#rays, #opaque rays}, optimizer.py:460-463,488-489; far[0] = the batch's own first ray), OR record = the
+ * rank's front record as lnr_shard_front_pack writes it (seg_order [n_seg] host, cap depth slots >= n_in).  Exactly one of the two. */
+int lnr_compact_rays_front(const float* rays_in, const float* depths_in, const uint8_t* keep, const int64_t* src_index,
+                           int32_t n_in, const int32_t* seg_start /*host*/, int32_t n_seg,
+                           float* rays_out, float* depths_out, int64_t* src_index_out,
+                           int32_t* out_seg_start, int32_t* n_out_dev,
+                           int32_t* counts_dev /*[2] or NULL*/, const int32_t* seg_order /*[n_seg] host or NULL*/, int32_t cap,
+                           float* record /*[LNR_FRONT_HEADER + cap] or NULL*/, void* stream);
+
 /* Sharded windows (one process per GPU, keyframes round-robin): the reference's `depth > far[0]` test (optimizer.py:460-461) uses the
  * FIRST ray of the whole batch = the first kept ray of the first keyframe, in window order, that kept any.  Each rank reports its
  * candidate as one 64-bit key = (seg_order of its first segment with a kept ray) << 32 | bits of that ray's far; INT64_MAX when it kept
@@ -376,6 +386,22 @@ int lnr_weights_gt(const float* s /*[n,S] metres*/, const float* g /*[n] metres*
 /* get_logits_grad (losses.py:54-62), defaults eps=2, l_free=0.25, l_occ=2.5. */
 int lnr_logits_grad(const float* s /*[n,S]*/, const float* g /*[n]*/, int32_t n_rays, int32_t n_samples,
                     float margin, float l_free, float l_occ, float* out, void* stream);
+
+/* Front-to-back inference, an opt-in route of Model.render_depth (the reference composites all N_samples_test samples of every ray:
+ * model_tcnn.py:73-105 -> rendering_tcnn.py:71-147).  The ray's sorted depths z [n_rays, n_samples] are drawn in full; the network is
+ * evaluated in blocks of 256 samples along the ray on the rays whose transmittance is still >= 2^-24 (what lies behind contributes less
+ * than fp32 resolution to the depth).  Per block b0: lnr_render_ftb_gather copies the alive rays' records and block depths into
+ * compact arrays for lnr_density_forward (rays form, n_rays_dev = n_alive_dev) and zeroes next_count_dev; lnr_render_ftb_composite
+ * (one wave per alive ray, the arithmetic and noise draw of lnr_render_forward) adds the block's contributions to depth_acc /
+ * opacity_acc [n_rays], updates transmittance [n_rays] (caller: ones / zeros before block 0) and appends surviving rays to next_idx.
+ * idx [cap] int32: alive ray indices, n_alive_dev their count; last != 0: nothing is appended.  depth = depth_acc + (1 - opacity_acc) far. */
+int lnr_render_ftb_gather(const float* rays, const float* z, int32_t n_samples, const int32_t* idx, const int32_t* n_alive_dev,
+                          int32_t cap, int32_t b0, int32_t block_samples, float* rays_c /*[cap,13]*/, float* z_c /*[cap,block]*/,
+                          int32_t* next_count_dev, void* stream);
+int lnr_render_ftb_composite(const float* sigma_c /*[cap,256]*/, const float* z, const float* rays, int32_t n_samples, const int32_t* idx,
+                             const int32_t* n_alive_dev, int32_t cap, int32_t b0, int32_t block_samples,
+                             const float* noise /*[n_rays,n_samples] explicit draws or NULL*/, float noise_std, uint64_t seed, float* transmittance, float* depth_acc, float* opacity_acc, int32_t* next_idx, int32_t* next_count_dev,
+                             int32_t last, void* stream);
 
 /* Fused Optimizer.compute_loss (optimizer.py:437-595, lidar branch) forward + backward:
  * render (as lnr_render_forward), weighted mean/var, JS divergence (:476-482,:614-626), dynamic

@@ -11,14 +11,17 @@ from ..common.ray_utils import LidarRayDirections
 
 @torch.no_grad()
 def compute_l1_depth(lidar_pose, ray_directions: LidarRayDirections, model, ray_sampler, world_cube, ray_range, device,
-                     max_rays=None, stride=None):
-    """-> mean L1 depth error in metres (float).  `lidar_pose`: a Pose; `stride`/`max_rays` subsample the scan
-    (the reference evaluates every ray; subsampling keeps tests short)."""
+                     max_rays=None, stride=None, indices=None):
+    """-> mean L1 depth error in metres (float).  `lidar_pose`: a Pose; `stride`/`max_rays` subsample the scan, `indices` names the
+    rays to score outright (the reference evaluates every ray; subsampling keeps tests short)."""
     scale = world_cube.scale_factor
     n = len(ray_directions)
-    idx = torch.arange(0, n, stride or 1)
-    if max_rays is not None and idx.numel() > max_rays:
-        idx = idx[torch.linspace(0, idx.numel() - 1, max_rays).long()]
+    if indices is not None:
+        idx = torch.as_tensor(indices, dtype=torch.int64).reshape(-1)
+    else:
+        idx = torch.arange(0, n, stride or 1)
+        if max_rays is not None and idx.numel() > max_rays:
+            idx = idx[torch.linspace(0, idx.numel() - 1, max_rays).long()]
     size = ray_directions._chunk_size
     err_sum, count = 0.0, 0
     T = lidar_pose.get_transformation_matrix().detach()

@@ -77,11 +77,12 @@ void ws_forget(const void* ws) {
 // (a thousand threads share the reads instead of one per parameter), rows combined through LDS in a fixed order: no
 // atomics, bit-reproducible.
 #define LNR_SLAB_GROUPS 16
-__global__ void __launch_bounds__(64 * LNR_SLAB_GROUPS)
-reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs, int n_mlp, float* __restrict__ grad, int overwrite) {
+// the fold of 64 consecutive parameters by one 1024-thread workgroup (`block` = which 64): reduce_slabs_kernel, and the extra workgroups
+// at the end of table_grad_reduce2_kernel's grid (one launch fewer per backward: ~4.5 us of a one-keyframe rank's 0.34 ms iteration)
+__device__ __forceinline__ void slab_fold_block(const float* __restrict__ slabs, int n_slabs, int n_mlp, float* __restrict__ grad, int overwrite, int block) {
     __shared__ float part[LNR_SLAB_GROUPS][64];
     const int px = threadIdx.x & 63, gy = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + px;
+    const int i = block * 64 + px;
     const int per = (n_slabs + LNR_SLAB_GROUPS - 1) / LNR_SLAB_GROUPS;
     int b = gy * per;
     const int b_end = min(n_slabs, b + per);
@@ -101,6 +102,10 @@ reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs, int n_mlp, flo
         for (int k = 0; k < LNR_SLAB_GROUPS; ++k) s += part[k][px];
         grad[i] = overwrite ? s : grad[i] + s;
     }
+}
+__global__ void __launch_bounds__(64 * LNR_SLAB_GROUPS)
+reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs, int n_mlp, float* __restrict__ grad, int overwrite) {
+    slab_fold_block(slabs, n_slabs, n_mlp, grad, overwrite, (int)blockIdx.x);
 }
 
 // Workgroup `o` owns floats [o << shift, (o+1) << shift) of the table gradient.  The encode-backward workgroups of
@@ -318,13 +323,20 @@ template <int PAIR, int RED_U, int MINW>
 __global__ void __launch_bounds__(1024, MINW)   // HIP: (max threads, min waves per SIMD)
 table_grad_reduce2_kernel(const LnrNetSpec spec, const void* __restrict__ regions_v, const RegionPlan plan, const int* __restrict__ counts, int bpg,
                           int maxo, long long* __restrict__ ovf, const int* __restrict__ ovf_flag, int epoch, float* __restrict__ grad_table,
-                          int64_t n_table_floats, int overwrite) {
+                          int64_t n_table_floats, int overwrite, const float* __restrict__ slabs, int n_slabs, int n_mlp, float* __restrict__ grad_mlp) {
     extern __shared__ long long acc[];
+    // slabs != NULL: the last ceil(n_mlp / 64) workgroups of the grid fold the MLP backward's weight-gradient slabs (slab_fold_block)
+    const int slab_blocks = slabs != nullptr ? (n_mlp + 63) / 64 : 0;
+    const int owner_blocks = (int)gridDim.x - slab_blocks;
+    if ((int)blockIdx.x >= owner_blocks) {                                   // (workgroup-uniform)
+        slab_fold_block(slabs, n_slabs, n_mlp, grad_mlp, overwrite, (int)blockIdx.x - owner_blocks);
+        return;
+    }
     // Owners in DESCENDING table order: the hardware starts workgroups in blockIdx order, the chip holds 512 of the ~900 at a time, and
     // the owners of the fine (x-pair) levels - the heaviest, and with the default network exactly 512 of them - sit at the END of the
     // table: started last they were the kernel's tail behind a half-empty chip; started first they fill it, and the lighter owners of
     // the coarse levels follow.
-    const int o = (int)gridDim.x - 1 - (int)blockIdx.x;
+    const int o = owner_blocks - 1 - (int)blockIdx.x;
     constexpr int slice = RED_SLICE, shift = LNR_SLICE_SHIFT;
     const uint32_t base = (uint32_t)o << shift;
     PHASE_INIT();
@@ -636,6 +648,7 @@ struct ReduceCtx {
     const LnrNetSpec* spec;
     const void* regions; const int* counts; long long* ovf; const int* ovf_flag; int epoch; float* grad_table;
     RegionPlan plan; int bpg, maxo, shift; int64_t n_table; int n_split; int overwrite;
+    const float* slabs; int n_slabs, n_mlp; float* grad_mlp;          // slabs != NULL: the weight-gradient fold rides in the reduce launch
 };
 
 template <int PAIR, int U, int W>
@@ -651,8 +664,9 @@ static int launch_reduce_variant(const ReduceCtx& c, int n_owners, hipStream_t s
                            c.ovf);
     }
     LnrProfScope prof("table_grad_reduce", st);
-    hipLaunchKernelGGL((table_grad_reduce2_kernel<PAIR, U, W>), dim3(n_owners), dim3(1024), lds, st, *c.spec, c.regions, c.plan, c.counts, c.bpg, c.maxo,
-                       c.ovf, c.ovf_flag, c.epoch, c.grad_table, c.n_table, c.overwrite);
+    const int slab_blocks = c.slabs != nullptr ? (c.n_mlp + 63) / 64 : 0;
+    hipLaunchKernelGGL((table_grad_reduce2_kernel<PAIR, U, W>), dim3(n_owners + slab_blocks), dim3(1024), lds, st, *c.spec, c.regions, c.plan, c.counts, c.bpg, c.maxo,
+                       c.ovf, c.ovf_flag, c.epoch, c.grad_table, c.n_table, c.overwrite, c.slabs, c.n_slabs, c.n_mlp, c.grad_mlp);
     return LNR_OK;
 }
 // 2 regions in flight per wave at 8 waves per SIMD (two workgroups per CU) measured best: 0.35 ms against 0.37 (4 in flight, 8 waves),
@@ -884,8 +898,11 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
     } else {
         ws_touch(workspace, layout_signature(spec, cap));
     }
+    // the weight-gradient fold rides in the table reduce's launch whenever both run in this call
+    const bool fold_in_reduce = want_grad && hash && L.nown > 0 && !(flags & LNR_BWD_DEFER_WEIGHT_FOLD);
     ReduceCtx rctx{spec, regions, counts, ovf, ovf_flag, epoch, grad_table, rplan, L.bpg, L.maxo, L.shift, spec->n_params - spec->n_mlp_params,
-                   (flags & LNR_BWD_TABLE_ATOMICS) ? 0 : L.n_split, (flags & LNR_BWD_OVERWRITE_GRAD) ? 1 : 0};
+                   (flags & LNR_BWD_TABLE_ATOMICS) ? 0 : L.n_split, (flags & LNR_BWD_OVERWRITE_GRAD) ? 1 : 0,
+                   fold_in_reduce ? slabs : nullptr, n_slabs, spec->n_mlp_params, grad_params};
     // hash grids (LNR_SPLIT_DX): the input gradient first, as launches of its own; the table-gradient partition follows behind the event
     const bool split = LNR_SPLIT_DX && hash;
     if (want_dfeat && !fused_freq) {
@@ -936,7 +953,7 @@ extern "C" int lnr_density_backward(const LnrNetSpec* spec, const float* params,
 #endif
     }
     // (folding the slabs right after the MLP backward instead was measured: +15 us in front of the encode backward, nothing gained)
-    if (flags & LNR_BWD_DEFER_WEIGHT_FOLD) return LNR_OK;            // the caller folds them with lnr_density_fold_weight_grads
+    if ((flags & LNR_BWD_DEFER_WEIGHT_FOLD) || fold_in_reduce) return LNR_OK;      // the caller folds them (lnr_density_fold_weight_grads) / done above
     const int n_mlp = spec->n_mlp_params;
     LnrProfScope prof_slabs("reduce_slabs", st);
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(lnr_div_up(n_mlp, 64)), dim3(64 * LNR_SLAB_GROUPS), 0, st, slabs, n_slabs, n_mlp, grad_params,

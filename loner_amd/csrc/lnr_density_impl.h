@@ -53,6 +53,7 @@ __device__ __forceinline__ float lnr_cos(float v) {
     return cosf(v);
 }
 
+#define LNR_K_ACT 10.0f
 __device__ __forceinline__ float act_fwd(float v, int kind) {
     switch (kind) {
         case LNR_ACT_RELU: return fmaxf(v, 0.0f);
@@ -60,8 +61,9 @@ __device__ __forceinline__ float act_fwd(float v, int kind) {
         case LNR_ACT_LEAKY_RELU: return v > 0.0f ? v : 0.01f * v;
         case LNR_ACT_EXPONENTIAL: return expf(v);
         case LNR_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
-        case LNR_ACT_SQUAREPLUS: return 0.5f * (v + sqrtf(v * v + 4.0f));
-        case LNR_ACT_SOFTPLUS: return v > 20.0f ? v : log1pf(expf(v));
+        // (tiny-cuda-nn: both on K_ACT v, result / K_ACT, K_ACT = 10 - oracle/network.py)
+        case LNR_ACT_SQUAREPLUS: { const float y = LNR_K_ACT * v; return 0.5f * (y + sqrtf(y * y + 4.0f)) * (1.0f / LNR_K_ACT); }
+        case LNR_ACT_SOFTPLUS: { const float y = LNR_K_ACT * v; return y > 20.0f ? v : log1pf(expf(y)) * (1.0f / LNR_K_ACT); }
         case LNR_ACT_TANH: return tanhf(v);
         default: return v;
     }
@@ -74,8 +76,8 @@ __device__ __forceinline__ float act_bwd(float v, int kind) {
         case LNR_ACT_LEAKY_RELU: return v > 0.0f ? 1.0f : 0.01f;
         case LNR_ACT_EXPONENTIAL: return expf(v);
         case LNR_ACT_SIGMOID: { float s = 1.0f / (1.0f + expf(-v)); return s * (1.0f - s); }
-        case LNR_ACT_SQUAREPLUS: return 0.5f * (1.0f + v / sqrtf(v * v + 4.0f));
-        case LNR_ACT_SOFTPLUS: return 1.0f / (1.0f + expf(-v));
+        case LNR_ACT_SQUAREPLUS: { const float y = LNR_K_ACT * v; return 0.5f * (1.0f + y / sqrtf(y * y + 4.0f)); }
+        case LNR_ACT_SOFTPLUS: return 1.0f / (1.0f + expf(-LNR_K_ACT * v));
         case LNR_ACT_TANH: { float t = tanhf(v); return 1.0f - t * t; }
         default: return 1.0f;
     }

@@ -133,12 +133,13 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
     // FQ (lnr_f16_freq.h): slot sl of this lane = coordinate sl % 3, frequency 4 (sl / 3) + g; a compile-time number of slots
     constexpr int fq_slots = LNR_FREQ_SLOTS_OF_KT(KT);
     const float fq_pg = __uint_as_float((uint32_t)(127 + g) << 23);        // 2^g
+    const bool fq_uni = FQ && ray_uniform(src, 32u);                       // a step's 32 samples lie on one ray: its record through the scalar cache
     // unit-cube point of the lane's sample in column tile t of `tile` (clamped to the last live sample)
     auto unit_point_of_column = [&](int64_t tile, int t, float (&xu)[3]) {
         int64_t m = tile * 32 + 16 * t + c;
         if (m >= M) m = M - 1;
         RawPoint rp;
-        load_raw_point(src, (uint32_t)m, src.pts ? 0u : (uint32_t)m / (uint32_t)src.n_samples, rp);
+        load_raw_point(src, (uint32_t)m, src.pts ? 0u : (uint32_t)m / (uint32_t)src.n_samples, rp, fq_uni);
         unit_point(src, rp, xu);
 #pragma unroll
         for (int d = 0; d < 3; ++d) xu[d] *= fq_pg;                        // the lane's share of the frequency (exact)

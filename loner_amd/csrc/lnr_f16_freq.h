@@ -63,9 +63,11 @@ __device__ __forceinline__ uint32_t freq_pair(float y, float dph, float& ds, flo
 #else
     sincos_f32(ph, &s, &c);
 #endif
-    const float h = lnr_add_rn(ph, LNR_PI_2_F);                              // the reference's second phase; e = its rounding error
-    const float bb = lnr_add_rn(h, -ph);
-    const float e = lnr_add_rn(lnr_add_rn(ph, -lnr_add_rn(h, -bb)), lnr_add_rn(LNR_PI_2_F, -bb));
+    // the reference's second phase h = rn(ph + fl(pi/2)) and e = its rounding error, by Fast2Sum (three operations): exact whenever
+    // |ph| >= fl(pi/2), and otherwise (h < pi: half an ulp is 1.2e-7) off by at most that - the size of v_sin_f32's own error; Knuth's
+    // branch-free TwoSum, exact everywhere, is six (freq_forward_h16_kernel, whose planes nf > 12 still use)
+    const float h = lnr_add_rn(ph, LNR_PI_2_F);
+    const float e = lnr_add_rn(LNR_PI_2_F, -lnr_add_rn(h, -ph));
     const float d = 4.371139000186243e-8f - e;
     const float c2 = __builtin_fmaf(-d, s, c);                               // cos(ph + d), |d| < 2.5e-4
     if constexpr (DERIV) {

@@ -195,6 +195,7 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
     // FQ (lnr_f16_freq.h): slot sl of this lane = coordinate sl % 3, frequency 4 (sl / 3) + g; a compile-time number of slots
     constexpr int fq_slots = LNR_FREQ_SLOTS_OF_KT(KT);
     const float fq_pg = __uint_as_float((uint32_t)(127 + g) << 23);      // 2^g
+    const bool fq_uni = FQ && ray_uniform(src, (uint32_t)TS) && M % TS == 0;      // (M % TS: the clamp of a ragged last tile would mix two rays)
     // the features of the NEXT step are in flight while this one goes through the layers
     // (samples past M: their planes are padded to m_pad, whatever they hold only reaches columns that are never stored)
     auto load_tile = [&](int64_t tile, u32x4 (&x)[F16_KB_MAX][CT]) __attribute__((always_inline)) {
@@ -204,7 +205,8 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
                 int64_t m = tile * TS + 16 * t + c;
                 if (m >= M) m = M - 1;                                     // (columns past the last sample are never stored)
                 RawPoint rp;
-                load_raw_point(src, (uint32_t)m, src.pts ? 0u : (uint32_t)m / (uint32_t)src.n_samples, rp);
+                // (fq_uni: a wave step's 16 CT samples lie on ONE ray - its record comes through the scalar cache, lnr_encoding.h)
+                load_raw_point(src, (uint32_t)m, src.pts ? 0u : (uint32_t)m / (uint32_t)src.n_samples, rp, fq_uni);
                 float xu[3];
                 unit_point(src, rp, xu);
 #pragma unroll

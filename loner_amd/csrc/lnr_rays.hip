@@ -166,12 +166,18 @@ extern "C" int lnr_build_window_rays(const float* const* directions, const float
     return LNR_OK;
 }
 
+struct SegOrder { int n; int order[LNR_MAX_SEG]; };
+// what lnr_compact_rays_front appends to the compaction (one launch instead of two: a one-keyframe rank's iteration is a chain of
+// ~4.7 us launches around 0.3 ms of real kernels): the loss normalisers of lnr_count_opaque (counts != NULL) or the rank's front record
+// of lnr_shard_front_pack (record != NULL)
+struct CompactTail { int32_t* counts; float* record; int cap; SegOrder ord; };
+
 // single-workgroup, order-preserving stream compaction (a window is at most a few thousand rays)
 __global__ void __launch_bounds__(1024)
 compact_rays_kernel(const float* __restrict__ rays_in, const float* __restrict__ depths_in, const uint8_t* __restrict__ keep,
                     const int64_t* __restrict__ src_in, int n_in, const SegTable seg, float* __restrict__ rays_out,
                     float* __restrict__ depths_out, int64_t* __restrict__ src_out, int32_t* __restrict__ out_seg_start,
-                    int32_t* __restrict__ n_out) {
+                    int32_t* __restrict__ n_out, const CompactTail tail) {
     __shared__ int wave_tot[16];
     __shared__ int running;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -204,6 +210,46 @@ compact_rays_kernel(const float* __restrict__ rays_in, const float* __restrict__
     }
     if (tid <= seg.n && seg.start[tid] >= n_in) out_seg_start[tid] = running;
     if (tid == 0) *n_out = running;
+    if (tail.counts == nullptr && tail.record == nullptr) return;
+    // ---- the tail reads what this workgroup has just written (compacted rays / depths / segment starts): visible after the barrier
+    __syncthreads();
+    const int n = running;
+    if (tail.counts != nullptr) {                       // = count_opaque_kernel (lnr_render.hip) with far[0] = this batch's own first ray
+        __shared__ int partial[16];
+        const float far0 = n > 0 ? rays_out[12] : 0.0f;
+        int c = 0;
+        for (int i = tid; i < n; i += 1024) {
+            const float d = depths_out[i];
+            c += ((d > 0.0f) && !(d > far0)) ? 1 : 0;
+        }
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if (lane == 0) partial[wave] = c;
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < 16; ++w) t += partial[w];
+            tail.counts[0] = n;
+            tail.counts[1] = t;
+        }
+    }
+    if (tail.record != nullptr) {                       // = shard_front_pack_kernel below
+        const int m = min(n, tail.cap);
+        if (tid == 0) {
+            long long k = 0x7FFFFFFFFFFFFFFFll;                      // no live ray on this rank
+            for (int sgi = 0; sgi < tail.ord.n; ++sgi) {
+                const int lo = out_seg_start[sgi], hi = out_seg_start[sgi + 1];
+                if (hi > lo) {
+                    k = ((long long)tail.ord.order[sgi] << 32) | (long long)__float_as_uint(rays_out[(size_t)lo * LNR_RAY_STRIDE + 12]);
+                    break;
+                }
+            }
+            tail.record[0] = __uint_as_float((uint32_t)((unsigned long long)k & 0xFFFFFFFFull));
+            tail.record[1] = __uint_as_float((uint32_t)((unsigned long long)k >> 32));
+            tail.record[2] = __int_as_float(m);
+            tail.record[3] = 0.0f;
+        }
+        for (int i = tid; i < tail.cap; i += 1024) tail.record[LNR_FRONT_HEADER + i] = i < m ? depths_out[i] : 0.0f;
+    }
 }
 
 extern "C" int lnr_compact_rays(const float* rays_in, const float* depths_in, const uint8_t* keep, const int64_t* src_index, int32_t n_in,
@@ -216,16 +262,45 @@ extern "C" int lnr_compact_rays(const float* rays_in, const float* depths_in, co
     seg.n = n_seg;
     for (int s = 0; s <= n_seg; ++s) seg.start[s] = seg_start[s];
     LNR_REQUIRE(seg.start[0] == 0 && seg.start[n_seg] == n_in, "lnr_compact_rays: seg_start must run from 0 to n_in");
+    CompactTail tail;
+    tail.counts = nullptr; tail.record = nullptr; tail.cap = 0; tail.ord.n = 0;
     hipLaunchKernelGGL(compact_rays_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, rays_in, depths_in, keep, src_index, n_in, seg,
-                       rays_out, depths_out, src_index_out, out_seg_start, n_out_dev);
+                       rays_out, depths_out, src_index_out, out_seg_start, n_out_dev, tail);
     LNR_CHECK_LAUNCH("lnr_compact_rays");
+    return LNR_OK;
+}
+
+extern "C" int lnr_compact_rays_front(const float* rays_in, const float* depths_in, const uint8_t* keep, const int64_t* src_index, int32_t n_in,
+                                      const int32_t* seg_start, int32_t n_seg, float* rays_out, float* depths_out, int64_t* src_index_out,
+                                      int32_t* out_seg_start, int32_t* n_out_dev, int32_t* counts_dev, const int32_t* seg_order, int32_t cap,
+                                      float* record, void* stream) {
+    LNR_REQUIRE(rays_in && depths_in && keep && seg_start && rays_out && depths_out && out_seg_start && n_out_dev, "lnr_compact_rays_front: null argument");
+    LNR_REQUIRE(n_seg >= 1 && n_seg <= LNR_MAX_SEG, "lnr_compact_rays_front: n_seg must be in [1,%d]", LNR_MAX_SEG);
+    LNR_REQUIRE((src_index == nullptr) == (src_index_out == nullptr), "lnr_compact_rays_front: src_index in/out must both be given or both be null");
+    LNR_REQUIRE((counts_dev != nullptr) != (record != nullptr), "lnr_compact_rays_front: pass counts_dev (unsharded batch) or record (sharded), one of them");
+    SegTable seg;
+    seg.n = n_seg;
+    for (int s = 0; s <= n_seg; ++s) seg.start[s] = seg_start[s];
+    LNR_REQUIRE(seg.start[0] == 0 && seg.start[n_seg] == n_in, "lnr_compact_rays_front: seg_start must run from 0 to n_in");
+    CompactTail tail;
+    tail.counts = counts_dev; tail.record = record; tail.cap = cap; tail.ord.n = 0;
+    if (record != nullptr) {
+        LNR_REQUIRE(seg_order != nullptr && cap >= n_in, "lnr_compact_rays_front: a front record of %d depth slots cannot hold the %d candidate rays of this rank", cap, n_in);
+        tail.ord.n = n_seg;
+        for (int s = 0; s < n_seg; ++s) {
+            LNR_REQUIRE(seg_order[s] >= 0 && (s == 0 || seg_order[s] > seg_order[s - 1]), "lnr_compact_rays_front: seg_order must be non-negative and ascending");
+            tail.ord.order[s] = seg_order[s];
+        }
+    }
+    hipLaunchKernelGGL(compact_rays_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, rays_in, depths_in, keep, src_index, n_in, seg,
+                       rays_out, depths_out, src_index_out, out_seg_start, n_out_dev, tail);
+    LNR_CHECK_LAUNCH("lnr_compact_rays_front");
     return LNR_OK;
 }
 
 // Sharded windows: which ray is "the first ray of the whole batch" (the reference compares every depth with ITS far, optimizer.py:460-461).
 // Every rank reports {window order of its first segment that kept a ray, the far of that ray} as one 64-bit key - order in the high
 // word, the float's bits in the low word - and a MIN all-reduce over the ranks leaves the key of the batch's first ray everywhere.
-struct SegOrder { int n; int order[LNR_MAX_SEG]; };
 __global__ void first_ray_key_kernel(const float* __restrict__ rays, const int32_t* __restrict__ out_seg_start, const SegOrder ord, long long* __restrict__ key) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     long long k = 0x7FFFFFFFFFFFFFFFll;                      // no live ray on this rank

@@ -518,6 +518,125 @@ extern "C" int lnr_render_forward(const float* sigma, const float* z, const floa
     return LNR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Front-to-back inference (opt-in route of Model.render_depth; the reference composites every sample of every ray,
+// src/models/model_tcnn.py:73-105 -> rendering_tcnn.py:71-147).  A front-to-back composite stops contributing once the transmittance is
+// gone: with T < 2^-24 in front of a sample every remaining weight is below the fp32 resolution of the rendered depth.  The ray's 2048
+// sorted depths are still drawn in full (the sampler's indices stay the reference's); the density network is then evaluated block by
+// block of B samples ALONG the ray, on the rays that are still alive:
+//   ftb_gather     alive rays' records and their depths of block b -> compact [n_alive, 13] / [n_alive, B] arrays (the density forward's
+//                  rays form), and the NEXT block's alive counter set to zero
+//   density forward on the compact arrays (live count on the device: no host round trip)
+//   ftb_composite  one wave per alive ray: alpha, transmittance and weights of the block exactly as render_ray forms them (same noise
+//                  draw per (ray, sample)), accumulated into per-ray depth / opacity sums; a ray whose transmittance stays >= 2^-24
+//                  appends itself to the next block's list (order arbitrary: rays are independent)
+// On a trained map about half of a scan's 134 M samples lie behind the first surface (profiles/r06_render_dead.txt).
+// ------------------------------------------------------------------------------------------------
+#define FTB_T_MIN 5.9604644775390625e-08f          /* 2^-24 */
+
+__global__ void __launch_bounds__(RENDER_BLOCK)
+ftb_gather_kernel(const float* __restrict__ rays, const float* __restrict__ z, int S, const int32_t* __restrict__ idx,
+                  const int32_t* __restrict__ n_alive, int cap, int b0, int B, float* __restrict__ rays_c, float* __restrict__ z_c,
+                  int32_t* __restrict__ next_count) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *next_count = 0;
+    const int lane = threadIdx.x & 63;
+    const int n = min(*n_alive, cap);
+    for (int j = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6); j < n; j += gridDim.x * RAYS_PER_BLOCK) {      // one wave per alive ray
+        const int ray = idx[j];
+        if (lane < LNR_RAY_STRIDE) rays_c[(size_t)j * LNR_RAY_STRIDE + lane] = rays[(size_t)ray * LNR_RAY_STRIDE + lane];
+        const float* src = z + (size_t)ray * S + b0;
+        float* dst = z_c + (size_t)j * B;
+        for (int i = 4 * lane; i < B; i += 256) *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(src + i);
+    }
+}
+
+__global__ void __launch_bounds__(RENDER_BLOCK)
+ftb_composite_kernel(const float* __restrict__ sigma_c, const float* __restrict__ z, const float* __restrict__ rays, int S,
+                     const int32_t* __restrict__ idx, const int32_t* __restrict__ n_alive, int cap, int b0, const float* __restrict__ noise,
+                     float noise_std, uint64_t seed, float* __restrict__ T_ray, float* __restrict__ depth_acc, float* __restrict__ opac_acc,
+                     int32_t* __restrict__ next_idx, int32_t* __restrict__ next_count, int last) {
+    constexpr int C = 4, B = 64 * C;                              // 256 samples per block, four per lane
+    const int lane = threadIdx.x & 63;
+    const int n = min(*n_alive, cap);
+    for (int j = blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6); j < n; j += gridDim.x * RAYS_PER_BLOCK) {
+        const int ray = idx[j];
+        const float* rec = rays + (size_t)ray * LNR_RAY_STRIDE;
+        const float dnorm = sqrtf(rec[3] * rec[3] + rec[4] * rec[4] + rec[5] * rec[5]);
+        const int i0 = b0 + C * lane;
+        const float4 zv = *reinterpret_cast<const float4*>(z + (size_t)ray * S + i0);
+        const float4 sv = *reinterpret_cast<const float4*>(sigma_c + (size_t)j * B + C * lane);
+        const float zl[C] = {zv.x, zv.y, zv.z, zv.w};
+        float dens[C] = {sv.x, sv.y, sv.z, sv.w};
+        if (noise != nullptr) {                                    // explicit draws [n_rays, S] (already scaled), as lnr_render_forward takes them
+            const float4 nv = *reinterpret_cast<const float4*>(noise + (size_t)ray * S + i0);
+            dens[0] += nv.x; dens[1] += nv.y; dens[2] += nv.z; dens[3] += nv.w;
+        } else if (noise_std > 0.0f) {
+#pragma unroll
+            for (int t = 0; t < C; ++t) dens[t] += lnr_rand_normal(seed, (uint64_t)ray, (uint32_t)(i0 + t)) * noise_std;
+        }
+        // the depth behind my last sample: the next lane's first, or - for the block's last sample - the next block's first
+        float z_after = __shfl_down(zl[0], 1, 64);
+        if (lane == 63) z_after = (b0 + B < S) ? z[(size_t)ray * S + b0 + B] : 0.0f;
+        float e[C], Tl[C], tprod = 1.0f;
+#pragma unroll
+        for (int t = 0; t < C; ++t) {
+            const int i = i0 + t;
+            float delta = (i < S - 1) ? ((t + 1 < C) ? zl[(t + 1 < C) ? t + 1 : t] : z_after) - zl[t] : 1e10f;
+            delta *= dnorm;
+            const float r = dens[t] > 0.0f ? dens[t] : 0.0f;
+            e[t] = expf(-delta * r);
+            Tl[t] = tprod;
+            tprod *= (1.0f - (1.0f - e[t]) + 1e-10f);                 // (1 - alpha + 1e-10 with alpha = 1 - e, as render_ray)
+        }
+        const float prefix = wave_excl_prod(tprod, lane) * T_ray[ray];
+        float o_part = 0.0f, d_part = 0.0f;
+#pragma unroll
+        for (int t = 0; t < C; ++t) {
+            const float w = (1.0f - e[t]) * (Tl[t] * prefix);
+            o_part += w;
+            d_part += w * zl[t];
+        }
+        const float o_sum = wave_sum(o_part), d_sum = wave_sum(d_part);
+        const float T_out = __shfl(prefix * tprod, 63, 64);
+        if (lane == 0) {
+            depth_acc[ray] += d_sum;
+            opac_acc[ray] += o_sum;
+            T_ray[ray] = T_out;
+            if (!last && T_out >= FTB_T_MIN) next_idx[atomicAdd(next_count, 1)] = ray;
+        }
+    }
+}
+
+extern "C" int lnr_render_ftb_gather(const float* rays, const float* z, int32_t n_samples, const int32_t* idx, const int32_t* n_alive_dev,
+                                     int32_t cap, int32_t b0, int32_t block_samples, float* rays_c, float* z_c, int32_t* next_count_dev,
+                                     void* stream) {
+    LNR_REQUIRE(rays && z && idx && n_alive_dev && rays_c && z_c && next_count_dev, "lnr_render_ftb_gather: null argument");
+    LNR_REQUIRE(cap >= 0 && block_samples > 0 && block_samples % 4 == 0 && b0 >= 0 && b0 % 4 == 0 && b0 + block_samples <= n_samples && n_samples % 4 == 0,
+                "lnr_render_ftb_gather: a block must lie inside the ray's samples (multiples of four)");
+    if (cap == 0) return LNR_OK;
+    const int blocks = lnr_div_up(cap, RAYS_PER_BLOCK);
+    hipLaunchKernelGGL(ftb_gather_kernel, dim3(blocks > 4096 ? 4096 : blocks), dim3(RENDER_BLOCK), 0, (hipStream_t)stream, rays, z, n_samples, idx,
+                       n_alive_dev, cap, b0, block_samples, rays_c, z_c, next_count_dev);
+    LNR_CHECK_LAUNCH("lnr_render_ftb_gather");
+    return LNR_OK;
+}
+
+extern "C" int lnr_render_ftb_composite(const float* sigma_c, const float* z, const float* rays, int32_t n_samples, const int32_t* idx,
+                                        const int32_t* n_alive_dev, int32_t cap, int32_t b0, int32_t block_samples, const float* noise, float noise_std,
+                                        uint64_t seed, float* transmittance, float* depth_acc, float* opacity_acc, int32_t* next_idx, int32_t* next_count_dev,
+                                        int32_t last, void* stream) {
+    LNR_REQUIRE(sigma_c && z && rays && idx && n_alive_dev && transmittance && depth_acc && opacity_acc && next_idx && next_count_dev,
+                "lnr_render_ftb_composite: null argument");
+    LNR_REQUIRE(block_samples == 256, "lnr_render_ftb_composite: blocks of 256 samples (one wave per ray, four samples per lane)");
+    LNR_REQUIRE(cap >= 0 && b0 >= 0 && b0 % 4 == 0 && b0 + block_samples <= n_samples && n_samples % 4 == 0, "lnr_render_ftb_composite: a block must lie inside the ray's samples");
+    if (cap == 0) return LNR_OK;
+    const int blocks = lnr_div_up(cap, RAYS_PER_BLOCK);
+    hipLaunchKernelGGL(ftb_composite_kernel, dim3(blocks > 4096 ? 4096 : blocks), dim3(RENDER_BLOCK), 0, (hipStream_t)stream, sigma_c, z, rays, n_samples,
+                       idx, n_alive_dev, cap, b0, noise, noise_std, seed, transmittance, depth_acc, opacity_acc, next_idx, next_count_dev, last);
+    LNR_CHECK_LAUNCH("lnr_render_ftb_composite");
+    return LNR_OK;
+}
+
 extern "C" int lnr_render_backward(const float* sigma, const float* z, const float* rays, int32_t n_rays, const int32_t* n_rays_dev,
                                    int32_t n_samples, const float* noise, float noise_std, uint64_t seed, const float* g_depth,
                                    const float* g_weights, const float* g_opacity, const float* g_variance, float* d_sigma,

@@ -79,6 +79,7 @@ _SIGNATURES = {
     "lnr_pose_forward": (C.c_int, [P, C.c_int32, P, P]),
     "lnr_pose_backward": (C.c_int, [P, P, P, C.c_int32, P, C.c_int32, P, C.c_int32, P]),
     "lnr_compact_rays": (C.c_int, [P, P, P, P, C.c_int32, C.POINTER(C.c_int32), C.c_int32, P, P, P, P, P, P]),
+    "lnr_compact_rays_front": (C.c_int, [P, P, P, P, C.c_int32, C.POINTER(C.c_int32), C.c_int32, P, P, P, P, P, P, C.POINTER(C.c_int32), C.c_int32, P, P]),
     "lnr_lidar_rays_backward": (C.c_int, [P, P, P, P, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), P,
                                           C.c_float, P, P]),
     "lnr_occ_interpolate": (C.c_int, [P, C.c_int32, P, C.c_int64, P, P]),
@@ -87,6 +88,8 @@ _SIGNATURES = {
     "lnr_sample_rays_uniform": (C.c_int, [P, C.c_int32, P, C.c_int32, C.c_float, P, P, C.c_uint64, P, P]),
     "lnr_render_forward": (C.c_int, [P, P, P, C.c_int32, P, C.c_int32, P, C.c_float, C.c_uint64, P, P, P, P, P]),
     "lnr_render_backward": (C.c_int, [P, P, P, C.c_int32, P, C.c_int32, P, C.c_float, C.c_uint64, P, P, P, P, P, P, P]),
+    "lnr_render_ftb_gather": (C.c_int, [P, P, C.c_int32, P, P, C.c_int32, C.c_int32, C.c_int32, P, P, P, P]),
+    "lnr_render_ftb_composite": (C.c_int, [P, P, P, C.c_int32, P, P, C.c_int32, C.c_int32, C.c_int32, P, C.c_float, C.c_uint64, P, P, P, P, P, C.c_int32, P]),
     "lnr_points_grad_to_rays": (C.c_int, [P, P, C.c_int32, P, C.c_int32, P, P]),
     "lnr_weights_gt": (C.c_int, [P, P, P, C.c_float, C.c_int32, C.c_int32, C.c_int32, P, P]),
     "lnr_logits_grad": (C.c_int, [P, P, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, P, P]),

@@ -376,7 +376,7 @@ class Optimizer:
 
                 def front_end(it_next):
                     b = self._build_window_rays(active, pose_dev, tab, n_out=valid_log[it_next:it_next + 1])
-                    b["front"] = self._sample_front(b["rays"], b["depths"], b["n_dev"])
+                    b["front"] = self._sample_front(b["rays"], b["depths"], b["n_dev"], pre=b)
                     return b
                 batch = front_end(0) if n_it > 0 else None
                 for it_idx in range(n_it):
@@ -430,7 +430,7 @@ class Optimizer:
                                                self._model.nerf_model._model_sigma.params, it_idx, want_ray_grads=any_free,
                                                want_param_grads=not os_.freeze_sigma_mlp, n_rays_dev=batch["n_dev"],
                                                loss_out=loss_log[it_idx], accumulate_into_param_grad=True, want_stats=False,
-                                               defer_grad_wait=True, poison=poison, shard_segments=(batch["seg_start"], tab.seg_order_c))
+                                               defer_grad_wait=True, poison=poison, shard_segments=(batch["seg_start"], tab.seg_order_c), pre=batch)
                 else:
                     out = self._join_without_rays(sigma_params[0] if sigma_params else None, want_param_grads=not os_.freeze_sigma_mlp)
                 if any_free:
@@ -605,8 +605,14 @@ class Optimizer:
         index = self._draw_window_indices(active, tab)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if index is None else 0
         rays_c, depths_c, keep, src_c = ops.build_window_rays(tab, T12, rr, self._scale_f, self._shift_f, index=index, seed=seed)
-        rays, depths, src, out_seg, n_dev = ops.compact_rays(rays_c, depths_c, keep, src_c, tab.seg_start, n_out=n_out)   # (the table's ctypes array: built once per phase)
-        return dict(rays=rays, depths=depths, src=src, seg_start=out_seg, n_dev=n_dev, T12=T12, tab=tab)
+        # (the table's ctypes arrays: built once per phase.)  The compaction launch also delivers what the loss needs next from the compacted
+        # batch - the normalisers {#rays, #opaque rays}, or this rank's front record in the sharded loop: one launch instead of two
+        if self._dist is not None:
+            rays, depths, src, out_seg, n_dev, rec = ops.compact_rays(rays_c, depths_c, keep, src_c, tab.seg_start, n_out=n_out,
+                                                                      front=(tab.seg_order_c, self._front_cap))
+            return dict(rays=rays, depths=depths, src=src, seg_start=out_seg, n_dev=n_dev, T12=T12, tab=tab, front_record=rec)
+        rays, depths, src, out_seg, n_dev, counts = ops.compact_rays(rays_c, depths_c, keep, src_c, tab.seg_start, n_out=n_out, want_counts=True)
+        return dict(rays=rays, depths=depths, src=src, seg_start=out_seg, n_dev=n_dev, T12=T12, tab=tab, counts=counts)
 
     def _pose_backward(self, batch, d_rays, pose_dev, free_mask_u8, poison=None, poison_tag=0):
         """dL/drays -> dL/d[R|t] per segment (HIP) -> dL/dpose6 (HIP, analytic axis-angle Jacobian)."""
@@ -640,10 +646,11 @@ class Optimizer:
             cfg.fixed_eps = lc["depth_eps"]
         return cfg
 
-    def _sample_front(self, rays, depths, n_rays_dev, draws=None, shard_segments=None):
+    def _sample_front(self, rays, depths, n_rays_dev, draws=None, shard_segments=None, pre=None):
         """The part of an iteration that does not touch the density parameters: loss normalisers and sample depths for `rays`
         (optimizer.py:437-470 up to the network call).  -> dict(counts, front_work, z, seed, far0).  shard_segments (sharded loop):
-        (compacted segment starts on the device, window position of every segment) of this rank's batch."""
+        (compacted segment starts on the device, window position of every segment) of this rank's batch.  pre: the batch dictionary of
+        _build_window_rays, whose compaction launch has already computed the counts / written the front record."""
         draws = draws if draws is not None else self._draws
         pc = self._consts()
         S, perturb, ogm = pc["S"], pc["perturb"], pc["ogm"]
@@ -667,9 +674,14 @@ class Optimizer:
             else:       # a caller outside the training loop (compute_loss): the batch is one segment at this rank's position
                 seg_start, seg_order = torch.tensor([0, n], device=dev, dtype=torch.int32), [self._dist.rank]
                 cap = self._dist.max_over_ranks(n)
-            front_work = self._dist.gather_front(ops.shard_front_pack(rays, seg_start, seg_order, depths, n_rays_dev, cap))
+            rec = pre.get("front_record") if (pre is not None and shard_segments is not None) else None
+            if rec is None:
+                rec = ops.shard_front_pack(rays, seg_start, seg_order, depths, n_rays_dev, cap)
+            front_work = self._dist.gather_front(rec)
         else:
-            counts = ops.count_opaque(rays, depths, n_rays_dev=n_rays_dev)
+            counts = pre.get("counts") if pre is not None else None
+            if counts is None:
+                counts = ops.count_opaque(rays, depths, n_rays_dev=n_rays_dev)
         if ogm:
             z = ops.sample_rays_occ(rays, self._occupancy_grid.detach(), S, perturb, u_jitter=u1, u_pdf=u2, seed=seed,
                                     n_rays_dev=n_rays_dev)
@@ -679,7 +691,7 @@ class Optimizer:
 
     def _loss_and_grads(self, rays, depths, params, iteration_idx, want_ray_grads, want_param_grads, n_rays_dev=None,
                         loss_out=None, accumulate_into_param_grad=False, draws=None, want_stats=True, defer_grad_wait=False,
-                        poison=None, front=None, input_grad_event=None, defer_weight_fold=False, shard_segments=None):
+                        poison=None, front=None, input_grad_event=None, defer_weight_fold=False, shard_segments=None, pre=None):
         """sample -> density -> fused render+loss(+backward) -> density backward.  rays [N,13], depths [N] on device.
         front: the result of _sample_front for these rays when the caller already ran it (the pipelined training loop);
         input_grad_event: recorded by the density backward as soon as d_rays is complete (ops.density_backward)."""
@@ -690,7 +702,7 @@ class Optimizer:
         dev = self._device
         n = rays.shape[0]
         if front is None:
-            front = self._sample_front(rays, depths, n_rays_dev, draws, shard_segments=shard_segments)
+            front = self._sample_front(rays, depths, n_rays_dev, draws, shard_segments=shard_segments, pre=pre)
         counts, front_work, z, seed, far0 = front["counts"], front["front_work"], front["z"], front["seed"], front["far0"]
         noise = None
         if draws is not None and noise_std > 0:

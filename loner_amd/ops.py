@@ -250,10 +250,12 @@ def pose_backward(pose6, d_transforms, mask=None, out=None, accumulate=False, po
     return out
 
 
-def compact_rays(rays, depths, keep, src_index, seg_start, n_out=None):
+def compact_rays(rays, depths, keep, src_index, seg_start, n_out=None, want_counts=False, front=None):
     """seg_start: python list [n_seg+1] (or the ctypes int32 array of a WindowTables).  -> (rays_out [cap,13], depths_out, src_out, out_seg_start dev int32
     [n_seg+1], n_out dev int32 [1]); only the first n_out rows are meaningful.  n_out (optional): an int32 [1] device tensor the
-    live count is written into (the training loop hands in a row of its per-iteration log instead of copying into it afterwards)."""
+    live count is written into (the training loop hands in a row of its per-iteration log instead of copying into it afterwards).
+    want_counts / front = (seg_order ctypes array or list, cap): the same launch also computes count_opaque's {#rays, #opaque rays} /
+    writes the rank's front record (shard_front_pack) - a sixth return value, counts int32 [2] or record float32 [FRONT_HEADER + cap]."""
     require_device(rays, depths, keep, src_index)
     n_in = rays.shape[0]
     dev = rays.device
@@ -269,6 +271,20 @@ def compact_rays(rays, depths, keep, src_index, seg_start, n_out=None):
         require_device(n_out)
         assert n_out.dtype == torch.int32 and n_out.numel() == 1 and n_out.is_contiguous()
     seg = seg_start if isinstance(seg_start, C.Array) else (C.c_int32 * (n_seg + 1))(*[int(v) for v in seg_start])
+    if want_counts or front is not None:
+        counts = rec = order = None
+        cap = 0
+        if front is not None:
+            order, cap = front
+            if not isinstance(order, C.Array):
+                order = (C.c_int32 * n_seg)(*[int(v) for v in order])
+            rec = torch.empty(hip.FRONT_HEADER + int(cap), device=dev, dtype=torch.float32)
+        else:
+            counts = torch.empty(2, device=dev, dtype=torch.int32)
+        check(load().lnr_compact_rays_front(_ptr(rays), _ptr(depths), _ptr(keep), _ptr(src_index), n_in, seg, n_seg,
+                                            _ptr(rays_out), _ptr(depths_out), _ptr(src_out), _ptr(out_seg), _ptr(n_out),
+                                            _ptr(counts), order, int(cap), _ptr(rec), _stream()), "lnr_compact_rays_front")
+        return rays_out, depths_out, src_out, out_seg, n_out, (rec if front is not None else counts)
     check(load().lnr_compact_rays(_ptr(rays), _ptr(depths), _ptr(keep), _ptr(src_index), n_in, seg, n_seg,
                                   _ptr(rays_out), _ptr(depths_out), _ptr(src_out), _ptr(out_seg), _ptr(n_out), _stream()),
           "lnr_compact_rays")
@@ -372,6 +388,21 @@ def sample_rays_uniform(rays, n_samples, perturb, u_jitter=None, seed=0, n_rays_
 
 
 # ---------------------------------------------------------------- rendering
+def ftb_gather(rays, z, idx, n_alive, b0, block, rays_c, z_c, next_count):
+    """front-to-back inference (lnr_render_ftb_gather): alive rays' records and block depths -> the compact arrays rays_c / z_c"""
+    require_device(rays, z, idx, n_alive, rays_c, z_c, next_count)
+    check(load().lnr_render_ftb_gather(_ptr(rays), _ptr(z), z.shape[1], _ptr(idx), _ptr(n_alive), rays.shape[0], int(b0), int(block),
+                                       _ptr(rays_c), _ptr(z_c), _ptr(next_count), _stream()), "lnr_render_ftb_gather")
+
+
+def ftb_composite(sigma_c, z, rays, idx, n_alive, b0, block, noise_std, seed, transmittance, depth_acc, opacity_acc, next_idx, next_count, last, noise=None):
+    """front-to-back inference (lnr_render_ftb_composite): one block's contributions of the alive rays; survivors appended to next_idx"""
+    require_device(sigma_c, z, rays, idx, n_alive, transmittance, depth_acc, opacity_acc, next_idx, next_count, noise)
+    check(load().lnr_render_ftb_composite(_ptr(sigma_c), _ptr(z), _ptr(rays), z.shape[1], _ptr(idx), _ptr(n_alive), rays.shape[0], int(b0), int(block),
+                                          _ptr(_f32c(noise) if noise is not None else None), float(noise_std), int(seed), _ptr(transmittance), _ptr(depth_acc), _ptr(opacity_acc), _ptr(next_idx),
+                                          _ptr(next_count), 1 if last else 0, _stream()), "lnr_render_ftb_composite")
+
+
 def render_forward(sigma, z, rays, noise=None, noise_std=0.0, seed=0, n_rays_dev=None, want_weights=True):
     """-> (depth, weights, opacity, variance); want_weights=False leaves the [n, S] weights unwritten (returns None for them)."""
     require_device(sigma, z, rays, noise)

@@ -39,7 +39,8 @@ vs this model).
 Remaining assumptions about tinycudann that nothing here can verify (the
 package is absent): fused position rounding, padding inputs fed the constant
 1, parameter order "MLP matrices, then tables", `mod T` applied to dense
-levels too, Xavier-uniform / uniform(-1e-4, 1e-4) initialisation.
+levels too, Xavier-uniform / uniform(-1e-4, 1e-4) initialisation, K_ACT = 10
+inside Squareplus and Softplus (non-default activations).
 """
 import math
 from dataclasses import dataclass, field
@@ -158,6 +159,9 @@ def init_params(spec: NetworkSpec, seed: int = 0) -> torch.Tensor:
     return torch.cat(chunks).float()
 
 
+K_ACT = 10.0
+
+
 def _activate(x: torch.Tensor, kind: str) -> torch.Tensor:
     if kind == "ReLU":
         return torch.relu(x)
@@ -171,10 +175,13 @@ def _activate(x: torch.Tensor, kind: str) -> torch.Tensor:
         return torch.exp(x)
     if kind == "Sigmoid":
         return torch.sigmoid(x)
+    # tiny-cuda-nn evaluates these two on K_ACT x and divides the result by K_ACT, K_ACT = 10 (its published activation code, read from
+    # memory like the rest of this file - the package is absent; rounds 1-5 used the unscaled forms)
     if kind == "Squareplus":
-        return 0.5 * (x + torch.sqrt(x * x + 4.0))   # hyper-parameter b=2 -> b^2 = 4
+        y = K_ACT * x
+        return 0.5 * (y + torch.sqrt(y * y + 4.0)) / K_ACT   # hyper-parameter b=2 -> b^2 = 4
     if kind == "Softplus":
-        return torch.nn.functional.softplus(x)
+        return torch.nn.functional.softplus(x, beta=K_ACT)   # log(1 + exp(K_ACT x)) / K_ACT
     if kind == "Tanh":
         return torch.tanh(x)
     raise ValueError(kind)

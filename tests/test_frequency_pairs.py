@@ -70,8 +70,7 @@ def test_hardware_sine_route_reproduces_both_features():
         C = (np.cos(2 * np.pi * np.float64(r)) + noise[1]).astype(f32)
         s, c = fma(C, dl, S), fma(-S, dl, C)
         h = (ph + H).astype(f32)
-        bb = (h - ph).astype(f32)
-        e = ((ph - (h - bb).astype(f32)).astype(f32) + (H - bb).astype(f32)).astype(f32)
+        e = (H - (h - ph).astype(f32)).astype(f32)                                       # Fast2Sum: exact for ph >= fl(pi/2), else within 1.2e-7
         d = (f32(4.371139000186243e-8) - e).astype(f32)
         c2 = fma(-d, s, c)
         worst_s = max(worst_s, float(np.abs(s - np.sin(ph.astype(np.float64))).max()))

@@ -113,6 +113,38 @@ def test_compact_rays_preserves_order_and_segments(ops):
     assert out_seg.cpu().tolist() == expect
 
 
+def test_compact_rays_with_counts_or_front_record_in_the_same_launch(ops):
+    """lnr_compact_rays_front: the compaction plus, in the same launch, the loss normalisers of lnr_count_opaque or the front record of
+    lnr_shard_front_pack - equal to the separate calls on the compacted batch, also when a leading segment keeps nothing, when nothing
+    is kept at all, and with depths on both sides of far[0]."""
+    from loner_amd import hip
+    gen = torch.Generator().manual_seed(13)
+    n = 2500
+    rays = torch.randn(n, 13, generator=gen)
+    rays[:, 12] = torch.rand(n, generator=gen) * 0.5 + 0.3                        # far
+    depths = torch.rand(n, generator=gen) * 1.2 - 0.1                              # some <= 0, some beyond far[0]
+    src = torch.randint(0, 65536, (n,), generator=gen)
+    seg = [0, 400, 1100, 1100, 2500]
+    for case in ("mixed", "first segment empty", "nothing kept"):
+        keep = (torch.rand(n, generator=gen) > 0.4).to(torch.uint8)
+        if case == "first segment empty":
+            keep[:400] = 0
+        if case == "nothing kept":
+            keep[:] = 0
+        r, d, s_, out_seg, n_out = ops.compact_rays(dv(rays), dv(depths), keep.to(DEV), src.to(DEV), seg)
+        ref_counts = ops.count_opaque(r, d, n_rays_dev=n_out)
+        r2, d2, s2, seg2, n2, counts = ops.compact_rays(dv(rays), dv(depths), keep.to(DEV), src.to(DEV), seg, want_counts=True)
+        m = int(n_out.item())
+        assert int(n2.item()) == m and torch.equal(seg2, out_seg) and torch.equal(r2[:m], r[:m]) and torch.equal(d2[:m], d[:m]) and torch.equal(s2[:m], s_[:m])
+        assert torch.equal(counts, ref_counts), (case, counts, ref_counts)
+        order, cap = [1, 3, 4, 6], n + 17
+        ref_rec = ops.shard_front_pack(r, out_seg, order, d, n_out, cap)
+        *_, rec = ops.compact_rays(dv(rays), dv(depths), keep.to(DEV), src.to(DEV), seg, front=(order, cap))
+        assert rec.shape[0] == hip.FRONT_HEADER + cap and torch.equal(rec.view(torch.int32), ref_rec.view(torch.int32)), case
+    with pytest.raises(RuntimeError, match="front record"):
+        ops.compact_rays(dv(rays), dv(depths), keep.to(DEV), src.to(DEV), seg, front=([0, 1, 2, 3], n - 1))
+
+
 # ------------------------------------------------------------------------------------------- occupancy / samplers
 def test_occ_interpolate_bit_exact(ops, golden):
     g = golden("g2_occ_lookup")
@@ -147,6 +179,19 @@ def test_occ_sampler_trained_grid_bit_identical_to_oracle(ops, golden, S):
     floor_rows, floor_z_rows, floor_z = {128: (0.9375, 0.96875, 0.9954), 512: (0.65625, 0.75, 0.9979)}[S]
     assert frac_rows >= floor_rows and frac_z_rows >= floor_z_rows and frac_z >= floor_z
     assert np.array_equal(zk[ref_same], zr[ref_same])
+
+
+def test_occ_sampler_at_the_training_shape_g15(ops, golden):
+    """G15 (512 rays x 512 samples, a trained grid - the shape the mapping loop runs; G4 is 64 rays): the kernel is bit-identical to the
+    oracle on every depth, and to the REFERENCE on every ray whose pdf torch's float32 exp happened to round correctly."""
+    g = golden("g15_sampler_512x512")
+    z = ops.sample_rays_occ(dv(g["rays"]), dv(g["grid"]), 512, 1.0, u_jitter=dv(g["u1"]), u_pdf=dv(g["u2"])).cpu().numpy()
+    zo = SP.sample_occupancy(g["rays"], g["grid"], 512, 1.0, g["u1"], g["u2"])
+    assert np.array_equal(z, zo)
+    zr = g["z"]
+    rows, same = float((z == zr).all(axis=1).mean()), float((z == zr).mean())
+    print(f"G15: kernel vs reference: rays identical {rows:.4f}, depths identical {same:.6f}, max |dz| {float(np.abs(z - zr).max()):.2e}")
+    assert rows >= 0.86 and same >= 0.9965 and float(np.abs(z - zr).max()) < 1e-6
 
 
 def test_occ_sampler_large_and_ragged_sample_counts(ops, golden):
@@ -209,6 +254,9 @@ NETS = {
     "freq_sine16": (dict(otype="Frequency", n_frequencies=3), dict(activation="Sine", n_neurons=16, n_hidden_layers=2)),
     "freq12_small": (dict(otype="Frequency", n_frequencies=12), dict(activation="ReLU", n_neurons=32, n_hidden_layers=1)),
     "freq16_h16": (dict(otype="Frequency", n_frequencies=16), dict(activation="Softplus", n_neurons=16, n_hidden_layers=1)),
+    # (Squareplus / Softplus carry tiny-cuda-nn's K_ACT = 10: oracle/network.py)
+    "hash_squareplus": (dict(otype="HashGrid", n_levels=4, n_features_per_level=2, log2_hashmap_size=12, base_resolution=8),
+                        dict(activation="Squareplus", n_neurons=32, n_hidden_layers=2)),
     "freq_tanh128": (dict(otype="Frequency", n_frequencies=5), dict(activation="Tanh", n_neurons=128, n_hidden_layers=2)),
     "freq_relu128x3": (dict(otype="Frequency", n_frequencies=12), dict(activation="ReLU", n_neurons=128, n_hidden_layers=3)),
     # 256 neurons x 2..3 hidden layers: the layer-by-layer route with the split-K weight gradient (lnr_density_wide.hip)

@@ -554,6 +554,70 @@ def test_checkpoint_written_here_renders_like_the_reference_loading_it(golden, t
     assert abs(l1 - float(g["l1"])) < 1e-4 * float(g["l1"])
 
 
+def test_front_to_back_render_depth_equals_the_full_route(tmp_path):
+    """Model.render_depth(front_to_back=True): the network is evaluated block by block along the ray and only on rays whose transmittance
+    is still >= 2^-24 (lnr_render_ftb_*).  On a trained-like checkpoint (dense surfaces: most rays die within the first blocks) and on
+    IDENTICAL random draws - importance draws and density noise replayed through the sampler's `draws` hook - the depth equals the
+    default route's to 1e-6 relative and the L1 metric to 1e-5; several ray chunks, a ragged last one, and the in-kernel generator."""
+    from loner_amd.analysis.l1_depth import compute_l1_depth
+    from loner_amd.common.pose import Pose
+    from loner_amd.common.ray_utils import LidarRayDirections
+    from loner_amd.common.sensors import LidarScan
+    from loner_amd.models.model_tcnn import Model, OccupancyGridModel
+    from loner_amd.models.ray_sampling import OccGridRaySampler
+    from loner_amd.utils import synthetic as SY
+    from tests import support
+    path = str(tmp_path / "final.tar")
+    support.write_repo_checkpoint(path)
+    n_test = 1024
+    mc = support.small_settings(48, 64, n_test=n_test).model_config.model
+    model, occ = Model(mc).to(DEV), OccupancyGridModel(mc.occ_model).to(DEV)
+    back = torch.load(path, map_location="cpu", weights_only=False)
+    model.load_state_dict(back["network_state_dict"])
+    occ.load_state_dict(back["occ_model_state_dict"])
+    sampler = OccGridRaySampler()
+    sampler.update_occ_grid(occ().detach())
+    dirs, ts = SY.lidar_pattern()
+    pose6 = SY.trajectory_pose6(4)[2]
+    sub = torch.arange(5, dirs.shape[1], 21)[:3000]
+    scan = LidarScan(dirs[:, sub].clone(), SY.scene_ranges(dirs, OP.transform_from_pose6(pose6))[sub], ts[sub])
+    lrd = LidarRayDirections(scan, chunk_size=4096)
+    wc = world_cube()
+    rays = lrd.fetch_chunk_rays(0, Pose(pose_tensor=pose6.clone(), fixed=True), wc, torch.tensor([1.0, 50.0]))
+    n = rays.shape[0]
+    assert n > 2500
+
+    class Draws:                                     # the same numbers for both routes: keyed by (kind, shape), not by call order
+        def pdf(self, m, h): return torch.rand(m, h, generator=torch.Generator().manual_seed(11))
+        def noise(self, m, s_): return torch.randn(m, s_, generator=torch.Generator().manual_seed(12))
+    sampler.set_draws(Draws())
+    model._FTB_RAYS = 1024                           # three chunks, the last one ragged
+    full = model.render_depth(rays, sampler, wc.scale_factor, testing=True)
+    ftb = model.render_depth(rays, sampler, wc.scale_factor, testing=True, front_to_back=True)
+    assert ftb.shape == full.shape == (n,) and torch.isfinite(ftb).all()
+    e = float(((ftb - full).abs() / full.abs().clamp_min(1e-6)).max())
+    # how much the route skipped: the transmittance behind the first block of the default route's own weights
+    out = model(rays, sampler, wc.scale_factor, testing=True, camera=False)
+    w = out["weights_fine"]
+    behind_first = 1.0 - w[:, :256].sum(1)          # = transmittance after block 0 (up to the 1e-10 terms)
+    dead_after_one = float((behind_first < 2.0 ** -24).float().mean())
+    print(f"front-to-back vs full route: max relative depth difference {e:.2e}; rays dead after the first 256 of {n_test} samples: {100 * dead_after_one:.1f} %")
+    assert e <= 1e-6
+    assert dead_after_one > 0.2                      # (the checkpoint is trained-like: the route has something to skip)
+    pose = Pose(pose_tensor=pose6.clone(), fixed=True)
+    l1_full = compute_l1_depth(pose, lrd, model, sampler, wc, torch.tensor([1.0, 50.0]), DEV)
+    model.cfg.render["front_to_back"] = True         # the configuration switch compute_l1_depth's caller sees
+    l1_ftb = compute_l1_depth(pose, lrd, model, sampler, wc, torch.tensor([1.0, 50.0]), DEV)
+    assert abs(l1_ftb - l1_full) <= 1e-5 * l1_full
+    # the in-kernel generator (no replayed draws): different launch sizes key different random numbers, so the two routes agree
+    # statistically only - the mean depth over the scan, dominated by the surfaces, within 1e-3
+    sampler.set_draws(None)
+    model.cfg.render["front_to_back"] = False
+    torch.manual_seed(5); a = model.render_depth(rays, sampler, wc.scale_factor, testing=True)
+    torch.manual_seed(5); b = model.render_depth(rays, sampler, wc.scale_factor, testing=True, front_to_back=True)
+    assert abs(float(a.mean()) - float(b.mean())) < 1e-3 * float(a.mean())
+
+
 def test_optimizer_survives_spawn_pickling_and_mask_ray_selection():
     """The reference constructs the Optimizer in the parent and hands it to the mapping process through spawn
     (src/loner.py:59,188,205): a constructed Optimizer must pickle (no live HIP handles) and work after unpickling.  Also the

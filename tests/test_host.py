@@ -254,3 +254,19 @@ def test_reference_shaped_stand_ins_behave_like_the_classes_they_stand_for():
     assert kf.get_lidar_scan() is scan and kf.get_lidar_pose() is pose and float(kf.get_time()) == 0.0
     with pytest.raises(AssertionError):
         kf.extra = 1
+
+
+def test_squareplus_and_softplus_carry_tiny_cuda_nn_k_act():
+    """tiny-cuda-nn evaluates Squareplus and Softplus on K_ACT x and divides by K_ACT, K_ACT = 10; the oracle's forms
+    against closed forms in float64, and their derivatives (what the kernels' act_bwd restates) against autograd."""
+    import torch
+    from oracle import network as NW
+    x = torch.linspace(-3.0, 3.0, 601, dtype=torch.float64, requires_grad=True)
+    sp = NW._activate(x, "Softplus")
+    assert torch.allclose(sp, torch.log1p(torch.exp(10.0 * x)) / 10.0, atol=1e-12)
+    assert torch.allclose(torch.autograd.grad(sp.sum(), x)[0], torch.sigmoid(10.0 * x), atol=1e-12)
+    sq = NW._activate(x, "Squareplus")
+    y = 10.0 * x
+    assert torch.allclose(sq, 0.5 * (y + torch.sqrt(y * y + 4.0)) / 10.0, atol=1e-12)
+    assert torch.allclose(torch.autograd.grad(sq.sum(), x)[0], 0.5 * (1.0 + y / torch.sqrt(y * y + 4.0)), atol=1e-12)
+    assert abs(float(NW._activate(torch.zeros(1), "Squareplus")) - 0.1) < 1e-7 and abs(float(NW._activate(torch.zeros(1), "Softplus")) - 0.0693147) < 1e-6

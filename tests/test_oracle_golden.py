@@ -113,6 +113,19 @@ def test_g4_occ_sampler_trained_grid(golden, S):
     assert np.abs(z2 - g[f"trained_z{S}"]).max() < 1e-3 or ind_mismatch > 0
 
 
+def test_g15_occ_sampler_at_the_training_shape(golden):
+    """G15: the reference's sampler on a trained grid at the mapping loop's batch shape (512 rays x 512 samples).  The oracle equals it
+    wherever torch's float32 exp rounded the sigmoid correctly; where it did not, the pdf differs in its last bit and a depth moves by
+    one ulp (fractions measured on this fixture: 86.9 % of the rays and 99.69 % of the depths identical, max 1.5e-7)."""
+    g = golden("g15_sampler_512x512")
+    z = SP.sample_occupancy(g["rays"], g["grid"], 512, 1.0, g["u1"], g["u2"])
+    zr = g["z"]
+    assert z.shape == zr.shape == (512, 512) and (np.diff(z, axis=1) >= 0).all()
+    rows, same, worst = float((z == zr).all(axis=1).mean()), float((z == zr).mean()), float(np.abs(z - zr).max())
+    print(f"G15: rays identical {rows:.4f}, depths identical {same:.6f}, max |dz| {worst:.2e}")
+    assert rows >= 0.86 and same >= 0.9965 and worst < 1e-6
+
+
 def test_g4_uniform_sampler_bit_exact(golden):
     g = golden("g4_samplers")
     assert np.array_equal(SP.sample_uniform(g["rays"], 128, 1.0, g["uniform_u128"]), g["uniform_z128"])
