@@ -65,15 +65,19 @@ def _deps_digest(path, seen=None):
     return hashlib.sha256("".join(f"{os.path.basename(k)}:{v}" for k, v in sorted(seen.items())).encode()).hexdigest()
 
 
+# the sources of the kernels profiles/traffic.json holds PMC traffic for (encode forward / backward, table-gradient reduce, the default
+# network's MLP kernels, Adam) and what they include
+TRAFFIC_SOURCES = ("lnr_encode.hip", "lnr_encoding.h", "lnr_density.hip", "lnr_density_api.h", "lnr_density_bf3.hip", "lnr_density_impl.h",
+                   "lnr_common.h", "lnr_optim.hip")
+
+
 def sources_digest():
-    """One digest over every kernel source and header (csrc/*.hip, csrc/*.h, include/*.h): what a measurement that outlives the build -
-    profiles/traffic.json's PMC passes - is stamped with, so that bench.py can tell when the kernels have changed since."""
+    """One digest over the kernel sources a measurement that outlives the build - profiles/traffic.json's PMC passes - was taken on, so
+    that bench.py can tell when those kernels have changed since."""
     h = hashlib.sha256()
-    for d in (CSRC, INCLUDE):
-        for f in sorted(os.listdir(d)):
-            if f.endswith((".hip", ".h")):
-                h.update(f.encode())
-                h.update(open(os.path.join(d, f), "rb").read())
+    for f in TRAFFIC_SOURCES:
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -28,6 +28,9 @@
 // load per operand, 16 MFMAs, repeat: latency-bound - so the parallelism has to come from the number of ranges: with 32 of them (512
 // workgroups for a 256 x 256 matrix, 2 waves per SIMD) the kernel took 0.84 ms per chunk, 7 TFLOP/s (profiles/r05_wide_networks.txt)
 #define LNR_WIDE_SPLITS 128
+#ifndef LNR_WIDE_F16_BWD
+#define LNR_WIDE_F16_BWD 1             /* fp16 mode: back-propagation and weight gradient on the f16 matrix pipe (0: round 5's fp32-MFMA kernels, A/B) */
+#endif
 #define LNR_WIDE_H 256
 #define WIDE_LDS_ROW 20                // floats per staged weight row of the forward: 16 + 4 padding (the 16 lanes of a 16-byte LDS read hit 16 distinct bank quads)
 #define WIDE_LDS_TROW 260              // floats per staged row of a transposed matrix (back-propagation): 256 + 4 padding, same reason
@@ -583,6 +586,234 @@ wide_dx_kernel(const float* __restrict__ WT, int n_kt, const float* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------ fp16 mode: the backward on the f16 matrix pipe
+// Rounds 5's fp16 mode multiplied dZ - an fp32 operand - on the fp32 MFMA (15.9 ms for a 256 x 2 backward at 2.1 M samples, 2.7 % of the f16
+// peak: VERDICT r5 weak #10).  Here dZ is converted to fp16 where it is consumed, scaled by an exact power of two per 32-sample tile -
+// 2^-e, e = the exponent of the tile's largest |d_sigma|: every dZ column is d_sigma[m] times O(1) factors, so the scaled values sit
+// around 1 whatever the loss magnitude, and what underflows fp16 lies 2^-14 below its tile's maximum - and the f16 MFMA results are
+// un-scaled in fp32 (the same scheme as the fused 128-wide kernels, lnr_f16_bwd_kernel.h, per tile instead of per workgroup step).
+// A tile whose d_sigma are all zero contributes nothing and is skipped.
+
+// 2^-e for the 32 samples [ml0, ml0 + 32) of the chunk (lanes (c, g): every lane calls it; the result is wave-uniform); 0: all-zero tile
+__device__ __forceinline__ float wide_tile_scale(const float* __restrict__ d_sigma, const WideSamples& smp, int64_t ml0, int64_t M, int lane, float* inv) {
+    const int64_t ml = ml0 + (lane & 31);
+    float v = ml < M ? __builtin_fabsf(d_sigma[smp.lo + ml]) : 0.0f;
+    v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64)); v = fmaxf(v, __shfl_xor(v, 4, 64));
+    v = fmaxf(v, __shfl_xor(v, 8, 64)); v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v)));
+    if (!(v > 0.0f) || !(v < 3.0e38f)) { *inv = 0.0f; return 0.0f; }        // nothing to propagate (or a non-finite d_sigma: left to the fp32 checks upstream)
+    uint32_t be = (__float_as_uint(v) >> 23) & 0xFFu;
+    be = be < 2u ? 2u : (be > 252u ? 252u : be);
+    *inv = __uint_as_float(be << 23);                                        // 2^e
+    return __uint_as_float((254u - be) << 23);                               // 2^-e
+}
+
+// dZ_prev = act'(Z_prev) . (W^T dZ) for a hidden matrix (TO_FEAT: the d_feature planes of the first layer) on v_mfma_f32_16x16x32_f16:
+// wide_layer_fwd_h_kernel's loop with the TRANSPOSED weights WT [n_rows][256] (fp16-rounded where staged) as the matrix and the scaled
+// dZ columns of the wave's 32 samples as the B operands.  n_rt = output row tiles (16 for a hidden matrix, in_dim / 16 for the first).
+template <bool TO_FEAT>
+__global__ void __launch_bounds__(256)
+wide_dx_h_kernel(const float* __restrict__ WT, int n_rt, const float* __restrict__ dz, int64_t chp, int act, WideSamples smp,
+                 const float* __restrict__ d_sigma, const float* __restrict__ z_prev, float* __restrict__ out, int64_t out_stride, int enc_dim) {
+    __shared__ __attribute__((aligned(16))) f16 w_h[2][LNR_WIDE_H * WIDE_LDS_HROW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int64_t M = wide_live(smp);
+    const int64_t n_tiles = (M + 15) / 16;
+    const int64_t n_pairs = (n_tiles + 1) / 2;
+    constexpr int K = LNR_WIDE_H, n_kb = K / 32;
+    const bool w_row = (int)threadIdx.x < 16 * n_rt;              // staging: thread j converts row j of WT (rows beyond the matrix: zeros)
+    const float* wsrc = WT + (size_t)(w_row ? threadIdx.x : 0) * K;
+    for (int64_t base = (int64_t)blockIdx.x * 4; base < n_pairs; base += (int64_t)gridDim.x * 4) {
+        const int64_t pair = base + wave;
+        const bool active = pair < n_pairs;
+        int64_t ml[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            ml[t] = (2 * (active ? pair : n_pairs - 1) + t) * 16 + c;
+            if (ml[t] >= M) ml[t] = M - 1;                        // (finite operands for padding columns; their results are not stored)
+        }
+        float inv_sc;
+        const float sc = wide_tile_scale(d_sigma, smp, (active ? pair : n_pairs - 1) * 32, M, lane, &inv_sc);
+        f32x4 Z[2][16];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int jt = 0; jt < 16; ++jt) Z[t][jt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        float4 s0, s1, s2, s3, s4, s5, s6, s7;
+        float xr[2][8];
+        f16x8 xb[2];
+        const float4 zero4 = float4{0.0f, 0.0f, 0.0f, 0.0f};
+#define WIDE_DXH_STAGE_LOAD(kb_)                                                                                            \
+        do {                                                                                                                \
+            const float* a_ = wsrc + 32 * (kb_);                                                                            \
+            s0 = *reinterpret_cast<const float4*>(a_); s1 = *reinterpret_cast<const float4*>(a_ + 4);                       \
+            s2 = *reinterpret_cast<const float4*>(a_ + 8); s3 = *reinterpret_cast<const float4*>(a_ + 12);                  \
+            s4 = *reinterpret_cast<const float4*>(a_ + 16); s5 = *reinterpret_cast<const float4*>(a_ + 20);                 \
+            s6 = *reinterpret_cast<const float4*>(a_ + 24); s7 = *reinterpret_cast<const float4*>(a_ + 28);                 \
+        } while (0)
+#define WIDE_DXH_STAGE_STORE(buf_)                                                                                          \
+        do {                                                                                                                \
+            if (!w_row) { s0 = s1 = s2 = s3 = s4 = s5 = s6 = s7 = zero4; }                                                  \
+            u32x4* d_ = reinterpret_cast<u32x4*>(&w_h[buf_][threadIdx.x * WIDE_LDS_HROW]);                                  \
+            d_[0] = u32x4{pack_h2(s0.x, s0.y), pack_h2(s0.z, s0.w), pack_h2(s1.x, s1.y), pack_h2(s1.z, s1.w)};              \
+            d_[1] = u32x4{pack_h2(s2.x, s2.y), pack_h2(s2.z, s2.w), pack_h2(s3.x, s3.y), pack_h2(s3.z, s3.w)};              \
+            d_[2] = u32x4{pack_h2(s4.x, s4.y), pack_h2(s4.z, s4.w), pack_h2(s5.x, s5.y), pack_h2(s5.z, s5.w)};              \
+            d_[3] = u32x4{pack_h2(s6.x, s6.y), pack_h2(s6.z, s6.w), pack_h2(s7.x, s7.y), pack_h2(s7.z, s7.w)};              \
+        } while (0)
+        auto x_load = [&](int kb) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) xr[t][r] = dz[(size_t)(32 * kb + 8 * g + r) * chp + ml[t]];
+        };
+        auto x_finish = [&]() {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                xb[t] = frag_from_dwords(pack_h2(xr[t][0] * sc, xr[t][1] * sc), pack_h2(xr[t][2] * sc, xr[t][3] * sc),
+                                         pack_h2(xr[t][4] * sc, xr[t][5] * sc), pack_h2(xr[t][6] * sc, xr[t][7] * sc));
+        };
+        WIDE_DXH_STAGE_LOAD(0);
+        x_load(0);
+        WIDE_DXH_STAGE_STORE(0);
+        x_finish();
+        __syncthreads();
+        for (int kb = 0; kb < n_kb; ++kb) {
+            const bool more = kb + 1 < n_kb;
+            if (more) { WIDE_DXH_STAGE_LOAD(kb + 1); x_load(kb + 1); }
+            const f16* wb = &w_h[kb & 1][c * WIDE_LDS_HROW + 8 * g];
+#pragma unroll
+            for (int jt = 0; jt < 16; ++jt) {
+                if (jt < n_rt) {                                  // (workgroup-uniform: the first layer has in_dim / 16 row tiles)
+                    const f16x8 wa = *reinterpret_cast<const f16x8*>(wb + 16 * jt * WIDE_LDS_HROW);
+                    Z[0][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, xb[0], Z[0][jt], 0, 0, 0);
+                    Z[1][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, xb[1], Z[1][jt], 0, 0, 0);
+                }
+            }
+            if (more) { WIDE_DXH_STAGE_STORE((kb + 1) & 1); x_finish(); }
+            __syncthreads();
+        }
+#undef WIDE_DXH_STAGE_LOAD
+#undef WIDE_DXH_STAGE_STORE
+        if (!active) continue;                                    // (workgroup-uniform loop; an idle wave stores nothing)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (2 * pair + t >= n_tiles) continue;
+            const int64_t col = (2 * pair + t) * 16 + c;
+            const bool live = col < M;
+#pragma unroll
+            for (int jt = 0; jt < 16; ++jt) {
+                if (jt < n_rt) {                                  // (no break: the loop must unroll for the accumulators to stay registers)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int k = 16 * jt + 4 * g + r;
+                        const float v = Z[t][jt][r] * inv_sc;
+                        if (TO_FEAT) {
+                            if (k < enc_dim && live) out[(size_t)k * out_stride + smp.lo + col] = v;
+                        } else {
+                            const size_t at = (size_t)k * chp + col;
+                            out[at] = live ? v * act_bwd(z_prev[at], act) : 0.0f;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// partial[split][j][k] = sum over the split's 32-sample tiles of dZ[j][s] in_k[s] on v_mfma_f32_16x16x32_f16: the work decomposition of
+// wide_dw_kernel (workgroup = 64 rows x 64 columns x one of LNR_WIDE_SPLITS strided tile sequences, wave = one row tile, the workgroups of a
+// split on one XCD), with K = 32 samples per MFMA: the wave's dZ operand is two 16-byte loads of 8 consecutive samples of its row, scaled
+// by the tile's 2^-e and rounded to fp16; the input operand - 64 columns x 32 samples, finished (activation / pair extraction) once per
+// workgroup - is staged through LDS as fp16 rows; every tile's product starts from zero and is added to the fp32 accumulators with its 2^e.
+template <int IN>
+__global__ void __launch_bounds__(256)
+wide_dw_h_kernel(const float* __restrict__ dz, int64_t chp, const float* __restrict__ in, int64_t in_stride, int enc_dim, int K, int act,
+                 WideSamples smp, const float* __restrict__ d_sigma, float* __restrict__ partial, int64_t n_mlp, int64_t layer_off) {
+    constexpr int ROW = 40;                                       // halves per staged column: 32 samples + 8 (80-byte rows: conflict-free 16-byte reads)
+    __shared__ __attribute__((aligned(16))) f16 b_s[2][64 * ROW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int n_cb = (K + 63) / 64, n_inner = 4 * n_cb;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int inner = q % n_inner, split = (q / n_inner) * 8 + xcd;
+    const int rb = inner & 3, cb = inner >> 2;
+    const int jt = 4 * rb + wave;
+    const int64_t M = wide_live(smp);
+    const int64_t n_t32 = (M + 31) / 32;
+    const float* dz_row = dz + (size_t)(16 * jt + c) * chp + 8 * g;
+    // the thread's share of the input operand: samples 8 sq .. 8 sq + 7 of column sc of the workgroup's 64
+    const int scol = threadIdx.x >> 2, sq = threadIdx.x & 3;
+    const int sk = 64 * cb + scol;
+    const bool s_load = sk < K && (IN == WIDE_IN_Z || sk < enc_dim);          // (else: a constant-one padding input, or beyond a ragged last block)
+    const float* s_src = in + (size_t)(IN == WIDE_IN_PAIR ? (sk >> 1) : sk) * in_stride + (IN == WIDE_IN_Z ? 0 : smp.lo) + 8 * sq;
+    auto finish1 = [&](float v, bool live) -> float {
+        if (!live) return 0.0f;                                   // (samples past the live count: whatever the planes hold there)
+        if (IN == WIDE_IN_PAIR) {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const h2 p = __builtin_bit_cast(h2, __builtin_bit_cast(uint32_t, v));
+            return s_load ? (float)((sk & 1) ? p.y : p.x) : 1.0f;
+        }
+        return act_fwd(v, act);                                   // (rounded to fp16 by the pack below)
+    };
+    auto stage = [&](int buf, int64_t tile, const float4& r0, const float4& r1) {
+        const int64_t m0 = tile * 32 + 8 * sq;
+        u32x4 h;
+        h.x = pack_h2(finish1(r0.x, m0 < M), finish1(r0.y, m0 + 1 < M)); h.y = pack_h2(finish1(r0.z, m0 + 2 < M), finish1(r0.w, m0 + 3 < M));
+        h.z = pack_h2(finish1(r1.x, m0 + 4 < M), finish1(r1.y, m0 + 5 < M)); h.w = pack_h2(finish1(r1.z, m0 + 6 < M), finish1(r1.w, m0 + 7 < M));
+        *reinterpret_cast<u32x4*>(&b_s[buf][scol * ROW + 8 * sq]) = h;
+    };
+    auto run = [&](auto nct_tag) {
+        constexpr int NCT = decltype(nct_tag)::value;
+        f32x4 acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const float4 zero4 = float4{0.0f, 0.0f, 0.0f, 0.0f};
+        float4 a0 = zero4, a1 = zero4, n0 = zero4, n1 = zero4, r0 = zero4, r1 = zero4;
+        int64_t tile = split;
+        if (tile < n_t32) {
+            if (s_load) { r0 = *reinterpret_cast<const float4*>(s_src + tile * 32); r1 = *reinterpret_cast<const float4*>(s_src + tile * 32 + 4); }
+            a0 = *reinterpret_cast<const float4*>(dz_row + tile * 32); a1 = *reinterpret_cast<const float4*>(dz_row + tile * 32 + 4);
+            stage(0, tile, r0, r1);
+        }
+        __syncthreads();
+        for (int it = 0; tile < n_t32; tile += LNR_WIDE_SPLITS, ++it) {         // (workgroup-uniform trip count: barriers inside)
+            const int64_t nt = tile + LNR_WIDE_SPLITS < n_t32 ? tile + LNR_WIDE_SPLITS : tile;
+            if (s_load) { r0 = *reinterpret_cast<const float4*>(s_src + nt * 32); r1 = *reinterpret_cast<const float4*>(s_src + nt * 32 + 4); }
+            n0 = *reinterpret_cast<const float4*>(dz_row + nt * 32); n1 = *reinterpret_cast<const float4*>(dz_row + nt * 32 + 4);
+            float inv_sc;
+            const float sc = wide_tile_scale(d_sigma, smp, tile * 32, M, lane, &inv_sc);
+            if (sc != 0.0f) {                                     // (wave-uniform, and the same for the four waves: no barrier inside)
+                const int64_t m0 = tile * 32 + 8 * g;
+                auto dzv = [&](float v, int i) { return m0 + i < M ? v * sc : 0.0f; };
+                const f16x8 a = frag_from_dwords(pack_h2(dzv(a0.x, 0), dzv(a0.y, 1)), pack_h2(dzv(a0.z, 2), dzv(a0.w, 3)),
+                                                 pack_h2(dzv(a1.x, 4), dzv(a1.y, 5)), pack_h2(dzv(a1.z, 6), dzv(a1.w, 7)));
+                const f16* bb = &b_s[it & 1][c * ROW + 8 * g];
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    const f16x8 b = *reinterpret_cast<const f16x8*>(bb + 16 * ct * ROW);
+                    const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, f32x4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[ct][r] = __builtin_fmaf(d[r], inv_sc, acc[ct][r]);
+                }
+            }
+            stage((it + 1) & 1, nt, r0, r1);
+            a0 = n0; a1 = n1;
+            __syncthreads();
+        }
+        float* out = partial + (size_t)(1 + split) * n_mlp + layer_off;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(size_t)(16 * jt + 4 * g + r) * K + 64 * cb + 16 * ct + c] = acc[ct][r];
+    };
+    const int n_ct = (K - 64 * cb) / 16;
+    if (n_ct >= 4) run(WideInt<4>{});
+    else if (n_ct == 3) run(WideInt<3>{});
+    else if (n_ct == 2) run(WideInt<2>{});
+    else run(WideInt<1>{});
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 bool lnr_wide_class(const LnrNetSpec* spec) {
     if (spec->n_neurons != LNR_WIDE_H || spec->n_hidden < 1 || spec->n_hidden > 3 || spec->in_dim % 16 != 0) return false;
@@ -676,18 +907,28 @@ static int wide_backward(const WideCtx& c, const float* d_sigma, float* dfeat, f
             const int64_t layer_off = l == 0 ? 0 : (int64_t)c.H * c.K1 + (int64_t)(l - 1) * c.H * c.H;
             const dim3 grid_w((unsigned)(4 * ((K + 63) / 64) * LNR_WIDE_SPLITS));
             if (!want_dw) {}                                       // frozen parameters (tracking phase): the input gradient only
+            else if (HALF && LNR_WIDE_F16_BWD && l > 0) hipLaunchKernelGGL((wide_dw_h_kernel<WIDE_IN_Z>), grid_w, block, 0, c.st, dz, c.chp, c.z(l - 1), c.chp, c.H, K, c.act, s, d_sigma, slabs, n_mlp, layer_off);
+            else if (HALF && LNR_WIDE_F16_BWD) hipLaunchKernelGGL((wide_dw_h_kernel<WIDE_IN_PAIR>), grid_w, block, 0, c.st, dz, c.chp, c.feat, c.m_pad, c.spec->enc_dim, K, c.act, s, d_sigma, slabs, n_mlp, layer_off);
             else if (l > 0) hipLaunchKernelGGL((wide_dw_kernel<HALF, WIDE_IN_Z>), grid_w, block, 0, c.st, dz, c.chp, c.z(l - 1), c.chp, c.H, K, c.act, s, slabs, n_mlp, layer_off);
             else if (HALF) hipLaunchKernelGGL((wide_dw_kernel<HALF, WIDE_IN_PAIR>), grid_w, block, 0, c.st, dz, c.chp, c.feat, c.m_pad, c.spec->enc_dim, K, c.act, s, slabs, n_mlp, layer_off);
             else hipLaunchKernelGGL((wide_dw_kernel<HALF, WIDE_IN_FEAT>), grid_w, block, 0, c.st, dz, c.chp, c.feat, c.m_pad, c.spec->enc_dim, K, c.act, s, slabs, n_mlp, layer_off);
             const int64_t count = (int64_t)c.H * K;
             if (want_dw) hipLaunchKernelGGL(wide_fold_kernel, dim3((unsigned)((count + 255) / 256)), block, 0, c.st, slabs, n_mlp, layer_off, count);
             if (l > 0) {
-                hipLaunchKernelGGL((wide_dx_kernel<HALF, false>), grid_p, block, 0, c.st, wt + (size_t)(l - 1) * c.H * c.H, c.H / 16, dz, c.chp, c.act, s,
-                                   c.z(l - 1), dz_other, c.chp, 0);
+                if (HALF && LNR_WIDE_F16_BWD)
+                    hipLaunchKernelGGL((wide_dx_h_kernel<false>), grid_p, block, 0, c.st, wt + (size_t)(l - 1) * c.H * c.H, c.H / 16, dz, c.chp, c.act, s, d_sigma,
+                                       c.z(l - 1), dz_other, c.chp, 0);
+                else
+                    hipLaunchKernelGGL((wide_dx_kernel<HALF, false>), grid_p, block, 0, c.st, wt + (size_t)(l - 1) * c.H * c.H, c.H / 16, dz, c.chp, c.act, s,
+                                       c.z(l - 1), dz_other, c.chp, 0);
                 float* t = dz; dz = dz_other; dz_other = t;
             } else if (want_dfeat) {
-                hipLaunchKernelGGL((wide_dx_kernel<HALF, true>), grid_p, block, 0, c.st, wt_first, K / 16, dz, c.chp, c.act, s, (const float*)nullptr, dfeat,
-                                   c.m_pad, c.spec->enc_dim);
+                if (HALF && LNR_WIDE_F16_BWD)
+                    hipLaunchKernelGGL((wide_dx_h_kernel<true>), grid_p, block, 0, c.st, wt_first, K / 16, dz, c.chp, c.act, s, d_sigma, (const float*)nullptr, dfeat,
+                                       c.m_pad, c.spec->enc_dim);
+                else
+                    hipLaunchKernelGGL((wide_dx_kernel<HALF, true>), grid_p, block, 0, c.st, wt_first, K / 16, dz, c.chp, c.act, s, (const float*)nullptr, dfeat,
+                                       c.m_pad, c.spec->enc_dim);
             }
         }
     }
