@@ -691,8 +691,9 @@ def main():
         try:
             od = "f16" if args.dtype == "f32" else "f32"
             o2, w2 = make_optimizer(od), build_window(args.keyframes)
-            if args.warmup > 0:
-                o2._do_iterate_optimizer(w2, [None], optimizer_settings=phase(args.warmup))
+            # (at least 10 warm-up iterations: this leg builds a second optimiser - 6 GB of workspace, another set of kernels - late in the
+            # process, and with the driver's --warmup 5 its short timed window caught one-time costs: 5.3 ms per step against 1.96 alone)
+            o2._do_iterate_optimizer(w2, [None], optimizer_settings=phase(max(args.warmup, 10)))
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             o2._do_iterate_optimizer(w2, [None], optimizer_settings=phase(args.steps))

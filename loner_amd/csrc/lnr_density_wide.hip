@@ -29,7 +29,13 @@
 // workgroups for a 256 x 256 matrix, 2 waves per SIMD) the kernel took 0.84 ms per chunk, 7 TFLOP/s (profiles/r05_wide_networks.txt)
 #define LNR_WIDE_SPLITS 128
 #ifndef LNR_WIDE_F16_BWD
-#define LNR_WIDE_F16_BWD 1             /* fp16 mode: back-propagation and weight gradient on the f16 matrix pipe (0: round 5's fp32-MFMA kernels, A/B) */
+#define LNR_WIDE_F16_BWD 1             /* fp16 mode: weight gradient and first-layer back-propagation on the f16 matrix pipe (0: round 5's fp32-MFMA kernels, A/B) */
+#endif
+// Back-propagation through a HIDDEN matrix on the f16 pipe: measured 292 us per chunk against 246 us for the fp32-MFMA kernel
+// (profiles/r06_wide_networks.txt) - with the matrix time gone the kernel is its plane traffic (dZ and Z_prev in, dZ_prev out as 4-byte
+// accesses of 64-byte row segments), and the fp32 kernel's epilogue carries less of it per MFMA.  Off; the kernel stays for the A/B.
+#ifndef LNR_WIDE_F16_DX_HIDDEN
+#define LNR_WIDE_F16_DX_HIDDEN 0
 #endif
 #define LNR_WIDE_H 256
 #define WIDE_LDS_ROW 20                // floats per staged weight row of the forward: 16 + 4 padding (the 16 lanes of a 16-byte LDS read hit 16 distinct bank quads)
@@ -587,17 +593,23 @@ wide_dx_kernel(const float* __restrict__ WT, int n_kt, const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ fp16 mode: the backward on the f16 matrix pipe
-// Rounds 5's fp16 mode multiplied dZ - an fp32 operand - on the fp32 MFMA (15.9 ms for a 256 x 2 backward at 2.1 M samples, 2.7 % of the f16
-// peak: VERDICT r5 weak #10).  Here dZ is converted to fp16 where it is consumed, scaled by an exact power of two per 32-sample tile -
+// Round 5's fp16 mode multiplied dZ - an fp32 operand - on the fp32 MFMA (15.9 ms for a 256 x 2 backward at 2.1 M samples, 2.7 % of the f16
+// peak: VERDICT r5 weak #10).  Per chunk of 131 072 samples (rocprofv3, profiles/r06_wide_networks.txt; fp32 MFMA -> f16 MFMA): weight
+// gradient of a hidden matrix 212 -> 180 us, of the first layer 111 -> 67 us, first-layer back-propagation 74 -> 63 us, hidden
+// back-propagation 246 -> 292 us (kept on the fp32 pipe): 15.9 -> ~14.5 ms - these kernels were never matrix-bound, their planes
+// cross L2 -> L1 four times (weight gradient: 1.07 GB per chunk and matrix at ~6 TB/s) or leave as 64-byte row segments.  Here dZ is converted to fp16 where it is consumed, scaled by an exact power of two per 32-sample tile -
 // 2^-e, e = the exponent of the tile's largest |d_sigma|: every dZ column is d_sigma[m] times O(1) factors, so the scaled values sit
 // around 1 whatever the loss magnitude, and what underflows fp16 lies 2^-14 below its tile's maximum - and the f16 MFMA results are
 // un-scaled in fp32 (the same scheme as the fused 128-wide kernels, lnr_f16_bwd_kernel.h, per tile instead of per workgroup step).
 // A tile whose d_sigma are all zero contributes nothing and is skipped.
 
-// 2^-e for the 32 samples [ml0, ml0 + 32) of the chunk (lanes (c, g): every lane calls it; the result is wave-uniform); 0: all-zero tile
-__device__ __forceinline__ float wide_tile_scale(const float* __restrict__ d_sigma, const WideSamples& smp, int64_t ml0, int64_t M, int lane, float* inv) {
+// 2^-e for the 32 samples [ml0, ml0 + 32) of the chunk (lanes (c, g): every lane calls it; the result is wave-uniform); 0: all-zero tile.
+// In two halves so that the load can be issued a tile ahead of its use (wide_dw_h_kernel: one exposed L2 round trip per tile otherwise).
+__device__ __forceinline__ float wide_tile_dsigma(const float* __restrict__ d_sigma, const WideSamples& smp, int64_t ml0, int64_t M, int lane) {
     const int64_t ml = ml0 + (lane & 31);
-    float v = ml < M ? __builtin_fabsf(d_sigma[smp.lo + ml]) : 0.0f;
+    return ml < M ? __builtin_fabsf(d_sigma[smp.lo + ml]) : 0.0f;
+}
+__device__ __forceinline__ float wide_tile_scale_of(float v, float* inv) {
     v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64)); v = fmaxf(v, __shfl_xor(v, 4, 64));
     v = fmaxf(v, __shfl_xor(v, 8, 64)); v = fmaxf(v, __shfl_xor(v, 16, 64));
     v = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v)));
@@ -606,6 +618,9 @@ __device__ __forceinline__ float wide_tile_scale(const float* __restrict__ d_sig
     be = be < 2u ? 2u : (be > 252u ? 252u : be);
     *inv = __uint_as_float(be << 23);                                        // 2^e
     return __uint_as_float((254u - be) << 23);                               // 2^-e
+}
+__device__ __forceinline__ float wide_tile_scale(const float* __restrict__ d_sigma, const WideSamples& smp, int64_t ml0, int64_t M, int lane, float* inv) {
+    return wide_tile_scale_of(wide_tile_dsigma(d_sigma, smp, ml0, M, lane), inv);
 }
 
 // dZ_prev = act'(Z_prev) . (W^T dZ) for a hidden matrix (TO_FEAT: the d_feature planes of the first layer) on v_mfma_f32_16x16x32_f16:
@@ -682,12 +697,27 @@ wide_dx_h_kernel(const float* __restrict__ WT, int n_rt, const float* __restrict
             const bool more = kb + 1 < n_kb;
             if (more) { WIDE_DXH_STAGE_LOAD(kb + 1); x_load(kb + 1); }
             const f16* wb = &w_h[kb & 1][c * WIDE_LDS_HROW + 8 * g];
+            if constexpr (!TO_FEAT) {
+                // a hidden matrix: all 16 row tiles, the loop of wide_layer_fwd_h_kernel - fragment jt + 1 requested in front of the MFMAs
+                // of fragment jt (with a branch per row tile and every read directly in front of its MFMAs the first version of this
+                // kernel took 317 us per chunk against the forward layer's 139)
+                f16x8 wa = *reinterpret_cast<const f16x8*>(wb);
 #pragma unroll
-            for (int jt = 0; jt < 16; ++jt) {
-                if (jt < n_rt) {                                  // (workgroup-uniform: the first layer has in_dim / 16 row tiles)
-                    const f16x8 wa = *reinterpret_cast<const f16x8*>(wb + 16 * jt * WIDE_LDS_HROW);
+                for (int jt = 0; jt < 16; ++jt) {
+                    const f16x8 wn = *reinterpret_cast<const f16x8*>(wb + 16 * (jt < 15 ? jt + 1 : 15) * WIDE_LDS_HROW);
                     Z[0][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, xb[0], Z[0][jt], 0, 0, 0);
                     Z[1][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, xb[1], Z[1][jt], 0, 0, 0);
+                    wa = wn;
+                }
+                WIDE_PIPELINE_LDS_MFMA_H();
+            } else {
+#pragma unroll
+                for (int jt = 0; jt < 16; ++jt) {
+                    if (jt < n_rt) {                              // (workgroup-uniform: the first layer has in_dim / 16 row tiles)
+                        const f16x8 wa = *reinterpret_cast<const f16x8*>(wb + 16 * jt * WIDE_LDS_HROW);
+                        Z[0][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, xb[0], Z[0][jt], 0, 0, 0);
+                        Z[1][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, xb[1], Z[1][jt], 0, 0, 0);
+                    }
                 }
             }
             if (more) { WIDE_DXH_STAGE_STORE((kb + 1) & 1); x_finish(); }
@@ -701,18 +731,29 @@ wide_dx_h_kernel(const float* __restrict__ WT, int n_rt, const float* __restrict
             if (2 * pair + t >= n_tiles) continue;
             const int64_t col = (2 * pair + t) * 16 + c;
             const bool live = col < M;
+            if constexpr (!TO_FEAT) {
+                // Z_prev of four row tiles (16 loads) in flight at a time, in front of the 16 products and stores that use them
 #pragma unroll
-            for (int jt = 0; jt < 16; ++jt) {
-                if (jt < n_rt) {                                  // (no break: the loop must unroll for the accumulators to stay registers)
+                for (int j0 = 0; j0 < 16; j0 += 4) {
+                    float zp[4][4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int k = 16 * jt + 4 * g + r;
-                        const float v = Z[t][jt][r] * inv_sc;
-                        if (TO_FEAT) {
-                            if (k < enc_dim && live) out[(size_t)k * out_stride + smp.lo + col] = v;
-                        } else {
-                            const size_t at = (size_t)k * chp + col;
-                            out[at] = live ? v * act_bwd(z_prev[at], act) : 0.0f;
+                    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) zp[jj][r] = z_prev[(size_t)(16 * (j0 + jj) + 4 * g + r) * chp + col];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            out[(size_t)(16 * (j0 + jj) + 4 * g + r) * chp + col] = live ? Z[t][j0 + jj][r] * inv_sc * act_bwd(zp[jj][r], act) : 0.0f;
+                }
+            } else {
+#pragma unroll
+                for (int jt = 0; jt < 16; ++jt) {
+                    if (jt < n_rt) {                              // (no break: the loop must unroll for the accumulators to stay registers)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int k = 16 * jt + 4 * g + r;
+                            if (k < enc_dim && live) out[(size_t)k * out_stride + smp.lo + col] = Z[t][jt][r] * inv_sc;
                         }
                     }
                 }
@@ -770,8 +811,10 @@ wide_dw_h_kernel(const float* __restrict__ dz, int64_t chp, const float* __restr
         for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         const float4 zero4 = float4{0.0f, 0.0f, 0.0f, 0.0f};
         float4 a0 = zero4, a1 = zero4, n0 = zero4, n1 = zero4, r0 = zero4, r1 = zero4;
+        float ds_c = 0.0f, ds_n = 0.0f;                           // the lane's |d_sigma| of the tile in hand / the next one (for the tile's scale)
         int64_t tile = split;
         if (tile < n_t32) {
+            ds_c = wide_tile_dsigma(d_sigma, smp, tile * 32, M, lane);
             if (s_load) { r0 = *reinterpret_cast<const float4*>(s_src + tile * 32); r1 = *reinterpret_cast<const float4*>(s_src + tile * 32 + 4); }
             a0 = *reinterpret_cast<const float4*>(dz_row + tile * 32); a1 = *reinterpret_cast<const float4*>(dz_row + tile * 32 + 4);
             stage(0, tile, r0, r1);
@@ -781,8 +824,9 @@ wide_dw_h_kernel(const float* __restrict__ dz, int64_t chp, const float* __restr
             const int64_t nt = tile + LNR_WIDE_SPLITS < n_t32 ? tile + LNR_WIDE_SPLITS : tile;
             if (s_load) { r0 = *reinterpret_cast<const float4*>(s_src + nt * 32); r1 = *reinterpret_cast<const float4*>(s_src + nt * 32 + 4); }
             n0 = *reinterpret_cast<const float4*>(dz_row + nt * 32); n1 = *reinterpret_cast<const float4*>(dz_row + nt * 32 + 4);
+            ds_n = wide_tile_dsigma(d_sigma, smp, nt * 32, M, lane);
             float inv_sc;
-            const float sc = wide_tile_scale(d_sigma, smp, tile * 32, M, lane, &inv_sc);
+            const float sc = wide_tile_scale_of(ds_c, &inv_sc);
             if (sc != 0.0f) {                                     // (wave-uniform, and the same for the four waves: no barrier inside)
                 const int64_t m0 = tile * 32 + 8 * g;
                 auto dzv = [&](float v, int i) { return m0 + i < M ? v * sc : 0.0f; };
@@ -798,7 +842,7 @@ wide_dw_h_kernel(const float* __restrict__ dz, int64_t chp, const float* __restr
                 }
             }
             stage((it + 1) & 1, nt, r0, r1);
-            a0 = n0; a1 = n1;
+            a0 = n0; a1 = n1; ds_c = ds_n;
             __syncthreads();
         }
         float* out = partial + (size_t)(1 + split) * n_mlp + layer_off;
@@ -915,7 +959,7 @@ static int wide_backward(const WideCtx& c, const float* d_sigma, float* dfeat, f
             const int64_t count = (int64_t)c.H * K;
             if (want_dw) hipLaunchKernelGGL(wide_fold_kernel, dim3((unsigned)((count + 255) / 256)), block, 0, c.st, slabs, n_mlp, layer_off, count);
             if (l > 0) {
-                if (HALF && LNR_WIDE_F16_BWD)
+                if (HALF && LNR_WIDE_F16_BWD && LNR_WIDE_F16_DX_HIDDEN)
                     hipLaunchKernelGGL((wide_dx_h_kernel<false>), grid_p, block, 0, c.st, wt + (size_t)(l - 1) * c.H * c.H, c.H / 16, dz, c.chp, c.act, s, d_sigma,
                                        c.z(l - 1), dz_other, c.chp, 0);
                 else

@@ -115,9 +115,13 @@ template <int ACT> __device__ __forceinline__ float fwd_act(float v, int kind) {
 // LAST = false: the activations become Bout, the next layer's B operands.  LAST = true: they are reduced against the output row
 // (wo: the lane's entries, rows 16jt + 4g + r) into part[t].
 // BIAS: the products of row tile jt start from bias[16jt + 4g .. +3] (bias_lane = the lane's bias + 4g) instead of zero.
-template <int HT, int ACT, int KB, int S, int CT, bool LAST, bool BIAS>
+// side(k): a piece of independent VALU work issued behind the MFMAs of row tile k - SIDE_BASE (the fused frequency kernels evaluate one
+// (sin, cos) slot of the NEXT step's features there: the matrix pipe is busy for ~130 cycles per row tile, and a wave that computes its
+// features in one block in front of its MFMAs leaves that time to whatever other wave the SIMD holds)
+struct FwdNoSide { __device__ __forceinline__ void operator()(int) const {} };
+template <int HT, int ACT, int KB, int S, int CT, bool LAST, bool BIAS, int SIDE_BASE = 0, typename Side = FwdNoSide>
 __device__ __forceinline__ void fwd_layer(const f16* Wl, const int (&koff)[F16_KB_MAX], const float* bias_lane, int act, const u32x4 (&Bin)[F16_KB_MAX][CT],
-                                          u32x4 (&Bout)[F16_KB_MAX][CT], const float (&wo)[HT][4], float (&part)[CT]) {
+                                          u32x4 (&Bout)[F16_KB_MAX][CT], const float (&wo)[HT][4], float (&part)[CT], Side side = Side()) {
     f16x8 a[2][KB];
     f32x4 Z[2][CT], z0[2];
     auto frags = [&](int jt, f16x8 (&dst)[KB], f32x4& zb) {
@@ -153,6 +157,7 @@ __device__ __forceinline__ void fwd_layer(const f16* Wl, const int (&koff)[F16_K
 #pragma unroll
             for (int t = 0; t < CT; ++t)
                 Z[jt & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[jt & 1][kb], __builtin_bit_cast(f16x8, Bin[kb][t]), Z[jt & 1][t], 0, 0, 0);
+        side(SIDE_BASE + jt);
         if (jt > 0) finish(jt - 1, Z[(jt - 1) & 1]);
     }
     finish(HT - 1, Z[(HT - 1) & 1]);
@@ -198,33 +203,40 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
     const bool fq_uni = FQ && ray_uniform(src, (uint32_t)TS) && M % TS == 0;      // (M % TS: the clamp of a ragged last tile would mix two rays)
     // the features of the NEXT step are in flight while this one goes through the layers
     // (samples past M: their planes are padded to m_pad, whatever they hold only reaches columns that are never stored)
-    auto load_tile = [&](int64_t tile, u32x4 (&x)[F16_KB_MAX][CT]) __attribute__((always_inline)) {
-        if constexpr (FQ) {
+    // FQ: the unit-cube points of a step's samples (x the lane's 2^g) ...
+    auto fq_points = [&](int64_t tile, float (&xu)[CT][3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            int64_t m = tile * TS + 16 * t + c;
+            if (m >= M) m = M - 1;                                     // (columns past the last sample are never stored)
+            RawPoint rp;
+            // (fq_uni: a wave step's 16 CT samples lie on ONE ray - its record comes through the scalar cache, lnr_encoding.h)
+            load_raw_point(src, (uint32_t)m, src.pts ? 0u : (uint32_t)m / (uint32_t)src.n_samples, rp, fq_uni);
+            unit_point(src, rp, xu[t]);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) xu[t][d] *= fq_pg;              // the lane's share of the frequency (exact)
+        }
+    };
+    // ... and ONE slot of their features (both column tiles): the unit of work interleaved with the previous step's MFMAs
+    auto fq_slot = [&](int sl, const float (&xu)[CT][3], u32x4 (&x)[F16_KB_MAX][CT]) __attribute__((always_inline)) {
+        if (sl < fq_slots) {                                           // (compile-time: sl is a literal of the unrolled callers)
 #pragma unroll
             for (int t = 0; t < CT; ++t) {
-                int64_t m = tile * TS + 16 * t + c;
-                if (m >= M) m = M - 1;                                     // (columns past the last sample are never stored)
-                RawPoint rp;
-                // (fq_uni: a wave step's 16 CT samples lie on ONE ray - its record comes through the scalar cache, lnr_encoding.h)
-                load_raw_point(src, (uint32_t)m, src.pts ? 0u : (uint32_t)m / (uint32_t)src.n_samples, rp, fq_uni);
-                float xu[3];
-                unit_point(src, rp, xu);
-#pragma unroll
-                for (int d = 0; d < 3; ++d) xu[d] *= fq_pg;                // the lane's share of the frequency (exact)
-#pragma unroll
-                for (int kb = 0; kb < F16_KB_MAX; ++kb) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int sl = 4 * kb + q;
-                        uint32_t v = 0u;
-                        if (kb < KT && sl < fq_slots) {                    // (compile-time)
-                            float d0, d1;
-                            v = freq_pair<false>(xu[sl % 3] * lnr_freq_slot_scale(sl), 0.0f, d0, d1);
-                        }
-                        x[kb][t][q] = v;
-                    }
-                }
+                float d0, d1;
+                x[sl >> 2][t][sl & 3] = freq_pair<false>(xu[t][sl % 3] * lnr_freq_slot_scale(sl), 0.0f, d0, d1);
             }
+        }
+    };
+    auto load_tile = [&](int64_t tile, u32x4 (&x)[F16_KB_MAX][CT]) __attribute__((always_inline)) {
+        if constexpr (FQ) {
+            float xu[CT][3];
+            fq_points(tile, xu);
+#pragma unroll
+            for (int kb = 0; kb < F16_KB_MAX; ++kb)
+#pragma unroll
+                for (int t = 0; t < CT; ++t) x[kb][t] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int sl = 0; sl < 4 * KT; ++sl) fq_slot(sl, xu, x);
             return;
         }
         const uint32_t m0 = (uint32_t)(tile * TS) * 4u;
@@ -240,20 +252,22 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
     };
     // (always inlined: with a run-time activation the body is large enough for the inliner to leave it a FUNCTION, and a call passes
     // the operand arrays through scratch memory - 500 bytes per lane)
-    auto run_tile = [&](int64_t tile, const u32x4 (&x)[F16_KB_MAX][CT]) __attribute__((always_inline)) {
+    // side: FwdNoSide, or the fused frequency kernels' job - slot k of the NEXT step's features behind the MFMAs of row tile k
+    auto run_tile = [&](int64_t tile, const u32x4 (&x)[F16_KB_MAX][CT], auto side) __attribute__((always_inline)) {
         float part[CT];
 #pragma unroll
         for (int t = 0; t < CT; ++t) part[t] = 0.0f;
         u32x4 B1[F16_KB_MAX][CT], B2[F16_KB_MAX][CT];
+        using SideT = decltype(side);
         if constexpr (NH == 1) {
-            fwd_layer<HT, ACT, KT, L::S0, CT, true, true>(Ws, koff0, bias_lane, act, x, B1, wo, part);
+            fwd_layer<HT, ACT, KT, L::S0, CT, true, true, 0, SideT>(Ws, koff0, bias_lane, act, x, B1, wo, part, side);
         } else if constexpr (NH == 2) {
-            fwd_layer<HT, ACT, KT, L::S0, CT, false, true>(Ws, koff0, bias_lane, act, x, B1, wo, part);
-            fwd_layer<HT, ACT, L::KBH, L::SH, CT, true, false>(Ws + L::OFF_H, koffh, bias_lane, act, B1, B2, wo, part);
+            fwd_layer<HT, ACT, KT, L::S0, CT, false, true, 0, SideT>(Ws, koff0, bias_lane, act, x, B1, wo, part, side);
+            fwd_layer<HT, ACT, L::KBH, L::SH, CT, true, false, HT, SideT>(Ws + L::OFF_H, koffh, bias_lane, act, B1, B2, wo, part, side);
         } else {
-            fwd_layer<HT, ACT, KT, L::S0, CT, false, true>(Ws, koff0, bias_lane, act, x, B1, wo, part);
-            fwd_layer<HT, ACT, L::KBH, L::SH, CT, false, false>(Ws + L::OFF_H, koffh, bias_lane, act, B1, B2, wo, part);
-            fwd_layer<HT, ACT, L::KBH, L::SH, CT, true, false>(Ws + L::OFF_H + L::H * L::SH, koffh, bias_lane, act, B2, B1, wo, part);
+            fwd_layer<HT, ACT, KT, L::S0, CT, false, true, 0, SideT>(Ws, koff0, bias_lane, act, x, B1, wo, part, side);
+            fwd_layer<HT, ACT, L::KBH, L::SH, CT, false, false, HT, SideT>(Ws + L::OFF_H, koffh, bias_lane, act, B1, B2, wo, part, side);
+            fwd_layer<HT, ACT, L::KBH, L::SH, CT, true, false, 2 * HT, SideT>(Ws + L::OFF_H + L::H * L::SH, koffh, bias_lane, act, B2, B1, wo, part, side);
         }
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
@@ -268,14 +282,39 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
     int64_t tile = (int64_t)blockIdx.x * nw + wave;
     u32x4 xa[F16_KB_MAX][CT], xb[F16_KB_MAX][CT];
     if (tile < n_tiles) load_tile(tile, xa);
-    if constexpr (ACT >= 0) {
+    if constexpr (FQ && ACT >= 0) {
+        // fused frequency encoding: the NEXT step's points are requested in front of this step's layers, and its features are evaluated
+        // slot by slot BEHIND the MFMAs of this step's row tiles (HT x NH of them; what does not fit there follows the last layer)
+        constexpr int N_SIDE = HT * NH;
+        float xu[CT][3];
+        auto zero_x = [&](u32x4 (&x)[F16_KB_MAX][CT]) {
+#pragma unroll
+            for (int kb = 0; kb < F16_KB_MAX; ++kb)
+#pragma unroll
+                for (int t = 0; t < CT; ++t) x[kb][t] = u32x4{0u, 0u, 0u, 0u};
+        };
+        for (; tile < n_tiles; tile += 2 * stride) {
+            const int64_t t1 = tile + stride, t2 = tile + 2 * stride;
+            fq_points(t1 < n_tiles ? t1 : tile, xu);
+            zero_x(xb);
+            run_tile(tile, xa, [&](int k) __attribute__((always_inline)) { fq_slot(k, xu, xb); });
+#pragma unroll
+            for (int sl = N_SIDE; sl < 4 * KT; ++sl) fq_slot(sl, xu, xb);
+            if (t1 >= n_tiles) break;
+            fq_points(t2 < n_tiles ? t2 : t1, xu);
+            zero_x(xa);
+            run_tile(t1, xb, [&](int k) __attribute__((always_inline)) { fq_slot(k, xu, xa); });
+#pragma unroll
+            for (int sl = N_SIDE; sl < 4 * KT; ++sl) fq_slot(sl, xu, xa);
+        }
+    } else if constexpr (ACT >= 0) {
         for (; tile < n_tiles; tile += 2 * stride) {                      // two steps per trip: the feature buffers alternate
             const int64_t t1 = tile + stride, t2 = tile + 2 * stride;
             load_tile(t1 < n_tiles ? t1 : tile, xb);                      // unconditional (clamped): a static number of loads in flight
-            run_tile(tile, xa);
+            run_tile(tile, xa, FwdNoSide());
             if (t1 >= n_tiles) break;
             load_tile(t2 < n_tiles ? t2 : t1, xa);
-            run_tile(t1, xb);
+            run_tile(t1, xb, FwdNoSide());
         }
     } else {
         // run-time activation: ONE copy of the step body (every activation of it carries the whole switch over the libm
@@ -283,7 +322,7 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
         for (; tile < n_tiles; tile += stride) {
             const int64_t t1 = tile + stride;
             load_tile(t1 < n_tiles ? t1 : tile, xb);
-            run_tile(tile, xa);
+            run_tile(tile, xa, FwdNoSide());
 #pragma unroll
             for (int kb = 0; kb < F16_KB_MAX; ++kb)
 #pragma unroll

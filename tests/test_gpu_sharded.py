@@ -359,6 +359,17 @@ def test_rccl_world_size_one_is_bit_identical_to_non_distributed():
         assert np.array_equal(a, b)
 
 
+def test_rccl_world_size_one_reduce_scatter_exchange_through_the_own_binding():
+    """The `reduce_scatter` exchange at RCCL world size 1 - reduce-scatter of the flat gradient, ranged Adam step, IN-PLACE all-gather of
+    the stepped chunk, all through lnr_comm_* (the library's own RCCL binding: DistContext picks it on the "nccl" backend) - is
+    bit-identical to the non-distributed run as well; and the binding's collectives are identities on every dtype it moves."""
+    n_it = 6
+    single = _single(2, n_it, keyed=True)
+    (r,) = _run(1, "nccl", 2, n_it, keyed=True, exchange="reduce_scatter")
+    assert r["step"] == n_it and r["exchange"] == "reduce_scatter"
+    assert np.array_equal(r["params"], single["params"]) and np.array_equal(r["grid"], single["grid"]) and np.array_equal(r["loss"], single["loss"])
+
+
 def test_bench_entry_point_spawns_its_ranks_and_reports_what_the_group_saw():
     """`python bench.py --gpus 2` (no launcher around it) on the one GPU of the box, ranks over gloo: the line's n_gpus is the
     process group's world size and the sharded window trains (the driver's SCALE runs use this entry point with RCCL)."""
