@@ -160,7 +160,7 @@ __device__ __forceinline__ int lnr_live_rays(int n_rays, const int32_t* n_rays_d
 // waves into a __device__ array; the launcher prints and clears them when LNR_PHASE_TIMING is set in the environment.
 #ifdef LNR_PHASE_TIMING
 #include <cstdio>
-#define LNR_N_PHASES 12
+#define LNR_N_PHASES 16
 #define PHASE_INIT() unsigned long long ph_acc[LNR_N_PHASES] = {}; unsigned long long ph_last = __builtin_amdgcn_s_memtime()
 #define PHASE(k) do { const unsigned long long ph_now = __builtin_amdgcn_s_memtime(); ph_acc[k] += ph_now - ph_last; ph_last = ph_now; } while (0)
 #define PHASE_FLUSH(sym, base) do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < LNR_N_PHASES; ++k_) if (ph_acc[k_]) atomicAdd(&sym[(base) + k_], ph_acc[k_]); } while (0)

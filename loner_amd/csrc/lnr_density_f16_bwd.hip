@@ -89,6 +89,15 @@ int LNR_BWD_ENTRY(const LnrNetSpec* spec, const float* params, const uint32_t* f
     }
 #undef LNR_F16_GEN_BWD_W
 #undef LNR_F16_GEN_BWD_A
+#ifdef LNR_PHASE_TIMING
+    if (getenv("LNR_PHASE_TIMING")) {
+        static const char* names[LNR_N_PHASES] = {"fill + first load", "step head (unit)", "forward layer 1", "forward layers 2..", "write images (hidden)",
+                                                  "dA = W^T dZ (hidden)", "barrier a", "dW hidden", "barrier b", "next step's features + d_sigma",
+                                                  "first layer dX + chain rule", "write x image", "barrier c", "dW first", "barrier d", "slab write"};
+        unsigned long long h[LNR_N_PHASES];
+        if (lnr_phase_fetch(HIP_SYMBOL(lnr_f16_bwd_phase_cycles), h, LNR_N_PHASES, st)) lnr_phase_print(LNR_BWD_FQ ? "mlp_backward_f16 fused" : "mlp_backward_f16 planes", names, h);
+    }
+#endif
     return LNR_OK;
 }
 #elif LNR_BWD_PART == 1

@@ -66,6 +66,13 @@ int LNR_FWD_ENTRY(const LnrNetSpec* spec, const float* params, const uint32_t* f
         default: if (akind == LNR_ACT_RELU) LNR_F16_GEN_FWD(16, LNR_ACT_RELU, 1); else LNR_F16_GEN_FWD(16, LNR_ACT_SINE, 1); break;   /* 256 neurons: one hidden layer */
     }
 #undef LNR_F16_GEN_FWD_A
+#ifdef LNR_PHASE_TIMING
+    if (getenv("LNR_PHASE_TIMING")) {
+        static const char* names[LNR_N_PHASES] = {"fill + first features", "next points (issue)", "layer 1 (+ side slots)", "layer 2 (+ side slots)", "output store", "left-over slots"};
+        unsigned long long h[LNR_N_PHASES];
+        if (lnr_phase_fetch(HIP_SYMBOL(lnr_f16_fwd_phase_cycles), h, LNR_N_PHASES, st)) lnr_phase_print(LNR_FWD_FQ ? "mlp_forward_f16 fused" : "mlp_forward_f16 planes", names, h);
+    }
+#endif
     return LNR_OK;
 }
 #else

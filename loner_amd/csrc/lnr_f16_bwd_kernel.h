@@ -67,6 +67,10 @@ __device__ __forceinline__ uint32_t relu_gate(uint32_t d_pair, uint32_t act_pair
 // dX = W1^T dZ is taken in a ROW ORDER that hands every lane the gradients of its OWN slots (rows 4g .. 4g+3 of row tile `it` = the
 // (sin, cos) pairs 2 it, 2 it + 1 of lane group g), so the chain rule through sin / cos is lane-local register arithmetic beside the
 // re-evaluation of the features for the weight gradient's input image.
+#ifdef LNR_PHASE_TIMING
+static __device__ unsigned long long lnr_f16_bwd_phase_cycles[LNR_N_PHASES];
+#endif
+
 template <int HT, int ACT, int NH, int KT, bool FQ = false>
 __global__ void __launch_bounds__(LNR_DENSITY_BLOCK, 1)          // one wave per SIMD: the gradient accumulators of all layers live in registers
 mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ params, const uint32_t* __restrict__ featp, int64_t m_pad,
@@ -76,6 +80,7 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
     extern __shared__ __attribute__((aligned(16))) f16 Ws[];
     using L = FwdLds<HT, NH, KT>;
     using B = BwdLds<HT, NH, KT>;
+    PHASE_INIT();
     constexpr int H = 16 * HT, KBH = L::KBH;
     constexpr int NO = HT >= 4 ? HT / 4 : 1;                               // row tiles of a gradient a wave owns: jt = wave + 4 i
     constexpr int NHID = NH - 1;                                            // hidden matrices
@@ -358,6 +363,7 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
         if (lane == 0) mx_s[wave] = mx0;
     }
     __syncthreads();
+    PHASE(0);
     for (int64_t step = 0; step < n_steps; ++step) {
         const int64_t tile = step * per_step + (int64_t)blockIdx.x * 4 + wave;
         const bool have_tile = tile < n_tiles;
@@ -392,6 +398,7 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
         }
         const float sc_dn = __uint_as_float((254u - e_unit) << 23), sc_up = __uint_as_float(e_unit << 23);
         const float dsd[2] = {ds[0] * sc_dn, ds[1] * sc_dn};
+        PHASE(1);
 
         // ---- forward, once: A[l] = inputs of hidden matrix l + 1 (B operands), Dv[l] = derivative of layer l's activation
         u32x4 A[NHID > 0 ? NHID : 1][F16_KB_MAX][2];
@@ -404,12 +411,14 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
             fwd_keep(T{}, T{}, KT_{}, S0_{}, Ws, koff0, x, A[0], Dv[0], dzp, dsd, ds);
         } else {
             fwd_keep(F{}, T{}, KT_{}, S0_{}, Ws, koff0, x, A[0], Dv[0], dzp, dsd, ds);
+            PHASE(2);
 #pragma unroll
             for (int l = 1; l < NH - 1; ++l)
                 fwd_keep(F{}, F{}, KH_{}, SH_{}, Ws + L::OFF_H + (l - 1) * H * L::SH, koffh, A[l - 1], A[l], Dv[RELU ? 0 : l], dzp, dsd, ds);
             fwd_keep(T{}, F{}, KH_{}, SH_{}, Ws + L::OFF_H + (NH - 2) * H * L::SH, koffh, A[NH - 2], A[0], Dv[0], dzp, dsd, ds);
         }
 
+        PHASE(3);
         // ---- backward through the hidden matrices l = NH-1 .. 1 (matrix l maps A[l-1] to layer l's pre-activations)
         if constexpr (NH > 1) {
 #pragma unroll
@@ -417,6 +426,7 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
                 const f16* Wl = Ws + L::OFF_H + (l - 1) * H * L::SH;
                 write_dz_image(dzp);
                 write_x_image_hidden(A[l - 1]);
+                PHASE(4);
                 // dA_{l-1} = W_l^T dZ_l (scaled domain), gated by layer l-1's derivative -> dZ_{l-1}
                 uint32_t dzn[HT][2][2];
                 f16x8 wt[2][KBH];                                          // W^T fragments of row tile it + 1 in flight behind the products of it
@@ -448,9 +458,13 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
                         }
                     }
                 }
+                PHASE(5);
                 __syncthreads();
+                PHASE(6);
                 accumulate_dw(std::integral_constant<int, HT>{}, F{}, acch[l - 1], HT, tr_lane_q);
+                PHASE(7);
                 __syncthreads();                                           // the images are rewritten by the next layer
+                PHASE(8);
 #pragma unroll
                 for (int jt = 0; jt < HT; ++jt)
 #pragma unroll
@@ -463,6 +477,7 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
         // here (L2) for the input image, together with the next step's operands (a static number of loads: the last step re-reads itself)
         if constexpr (!FQ) load_step(step, x, ds);
         load_step(step + 1 < n_steps ? step + 1 : step, xn, dsn);
+        PHASE(9);
         if constexpr (FQ) {
             // the features again (input image of the weight gradient) and, with them, the input gradient: slot pair `it` of every lane
             float xu[2][3], acc[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
@@ -539,14 +554,19 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
                 }
             }
         }
+        PHASE(10);
         write_x_image_first(x);
         {
             const float mxn = wave_max(fmaxf(fabsf(dsn[0]), fabsf(dsn[1])));   // the next step's maximum, exchanged through the other buffer
             if (lane == 0) mx_s[4 * (int)((step + 1) & 1) + wave] = mxn;
         }
+        PHASE(11);
         __syncthreads();
+        PHASE(12);
         accumulate_dw(std::integral_constant<int, 2 * KT>{}, T{}, acc0, nt0, tr_lane_p);
+        PHASE(13);
         __syncthreads();                                                   // the images are rewritten by the next step
+        PHASE(14);
 #pragma unroll
         for (int kb = 0; kb < F16_KB_MAX; ++kb) { x[kb][0] = xn[kb][0]; x[kb][1] = xn[kb][1]; }
         ds[0] = dsn[0]; ds[1] = dsn[1];
@@ -594,4 +614,6 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
     __syncthreads();
     for (int i = threadIdx.x; i < 16 * H; i += blockDim.x)
         slab[H * in_dim + NHID * H * H + i] = i < H ? ((dwo_s[i] + dwo_s[H + i]) + (dwo_s[2 * H + i] + dwo_s[3 * H + i])) : 0.0f;
+    PHASE(15);
+    PHASE_FLUSH(lnr_f16_bwd_phase_cycles, 0);
 }

@@ -43,8 +43,11 @@ template <bool SWZ> __device__ __forceinline__ int fwd_slot(int col, int row) {
 }
 
 // fp32 parameters (tinycudann layout: W1 [H][in_dim], hidden [H][H] each, output row [H]) -> the fp16 LDS copy described above.
-// Trip counts are compile-time and the loops unrolled by 8: as `for (i = tid; i < n; i += blockDim.x)` every element was one exposed
-// L2 round trip (128 in a row for the 128 x 2 network: ~20 us in front of the first MFMA of every workgroup).
+// The fill is the fixed cost of every launch (each persistent workgroup converts the whole network in front of its first MFMA), and it
+// is made of exposed L2 round trips: as `for (i = tid; i < n; i += blockDim.x)` every element was one (128 in a row for the 128 x 2
+// network: ~20 us); unrolled by 8 it was 14 rounds (~13 us of the 161 us north-star forward, profiles/r06_north_star_fixed_cost.txt).
+// Now a thread takes 2 (first layer: a (sin, cos) pair / two neighbouring features) or 4 (hidden: one lane group's four neurons)
+// consecutive parameters per load and the trip counts are compile-time and fully unrolled: every load of the fill is in flight at once.
 // FQ (the frequency encoding computed in the kernel, lnr_f16_freq.h): K position `col` of a first-layer row holds the weight of the
 // feature the fused kernels evaluate there (nf = n_frequencies), padding positions zero.
 template <int HT, int NH, int KT, bool FQ = false>
@@ -53,24 +56,69 @@ __device__ __forceinline__ void fwd_fill_weights(f16* Ws, const float* __restric
     constexpr int NT = LNR_DENSITY_BLOCK;
     const int n0 = L::H * in_dim, tid = threadIdx.x;
     static_assert((L::H * L::K0) % NT == 0 && (L::H * L::KH) % NT == 0, "whole trips");
+    constexpr int T0 = (L::H * L::K0 + 2 * NT - 1) / (2 * NT), TH = (L::H * L::KH + 4 * NT - 1) / (4 * NT);   // vector trips (the last one may be partial)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    // vector form: 8-/16-byte loads need even first-layer rows (in_dim, enc_dim) and a 16-byte aligned parameter vector
+    const bool vec = ((in_dim | enc_dim) & 1) == 0 && (reinterpret_cast<uintptr_t>(params) & 15u) == 0;
+    if (vec) {
+        f32x2 w0[T0];
+        f32x4 wh[NH > 1 ? NH - 1 : 1][TH];
+#pragma unroll
+        for (int it = 0; it < T0; ++it) {
+            const int i = 2 * (it * NT + tid), row = i / L::K0 % L::H, col = i % L::K0;     // (% H: a partial last trip re-reads row 0, not stored)
+            int k = col;
+            if constexpr (FQ) k = lnr_freq_feature_at(col, nf);          // (col even: the pair's sine; its cosine is the next parameter)
+            const bool live = FQ ? k >= 0 : col < enc_dim;
+            w0[it] = *reinterpret_cast<const f32x2*>(params + row * in_dim + (live ? k : 0));
+            if (!live) w0[it] = f32x2{0.0f, 0.0f};
+        }
+        if constexpr (NH > 1) {
+#pragma unroll
+            for (int l = 0; l < NH - 1; ++l)
+#pragma unroll
+                for (int it = 0; it < TH; ++it) {
+                    const int i = 4 * (it * NT + tid), row = i / L::KH % L::H, p = i % L::KH;
+                    const int g = (p >> 3) & 3, ii = p & 7;
+                    const int n = (p & ~31) + (ii < 4 ? 4 * g + ii : 16 + 4 * g + ii - 4);   // the neurons K slots p .. p + 3 stand for: n .. n + 3
+                    wh[l][it] = *reinterpret_cast<const f32x4*>(params + n0 + (l * L::H + row) * L::H + (n < L::H ? n : 0));
+                    if (n >= L::H) wh[l][it] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                }
+        }
+#pragma unroll
+        for (int it = 0; it < T0; ++it) {
+            const int i = 2 * (it * NT + tid), row = i / L::K0, col = i % L::K0;
+            if (i < L::H * L::K0) *reinterpret_cast<uint32_t*>(Ws + row * L::S0 + fwd_slot<L::SWZ0>(col, row)) = pack_h2(w0[it][0], w0[it][1]);
+        }
+        if constexpr (NH > 1) {
+#pragma unroll
+            for (int l = 0; l < NH - 1; ++l)
+#pragma unroll
+                for (int it = 0; it < TH; ++it) {
+                    const int i = 4 * (it * NT + tid), row = i / L::KH, p = i % L::KH;
+                    if (i < L::H * L::KH) *reinterpret_cast<uint2*>(Ws + L::OFF_H + (l * L::H + row) * L::SH + fwd_slot<L::SWZH>(p, row)) =
+                        make_uint2(pack_h2(wh[l][it][0], wh[l][it][1]), pack_h2(wh[l][it][2], wh[l][it][3]));
+                }
+        }
+    } else {
 #pragma unroll 8
-    for (int it = 0; it < L::H * L::K0 / NT; ++it) {
-        const int i = it * NT + tid, row = i / L::K0, col = i % L::K0;
-        int k = col;
-        if constexpr (FQ) k = lnr_freq_feature_at(col, nf);
-        const bool live = FQ ? k >= 0 : col < enc_dim;
-        const float w = params[row * in_dim + (live ? k : 0)];
-        Ws[row * L::S0 + fwd_slot<L::SWZ0>(col, row)] = live ? (f16)w : (f16)0.0f;
-    }
-    if constexpr (NH > 1) {
-        for (int l = 0; l < NH - 1; ++l) {
+        for (int it = 0; it < L::H * L::K0 / NT; ++it) {
+            const int i = it * NT + tid, row = i / L::K0, col = i % L::K0;
+            int k = col;
+            if constexpr (FQ) k = lnr_freq_feature_at(col, nf);
+            const bool live = FQ ? k >= 0 : col < enc_dim;
+            const float w = params[row * in_dim + (live ? k : 0)];
+            Ws[row * L::S0 + fwd_slot<L::SWZ0>(col, row)] = live ? (f16)w : (f16)0.0f;
+        }
+        if constexpr (NH > 1) {
+            for (int l = 0; l < NH - 1; ++l) {
 #pragma unroll 8
-            for (int it = 0; it < L::H * L::KH / NT; ++it) {
-                const int i = it * NT + tid, row = i / L::KH, p = i % L::KH;
-                const int g = (p >> 3) & 3, ii = p & 7;
-                const int n = (p & ~31) + (ii < 4 ? 4 * g + ii : 16 + 4 * g + ii - 4);       // the neuron K slot p stands for
-                const float w = params[n0 + (l * L::H + row) * L::H + (n < L::H ? n : 0)];
-                Ws[L::OFF_H + (l * L::H + row) * L::SH + fwd_slot<L::SWZH>(p, row)] = n < L::H ? (f16)w : (f16)0.0f;
+                for (int it = 0; it < L::H * L::KH / NT; ++it) {
+                    const int i = it * NT + tid, row = i / L::KH, p = i % L::KH;
+                    const int g = (p >> 3) & 3, ii = p & 7;
+                    const int n = (p & ~31) + (ii < 4 ? 4 * g + ii : 16 + 4 * g + ii - 4);       // the neuron K slot p stands for
+                    const float w = params[n0 + (l * L::H + row) * L::H + (n < L::H ? n : 0)];
+                    Ws[L::OFF_H + (l * L::H + row) * L::SH + fwd_slot<L::SWZH>(p, row)] = n < L::H ? (f16)w : (f16)0.0f;
+                }
             }
         }
     }
@@ -78,7 +126,13 @@ __device__ __forceinline__ void fwd_fill_weights(f16* Ws, const float* __restric
     for (int i = tid; i < L::H; i += NT) {
         Ws[L::OFF_O + i] = (f16)params[n0 + (NH - 1) * L::H * L::H + i];
         float b = 0.0f;
-        for (int k = enc_dim; k < in_dim; ++k) b += (float)(f16)params[i * in_dim + k];
+        for (int k0 = enc_dim; k0 < in_dim; k0 += 8) {                    // (eight loads in flight; the sum in index order)
+            float w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = params[i * in_dim + (k0 + j < in_dim ? k0 + j : k0)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (k0 + j < in_dim) b += (float)(f16)w[j];
+        }
         bias[i] = b;
     }
 }
@@ -163,6 +217,10 @@ __device__ __forceinline__ void fwd_layer(const f16* Wl, const int (&koff)[F16_K
     finish(HT - 1, Z[(HT - 1) & 1]);
 }
 
+#ifdef LNR_PHASE_TIMING
+static __device__ unsigned long long lnr_f16_fwd_phase_cycles[LNR_N_PHASES];
+#endif
+
 // FQ: the network's input is the frequency encoding of `src`'s points, evaluated here (lnr_f16_freq.h); featp / m_pad unused.
 template <int HT, int ACT, int NH, int KT, int CT, bool FQ = false>
 __global__ void __launch_bounds__(LNR_DENSITY_BLOCK, 2)          // two waves per SIMD: <= 256 registers (two workgroups share a CU's LDS)
@@ -174,6 +232,7 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
     static_assert(NH >= 1 && NH <= F16_NH_MAX && KT >= 1 && KT <= F16_KB_MAX, "shape");
     static_assert(L::KBH <= F16_KB_MAX || NH == 1, "256 neurons: one hidden layer");
     constexpr int TS = 16 * CT;                                           // samples per wave step
+    PHASE_INIT();
     fwd_fill_weights<HT, NH, KT, FQ>(Ws, params, spec.in_dim, spec.enc_dim, spec.n_frequencies);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -263,7 +322,9 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
             fwd_layer<HT, ACT, KT, L::S0, CT, true, true, 0, SideT>(Ws, koff0, bias_lane, act, x, B1, wo, part, side);
         } else if constexpr (NH == 2) {
             fwd_layer<HT, ACT, KT, L::S0, CT, false, true, 0, SideT>(Ws, koff0, bias_lane, act, x, B1, wo, part, side);
+            PHASE(2);
             fwd_layer<HT, ACT, L::KBH, L::SH, CT, true, false, HT, SideT>(Ws + L::OFF_H, koffh, bias_lane, act, B1, B2, wo, part, side);
+            PHASE(3);
         } else {
             fwd_layer<HT, ACT, KT, L::S0, CT, false, true, 0, SideT>(Ws, koff0, bias_lane, act, x, B1, wo, part, side);
             fwd_layer<HT, ACT, L::KBH, L::SH, CT, false, false, HT, SideT>(Ws + L::OFF_H, koffh, bias_lane, act, B1, B2, wo, part, side);
@@ -277,11 +338,13 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
             const int64_t m = tile * TS + 16 * t + c;
             if (g == 0 && m < M) sigma[m] = finite_or_clipped<true>(v, clip_flag);
         }
+        PHASE(4);
     };
     const int64_t stride = (int64_t)gridDim.x * nw;
     int64_t tile = (int64_t)blockIdx.x * nw + wave;
     u32x4 xa[F16_KB_MAX][CT], xb[F16_KB_MAX][CT];
     if (tile < n_tiles) load_tile(tile, xa);
+    PHASE(0);
     if constexpr (FQ && ACT >= 0) {
         // fused frequency encoding: the NEXT step's points are requested in front of this step's layers, and its features are evaluated
         // slot by slot BEHIND the MFMAs of this step's row tiles (HT x NH of them; what does not fit there follows the last layer)
@@ -297,15 +360,19 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
             const int64_t t1 = tile + stride, t2 = tile + 2 * stride;
             fq_points(t1 < n_tiles ? t1 : tile, xu);
             zero_x(xb);
+            PHASE(1);
             run_tile(tile, xa, [&](int k) __attribute__((always_inline)) { fq_slot(k, xu, xb); });
 #pragma unroll
             for (int sl = N_SIDE; sl < 4 * KT; ++sl) fq_slot(sl, xu, xb);
+            PHASE(5);
             if (t1 >= n_tiles) break;
             fq_points(t2 < n_tiles ? t2 : t1, xu);
             zero_x(xa);
+            PHASE(1);
             run_tile(t1, xb, [&](int k) __attribute__((always_inline)) { fq_slot(k, xu, xa); });
 #pragma unroll
             for (int sl = N_SIDE; sl < 4 * KT; ++sl) fq_slot(sl, xu, xa);
+            PHASE(5);
         }
     } else if constexpr (ACT >= 0) {
         for (; tile < n_tiles; tile += 2 * stride) {                      // two steps per trip: the feature buffers alternate
@@ -329,4 +396,5 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
                 for (int t = 0; t < CT; ++t) xa[kb][t] = xb[kb][t];
         }
     }
+    PHASE_FLUSH(lnr_f16_fwd_phase_cycles, 0);
 }
