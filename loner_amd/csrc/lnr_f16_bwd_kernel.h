@@ -139,42 +139,71 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
     constexpr int fq_slots = LNR_FREQ_SLOTS_OF_KT(KT);
     const float fq_pg = __uint_as_float((uint32_t)(127 + g) << 23);        // 2^g
     const bool fq_uni = FQ && ray_uniform(src, 32u);                       // a step's 32 samples lie on one ray: its record through the scalar cache
-    // unit-cube point of the lane's sample in column tile t of `tile` (clamped to the last live sample)
-    auto unit_point_of_column = [&](int64_t tile, int t, float (&xu)[3]) {
-        int64_t m = tile * 32 + 16 * t + c;
-        if (m >= M) m = M - 1;
-        RawPoint rp;
-        load_raw_point(src, (uint32_t)m, src.pts ? 0u : (uint32_t)m / (uint32_t)src.n_samples, rp, fq_uni);
-        unit_point(src, rp, xu);
+    // FQ: the points of a step's two column tiles are REQUESTED (loads only) well before they are turned into unit-cube coordinates:
+    // with one wave per SIMD nothing else covers a memory round trip (phase timers, profiles/r06_fp16_mlp_phases.txt: requested and
+    // consumed in one place, the next step's points were 12 % of the kernel, the current step's re-read part of another 22 %).
+    auto request_points = [&](int64_t tile, RawPoint (&rp)[2]) __attribute__((always_inline)) {
+        if (fq_uni) {
+            // the step's 32 samples lie on one ray: its index from wave-uniform operands (one scalar division, not one per lane and tile)
+            const uint32_t m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tile * 32));
+            const uint32_t ray = m0 / (uint32_t)__builtin_amdgcn_readfirstlane(src.n_samples);
 #pragma unroll
-        for (int d = 0; d < 3; ++d) xu[d] *= fq_pg;                        // the lane's share of the frequency (exact)
+            for (int t = 0; t < 2; ++t) load_raw_point(src, m0 + 16u * t + (uint32_t)c, ray, rp[t], true);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                int64_t m = tile * 32 + 16 * t + c;
+                if (m >= M) m = M - 1;                                      // (clamped to the last live sample)
+                load_raw_point(src, (uint32_t)m, src.pts ? 0u : (uint32_t)m / (uint32_t)src.n_samples, rp[t], false);
+            }
+        }
+    };
+    auto unit_points = [&](const RawPoint (&rp)[2], float (&xu)[2][3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            unit_point(src, rp[t], xu[t]);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) xu[t][d] *= fq_pg;                  // the lane's share of the frequency (exact)
+        }
+    };
+    // one slot of a step's features (both column tiles); pinned where it is written (see fq_slot of the forward kernel)
+    auto fq_slot = [&](int sl, const float (&xu)[2][3], u32x4 (&x)[F16_KB_MAX][2]) __attribute__((always_inline)) {
+        if (sl < fq_slots) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float d0, d1;
+                float y = xu[t][sl % 3];
+                asm volatile("" : "+v"(y));
+                uint32_t v = freq_pair<false>(y * lnr_freq_slot_scale(sl), 0.0f, d0, d1);
+                asm volatile("" : "+v"(v));
+                x[sl >> 2][t][sl & 3] = v;
+            }
+        }
+    };
+    auto zero_x = [&](u32x4 (&x)[F16_KB_MAX][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kb = 0; kb < F16_KB_MAX; ++kb) { x[kb][0] = u32x4{0u, 0u, 0u, 0u}; x[kb][1] = u32x4{0u, 0u, 0u, 0u}; }
     };
 
     // features (B operands of the first layer; the constant-one padding reads as zero, its weights' gradient is accb below) and
     // d_sigma of a step; a wave without a tile re-reads the last one with d_sigma = 0 (finite operands, zero gradient)
-    auto load_step = [&](int64_t step, u32x4 (&x)[F16_KB_MAX][2], float (&ds)[2]) {
+    float xu_c[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};          // FQ: the current step's points (x 2^g), kept for its first-layer stage
+    auto load_step = [&](int64_t step, u32x4 (&x)[F16_KB_MAX][2], float (&ds)[2]) {     // (FQ: the first step only)
         const int64_t tile = step * per_step + (int64_t)blockIdx.x * 4 + wave;
         const bool have = tile < n_tiles;
         const int64_t tc = have ? tile : n_tiles - 1;
         const uint32_t m0 = (uint32_t)(tc * 32) * 4u;
+        if constexpr (FQ) {
+            RawPoint rp[2];
+            request_points(tc, rp);
+            unit_points(rp, xu_c);
+            zero_x(x);
+#pragma unroll
+            for (int sl = 0; sl < 4 * KT; ++sl) fq_slot(sl, xu_c, x);
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            if constexpr (FQ) {
-                float xu[3];
-                unit_point_of_column(tc, t, xu);
-#pragma unroll
-                for (int kb = 0; kb < F16_KB_MAX; ++kb)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int sl = 4 * kb + q;
-                        uint32_t v = 0u;
-                        if (kb < KT && sl < fq_slots) {
-                            float d0, d1;
-                            v = freq_pair<false>(xu[sl % 3] * lnr_freq_slot_scale(sl), 0.0f, d0, d1);
-                        }
-                        x[kb][t][q] = v;
-                    }
-            } else {
+            if constexpr (!FQ) {
 #pragma unroll
             for (int kb = 0; kb < F16_KB_MAX; ++kb)
 #pragma unroll
@@ -293,7 +322,8 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
     // dW += dZ^T (own row tiles) x inputs^T over the four waves' images, accumulated by the MFMAs themselves; NT_L column tiles
     // (nt of them live).  Work units = (wave image, half of the column tiles); the fragments of the next unit are requested before
     // the products of the current one are issued.
-    auto accumulate_dw = [&](auto nt_tag, auto ones_tag, f32x4 (&acc)[NO][decltype(nt_tag)::value], int nt, int xlane) {
+    // side(u): independent VALU work issued behind the MFMAs of unit u (FQ: one slot of the next step's features)
+    auto accumulate_dw = [&](auto nt_tag, auto ones_tag, f32x4 (&acc)[NO][decltype(nt_tag)::value], int nt, int xlane, auto side) {
         constexpr int NT_L = decltype(nt_tag)::value;
         constexpr bool ONES = decltype(ones_tag)::value;                    // also accumulate dZ^T x 1 (the padding columns of the first layer)
         constexpr int HALF = NT_L >= 4 ? NT_L / 2 : NT_L, NU = 4 * (NT_L / HALF);
@@ -329,8 +359,10 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
                     for (int i = 0; i < NO; ++i) acc[i][k0 + k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u & 1][i], b[u & 1][k], acc[i][k0 + k], 0, 0, 0);
                 }
             }
+            side(u);
         }
     };
+    constexpr int NU_FIRST = 4 * ((2 * KT) / ((2 * KT) >= 4 ? KT : 2 * KT));   // units of the first layer's accumulate_dw (its NU)
 
     // W^T fragments through the transposing read: rows = four consecutive output neurons j, columns = 16 inputs of tile `it`.
     // Hidden matrices: input neuron n of tile it sits at K slot 32 (it >> 1) + 8 (n % 16 / 4) + 4 (it & 1) + n % 4 of its row.
@@ -461,7 +493,7 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
                 PHASE(5);
                 __syncthreads();
                 PHASE(6);
-                accumulate_dw(std::integral_constant<int, HT>{}, F{}, acch[l - 1], HT, tr_lane_q);
+                accumulate_dw(std::integral_constant<int, HT>{}, F{}, acch[l - 1], HT, tr_lane_q, FwdNoSide());
                 PHASE(7);
                 __syncthreads();                                           // the images are rewritten by the next layer
                 PHASE(8);
@@ -475,15 +507,29 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
         write_dz_image(dzp);
         // The features are not kept across the hidden layers (32 registers at the point of highest pressure): they are read again
         // here (L2) for the input image, together with the next step's operands (a static number of loads: the last step re-reads itself)
-        if constexpr (!FQ) load_step(step, x, ds);
-        load_step(step + 1 < n_steps ? step + 1 : step, xn, dsn);
+        RawPoint rn[2];                                                    // FQ: the next step's points and d_sigma, requested here ...
+        float dsn_raw[2] = {0.0f, 0.0f};
+        bool dsn_ok[2] = {false, false};
+        if constexpr (!FQ) {
+            load_step(step, x, ds);
+            load_step(step + 1 < n_steps ? step + 1 : step, xn, dsn);
+        } else {
+            const int64_t ntile = (step + 1 < n_steps ? step + 1 : step) * per_step + (int64_t)blockIdx.x * 4 + wave;
+            const bool nhave = ntile < n_tiles;
+            const int64_t ntc = nhave ? ntile : n_tiles - 1;
+            request_points(ntc, rn);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int64_t m = ntc * 32 + 16 * t + c;
+                dsn_ok[t] = nhave && m < M;
+                dsn_raw[t] = d_sigma[dsn_ok[t] ? m : 0];
+            }
+        }
         PHASE(9);
         if constexpr (FQ) {
             // the features again (input image of the weight gradient) and, with them, the input gradient: slot pair `it` of every lane
-            float xu[2][3], acc[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
-            const int64_t tcl = have_tile ? tile : n_tiles - 1;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) unit_point_of_column(tcl, t, xu[t]);
+            float (&xu)[2][3] = xu_c;
+            float acc[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
             const float dph_g = fq_pg * LNR_PI_F;                          // d(phase)/dx of the lane's share; x 2^(4 (sl / 3)) per slot
 #pragma unroll
             for (int kb = 0; kb < F16_KB_MAX; ++kb) { x[kb][0] = u32x4{0u, 0u, 0u, 0u}; x[kb][1] = u32x4{0u, 0u, 0u, 0u}; }
@@ -556,6 +602,13 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
         }
         PHASE(10);
         write_x_image_first(x);
+        float xu_n[2][3];
+        if constexpr (FQ) {                                                // ... and consumed here, a first-layer stage later
+#pragma unroll
+            for (int t = 0; t < 2; ++t) dsn[t] = dsn_ok[t] ? dsn_raw[t] : 0.0f;
+            unit_points(rn, xu_n);
+            zero_x(xn);
+        }
         {
             const float mxn = wave_max(fmaxf(fabsf(dsn[0]), fabsf(dsn[1])));   // the next step's maximum, exchanged through the other buffer
             if (lane == 0) mx_s[4 * (int)((step + 1) & 1) + wave] = mxn;
@@ -563,19 +616,38 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
         PHASE(11);
         __syncthreads();
         PHASE(12);
-        accumulate_dw(std::integral_constant<int, 2 * KT>{}, T{}, acc0, nt0, tr_lane_p);
+        if constexpr (FQ) {
+            // the next step's features, one slot behind the MFMAs of each unit of the weight gradient (the rest after it)
+            accumulate_dw(std::integral_constant<int, 2 * KT>{}, T{}, acc0, nt0, tr_lane_p, [&](int u) __attribute__((always_inline)) { fq_slot(u, xu_n, xn); });
+#pragma unroll
+            for (int sl = NU_FIRST; sl < 4 * KT; ++sl) fq_slot(sl, xu_n, xn);
+        } else {
+            accumulate_dw(std::integral_constant<int, 2 * KT>{}, T{}, acc0, nt0, tr_lane_p, FwdNoSide());
+        }
         PHASE(13);
         __syncthreads();                                                   // the images are rewritten by the next step
         PHASE(14);
 #pragma unroll
         for (int kb = 0; kb < F16_KB_MAX; ++kb) { x[kb][0] = xn[kb][0]; x[kb][1] = xn[kb][1]; }
         ds[0] = dsn[0]; ds[1] = dsn[1];
+        if constexpr (FQ) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) xu_c[t][d] = xu_n[t][d];
+        }
     }
 
-    // ---- the workgroup's slab (parameter layout, unpadded): every row tile is owned by exactly one wave
+    // ---- the workgroup's slab (parameter layout, unpadded): every row tile is owned by exactly one wave.  A row tile's 16 rows are one
+    // contiguous piece of the slab (16 x in_dim / 16 x H floats): the wave lays it out in its own image area (free after the last
+    // barrier; LDS operations of one wave complete in order, so no barrier) and copies it out as whole 256-byte rows of the wave.
+    // Written straight from the accumulator layout - 4-byte stores at a row stride per lane, for the fused first layer at scattered
+    // feature positions too - the 120 KB slab of the 128 x 2 network took 25 - 30 us per workgroup (profiles/r06_fp16_mlp_phases.txt).
     const int n_mlp = spec.n_mlp_params, in_dim = spec.in_dim;
     const float unit = __uint_as_float(e_unit << 23);
     float* slab = slabs + (size_t)blockIdx.x * n_mlp;
+    float* stg = reinterpret_cast<float*>(img);
+    static_assert((size_t)B::IMG_WAVE * sizeof(f16) >= 16u * 32u * KT * sizeof(float) && (size_t)B::IMG_WAVE * sizeof(f16) >= 16u * H * sizeof(float), "a row tile fits the wave's image area");
 #pragma unroll
     for (int i = 0; i < NO; ++i) {
         const int jt = wave + 4 * i;
@@ -587,18 +659,26 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
                     const int col = 16 * kt + c;
                     if constexpr (FQ) {                                     // K position -> the feature evaluated there; the ones-padding columns once
                         const int k = lnr_freq_feature_at(col, spec.n_frequencies);
-                        if (k >= 0) slab[(16 * jt + 4 * g + r) * in_dim + k] = unit * acc0[i][kt][r];
-                        if (kt == 0 && spec.enc_dim + c < in_dim) slab[(16 * jt + 4 * g + r) * in_dim + spec.enc_dim + c] = unit * accb[i][r];
+                        if (k >= 0) stg[(4 * g + r) * in_dim + k] = unit * acc0[i][kt][r];
+                        if (kt == 0 && spec.enc_dim + c < in_dim) stg[(4 * g + r) * in_dim + spec.enc_dim + c] = unit * accb[i][r];
                     } else
-                    if (col < in_dim) slab[(16 * jt + 4 * g + r) * in_dim + col] = unit * (col < spec.enc_dim ? acc0[i][kt][r] : accb[i][r]);
+                    if (col < in_dim) stg[(4 * g + r) * in_dim + col] = unit * (col < spec.enc_dim ? acc0[i][kt][r] : accb[i][r]);
                 }
+            {
+                float* dst = slab + 16 * jt * in_dim;
+                for (int j = lane; j < 16 * in_dim; j += 64) dst[j] = stg[j];
+            }
             if constexpr (NHID > 0) {
 #pragma unroll
-                for (int l = 0; l < NHID; ++l)
+                for (int l = 0; l < NHID; ++l) {
 #pragma unroll
                     for (int kt = 0; kt < HT; ++kt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) slab[H * in_dim + l * H * H + (16 * jt + 4 * g + r) * H + 16 * kt + c] = unit * acch[l][i][kt][r];
+                        for (int r = 0; r < 4; ++r) stg[(4 * g + r) * H + 16 * kt + c] = unit * acch[l][i][kt][r];
+                    float* dst = slab + H * in_dim + l * H * H + 16 * jt * H;
+#pragma unroll
+                    for (int j = 0; j < 16 * H / 64; ++j) dst[64 * j + lane] = stg[64 * j + lane];
+                }
             }
         }
     }

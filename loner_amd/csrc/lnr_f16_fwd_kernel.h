@@ -263,18 +263,38 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
     // the features of the NEXT step are in flight while this one goes through the layers
     // (samples past M: their planes are padded to m_pad, whatever they hold only reaches columns that are never stored)
     // FQ: the unit-cube points of a step's samples (x the lane's 2^g) ...
-    auto fq_points = [&](int64_t tile, float (&xu)[CT][3]) __attribute__((always_inline)) {
+    // The loads and the arithmetic are separate: the main loop requests a step's points one whole step before it turns them into
+    // features (phase timers, profiles/r06_fp16_mlp_phases.txt: requested and consumed in one place, the round trip was 35 % of a wave's
+    // time with two waves per SIMD to cover it).
+    auto fq_request = [&](int64_t tile, RawPoint (&rp)[CT]) __attribute__((always_inline)) {
+        if (fq_uni) {
+            // a wave step's 16 CT samples lie on ONE ray: its index from wave-uniform operands (one scalar division instead of a
+            // per-lane one for every column tile), its record through the scalar cache (lnr_encoding.h); M % TS == 0: nothing to clamp
+            const uint32_t m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tile * TS));
+            const uint32_t ray = m0 / (uint32_t)__builtin_amdgcn_readfirstlane(src.n_samples);
+#pragma unroll
+            for (int t = 0; t < CT; ++t) load_raw_point(src, m0 + 16u * t + (uint32_t)c, ray, rp[t], true);
+        } else {
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                int64_t m = tile * TS + 16 * t + c;
+                if (m >= M) m = M - 1;                                 // (columns past the last sample are never stored)
+                load_raw_point(src, (uint32_t)m, src.pts ? 0u : (uint32_t)m / (uint32_t)src.n_samples, rp[t], false);
+            }
+        }
+    };
+    auto fq_unit = [&](const RawPoint (&rp)[CT], float (&xu)[CT][3]) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
-            int64_t m = tile * TS + 16 * t + c;
-            if (m >= M) m = M - 1;                                     // (columns past the last sample are never stored)
-            RawPoint rp;
-            // (fq_uni: a wave step's 16 CT samples lie on ONE ray - its record comes through the scalar cache, lnr_encoding.h)
-            load_raw_point(src, (uint32_t)m, src.pts ? 0u : (uint32_t)m / (uint32_t)src.n_samples, rp, fq_uni);
-            unit_point(src, rp, xu[t]);
+            unit_point(src, rp[t], xu[t]);
 #pragma unroll
             for (int d = 0; d < 3; ++d) xu[t][d] *= fq_pg;              // the lane's share of the frequency (exact)
         }
+    };
+    auto fq_points = [&](int64_t tile, float (&xu)[CT][3]) __attribute__((always_inline)) {
+        RawPoint rp[CT];
+        fq_request(tile, rp);
+        fq_unit(rp, xu);
     };
     // ... and ONE slot of their features (both column tiles): the unit of work interleaved with the previous step's MFMAs
     auto fq_slot = [&](int sl, const float (&xu)[CT][3], u32x4 (&x)[F16_KB_MAX][CT]) __attribute__((always_inline)) {
@@ -282,7 +302,13 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
 #pragma unroll
             for (int t = 0; t < CT; ++t) {
                 float d0, d1;
-                x[sl >> 2][t][sl & 3] = freq_pair<false>(xu[t][sl % 3] * lnr_freq_slot_scale(sl), 0.0f, d0, d1);
+                // pinned between two empty volatile statements: nothing orders this arithmetic otherwise, and instruction selection
+                // gathered the slots of a whole step in front of its first MFMA (the sched_barriers only bind the later scheduler)
+                float y = xu[t][sl % 3];
+                asm volatile("" : "+v"(y));
+                uint32_t v = freq_pair<false>(y * lnr_freq_slot_scale(sl), 0.0f, d0, d1);
+                asm volatile("" : "+v"(v));
+                x[sl >> 2][t][sl & 3] = v;
             }
         }
     };
@@ -356,9 +382,12 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
 #pragma unroll
                 for (int t = 0; t < CT; ++t) x[kb][t] = u32x4{0u, 0u, 0u, 0u};
         };
+        RawPoint rp[CT];                                                  // the points of step tile + stride, requested one step earlier
+        if (tile < n_tiles) fq_request(tile + stride < n_tiles ? tile + stride : tile, rp);
         for (; tile < n_tiles; tile += 2 * stride) {
-            const int64_t t1 = tile + stride, t2 = tile + 2 * stride;
-            fq_points(t1 < n_tiles ? t1 : tile, xu);
+            const int64_t t1 = tile + stride, t2 = tile + 2 * stride, t3 = tile + 3 * stride;
+            fq_unit(rp, xu);
+            fq_request(t2 < n_tiles ? t2 : tile, rp);
             zero_x(xb);
             PHASE(1);
             run_tile(tile, xa, [&](int k) __attribute__((always_inline)) { fq_slot(k, xu, xb); });
@@ -366,7 +395,8 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
             for (int sl = N_SIDE; sl < 4 * KT; ++sl) fq_slot(sl, xu, xb);
             PHASE(5);
             if (t1 >= n_tiles) break;
-            fq_points(t2 < n_tiles ? t2 : t1, xu);
+            fq_unit(rp, xu);
+            fq_request(t3 < n_tiles ? t3 : t1, rp);
             zero_x(xa);
             PHASE(1);
             run_tile(t1, xb, [&](int k) __attribute__((always_inline)) { fq_slot(k, xu, xa); });

@@ -1,0 +1,9 @@
+#!/bin/bash
+# round 6, call 14: vectorised weight fill (fixed cost of the fp16 MLP launches) + per-phase cycles of the fused frequency kernels
+set +e
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -m gpu -q -x --no-header -p no:cacheprovider -k "fp16 or freq or f16 or general" > gpurun_out/pytest_gpu_subset.log 2>&1 < /dev/null; tail -3 gpurun_out/pytest_gpu_subset.log
+timeout 300 python tools/probe_ns_sizes.py 2>&1 < /dev/null | grep -E "^[0-9]" > gpurun_out/r06_ns_sizes.txt; cat gpurun_out/r06_ns_sizes.txt
+LNR_PHASE_TIMING=1 LNR_LIB_PATH=$PWD/loner_amd/_lib/libloner_hip_phase.so timeout 300 python tools/probe_ns_trace.py 4096 > gpurun_out/r06_ns_phases.txt 2>&1 < /dev/null
+grep "lnr phases" gpurun_out/r06_ns_phases.txt | tail -22
