@@ -394,8 +394,8 @@ def north_star_network_leg(n_rays, n_samples, device):
     ds = torch.randn(n_rays, n_samples, generator=g).to(device); dr = torch.zeros(n_rays, 13, device=device)
     p = (torch.rand(int(spec.n_params), generator=g) - 0.5).to(device); grad = torch.zeros_like(p)
 
-    def timed(fn, n=5):
-        fn(); torch.cuda.synchronize()
+    def timed(fn, n=20):
+        fn(); fn(); torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(n):

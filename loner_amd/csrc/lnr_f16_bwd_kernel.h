@@ -139,23 +139,42 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
     constexpr int fq_slots = LNR_FREQ_SLOTS_OF_KT(KT);
     const float fq_pg = __uint_as_float((uint32_t)(127 + g) << 23);        // 2^g
     const bool fq_uni = FQ && ray_uniform(src, 32u);                       // a step's 32 samples lie on one ray: its record through the scalar cache
+    const int ns_shift = (src.n_samples > 0 && (src.n_samples & (src.n_samples - 1)) == 0) ? __builtin_ctz((unsigned)src.n_samples) : -1;   // samples per ray a power of two: a shift
     // FQ: the points of a step's two column tiles are REQUESTED (loads only) well before they are turned into unit-cube coordinates:
     // with one wave per SIMD nothing else covers a memory round trip (phase timers, profiles/r06_fp16_mlp_phases.txt: requested and
     // consumed in one place, the next step's points were 12 % of the kernel, the current step's re-read part of another 22 %).
     auto request_points = [&](int64_t tile, RawPoint (&rp)[2]) __attribute__((always_inline)) {
+        uint32_t mm[2], rr[2];
         if (fq_uni) {
-            // the step's 32 samples lie on one ray: its index from wave-uniform operands (one scalar division, not one per lane and tile)
+            // the step's samples lie on ONE ray: its index from wave-uniform operands (a shift or one scalar division instead of a
+            // per-lane division for every column tile); nothing to clamp (the sample count is a multiple of the step)
             const uint32_t m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tile * 32));
-            const uint32_t ray = m0 / (uint32_t)__builtin_amdgcn_readfirstlane(src.n_samples);
+            const uint32_t ray = ns_shift >= 0 ? m0 >> ns_shift : m0 / (uint32_t)__builtin_amdgcn_readfirstlane(src.n_samples);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) load_raw_point(src, m0 + 16u * t + (uint32_t)c, ray, rp[t], true);
+            for (int t = 0; t < 2; ++t) { mm[t] = m0 + 16u * t + (uint32_t)c; rr[t] = ray; }
         } else {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 int64_t m = tile * 32 + 16 * t + c;
                 if (m >= M) m = M - 1;                                      // (clamped to the last live sample)
-                load_raw_point(src, (uint32_t)m, src.pts ? 0u : (uint32_t)m / (uint32_t)src.n_samples, rp[t], false);
+                mm[t] = (uint32_t)m;
+                rr[t] = src.pts ? 0u : (uint32_t)m / (uint32_t)src.n_samples;
             }
+        }
+        // The SAME seven vector loads per column tile whatever the source, only their addresses differ (points: origin = the point,
+        // direction / depth = any valid address, ignored by unit_point).  Loads inside the branches of load_raw_point ended in
+        // register copies of the loaded values at the join - a wait for them right where they had been issued - and a scalar load
+        // of the ray record would share its counter with the LDS (lgkmcnt): the next weight fragment would wait for it.
+        const bool is_pts = src.pts != nullptr;
+        const float* b_od = is_pts ? src.pts : src.rays;
+        const float* b_z = is_pts ? src.pts : src.z;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint32_t oo = is_pts ? mm[t] * 12u : rr[t] * (uint32_t)(LNR_RAY_STRIDE * 4);
+            const uint32_t od = is_pts ? 0u : oo + 12u, oz = is_pts ? 0u : mm[t] * 4u;
+            rp[t].o0 = ld32<float>(b_od, oo); rp[t].o1 = ld32<float>(b_od, oo + 4u); rp[t].o2 = ld32<float>(b_od, oo + 8u);
+            rp[t].d0 = ld32<float>(b_od, od); rp[t].d1 = ld32<float>(b_od, od + 4u); rp[t].d2 = ld32<float>(b_od, od + 8u);
+            rp[t].z = ld32<float>(b_z, oz);
         }
     };
     auto unit_points = [&](const RawPoint (&rp)[2], float (&xu)[2][3]) __attribute__((always_inline)) {
@@ -249,8 +268,13 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
                     dzp[jt][t][0] = pack_h2(dz[0], dz[1]);
                     dzp[jt][t][1] = pack_h2(dz[2], dz[3]);
                 } else {
-                    Aout[jt >> 1][t][2 * (jt & 1)] = pack_h2(fwd_act<ACT>(z[t][0], act), fwd_act<ACT>(z[t][1], act));
-                    Aout[jt >> 1][t][2 * (jt & 1) + 1] = pack_h2(fwd_act<ACT>(z[t][2], act), fwd_act<ACT>(z[t][3], act));
+                    if constexpr (RELU) {
+                        Aout[jt >> 1][t][2 * (jt & 1)] = relu_pack_h2(z[t][0], z[t][1]);
+                        Aout[jt >> 1][t][2 * (jt & 1) + 1] = relu_pack_h2(z[t][2], z[t][3]);
+                    } else {
+                        Aout[jt >> 1][t][2 * (jt & 1)] = pack_h2(fwd_act<ACT>(z[t][0], act), fwd_act<ACT>(z[t][1], act));
+                        Aout[jt >> 1][t][2 * (jt & 1) + 1] = pack_h2(fwd_act<ACT>(z[t][2], act), fwd_act<ACT>(z[t][3], act));
+                    }
                     if constexpr (!RELU) {
                         Dout[jt >> 1][t][2 * (jt & 1)] = pack_h2(gact_d<ACT>(z[t][0], act), gact_d<ACT>(z[t][1], act));
                         Dout[jt >> 1][t][2 * (jt & 1) + 1] = pack_h2(gact_d<ACT>(z[t][2], act), gact_d<ACT>(z[t][3], act));
@@ -508,6 +532,7 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
         // The features are not kept across the hidden layers (32 registers at the point of highest pressure): they are read again
         // here (L2) for the input image, together with the next step's operands (a static number of loads: the last step re-reads itself)
         RawPoint rn[2];                                                    // FQ: the next step's points and d_sigma, requested here ...
+        float xu_n[2][3];                                                  // ... and consumed behind the first layer's products
         float dsn_raw[2] = {0.0f, 0.0f};
         bool dsn_ok[2] = {false, false};
         if constexpr (!FQ) {
@@ -557,6 +582,18 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
                     }
                 }
             }
+            // the next step's points and d_sigma are taken over HERE, in front of the d_pts stores: loads and stores share one in-order
+            // counter (vmcnt) and the stores sit in a branch, so a wait for these loads placed behind them would be a wait for the
+            // stores' acknowledgement (a memory round trip with nothing to cover it)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) dsn[t] = dsn_ok[t] ? dsn_raw[t] : 0.0f;
+            unit_points(rn, xu_n);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {                                  // (pinned: nothing else keeps this arithmetic in front of the stores)
+                asm volatile("" : "+v"(dsn[t]));
+#pragma unroll
+                for (int d = 0; d < 3; ++d) asm volatile("" : "+v"(xu_n[t][d]));
+            }
             if (want_dfeat) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
@@ -602,13 +639,7 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
         }
         PHASE(10);
         write_x_image_first(x);
-        float xu_n[2][3];
-        if constexpr (FQ) {                                                // ... and consumed here, a first-layer stage later
-#pragma unroll
-            for (int t = 0; t < 2; ++t) dsn[t] = dsn_ok[t] ? dsn_raw[t] : 0.0f;
-            unit_points(rn, xu_n);
-            zero_x(xn);
-        }
+        if constexpr (FQ) zero_x(xn);
         {
             const float mxn = wave_max(fmaxf(fabsf(dsn[0]), fabsf(dsn[1])));   // the next step's maximum, exchanged through the other buffer
             if (lane == 0) mx_s[4 * (int)((step + 1) & 1) + wave] = mxn;

@@ -15,11 +15,22 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f16x8 frag_from_dwords(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
     return __builtin_bit_cast(f16x8, u32x4{a, b, c, d});
 }
+// (as ONE vector conversion: v_cvt_pk_f16_f32, round to nearest even; written as two scalar casts the pair is two v_cvt_f16_f32 and a
+// v_perm_b32 whenever the values come out of an MFMA)
 __device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    return __builtin_bit_cast(uint32_t, h2{(f16)lo, (f16)hi});
+    typedef float f2_ __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2_{lo, hi}, h2));
 }
 __device__ __forceinline__ float round_f16(float v) { return (float)(f16)v; }
+// ReLU of two values rounded to fp16, on the packed pair: one v_pk_max_i16 on the bit patterns (negative halves, -0 included, are
+// negative integers; rounding and max(., 0) commute: rounding is monotone and keeps 0) instead of one integer max per fp32 value in
+// front of the conversion.  A NaN with a clear sign bit stays NaN, as with the fp32 form (fwd_act).
+__device__ __forceinline__ uint32_t relu_pack_h2(float lo, float hi) {
+    typedef short s16x2_ __attribute__((ext_vector_type(2)));
+    const s16x2_ v = __builtin_bit_cast(s16x2_, pack_h2(lo, hi));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(v, s16x2_{0, 0}));
+}
 
 __device__ __forceinline__ int64_t live_samples(int64_t n_points, const int32_t* n_rays_dev, int n_rays, int n_samples) {
     return n_rays_dev ? (int64_t)lnr_live_rays(n_rays, n_rays_dev) * n_samples : n_points;

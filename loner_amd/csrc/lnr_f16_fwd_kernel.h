@@ -189,9 +189,17 @@ __device__ __forceinline__ void fwd_layer(const f16* Wl, const int (&koff)[F16_K
             if constexpr (LAST) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) part[t] = __builtin_fmaf(wo[jt][r], fwd_act<ACT>(z[t][r], act), part[t]);
+                // (pinned to its row: left free, one column tile's whole chain - 32 dependent fmas - was sunk below the layer, behind the
+                // other tile's store branch, with no MFMA left to issue beside it)
+                asm volatile("" : "+v"(part[t]));
             } else {
-                Bout[jt >> 1][t][2 * (jt & 1)] = pack_h2(fwd_act<ACT>(z[t][0], act), fwd_act<ACT>(z[t][1], act));
-                Bout[jt >> 1][t][2 * (jt & 1) + 1] = pack_h2(fwd_act<ACT>(z[t][2], act), fwd_act<ACT>(z[t][3], act));
+                if constexpr (ACT == LNR_ACT_RELU) {
+                    Bout[jt >> 1][t][2 * (jt & 1)] = relu_pack_h2(z[t][0], z[t][1]);
+                    Bout[jt >> 1][t][2 * (jt & 1) + 1] = relu_pack_h2(z[t][2], z[t][3]);
+                } else {
+                    Bout[jt >> 1][t][2 * (jt & 1)] = pack_h2(fwd_act<ACT>(z[t][0], act), fwd_act<ACT>(z[t][1], act));
+                    Bout[jt >> 1][t][2 * (jt & 1) + 1] = pack_h2(fwd_act<ACT>(z[t][2], act), fwd_act<ACT>(z[t][3], act));
+                }
             }
         }
     };
@@ -260,6 +268,7 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
     constexpr int fq_slots = LNR_FREQ_SLOTS_OF_KT(KT);
     const float fq_pg = __uint_as_float((uint32_t)(127 + g) << 23);      // 2^g
     const bool fq_uni = FQ && ray_uniform(src, (uint32_t)TS) && M % TS == 0;      // (M % TS: the clamp of a ragged last tile would mix two rays)
+    const int ns_shift = (src.n_samples > 0 && (src.n_samples & (src.n_samples - 1)) == 0) ? __builtin_ctz((unsigned)src.n_samples) : -1;   // samples per ray a power of two: a shift
     // the features of the NEXT step are in flight while this one goes through the layers
     // (samples past M: their planes are padded to m_pad, whatever they hold only reaches columns that are never stored)
     // FQ: the unit-cube points of a step's samples (x the lane's 2^g) ...
@@ -267,20 +276,37 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
     // features (phase timers, profiles/r06_fp16_mlp_phases.txt: requested and consumed in one place, the round trip was 35 % of a wave's
     // time with two waves per SIMD to cover it).
     auto fq_request = [&](int64_t tile, RawPoint (&rp)[CT]) __attribute__((always_inline)) {
+        uint32_t mm[CT], rr[CT];
         if (fq_uni) {
-            // a wave step's 16 CT samples lie on ONE ray: its index from wave-uniform operands (one scalar division instead of a
-            // per-lane one for every column tile), its record through the scalar cache (lnr_encoding.h); M % TS == 0: nothing to clamp
+            // the step's samples lie on ONE ray: its index from wave-uniform operands (a shift or one scalar division instead of a
+            // per-lane division for every column tile); nothing to clamp (the sample count is a multiple of the step)
             const uint32_t m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tile * TS));
-            const uint32_t ray = m0 / (uint32_t)__builtin_amdgcn_readfirstlane(src.n_samples);
+            const uint32_t ray = ns_shift >= 0 ? m0 >> ns_shift : m0 / (uint32_t)__builtin_amdgcn_readfirstlane(src.n_samples);
 #pragma unroll
-            for (int t = 0; t < CT; ++t) load_raw_point(src, m0 + 16u * t + (uint32_t)c, ray, rp[t], true);
+            for (int t = 0; t < CT; ++t) { mm[t] = m0 + 16u * t + (uint32_t)c; rr[t] = ray; }
         } else {
 #pragma unroll
             for (int t = 0; t < CT; ++t) {
                 int64_t m = tile * TS + 16 * t + c;
-                if (m >= M) m = M - 1;                                 // (columns past the last sample are never stored)
-                load_raw_point(src, (uint32_t)m, src.pts ? 0u : (uint32_t)m / (uint32_t)src.n_samples, rp[t], false);
+                if (m >= M) m = M - 1;                                      // (clamped to the last live sample)
+                mm[t] = (uint32_t)m;
+                rr[t] = src.pts ? 0u : (uint32_t)m / (uint32_t)src.n_samples;
             }
+        }
+        // The SAME seven vector loads per column tile whatever the source, only their addresses differ (points: origin = the point,
+        // direction / depth = any valid address, ignored by unit_point).  Loads inside the branches of load_raw_point ended in
+        // register copies of the loaded values at the join - a wait for them right where they had been issued - and a scalar load
+        // of the ray record would share its counter with the LDS (lgkmcnt): the next weight fragment would wait for it.
+        const bool is_pts = src.pts != nullptr;
+        const float* b_od = is_pts ? src.pts : src.rays;
+        const float* b_z = is_pts ? src.pts : src.z;
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const uint32_t oo = is_pts ? mm[t] * 12u : rr[t] * (uint32_t)(LNR_RAY_STRIDE * 4);
+            const uint32_t od = is_pts ? 0u : oo + 12u, oz = is_pts ? 0u : mm[t] * 4u;
+            rp[t].o0 = ld32<float>(b_od, oo); rp[t].o1 = ld32<float>(b_od, oo + 4u); rp[t].o2 = ld32<float>(b_od, oo + 8u);
+            rp[t].d0 = ld32<float>(b_od, od); rp[t].d1 = ld32<float>(b_od, od + 4u); rp[t].d2 = ld32<float>(b_od, od + 8u);
+            rp[t].z = ld32<float>(b_z, oz);
         }
     };
     auto fq_unit = [&](const RawPoint (&rp)[CT], float (&xu)[CT][3]) __attribute__((always_inline)) {
@@ -338,6 +364,7 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
     // (always inlined: with a run-time activation the body is large enough for the inliner to leave it a FUNCTION, and a call passes
     // the operand arrays through scratch memory - 500 bytes per lane)
     // side: FwdNoSide, or the fused frequency kernels' job - slot k of the NEXT step's features behind the MFMAs of row tile k
+    const __amdgpu_buffer_rsrc_t sig_rsrc = __builtin_amdgcn_make_buffer_rsrc(sigma, 0, (int)(M * 4), 0x00020000);   // (M <= 2^25: lnr_density_forward)
     auto run_tile = [&](int64_t tile, const u32x4 (&x)[F16_KB_MAX][CT], auto side) __attribute__((always_inline)) {
         float part[CT];
 #pragma unroll
@@ -362,7 +389,13 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
             const int64_t m = tile * TS + 16 * t + c;
-            if (g == 0 && m < M) sigma[m] = finite_or_clipped<true>(v, clip_flag);
+            // ONE unconditional store per column tile (lanes with nothing to store get an offset beyond the buffer: dropped by the
+            // range check).  Loads and stores share one in-order counter (vmcnt); behind a branch the compiler cannot count the store,
+            // and the wait for the next step's points - requested a whole step earlier, in front of it - became a wait for everything
+            // outstanding, i.e. for this store's acknowledgement: a memory round trip per step with only the SIMD's other wave to
+            // cover it (30 % of a wave's time, profiles/r06_fp16_mlp_phases.txt).
+            v = finite_or_clipped<true>(v, clip_flag);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), sig_rsrc, (g == 0 && m < M) ? (int)((uint32_t)m * 4u) : (int)0x80000000u, 0, 0);
         }
         PHASE(4);
     };
@@ -387,7 +420,7 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
         for (; tile < n_tiles; tile += 2 * stride) {
             const int64_t t1 = tile + stride, t2 = tile + 2 * stride, t3 = tile + 3 * stride;
             fq_unit(rp, xu);
-            fq_request(t2 < n_tiles ? t2 : tile, rp);
+            fq_request(t2 < n_tiles ? t2 : tile, rp);                      // a whole step ahead of its use (the output stores in between are countable: run_tile)
             zero_x(xb);
             PHASE(1);
             run_tile(tile, xa, [&](int k) __attribute__((always_inline)) { fq_slot(k, xu, xb); });
