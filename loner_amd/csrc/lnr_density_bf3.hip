@@ -291,6 +291,17 @@ mlp_backward_bf3_kernel(const float* __restrict__ params, int n_mlp, const float
                     *reinterpret_cast<float2*>(T + (16 * jt + 4 * g + r) * BF3_TS + 2 * c) = make_float2(dz[jt][0][r], dz[jt][1][r]);   // samples 2c, 2c + 1
                 }
             }
+            // The weight gradient's B operand is taken over (split into its bf16 terms) HERE, in front of the d_feature stores: loads
+            // and stores share one in-order counter (vmcnt) and the stores sit in a branch the compiler cannot count, so a wait for
+            // these loads placed behind them was a wait for the eight stores' acknowledgement (profiles/r06_fp16_mlp_phases.txt has
+            // the finding for the fp16 kernels; here two waves per SIMD covered most of it: 0.209 -> 0.206 ms in the default bench).
+            Frag3 xs[2];
+            bf3_split8(xraw[0], xs[0]);
+            bf3_split8(xraw[1], xs[1]);
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int t3 = 0; t3 < 3; ++t3) asm volatile("" : "+v"(xs[it].t[t3]));
             // dX = W1^T dZ: the lane's own dZ values are the B operand under the K permutation (slots 0-3: row tile 2kb, 4-7: 2kb+1)
             if (want_dfeat) {
                 f32x4 D[2][2];                                // [t][it]
@@ -329,9 +340,6 @@ mlp_backward_bf3_kernel(const float* __restrict__ params, int n_mlp, const float
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // dW1[neuron][feature] += sum over the 32 samples of dZ[neuron][s] X[feature][s]
-            Frag3 xs[2];
-            bf3_split8(xraw[0], xs[0]);
-            bf3_split8(xraw[1], xs[1]);
 #pragma unroll
             for (int jt = 0; jt < HT; ++jt) {
                 const float4 a0 = *reinterpret_cast<const float4*>(T + (16 * jt + c) * BF3_TS + 8 * g);

@@ -45,7 +45,7 @@ template <bool SWZ> __device__ __forceinline__ int fwd_slot(int col, int row) {
 // fp32 parameters (tinycudann layout: W1 [H][in_dim], hidden [H][H] each, output row [H]) -> the fp16 LDS copy described above.
 // The fill is the fixed cost of every launch (each persistent workgroup converts the whole network in front of its first MFMA), and it
 // is made of exposed L2 round trips: as `for (i = tid; i < n; i += blockDim.x)` every element was one (128 in a row for the 128 x 2
-// network: ~20 us); unrolled by 8 it was 14 rounds (~13 us of the 161 us north-star forward, profiles/r06_north_star_fixed_cost.txt).
+// network: ~20 us); unrolled by 8 it was 14 rounds (~13 us of the 161 us north-star forward, profiles/r06_fp16_mlp_phases.txt).
 // Now a thread takes 2 (first layer: a (sin, cos) pair / two neighbouring features) or 4 (hidden: one lane group's four neurons)
 // consecutive parameters per load and the trip counts are compile-time and fully unrolled: every load of the fill is in flight at once.
 // FQ (the frequency encoding computed in the kernel, lnr_f16_freq.h): K position `col` of a first-layer row holds the weight of the
