@@ -988,6 +988,39 @@ def test_fp16_mode_general_networks(ops, name):
     assert torch.equal(ops.density_backward(spec_h, dv(params), dv(d_sigma), None, pts=dv(pts), want_d_pts=True), d_pts)
 
 
+@pytest.mark.parametrize("name,S,live", [("freq_relu128", 64, 37), ("freq_relu128", 20, 50), ("freq12_small", 96, 50), ("freq_relu3", 33, 41)])
+def test_fused_frequency_rays_form_equals_points_form(ops, name, S, live):
+    """The fused frequency kernels take their points from rays + depths (o + d z, rounded as the reference rounds it) through three
+    request routes: one ray per wave step (S a multiple of 32: its index from a shift / one scalar division, the record loaded once),
+    a ray per lane (any S), and explicit points.  All three are the same function of the same points, bit for bit - forward, the
+    weight gradient and the input gradient - with a device-side live-ray count that leaves the last tile ragged."""
+    from loner_amd import hip
+    enc, net = NETS[name]
+    net16 = dict(net, precision="fp16")
+    spec_o, spec_h = NW.NetworkSpec.from_config(enc, net16), hip.make_net_spec(enc, net16)
+    params = dv(NW.init_params(spec_o, 4))
+    gen = torch.Generator().manual_seed(21)
+    n = 50
+    rays = torch.zeros(n, 13); rays[:, 0:3] = torch.rand(n, 3, generator=gen) * 0.3 - 0.15
+    rays[:, 3:6] = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=1); rays[:, 11] = 0.02; rays[:, 12] = 0.6
+    z = torch.sort(torch.rand(n, S, generator=gen) * 0.55 + 0.02, dim=1).values
+    d_sigma = torch.randn(n, S, generator=gen) * torch.logspace(-4, 0, n)[:, None]
+    R, Z, DS = dv(rays), dv(z), dv(d_sigma)
+    n_dev = torch.tensor([live], dtype=torch.int32, device=DEV)
+    pts = (R[:live, None, 0:3] + R[:live, None, 3:6] * Z[:live, :, None]).reshape(-1, 3).contiguous()    # (separate multiply and add: no fma)
+    s_rays = ops.density_forward(spec_h, params, rays=R, z=Z, n_rays_dev=n_dev)
+    s_pts = ops.density_forward(spec_h, params, pts=pts)
+    assert torch.equal(s_rays.reshape(n, S)[:live].reshape(-1), s_pts.reshape(-1)) and float(s_pts.abs().max()) > 0
+    g_rays, g_pts = torch.zeros(int(spec_h.n_params), device=DEV), torch.zeros(int(spec_h.n_params), device=DEV)
+    p_rays = ops.density_backward(spec_h, params, DS, g_rays, rays=R, z=Z, n_rays_dev=n_dev, want_d_pts=True)
+    p_pts = ops.density_backward(spec_h, params, DS[:live].reshape(-1).contiguous(), g_pts, pts=pts, want_d_pts=True)
+    assert torch.equal(g_rays, g_pts) and float(g_rays.abs().max()) > 0
+    assert torch.equal(p_rays.reshape(n * S, 3)[:live * S], p_pts.reshape(-1, 3))
+    # and against the oracle (same storage rounding) on the live samples
+    ref = NW.density(spec_o, params.cpu(), pts.cpu())
+    assert float((s_pts.cpu().reshape(-1) - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+
+
 def test_fp16_mode_refuses_what_it_does_not_cover(ops):
     from loner_amd import hip
     many_inputs = (dict(otype="Frequency", n_frequencies=24), dict(activation="ReLU", n_neurons=128, n_hidden_layers=2))
