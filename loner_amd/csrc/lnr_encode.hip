@@ -671,7 +671,10 @@ __device__ unsigned long long lnr_phase_cycles[2 * LNR_N_PHASES];          // [8
 // XP: the launch's levels take x-pair records (compile-time: the two record formats share little code, and a kernel that carries both
 // spills ~60 SGPRs into VGPR lanes inside the batch loop)
 template <int F, int DXM, bool XP>
-__global__ void __launch_bounds__(ENC_BWD_BLOCK, 4)   // (max threads, min waves per SIMD): 128 VGPRs
+#ifndef LNR_ENC_BWD_WAVES
+#define LNR_ENC_BWD_WAVES 4
+#endif
+__global__ void __launch_bounds__(ENC_BWD_BLOCK, LNR_ENC_BWD_WAVES)   // (max threads, min waves per SIMD): 4 = 128 VGPRs
 encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, const PointSrc src, const float* __restrict__ dfeat,
                        float* __restrict__ dxl, int64_t m_pad, int bpg, const LevelList list, const EncSink sink) {
     constexpr bool WANT_DX = DXM != ENC_DX_NONE;          // dxl: the d/dx planes (ENC_DX_PLANES) or d_rays [n_rays,13] (ENC_DX_RAYS)
@@ -1462,13 +1465,21 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
 #endif
             LnrProfScope prof("encode_backward", st);
             const int maxo4 = (maxo + 3) & ~3;
-            const size_t lds = (size_t)(2 * maxo4 + 4 * maxo) * sizeof(int) + (size_t)ENC_STAGE_RECORDS * (spec->n_features >= 2 ? 16 : 8);
+            size_t lds = (size_t)(2 * maxo4 + 4 * maxo) * sizeof(int) + (size_t)ENC_STAGE_RECORDS * (spec->n_features >= 2 ? 16 : 8);
+            // development probe (profiles/r06_occupancy_probes.txt): unused LDS behind the staging buffer, so that ONE workgroup fits a CU
+            // (two waves per SIMD instead of four) - does the pair wait for latencies more waves would cover, or for throughput?
+            static const int lds_pad = getenv("LNR_ENC_BWD_LDS_PAD") ? atoi(getenv("LNR_ENC_BWD_LDS_PAD")) : 0;
+            lds += (size_t)lds_pad;
             if (rec_levels.n > 0) {
                 const dim3 grid((unsigned)(rec_levels.n * bpg));
                 sink.xcd_affine = lnr_xcd_affine(rec_levels.n, cap_points, false) ? 1 : 0;
                 LNR_LAUNCH_F(encode_backward_kernel, *spec, table, *src, dfeat, dx_out, m_pad, bpg, rec_levels, sink);
             }
             if (xp_levels.n > 0) {                                          // n_features == 2
+                // development probe: a smaller staging buffer for the x-pair launch (4 records per sample + straddling cells), so that
+                // three workgroups fit a CU when the kernel is built for six waves per SIMD (-DLNR_ENC_BWD_WAVES=6)
+                static const int xp_stage = getenv("LNR_ENC_BWD_XP_STAGE") ? atoi(getenv("LNR_ENC_BWD_XP_STAGE")) : 0;
+                if (xp_stage > 0) lds = (size_t)(2 * maxo4 + 4 * maxo) * sizeof(int) + (size_t)xp_stage * 16 + (size_t)lds_pad;
                 const dim3 grid((unsigned)(xp_levels.n * bpg));
                 sink.xcd_affine = lnr_xcd_affine(xp_levels.n, cap_points, false) ? 1 : 0;
                 LNR_LAUNCH_DXM(encode_backward_kernel, 2, true, *spec, table, *src, dfeat, dx_out, m_pad, bpg, xp_levels, sink);
