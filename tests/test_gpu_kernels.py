@@ -1021,6 +1021,29 @@ def test_fused_frequency_rays_form_equals_points_form(ops, name, S, live):
     assert float((s_pts.cpu().reshape(-1) - ref).abs().max()) < 2e-3 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("name", ["freq_relu128", "hash_f4_2hidden", "freq_wide256"])
+def test_fp16_mlp_weight_fill_with_a_parameter_vector_that_is_not_16_byte_aligned(ops, name):
+    """The fp16 MLP kernels read the network into LDS with 8- and 16-byte loads when the parameter vector allows it and element by
+    element when it does not (a view that starts 4 bytes into an allocation): the same network either way, bit for bit."""
+    from loner_amd import hip
+    enc, net = NETS[name]
+    net16 = dict(net, precision="fp16")
+    spec_o, spec_h = NW.NetworkSpec.from_config(enc, net16), hip.make_net_spec(enc, net16)
+    params = dv(NW.init_params(spec_o, 6))
+    shifted = torch.empty(params.numel() + 1, device=DEV)[1:]
+    shifted.copy_(params)
+    assert params.data_ptr() % 16 == 0 and shifted.data_ptr() % 16 == 4
+    gen = torch.Generator().manual_seed(2)
+    n = 777
+    pts = dv(torch.rand(n, 3, generator=gen) * 1.9 - 0.95)
+    d_sigma = dv(torch.randn(n, generator=gen))
+    assert torch.equal(ops.density_forward(spec_h, params, pts=pts), ops.density_forward(spec_h, shifted, pts=pts))
+    g_a, g_s = torch.zeros(int(spec_h.n_params), device=DEV), torch.zeros(int(spec_h.n_params), device=DEV)
+    p_a = ops.density_backward(spec_h, params, d_sigma, g_a, pts=pts, want_d_pts=True)
+    p_s = ops.density_backward(spec_h, shifted, d_sigma, g_s, pts=pts, want_d_pts=True)
+    assert torch.equal(g_a, g_s) and torch.equal(p_a, p_s) and float(g_a.abs().max()) > 0
+
+
 def test_fp16_mode_refuses_what_it_does_not_cover(ops):
     from loner_amd import hip
     many_inputs = (dict(otype="Frequency", n_frequencies=24), dict(activation="ReLU", n_neurons=128, n_hidden_layers=2))
