@@ -1,0 +1,8 @@
+#!/bin/bash
+# round 6, call 22: final kernel stats + PMC traffic of the quick bench command; driver command; default bench
+set +e
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+bash tools/gpu_run.sh "stats::--quick --steps 30 --warmup 10" keep:r06 "pmc:FETCH_SIZE" "pmc:WRITE_SIZE" 2>&1 | tail -30
+LNR_COMMIT=$1 python tools/traffic_from_pmc.py gpurun_out/r06_traffic.json | tail -12
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r06_bench_driver_command.log 2> gpurun_out/r06_bench_driver_command.err; tail -1 gpurun_out/r06_bench_driver_command.log | cut -c1-400
