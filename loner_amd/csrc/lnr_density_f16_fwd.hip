@@ -10,6 +10,12 @@
 
 #define LNR_F16_FWD_CT 2             // 16-sample column tiles per wave step
 
+#ifdef LNR_DEV_PROBES
+#define LNR_F16_FWD_PROBE_ONE_PER_CU (getenv("LNR_F16_FWD_ONE_PER_CU") != nullptr)
+#else
+#define LNR_F16_FWD_PROBE_ONE_PER_CU false
+#endif
+
 #if LNR_FWD_FQ
 #define LNR_FWD_ENTRY lnr_mlp_fwd_f16_freq
 #define LNR_FWD_OTHER lnr_mlp_fwd_f16_freq_other
@@ -30,7 +36,7 @@ int LNR_FWD_OTHER(const LnrNetSpec* spec, const float* params, const uint32_t* f
         const size_t lds = FwdLds<HT, NH, KT>::BYTES;                                                                            \
         /* persistent: every workgroup converts the weights into its LDS once, so no more workgroups than the chip holds */      \
         int64_t resident = 256 * (int64_t)((size_t)LNR_LDS_LIMIT / lds >= 2 ? 2 : 1);                                            \
-        if (getenv("LNR_F16_FWD_ONE_PER_CU")) resident = 256;  /* development probe: one wave per SIMD */                         \
+        if (LNR_F16_FWD_PROBE_ONE_PER_CU) resident = 256;  /* development probe (-DLNR_DEV_PROBES): one wave per SIMD */          \
         const dim3 grid((unsigned)(blocks < resident ? blocks : resident));                                                      \
         int rc_ = f16_set_lds(mlp_forward_f16_gen_kernel<HT, ACT, NH, KT, LNR_F16_FWD_CT, LNR_FWD_FQ != 0>, lds, "lnr_density_forward"); \
         if (rc_) return rc_;                                                                                                     \

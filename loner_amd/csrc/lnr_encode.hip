@@ -1466,9 +1466,13 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
             LnrProfScope prof("encode_backward", st);
             const int maxo4 = (maxo + 3) & ~3;
             size_t lds = (size_t)(2 * maxo4 + 4 * maxo) * sizeof(int) + (size_t)ENC_STAGE_RECORDS * (spec->n_features >= 2 ? 16 : 8);
-            // development probe (profiles/r06_occupancy_probes.txt): unused LDS behind the staging buffer, so that ONE workgroup fits a CU
+            // development probe (-DLNR_DEV_PROBES builds only; profiles/r06_occupancy_probes.txt): unused LDS behind the staging buffer, so that ONE workgroup fits a CU
             // (two waves per SIMD instead of four) - does the pair wait for latencies more waves would cover, or for throughput?
+#ifdef LNR_DEV_PROBES
             static const int lds_pad = getenv("LNR_ENC_BWD_LDS_PAD") ? atoi(getenv("LNR_ENC_BWD_LDS_PAD")) : 0;
+#else
+            const int lds_pad = 0;
+#endif
             lds += (size_t)lds_pad;
             if (rec_levels.n > 0) {
                 const dim3 grid((unsigned)(rec_levels.n * bpg));
@@ -1478,8 +1482,10 @@ int lnr_encode_backward(const LnrNetSpec* spec, const float* params, const Point
             if (xp_levels.n > 0) {                                          // n_features == 2
                 // development probe: a smaller staging buffer for the x-pair launch (4 records per sample + straddling cells), so that
                 // three workgroups fit a CU when the kernel is built for six waves per SIMD (-DLNR_ENC_BWD_WAVES=6)
+#ifdef LNR_DEV_PROBES
                 static const int xp_stage = getenv("LNR_ENC_BWD_XP_STAGE") ? atoi(getenv("LNR_ENC_BWD_XP_STAGE")) : 0;
                 if (xp_stage > 0) lds = (size_t)(2 * maxo4 + 4 * maxo) * sizeof(int) + (size_t)xp_stage * 16 + (size_t)lds_pad;
+#endif
                 const dim3 grid((unsigned)(xp_levels.n * bpg));
                 sink.xcd_affine = lnr_xcd_affine(xp_levels.n, cap_points, false) ? 1 : 0;
                 LNR_LAUNCH_DXM(encode_backward_kernel, 2, true, *spec, table, *src, dfeat, dx_out, m_pad, bpg, xp_levels, sink);
