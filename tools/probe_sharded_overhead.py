@@ -20,6 +20,7 @@ from loner_amd.mapping.sharding import DistContext             # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=300)
 ap.add_argument("--warmup", type=int, default=20)
+ap.add_argument("--only", type=int, default=-1, help="run one configuration of the list below (for a kernel trace of exactly that loop)")
 a = ap.parse_args()
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29713")
@@ -27,11 +28,13 @@ torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 phase = lambda n: OptimizationSettings(n, False, False, False, True)
 import gc
-for form, front, native, grad in ((None, None, None, None),
+for i_cfg, (form, front, native, grad) in enumerate(((None, None, None, None),
                                   ("all_reduce", "inline", False, "async"), ("all_reduce", "async", False, "async"),
                                   ("reduce_scatter", "inline", False, "async"), ("reduce_scatter", "async", False, "async"),
                                   ("all_reduce", "inline", True, "async"), ("all_reduce", "async", True, "async"),
-                                  ("reduce_scatter", "inline", True, "async"), ("reduce_scatter", "async", True, "async")):
+                                  ("reduce_scatter", "inline", True, "async"), ("reduce_scatter", "async", True, "async"))):
+    if a.only >= 0 and i_cfg != a.only:
+        continue
     opt = bench.make_bench_optimizer(512, 512, "f32")
     window = bench.build_window(8)[:1]
     if form is not None:
