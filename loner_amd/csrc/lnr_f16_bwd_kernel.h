@@ -166,8 +166,8 @@ mlp_backward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ par
         // register copies of the loaded values at the join - a wait for them right where they had been issued - and a scalar load
         // of the ray record would share its counter with the LDS (lgkmcnt): the next weight fragment would wait for it.
         const bool is_pts = src.pts != nullptr;
-        const float* b_od = is_pts ? src.pts : src.rays;
-        const float* b_z = is_pts ? src.pts : src.z;
+        const float* b_od = uniform_ptr(is_pts ? src.pts : src.rays);      // (as scalar registers: base + 32-bit lane offset, no 64-bit lane arithmetic)
+        const float* b_z = uniform_ptr(is_pts ? src.pts : src.z);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const uint32_t oo = is_pts ? mm[t] * 12u : rr[t] * (uint32_t)(LNR_RAY_STRIDE * 4);

@@ -46,6 +46,32 @@ __device__ __forceinline__ float lnr_freq_slot_scale(int sl) { return __uint_as_
 #define LNR_FREQ_HW_SIN 1
 #endif
 
+// The slot-independent part of a phase.  Slot sl of a lane evaluates y = xg S with xg = x 2^g (the lane's share) and S = 2^(4 (sl / 3)) a
+// literal; scaling by a power of two commutes with every rounding below, so ph(y) = S ph(xg) and dl(y) = S dl(xg) EXACTLY: the three
+// instructions that produce them are shared by the three slots of a coordinate, a slot scales them (nothing at all for S = 1).
+struct FreqBase { float ph0, dl0; };
+__device__ __forceinline__ FreqBase freq_base(float xg) {
+    FreqBase b;
+    b.ph0 = lnr_mul_rn(xg, LNR_PI_F);
+    const float e1 = __builtin_fmaf(xg, LNR_PI_F, -b.ph0);
+    b.dl0 = __builtin_fmaf(xg, 8.742278000372485e-8f, -e1);
+    return b;
+}
+// freq_pair<false>(xg S, ...) from the shared part (bit-identical; LNR_FREQ_HW_SIN route only)
+__device__ __forceinline__ uint32_t freq_pair_scaled(float xg, const FreqBase& b, float S) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const float ph = b.ph0 * S, dl = b.dl0 * S;                                // (exact)
+    const float r = __builtin_amdgcn_fractf(xg * (0.5f * S));
+    const float Sn = __builtin_amdgcn_sinf(r), Cs = __builtin_amdgcn_cosf(r);
+    const float s = __builtin_fmaf(Cs, dl, Sn);
+    const float c = __builtin_fmaf(-Sn, dl, Cs);
+    const float h = lnr_add_rn(ph, LNR_PI_2_F);
+    const float e = lnr_add_rn(LNR_PI_2_F, -lnr_add_rn(h, -ph));
+    const float d = 4.371139000186243e-8f - e;
+    const float c2 = __builtin_fmaf(-d, s, c);
+    return __builtin_bit_cast(uint32_t, h2{(_Float16)s, (_Float16)c2});
+}
+
 // the (sin, cos-like) feature pair of one slot from y = x 2^f (exact, f <= 11) and, for the backward, d(pair)/dx: ds = dph cos(ph),
 // dc = -dph (sin(ph) + d cos(ph)) with dph = 2^f pi (freq_backward_kernel's arithmetic)
 template <bool DERIV>

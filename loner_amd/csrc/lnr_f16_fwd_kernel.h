@@ -298,8 +298,8 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
         // register copies of the loaded values at the join - a wait for them right where they had been issued - and a scalar load
         // of the ray record would share its counter with the LDS (lgkmcnt): the next weight fragment would wait for it.
         const bool is_pts = src.pts != nullptr;
-        const float* b_od = is_pts ? src.pts : src.rays;
-        const float* b_z = is_pts ? src.pts : src.z;
+        const float* b_od = uniform_ptr(is_pts ? src.pts : src.rays);      // (as scalar registers: base + 32-bit lane offset, no 64-bit lane arithmetic)
+        const float* b_z = uniform_ptr(is_pts ? src.pts : src.z);
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
             const uint32_t oo = is_pts ? mm[t] * 12u : rr[t] * (uint32_t)(LNR_RAY_STRIDE * 4);
@@ -336,6 +336,28 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
                 asm volatile("" : "+v"(v));
                 x[sl >> 2][t][sl & 3] = v;
             }
+        }
+    };
+    // the same slot from the coordinate's shared phase part (freq_base: three instructions per coordinate instead of per slot)
+    auto fq_slot_shared = [&](int sl, const float (&xu)[CT][3], const FreqBase (&fb)[CT][3], u32x4 (&x)[F16_KB_MAX][CT]) __attribute__((always_inline)) {
+        if (sl < fq_slots) {
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+#if LNR_FREQ_HW_SIN
+                float y = xu[t][sl % 3];
+                asm volatile("" : "+v"(y));                               // (pinned: see fq_slot)
+                uint32_t v = freq_pair_scaled(y, fb[t][sl % 3], lnr_freq_slot_scale(sl));
+                asm volatile("" : "+v"(v));
+                x[sl >> 2][t][sl & 3] = v;
+#else
+                (void)fb;
+                float d0, d1;
+                x[sl >> 2][t][sl & 3] = freq_pair<false>(xu[t][sl % 3] * lnr_freq_slot_scale(sl), 0.0f, d0, d1);
+#endif
+            }
+        } else if (sl < 4 * KT) {                                         // a dead slot of a live K block: zero (its weights are zero too)
+#pragma unroll
+            for (int t = 0; t < CT; ++t) x[sl >> 2][t][sl & 3] = 0u;
         }
     };
     auto load_tile = [&](int64_t tile, u32x4 (&x)[F16_KB_MAX][CT]) __attribute__((always_inline)) {
@@ -409,11 +431,12 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
         // slot by slot BEHIND the MFMAs of this step's row tiles (HT x NH of them; what does not fit there follows the last layer)
         constexpr int N_SIDE = HT * NH;
         float xu[CT][3];
-        auto zero_x = [&](u32x4 (&x)[F16_KB_MAX][CT]) {
+        FreqBase fb[CT][3];                                               // the shared phase part of every coordinate (lnr_f16_freq.h)
+        auto fq_bases = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int kb = 0; kb < F16_KB_MAX; ++kb)
+            for (int t = 0; t < CT; ++t)
 #pragma unroll
-                for (int t = 0; t < CT; ++t) x[kb][t] = u32x4{0u, 0u, 0u, 0u};
+                for (int d = 0; d < 3; ++d) fb[t][d] = freq_base(xu[t][d]);
         };
         RawPoint rp[CT];                                                  // the points of step tile + stride, requested one step earlier
         if (tile < n_tiles) fq_request(tile + stride < n_tiles ? tile + stride : tile, rp);
@@ -421,20 +444,21 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
             const int64_t t1 = tile + stride, t2 = tile + 2 * stride, t3 = tile + 3 * stride;
             fq_unit(rp, xu);
             fq_request(t2 < n_tiles ? t2 : tile, rp);                      // a whole step ahead of its use (the output stores in between are countable: run_tile)
-            zero_x(xb);
+            fq_bases();
             PHASE(1);
-            run_tile(tile, xa, [&](int k) __attribute__((always_inline)) { fq_slot(k, xu, xb); });
+            // (every dword of the live K blocks is written by its slot - dead slots as zero - so the buffers need no clearing)
+            run_tile(tile, xa, [&](int k) __attribute__((always_inline)) { fq_slot_shared(k, xu, fb, xb); });
 #pragma unroll
-            for (int sl = N_SIDE; sl < 4 * KT; ++sl) fq_slot(sl, xu, xb);
+            for (int sl = N_SIDE; sl < 4 * KT; ++sl) fq_slot_shared(sl, xu, fb, xb);
             PHASE(5);
             if (t1 >= n_tiles) break;
             fq_unit(rp, xu);
             fq_request(t3 < n_tiles ? t3 : t1, rp);
-            zero_x(xa);
+            fq_bases();
             PHASE(1);
-            run_tile(t1, xb, [&](int k) __attribute__((always_inline)) { fq_slot(k, xu, xa); });
+            run_tile(t1, xb, [&](int k) __attribute__((always_inline)) { fq_slot_shared(k, xu, fb, xa); });
 #pragma unroll
-            for (int sl = N_SIDE; sl < 4 * KT; ++sl) fq_slot(sl, xu, xa);
+            for (int sl = N_SIDE; sl < 4 * KT; ++sl) fq_slot_shared(sl, xu, fb, xa);
             PHASE(5);
         }
     } else if constexpr (ACT >= 0) {

@@ -93,3 +93,33 @@ def test_sampler_prefix_sums_are_exact_in_float64():
         for j, i in enumerate(range(0, K, chunk)):
             out[i:i + chunk] = pre[j] + np.cumsum(pdf[i:i + chunk].astype(np.float64))
         assert np.array_equal(seq.astype(f32), out.astype(f32)) and np.array_equal(seq, out)
+
+
+def test_shared_phase_part_scales_exactly():
+    """freq_base / freq_pair_scaled (lnr_f16_freq.h): the three slots of a coordinate evaluate y = xg S with S = 1, 2^4, 2^8 (a literal
+    power of two).  Scaling by a power of two commutes with every rounding of the phase part, so ph(y) = S ph(xg), dl(y) = S dl(xg)
+    and the argument of v_fract_f32 is the same number - the per-coordinate form is the per-slot form bit for bit (no overflow or
+    underflow: xg in [0, 8), S <= 2^8).  The fma is modelled in exact rational arithmetic here (double is not enough to tell)."""
+    from fractions import Fraction
+    rng = np.random.default_rng(7)
+    PI, DPI = f32(np.pi), f32(8.742278000372485e-8)
+
+    def rn(q):                                                            # round a Fraction to float32, to nearest even
+        v = f32(float(q))                                                 # (float(q) is correctly rounded to double; a second rounding to
+        lo, hi = np.nextafter(v, f32(-np.inf)), np.nextafter(v, f32(np.inf))   # float32 may be off by one ulp: pick the nearest of three)
+        best = min((lo, v, hi), key=lambda c: (abs(Fraction(float(c)) - q), int(np.float32(c).view(np.uint32)) & 1))
+        return f32(best)
+
+    for _ in range(400):
+        xg = f32(rng.random() * 2 ** rng.integers(0, 4))
+        ph0 = f32(xg * PI)
+        e10 = rn(Fraction(float(xg)) * Fraction(float(PI)) - Fraction(float(ph0)))
+        dl0 = rn(Fraction(float(xg)) * Fraction(float(DPI)) - Fraction(float(e10)))
+        for j in (0, 1, 2):
+            S = f32(2 ** (4 * j))
+            y = f32(xg * S)
+            ph = f32(y * PI)
+            e1 = rn(Fraction(float(y)) * Fraction(float(PI)) - Fraction(float(ph)))
+            dl = rn(Fraction(float(y)) * Fraction(float(DPI)) - Fraction(float(e1)))
+            assert ph == f32(ph0 * S) and dl == f32(dl0 * S)
+            assert f32(y * f32(0.5)) == f32(xg * f32(0.5 * float(S)))
