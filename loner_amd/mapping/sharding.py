@@ -234,8 +234,40 @@ class DistContext:
         self.rank = dist.get_rank(group)
         if exchange is None:
             exchange = "reduce_scatter" if self.world_size >= 4 else "all_reduce"
-        if native is None:
-            native = dist.get_backend(group) == "nccl" and torch.cuda.is_available()
+        # native None: the HIP library's own RCCL binding whenever the process group is RCCL ("nccl") and every rank can bring its
+        # communicators up - the ranks agree on that through the process group, and fall back TOGETHER to torch.distributed over the
+        # same RCCL (a slower enqueue, the same collectives) with a warning: the binding has only ever run at RCCL world size 1
+        # (DESIGN 5), and a rank that fails alone would leave the others waiting in ncclCommInitRank.  True: required (raises);
+        # False: torch.distributed for everything (any backend: what the gloo tests on CPU exercise)
+        self.native = None
+        if native is None and dist.get_backend(group) == "nccl" and torch.cuda.is_available():
+            from .. import hip
+            ok, err = 0, None
+            try:
+                ok = 1 if hip.load().lnr_comm_available() else 0
+                if not ok:
+                    err = "librccl.so.1 could not be loaded by the HIP library"
+            except Exception as e:                                        # (the library itself missing is an error elsewhere, loudly)
+                err = str(e)
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if int(flag) == 1:
+                try:
+                    self.native = NativeComm(group)
+                except Exception as e:
+                    err = str(e)
+                flag = torch.tensor([1 if self.native is not None else 0], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                if int(flag) == 0 and self.native is not None:
+                    self.native.close()
+                    self.native = None
+            if self.native is None:
+                import warnings
+                warnings.warn(f"loner_amd sharding: the library's own RCCL binding is not available on every rank ({err or 'another rank failed'}); "
+                              "collectives go through torch.distributed (ProcessGroupNCCL)")
+            native = self.native is not None
+        elif native is None:
+            native = False
         # front None: "inline" with the library's own RCCL binding - one enqueue on the compute stream through a communicator of its own,
         # so it never queues behind the gradient exchange in flight on the side stream; "async" through torch.distributed, where a
         # synchronous collective shares ProcessGroupNCCL's one communicator with the asynchronous gradient exchange and would stall the
@@ -245,10 +277,7 @@ class DistContext:
         if exchange not in ("all_reduce", "reduce_scatter") or payload not in ("fp32", "bf16") or front not in ("inline", "async"):
             raise ValueError(f"unknown gradient exchange {exchange!r} / payload {payload!r} / front {front!r}")
         self.exchange, self.payload, self.front = exchange, payload, front
-        # native None: the HIP library's own RCCL binding whenever the process group is RCCL ("nccl") and the library can load it;
-        # False: torch.distributed for everything (any backend: what the gloo tests on CPU exercise)
-        self.native = None
-        if native:
+        if native and self.native is None:
             self.native = NativeComm(group)
 
     # ---- the front of an iteration: far[0] and the loss normalisers -----------------------------------------------------
