@@ -416,8 +416,9 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
             // and the wait for the next step's points - requested a whole step earlier, in front of it - became a wait for everything
             // outstanding, i.e. for this store's acknowledgement: a memory round trip per step with only the SIMD's other wave to
             // cover it (30 % of a wave's time, profiles/r06_fp16_mlp_phases.txt).
-            v = finite_or_clipped<true>(v, clip_flag);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), sig_rsrc, (g == 0 && m < M) ? (int)((uint32_t)m * 4u) : (int)0x80000000u, 0, 0);
+            const bool stored = g == 0 && m < M;
+            if (stored) v = finite_or_clipped<true>(v, clip_flag);         // (the guard counts stored values only; the STORE sits behind the join)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), sig_rsrc, stored ? (int)((uint32_t)m * 4u) : (int)0x80000000u, 0, 0);
         }
         PHASE(4);
     };
