@@ -23,11 +23,17 @@ __device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2_{lo, hi}, h2));
 }
 __device__ __forceinline__ float round_f16(float v) { return (float)(f16)v; }
-// a wave-uniform pointer the compiler cannot prove uniform (a select between kernel arguments inside divergent code), as scalar registers
-template <typename T> __device__ __forceinline__ T* uniform_ptr(T* p) {
+// A wave-uniform GLOBAL base address the compiler cannot prove uniform (a select between kernel arguments inside divergent code), as
+// scalar registers, and a load of base + 32-bit lane offset from it.  The pointer keeps its address space: rebuilt from integers as a
+// generic pointer the loads became FLAT loads, which count against vmcnt AND lgkmcnt - every wait for them was a wait for everything.
+__device__ __forceinline__ uint64_t uniform_base(const void* p) {
     const uint64_t v = reinterpret_cast<uint64_t>(p);
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-    return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
+    return ((uint64_t)hi << 32) | lo;
+}
+template <typename T> __device__ __forceinline__ T ld32_at(uint64_t base, uint32_t byte_off) {
+    typedef const T __attribute__((address_space(1)))* GP;
+    return *(GP)(base + (uint64_t)byte_off);
 }
 // ReLU of two values rounded to fp16, on the packed pair: one v_pk_max_i16 on the bit patterns (negative halves, -0 included, are
 // negative integers; rounding and max(., 0) commute: rounding is monotone and keeps 0) instead of one integer max per fp32 value in

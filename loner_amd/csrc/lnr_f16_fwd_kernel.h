@@ -298,15 +298,15 @@ mlp_forward_f16_gen_kernel(const LnrNetSpec spec, const float* __restrict__ para
         // register copies of the loaded values at the join - a wait for them right where they had been issued - and a scalar load
         // of the ray record would share its counter with the LDS (lgkmcnt): the next weight fragment would wait for it.
         const bool is_pts = src.pts != nullptr;
-        const float* b_od = uniform_ptr(is_pts ? src.pts : src.rays);      // (as scalar registers: base + 32-bit lane offset, no 64-bit lane arithmetic)
-        const float* b_z = uniform_ptr(is_pts ? src.pts : src.z);
+        const uint64_t b_od = uniform_base(is_pts ? src.pts : src.rays);   // (as scalar registers: base + 32-bit lane offset, no 64-bit lane arithmetic)
+        const uint64_t b_z = uniform_base(is_pts ? src.pts : src.z);
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
             const uint32_t oo = is_pts ? mm[t] * 12u : rr[t] * (uint32_t)(LNR_RAY_STRIDE * 4);
             const uint32_t od = is_pts ? 0u : oo + 12u, oz = is_pts ? 0u : mm[t] * 4u;
-            rp[t].o0 = ld32<float>(b_od, oo); rp[t].o1 = ld32<float>(b_od, oo + 4u); rp[t].o2 = ld32<float>(b_od, oo + 8u);
-            rp[t].d0 = ld32<float>(b_od, od); rp[t].d1 = ld32<float>(b_od, od + 4u); rp[t].d2 = ld32<float>(b_od, od + 8u);
-            rp[t].z = ld32<float>(b_z, oz);
+            rp[t].o0 = ld32_at<float>(b_od, oo); rp[t].o1 = ld32_at<float>(b_od, oo + 4u); rp[t].o2 = ld32_at<float>(b_od, oo + 8u);
+            rp[t].d0 = ld32_at<float>(b_od, od); rp[t].d1 = ld32_at<float>(b_od, od + 4u); rp[t].d2 = ld32_at<float>(b_od, od + 8u);
+            rp[t].z = ld32_at<float>(b_z, oz);
         }
     };
     auto fq_unit = [&](const RawPoint (&rp)[CT], float (&xu)[CT][3]) __attribute__((always_inline)) {
