@@ -674,6 +674,11 @@ template <int F, int DXM, bool XP>
 #ifndef LNR_ENC_BWD_WAVES
 #define LNR_ENC_BWD_WAVES 4
 #endif
+// 1: the d/dx term and the next batch's inputs are taken over in front of the record copy-out (see the batch loop): encode_backward
+// 0.832 -> 0.783 ms, the iteration 1.918 -> 1.867 ms (profiles/r06_encode_backward_dx_before_copyout.txt); 0: the d/dx term after the passes
+#ifndef LNR_ENC_DX_BEFORE_COPYOUT
+#define LNR_ENC_DX_BEFORE_COPYOUT 1
+#endif
 __global__ void __launch_bounds__(ENC_BWD_BLOCK, LNR_ENC_BWD_WAVES)   // (max threads, min waves per SIMD): 4 = 128 VGPRs
 encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, const PointSrc src, const float* __restrict__ dfeat,
                        float* __restrict__ dxl, int64_t m_pad, int bpg, const LevelList list, const EncSink sink) {
@@ -897,6 +902,31 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
             PHASE(6);
             __syncthreads();
             PHASE(7);
+#if LNR_ENC_DX_BEFORE_COPYOUT
+            // Everything this batch still WAITS for from memory is taken over here, in front of the copy-out: the next batch's inputs
+            // (requested at the top) and the gathers of the d/dx term.  Loads and stores share one in-order counter (vmcnt) and the record
+            // stores below are invisible to the compiler (inline asm, data-dependent trip count): a wait placed behind them - the d/dx
+            // term after the passes, the inputs at the loop's end - is a wait for the stores' acknowledgement as well.
+            if (pass == NPASS - 1) {
+#pragma unroll
+                for (int f = 0; f < F; ++f) asm volatile("" : "+v"(g_next[f]));
+                asm volatile("" : "+v"(p_next.z));
+                if constexpr (WANT_DX) {
+                    float dx[3] = {0.0f, 0.0f, 0.0f};
+                    if (any && !DBG_SKIP(2)) {
+                        if constexpr (EARLY_DX) dx_from_entries<F>(L, c, g, tv, dx);
+                        else { float tl[8][F]; gather_entries<F>(table, e, tl); dx_from_entries<F>(L, c, g, tl, dx); }
+                    }
+                    if constexpr (DXM == ENC_DX_RAYS) {
+                        if (wave_any && !DBG_SKIP(1))            // wave-uniform; lane 0 holds the wave's first (live) sample
+                            ray_accumulate_dx(dxl, (uint32_t)__builtin_amdgcn_readfirstlane((int)ray_cur), p_cur.z, dx, lane, src.n_rays);
+                    } else if (live) {
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) st32<float>(dxplanes, (uint32_t)d * plane_bytes + m * 4u, dx[d]);
+                    }
+                }
+            }
+#endif
             // ---- D: linear copy-out; neighbouring lanes write neighbouring records of the same region
             const int total = s_total;
             if (xp) {
@@ -943,6 +973,24 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
             // no barrier here: the next histogram only touches cnt[], and its first barrier orders D before the next B/C
             PHASE(8);
         }
+#if LNR_ENC_DX_BEFORE_COPYOUT
+        if (!(emit && !DBG_SKIP(16))) {                       // (no passes ran: parameters frozen)
+            if constexpr (WANT_DX) {
+                float dx[3] = {0.0f, 0.0f, 0.0f};
+                if (any && !DBG_SKIP(2)) {
+                    if constexpr (EARLY_DX) dx_from_entries<F>(L, c, g, tv, dx);
+                    else { float tl[8][F]; gather_entries<F>(table, e, tl); dx_from_entries<F>(L, c, g, tl, dx); }
+                }
+                if constexpr (DXM == ENC_DX_RAYS) {
+                    if (wave_any && !DBG_SKIP(1))            // wave-uniform; lane 0 holds the wave's first (live) sample
+                        ray_accumulate_dx(dxl, (uint32_t)__builtin_amdgcn_readfirstlane((int)ray_cur), p_cur.z, dx, lane, src.n_rays);
+                } else if (live) {
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) st32<float>(dxplanes, (uint32_t)d * plane_bytes + m * 4u, dx[d]);
+                }
+            }
+        }
+#else
         if constexpr (WANT_DX) {
             float dx[3] = {0.0f, 0.0f, 0.0f};
             if (any && !DBG_SKIP(2)) {
@@ -957,6 +1005,7 @@ encode_backward_kernel(const LnrNetSpec spec, const float* __restrict__ table, c
                 for (int d = 0; d < 3; ++d) st32<float>(dxplanes, (uint32_t)d * plane_bytes + m * 4u, dx[d]);
             }
         }
+#endif
         PHASE(9);
     }
     PHASE_FLUSH(lnr_phase_cycles, xp ? LNR_N_PHASES : 0);
